@@ -1,0 +1,248 @@
+"""ctypes binding of the C ABI declared in include/mi355env.h (libmi355env.so).
+
+There is no CPU fallback: if the HIP library has not been built, or no MI355X is visible, creating an
+environment raises.  The binding is generic over (shared object, symbol prefix) only so that the test-suite can
+drive the SAME host code against a checker library; the package itself only ever loads libmi355env.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+MI_OK = 0
+MI_HOST, MI_DEVICE = 0, 1
+MI_F32, MI_F64, MI_I64 = 0, 1, 2
+FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
+ABI_VERSION = 1
+
+ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4}
+AUTORESET = {"NextStep": 0, "SameStep": 1, "Disabled": 2}
+NP_DTYPES = {MI_F32: np.float32, MI_F64: np.float64, MI_I64: np.int64}
+
+# Every symbol include/mi355env.h declares (tests/test_abi.py checks the built library exports all of them).
+SYMBOLS = [
+    "abi_version", "last_error", "device_count", "create", "destroy", "get_layout", "set_stream", "synchronize",
+    "seed", "seed_sequence", "reset", "step", "action_seed", "rollout", "get_stats", "reset_stats", "get_state",
+    "set_state", "get_rng",
+]
+
+
+class MiConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("kind", C.c_int32), ("num_envs", C.c_int32), ("max_episode_steps", C.c_int32),
+                ("autoreset_mode", C.c_int32), ("reserved", C.c_int32 * 3), ("params", C.c_double * 8)]
+
+
+class MiLayout(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("obs_dtype", C.c_int32), ("act_dim", C.c_int32), ("act_dtype", C.c_int32),
+                ("state_dim", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class MiStepIO(C.Structure):
+    _fields_ = [("actions", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
+                ("truncated", C.c_void_p), ("final_obs", C.c_void_p), ("episode_return", C.c_void_p),
+                ("episode_length", C.c_void_p)]
+
+
+class MiRolloutIO(C.Structure):
+    _fields_ = [("actions_in", C.c_void_p), ("actions_out", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p),
+                ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
+
+
+class MiStats(C.Structure):
+    _fields_ = [("env_steps", C.c_uint64), ("reset_steps", C.c_uint64), ("episodes", C.c_uint64), ("return_sum", C.c_double),
+                ("length_sum", C.c_uint64)]
+
+
+class NativeError(RuntimeError):
+    """A libmi355env call failed; ``code`` is the mi_status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[mi_status {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmi355env.so")
+
+
+class NativeLib:
+    """A loaded shared object exposing the mi355env ABI under ``prefix`` (product: ``mi_``)."""
+
+    def __init__(self, path: str, prefix: str = "mi_"):
+        self.path, self.prefix = path, prefix
+        self.dll = C.CDLL(path)
+        f = self._fn
+        vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+        self.abi_version = f("abi_version", [], i32)
+        self.last_error = f("last_error", [], C.c_char_p)
+        self.device_count = f("device_count", [], i32)
+        self.create = f("create", [C.POINTER(MiConfig), i32, C.POINTER(vp)], i32)
+        self.destroy = f("destroy", [vp], None)
+        self.get_layout = f("get_layout", [vp, C.POINTER(MiLayout)], i32)
+        self.set_stream = f("set_stream", [vp, vp], i32)
+        self.synchronize = f("synchronize", [vp], i32)
+        self.seed = f("seed", [vp, vp, vp], i32)
+        self.seed_sequence = f("seed_sequence", [vp, u64, u64, vp], i32)
+        self.reset = f("reset", [vp, vp, vp, vp, i32], i32)
+        self.step = f("step", [vp, C.POINTER(MiStepIO), i32], i32)
+        self.action_seed = f("action_seed", [vp, vp], i32)
+        self.rollout = f("rollout", [vp, i32, C.POINTER(MiRolloutIO)], i32)
+        self.get_stats = f("get_stats", [vp, C.POINTER(MiStats)], i32)
+        self.reset_stats = f("reset_stats", [vp], i32)
+        self.get_state = f("get_state", [vp, vp, vp, vp], i32)
+        self.set_state = f("set_state", [vp, vp, vp, vp], i32)
+        self.get_rng = f("get_rng", [vp, vp], i32)
+        if self.abi_version() != ABI_VERSION:
+            raise ImportError(f"{path}: ABI version {self.abi_version()} != binding version {ABI_VERSION}")
+
+    def _fn(self, name, argtypes, restype):
+        fn = getattr(self.dll, self.prefix + name)
+        fn.argtypes, fn.restype = argtypes, restype
+        return fn
+
+    def check(self, rc: int):
+        if rc != MI_OK:
+            msg = self.last_error()
+            raise NativeError(rc, msg.decode() if msg else "unknown error")
+
+
+_LIB = None
+
+
+def load_library() -> NativeLib:
+    """Load libmi355env.so (built by ``python -m gymnasium_amd.csrc.build`` / ``__graft_entry__.build()``)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: the HIP engine has not been built. Run `python -m gymnasium_amd.csrc.build` "
+                "(needs hipcc, --offload-arch=gfx950). gymnasium_amd has no CPU fallback.")
+        _LIB = NativeLib(path, "mi_")
+    return _LIB
+
+
+def _ptr(a):
+    """Raw address of a NumPy array / int address / None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    return a.ctypes.data
+
+
+def pcg_words(gen: np.random.Generator) -> np.ndarray:
+    """{state_hi, state_lo, inc_hi, inc_lo} of a NumPy PCG64 generator."""
+    st = gen.bit_generator.state
+    if st["bit_generator"] != "PCG64":
+        raise ValueError(f"expected a PCG64 generator, got {st['bit_generator']}")
+    s, i, m = st["state"]["state"], st["state"]["inc"], (1 << 64) - 1
+    return np.array([s >> 64, s & m, i >> 64, i & m], dtype=np.uint64)
+
+
+def set_pcg_words(gen: np.random.Generator, words) -> None:
+    st = gen.bit_generator.state
+    st["state"]["state"] = (int(words[0]) << 64) | int(words[1])
+    st["state"]["inc"] = (int(words[2]) << 64) | int(words[3])
+    st["has_uint32"], st["uinteger"] = 0, 0
+    gen.bit_generator.state = st
+
+
+class Engine:
+    """One mi_vecenv handle.  Thin, allocation-free wrappers; pointers are NumPy arrays or raw device addresses."""
+
+    def __init__(self, lib: NativeLib, kind: str, num_envs: int, max_episode_steps: int | None, autoreset_mode: str,
+                 params=(), device: int = 0):
+        self.lib = lib
+        cfg = MiConfig()
+        cfg.struct_size = C.sizeof(MiConfig)
+        cfg.kind = ENV_KINDS[kind]
+        cfg.num_envs = int(num_envs)
+        cfg.max_episode_steps = int(max_episode_steps) if max_episode_steps else 0
+        cfg.autoreset_mode = AUTORESET[autoreset_mode]
+        for k, p in enumerate(params):
+            cfg.params[k] = float(p)
+        handle = C.c_void_p()
+        lib.check(lib.create(C.byref(cfg), int(device), C.byref(handle)))
+        self.handle = handle
+        self.num_envs = int(num_envs)
+        lay = MiLayout()
+        lib.check(lib.get_layout(handle, C.byref(lay)))
+        self.obs_dim, self.act_dim, self.state_dim = lay.obs_dim, lay.act_dim, lay.state_dim
+        self.obs_dtype, self.act_dtype = NP_DTYPES[lay.obs_dtype], NP_DTYPES[lay.act_dtype]
+        self._step_io = MiStepIO()
+        self._rollout_io = MiRolloutIO()
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.destroy(self.handle)
+            self.handle = None
+
+    def set_stream(self, stream_ptr):
+        self.lib.check(self.lib.set_stream(self.handle, stream_ptr))
+
+    def synchronize(self):
+        self.lib.check(self.lib.synchronize(self.handle))
+
+    def seed(self, words: np.ndarray, mask=None):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        assert words.shape == (self.num_envs, 4)
+        self.lib.check(self.lib.seed(self.handle, _ptr(words), _ptr(mask)))
+
+    def seed_sequence(self, base_seed: int, first_index: int = 0, mask=None):
+        self.lib.check(self.lib.seed_sequence(self.handle, base_seed, first_index, _ptr(mask)))
+
+    def reset(self, mask, bounds, obs, loc=MI_HOST):
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.float64)
+        self.lib.check(self.lib.reset(self.handle, _ptr(mask), _ptr(b), _ptr(obs), loc))
+
+    def step(self, actions, obs, reward, terminated, truncated, final_obs=None, episode_return=None,
+             episode_length=None, loc=MI_HOST):
+        io = self._step_io
+        io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
+        io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
+        io.episode_return, io.episode_length = _ptr(episode_return), _ptr(episode_length)
+        self.lib.check(self.lib.step(self.handle, C.byref(io), loc))
+
+    def action_seed(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        self.lib.check(self.lib.action_seed(self.handle, _ptr(w)))
+
+    def rollout(self, T, actions_in=None, actions_out=None, obs=None, reward=None, terminated=None, truncated=None):
+        io = self._rollout_io
+        io.actions_in, io.actions_out, io.obs = _ptr(actions_in), _ptr(actions_out), _ptr(obs)
+        io.reward, io.terminated, io.truncated = _ptr(reward), _ptr(terminated), _ptr(truncated)
+        self.lib.check(self.lib.rollout(self.handle, int(T), C.byref(io)))
+
+    def stats(self) -> dict:
+        st = MiStats()
+        self.lib.check(self.lib.get_stats(self.handle, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in MiStats._fields_}
+
+    def reset_stats(self):
+        self.lib.check(self.lib.reset_stats(self.handle))
+
+    def get_state(self):
+        state = np.empty((self.num_envs, self.state_dim), dtype=np.float64)
+        elapsed = np.empty(self.num_envs, dtype=np.int32)
+        flags = np.empty(self.num_envs, dtype=np.uint8)
+        self.lib.check(self.lib.get_state(self.handle, _ptr(state), _ptr(elapsed), _ptr(flags)))
+        return state, elapsed, flags
+
+    def set_state(self, state=None, elapsed=None, flags=None):
+        if state is not None:
+            state = np.ascontiguousarray(state, dtype=np.float64)
+            assert state.shape == (self.num_envs, self.state_dim)
+        if elapsed is not None:
+            elapsed = np.ascontiguousarray(elapsed, dtype=np.int32)
+        if flags is not None:
+            flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self.lib.check(self.lib.set_state(self.handle, _ptr(state), _ptr(elapsed), _ptr(flags)))
+
+    def get_rng(self) -> np.ndarray:
+        words = np.empty((self.num_envs, 4), dtype=np.uint64)
+        self.lib.check(self.lib.get_rng(self.handle, _ptr(words)))
+        return words

@@ -1,0 +1,41 @@
+"""Exception types of the path (mirror of gymnasium/error.py; same names, same base classes)."""
+
+
+class Error(Exception):
+    """Base error of the package (gymnasium.error.Error)."""
+
+
+class UnregisteredEnv(Error):
+    """Unknown environment id."""
+
+
+class NamespaceNotFound(UnregisteredEnv):
+    """Unknown namespace."""
+
+
+class NameNotFound(UnregisteredEnv):
+    """Unknown name."""
+
+
+class VersionNotFound(UnregisteredEnv):
+    """Unknown version."""
+
+
+class RegistrationError(Error):
+    """Bad ``register`` arguments."""
+
+
+class DependencyNotInstalled(Error):
+    """A required dependency is missing."""
+
+
+class ResetNeeded(Error):
+    """``step`` called before ``reset``."""
+
+
+class InvalidAction(Error):
+    """Action outside the action space."""
+
+
+class ClosedEnvironmentError(Error):
+    """Use after ``close``."""

@@ -1,0 +1,411 @@
+"""HipVectorEnv: a gymnasium.vector.VectorEnv whose sub-environments are lanes of an MI355X kernel.
+
+Host-side mirror of the reference's vectoriser for this path.  It replaces, with ONE C-ABI call per method,
+
+  gymnasium/vector/sync_vector_env.py:76-185   __init__  (spaces, metadata["autoreset_mode"], buffers)
+  gymnasium/vector/sync_vector_env.py:187-264  reset     (seed fan-out seed+i, options["reset_mask"])
+  gymnasium/vector/sync_vector_env.py:266-337  step      (NEXT_STEP / SAME_STEP / DISABLED autoreset)
+  gymnasium/wrappers/common.py:116-150         TimeLimit (max_episode_steps, folded into the kernel)
+  gymnasium/wrappers/vector/common.py:156-235  RecordEpisodeStatistics (optional, accumulated on device)
+
+and is created through the reference's own plug-in boundary, ``make_vec(id, num_envs,
+vectorization_mode="vector_entry_point", **kwargs)`` (envs/registration.py:933-963), which calls the subclass
+as ``creator(num_envs=..., max_episode_steps=..., **kwargs)``.
+
+Observations/rewards/terminations/truncations have the reference's shapes and dtypes ((N, obs_dim) float32,
+(N,) float64, (N,) bool, (N,) bool).  With ``output="numpy"`` they are NumPy arrays (copies unless
+``copy=False``, like SyncVectorEnv); with ``output="torch"`` they are tensors resident in HBM and nothing
+crosses PCIe (VectorEnv is generic in its array type, vector_env.py:20,42).
+"""
+from __future__ import annotations
+
+import time
+from typing import Any
+
+import numpy as np
+
+from .. import _native
+from ..gym_api import AutoresetMode, VectorEnv, batch_space, error, seeding
+
+_U64 = (1 << 64) - 1
+
+
+def _verify_number_and_cast(x) -> float:
+    """envs/classic_control/utils.py:9-15."""
+    try:
+        return float(x)
+    except (ValueError, TypeError) as e:
+        raise ValueError(f"An option ({x}) could not be converted to a float.") from e
+
+
+def parse_low_high(options, default_low, default_high):
+    """envs/classic_control/utils.py:17-46 maybe_parse_reset_bounds."""
+    if options is None:
+        return None
+    low = _verify_number_and_cast(options.get("low") if "low" in options else default_low)
+    high = _verify_number_and_cast(options.get("high") if "high" in options else default_high)
+    if low > high:
+        raise ValueError(f"Lower bound ({low}) must be lower than higher bound ({high}).")
+    return (low, high)
+
+
+def _pcg_words_for_seed(seed: int) -> np.ndarray:
+    gen, _ = seeding.np_random(seed)
+    return _native.pcg_words(gen)
+
+
+class HipVectorEnv(VectorEnv):
+    """Base class; subclasses set KIND, spaces, default reset bounds and constructor params."""
+
+    KIND: str = ""
+    DEFAULT_MAX_EPISODE_STEPS: int | None = None
+    metadata: dict[str, Any] = {"render_modes": [], "autoreset_mode": AutoresetMode.NEXT_STEP}
+
+    # -- to be provided by subclasses ------------------------------------------------------------------
+    def _single_spaces(self):
+        raise NotImplementedError
+
+    def _engine_params(self) -> tuple:
+        return ()
+
+    def _parse_reset_options(self, options):
+        """Return the env-specific (b0, b1) reset bounds or None for defaults; raise ValueError like the reference."""
+        return None
+
+    # --------------------------------------------------------------------------------------------------
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, autoreset_mode=AutoresetMode.NEXT_STEP,
+                 render_mode: str | None = None, device=None, output: str = "numpy", copy: bool = True,
+                 env_index_offset: int = 0, record_episode_statistics: bool = False, _engine_factory=None):
+        if render_mode is not None:
+            raise error.Error("gymnasium_amd sub-environments live on the GPU and cannot render; use render_mode=None")
+        if output not in ("numpy", "torch"):
+            raise ValueError(f"output must be 'numpy' or 'torch', got {output!r}")
+        self.num_envs = int(num_envs)
+        if self.num_envs < 1:
+            raise ValueError(f"num_envs must be >= 1, got {num_envs}")
+        self.autoreset_mode = autoreset_mode if isinstance(autoreset_mode, AutoresetMode) else AutoresetMode(autoreset_mode)
+        self.metadata = dict(type(self).metadata)
+        self.metadata["autoreset_mode"] = self.autoreset_mode
+        self.render_mode = None
+        self.copy = bool(copy)
+        self.output = output
+        self.max_episode_steps = self.DEFAULT_MAX_EPISODE_STEPS if max_episode_steps is None else max_episode_steps
+        self.env_index_offset = int(env_index_offset)
+        self.record_episode_statistics = bool(record_episode_statistics)
+
+        self.single_observation_space, self.single_action_space = self._single_spaces()
+        self.observation_space = batch_space(self.single_observation_space, self.num_envs)
+        self.action_space = batch_space(self.single_action_space, self.num_envs)
+
+        self._device_index = _resolve_device(device)
+        if _engine_factory is None:
+            lib = _native.load_library()  # raises ImportError if the HIP library was not built
+            self._engine = _native.Engine(lib, self.KIND, self.num_envs, self.max_episode_steps, self.autoreset_mode.value,
+                                          self._engine_params(), self._device_index)
+        else:  # test seam: tests drive this host class against a checker backend; never used by the package itself
+            self._engine = _engine_factory(self.KIND, self.num_envs, self.max_episode_steps, self.autoreset_mode.value,
+                                           self._engine_params(), self._device_index)
+        eng = self._engine
+        self._discrete = eng.act_dtype is np.int64
+        self._act_shape = (self.num_envs,) if self._discrete else (self.num_envs, eng.act_dim)
+        self._seeded = False
+        self._has_reset = False
+        self._alloc_buffers()
+        if self.record_episode_statistics:
+            self.episode_count = 0
+            self._episode_start = np.zeros(self.num_envs)
+            self._prev_dones = np.zeros(self.num_envs, dtype=np.bool_)
+
+    # -- buffers ---------------------------------------------------------------------------------------
+    def _alloc_buffers(self):
+        N, eng = self.num_envs, self._engine
+        if self.output == "torch":
+            import torch
+
+            self._torch = torch
+            dev = torch.device("cuda", self._device_index)
+            self._tdev = dev
+            self._obs = torch.zeros((N, eng.obs_dim), dtype=torch.float32, device=dev)
+            self._rew = torch.zeros((N,), dtype=torch.float64, device=dev)
+            self._term = torch.zeros((N,), dtype=torch.bool, device=dev)
+            self._trunc = torch.zeros((N,), dtype=torch.bool, device=dev)
+            self._final = torch.zeros((N, eng.obs_dim), dtype=torch.float32, device=dev) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
+            self._ep_r = torch.zeros((N,), dtype=torch.float64, device=dev) if self.record_episode_statistics else None
+            self._ep_l = torch.zeros((N,), dtype=torch.int32, device=dev) if self.record_episode_statistics else None
+            self._loc = _native.MI_DEVICE
+        else:
+            self._obs = np.zeros((N, eng.obs_dim), dtype=eng.obs_dtype)
+            self._rew = np.zeros((N,), dtype=np.float64)
+            self._term = np.zeros((N,), dtype=np.bool_)
+            self._trunc = np.zeros((N,), dtype=np.bool_)
+            self._final = np.zeros((N, eng.obs_dim), dtype=eng.obs_dtype) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
+            self._ep_r = np.zeros((N,), dtype=np.float64) if self.record_episode_statistics else None
+            self._ep_l = np.zeros((N,), dtype=np.int32) if self.record_episode_statistics else None
+            self._loc = _native.MI_HOST
+
+    def _p(self, buf):
+        if buf is None:
+            return None
+        return buf.data_ptr() if self.output == "torch" else buf
+
+    def _out(self, buf):
+        if not self.copy:
+            return buf
+        return buf.clone() if self.output == "torch" else buf.copy()
+
+    def _bind_stream(self):
+        if self.output == "torch":
+            self._engine.set_stream(self._torch.cuda.current_stream(self._tdev).cuda_stream)
+
+    # -- seeding ---------------------------------------------------------------------------------------
+    def _seed_engines(self, seed, mask):
+        """SyncVectorEnv seed fan-out (sync_vector_env.py:204-212): int -> seed+i, list -> per env, None -> keep."""
+        N, off = self.num_envs, self.env_index_offset
+        if seed is None:
+            if not self._seeded:  # like Env.np_random's lazy OS-entropy seeding (core.py:227-236)
+                base = int(np.random.SeedSequence().generate_state(1, np.uint64)[0]) >> 1
+                self._engine.seed_sequence(base, off, None)
+                self._seeded = True
+            return
+        if isinstance(seed, (int, np.integer)) and not isinstance(seed, bool):
+            seed = int(seed)
+            if seed < 0:
+                raise error.Error(f"Seed must be greater or equal to zero, actual value: {seed}")
+            if seed + off + N - 1 <= _U64:
+                self._engine.seed_sequence(seed, off, mask)  # SeedSequence + PCG64 seeding evaluated on device
+            else:  # beyond 64 bits: NumPy on the host
+                words = np.stack([_pcg_words_for_seed(seed + off + i) for i in range(N)])
+                self._engine.seed(words, mask)
+            self._seeded = True
+            return
+        seeds = list(seed)
+        if len(seeds) != N:
+            raise ValueError(f"If seeds are passed as a list the length must match num_envs={N} but got length={len(seeds)}.")
+        words = np.zeros((N, 4), dtype=np.uint64)
+        smask = np.zeros(N, dtype=np.uint8)
+        for i, s in enumerate(seeds):
+            if s is None:
+                continue
+            words[i] = _pcg_words_for_seed(s)
+            smask[i] = 1
+        if not self._seeded and not smask.all():
+            base = int(np.random.SeedSequence().generate_state(1, np.uint64)[0]) >> 1
+            self._engine.seed_sequence(base, off, None)
+        if mask is not None:
+            smask &= np.asarray(mask, dtype=np.uint8)
+        if smask.any():
+            self._engine.seed(words, smask)
+        self._seeded = True
+
+    # -- API -------------------------------------------------------------------------------------------
+    def reset(self, *, seed=None, options=None):
+        """Reset the sub-environments (all, or options["reset_mask"]) and return (observations, infos)."""
+        self._check_open()
+        if isinstance(seed, (int, np.integer)) and not isinstance(seed, bool):
+            super().reset(seed=int(seed))
+        mask = None
+        if options is not None and "reset_mask" in options:
+            options = dict(options)
+            reset_mask = options.pop("reset_mask")
+            if not isinstance(reset_mask, np.ndarray):
+                raise TypeError(f"`options['reset_mask']` must be a numpy array, got {type(reset_mask)}")
+            if reset_mask.shape != (self.num_envs,):
+                raise ValueError(f"`options['reset_mask']` must have shape `({self.num_envs},)`, got {reset_mask.shape}")
+            if reset_mask.dtype != np.bool_:
+                raise TypeError(f"`options['reset_mask']` must have `dtype=np.bool_`, got {reset_mask.dtype}")
+            if not np.any(reset_mask):
+                raise ValueError(f"`options['reset_mask']` must contain a boolean array with at least one True value, got reset_mask={reset_mask}")
+            mask = np.ascontiguousarray(reset_mask).view(np.uint8)
+        bounds = self._parse_reset_options(options if options else None)
+        self._seed_engines(seed, mask)
+        self._bind_stream()
+        if self.output == "torch":
+            dmask = None
+            if mask is not None:
+                dmask = self._torch.from_numpy(mask.copy()).to(self._tdev)
+            self._engine.reset(None if dmask is None else dmask.data_ptr(), bounds, self._obs.data_ptr(), _native.MI_DEVICE)
+        else:
+            self._engine.reset(mask, bounds, self._obs, _native.MI_HOST)
+        self._has_reset = True
+        if self.record_episode_statistics:
+            now = time.perf_counter()
+            if mask is None:
+                self._episode_start[:] = now
+                self._prev_dones[:] = False
+            else:
+                self._episode_start[mask.view(np.bool_)] = now
+                self._prev_dones[mask.view(np.bool_)] = False
+        return self._out(self._obs), {}
+
+    def _coerce_actions(self, actions):
+        eng = self._engine
+        if self.output == "torch" and hasattr(actions, "data_ptr"):
+            t = self._torch
+            want = t.int64 if self._discrete else t.float32
+            if actions.device != self._tdev or actions.dtype != want or not actions.is_contiguous():
+                actions = actions.to(device=self._tdev, dtype=want).contiguous()
+            if actions.numel() != self.num_envs * eng.act_dim:
+                raise ValueError(f"actions must have {self.num_envs * eng.act_dim} elements, got shape {tuple(actions.shape)}")
+            return actions, actions.data_ptr()
+        a = np.asarray(actions)
+        if self._discrete:
+            if not np.issubdtype(a.dtype, np.integer):
+                raise AssertionError(f"{actions!r} ({type(actions)}) invalid")
+            a = np.ascontiguousarray(a, dtype=np.int64)
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.size != self.num_envs * eng.act_dim:
+            raise ValueError(f"actions must have shape {self._act_shape}, got {a.shape}")
+        if self.output == "torch":
+            ta = self._torch.from_numpy(a).to(self._tdev)
+            return ta, ta.data_ptr()
+        return a, a
+
+    def step(self, actions):
+        """One lockstep step of every sub-environment: (obs, rewards, terminations, truncations, infos)."""
+        self._check_open()
+        if not self._has_reset:
+            raise AssertionError("Call reset before using step method.")
+        keep, aptr = self._coerce_actions(actions)
+        self._bind_stream()
+        try:
+            self._engine.step(aptr, self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc),
+                              self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc)
+        except _native.NativeError as e:
+            if e.code == -1:  # MI_ERR_INVALID_ARGUMENT: action outside the space (cartpole.py:165-167 asserts)
+                raise AssertionError(e.message) from e
+            if e.code == -5:
+                raise AssertionError(e.message) from e
+            raise
+        del keep
+        infos = self._build_infos()
+        return self._out(self._obs), self._out(self._rew), self._out(self._term), self._out(self._trunc), infos
+
+    def _build_infos(self) -> dict:
+        infos: dict[str, Any] = {}
+        need_final = self.autoreset_mode == AutoresetMode.SAME_STEP
+        if not need_final and not self.record_episode_statistics:
+            return infos
+        if self.output == "torch":
+            dones = (self._term | self._trunc).cpu().numpy()
+        else:
+            dones = np.logical_or(self._term, self._trunc)
+        any_done = bool(dones.any())
+        if need_final and any_done:
+            # sync_vector_env.py:309-317 via VectorEnv._add_info: object array of per-env observations
+            final = self._final.cpu().numpy() if self.output == "torch" else self._final
+            arr = np.full(self.num_envs, None, dtype=object)
+            for i in np.flatnonzero(dones):
+                arr[i] = final[i].copy()
+            infos["final_obs"], infos["_final_obs"] = arr, dones.copy()
+            infos["final_info"], infos["_final_info"] = {}, dones.copy()
+        if self.record_episode_statistics:
+            now = time.perf_counter()
+            if self.autoreset_mode != AutoresetMode.SAME_STEP:
+                self._episode_start[self._prev_dones] = now
+            self._prev_dones = dones
+            if any_done:
+                r = self._ep_r.cpu().numpy() if self.output == "torch" else self._ep_r.copy()
+                ln = self._ep_l.cpu().numpy() if self.output == "torch" else self._ep_l.copy()
+                infos["episode"] = {"r": r, "l": ln.astype(np.int64),
+                                    "t": np.where(dones, np.round(now - self._episode_start, 6), 0.0)}
+                infos["_episode"] = dones.copy()
+                self.episode_count += int(dones.sum())
+                if self.autoreset_mode == AutoresetMode.SAME_STEP:
+                    self._episode_start[dones] = now
+        return infos
+
+    # -- fused rollouts ---------------------------------------------------------------------------------
+    def rollout(self, num_steps: int, actions=None, *, return_actions: bool = True):
+        """``num_steps`` consecutive ``step()`` calls in ONE kernel launch; trajectories are time-major tensors in HBM.
+
+        With ``actions=None`` the random policy ``action_space.sample()`` (spaces/multi_discrete.py:176-178,
+        spaces/box.py:463-465) is evaluated on device from the action space's own PCG64 stream, which is then
+        advanced on the host by the number of draws consumed -- so
+        ``rollout(T)`` == ``[step(action_space.sample()) for _ in range(T)]`` bit for bit.
+        Requires ``output="torch"``.  Returns dict(obs, rewards, terminations, truncations[, actions]).
+        """
+        self._check_open()
+        if self.output != "torch":
+            raise error.Error("rollout() returns device tensors; create the env with output='torch'")
+        if not self._has_reset:
+            raise AssertionError("Call reset before using rollout.")
+        t, eng, N, T = self._torch, self._engine, self.num_envs, int(num_steps)
+        dev = self._tdev
+        self._bind_stream()
+        act_dtype = t.int64 if self._discrete else t.float32
+        act_shape = (T, N) if self._discrete else (T, N, eng.act_dim)
+        a_in = a_out = None
+        if actions is not None:
+            a_in = actions.to(device=dev, dtype=act_dtype).contiguous()
+            if tuple(a_in.shape) != act_shape:
+                raise ValueError(f"actions must have shape {act_shape}, got {tuple(a_in.shape)}")
+        else:
+            eng.action_seed(_native.pcg_words(self.action_space.np_random))
+            if return_actions:
+                a_out = t.empty(act_shape, dtype=act_dtype, device=dev)
+        obs = t.empty((T, N, eng.obs_dim), dtype=t.float32, device=dev)
+        rew = t.empty((T, N), dtype=t.float64, device=dev)
+        term = t.empty((T, N), dtype=t.bool, device=dev)
+        trunc = t.empty((T, N), dtype=t.bool, device=dev)
+        eng.rollout(T, None if a_in is None else a_in.data_ptr(), None if a_out is None else a_out.data_ptr(),
+                    obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr())
+        if actions is None:
+            self.action_space.np_random.bit_generator.advance(T * N * eng.act_dim)
+        out = {"obs": obs, "rewards": rew, "terminations": term, "truncations": trunc}
+        if a_out is not None:
+            out["actions"] = a_out
+        elif a_in is not None and return_actions:
+            out["actions"] = a_in
+        # the vector env's "current" buffers follow the last step, as after T step() calls
+        self._obs.copy_(obs[-1]); self._rew.copy_(rew[-1]); self._term.copy_(term[-1]); self._trunc.copy_(trunc[-1])
+        return out
+
+    # -- bookkeeping -----------------------------------------------------------------------------------
+    def statistics(self) -> dict:
+        """Running totals kept on device: env_steps, reset_steps, episodes, return_sum, length_sum."""
+        return self._engine.stats()
+
+    def reset_statistics(self):
+        self._engine.reset_stats()
+
+    def get_state(self):
+        """(state[N, state_dim] float64, elapsed_steps[N] int32, flags[N] uint8) -- checkpoint of the sub-environments."""
+        return self._engine.get_state()
+
+    def set_state(self, state=None, elapsed_steps=None, flags=None):
+        self._engine.set_state(state, elapsed_steps, flags)
+        self._has_reset = True
+
+    def get_rng_state(self) -> np.ndarray:
+        """Per-env PCG64 words [N, 4] = {state_hi, state_lo, inc_hi, inc_lo}."""
+        return self._engine.get_rng()
+
+    def synchronize(self):
+        self._engine.synchronize()
+
+    def _check_open(self):
+        if self.closed:
+            raise error.ClosedEnvironmentError(f"Trying to operate on `{type(self).__name__}`, after a call to `close()`.")
+
+    def close_extras(self, **kwargs):
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng.close()
+            self._engine = None
+
+
+def _resolve_device(device) -> int:
+    """None -> LOCAL_RANK (one process per GPU) or 0; 'cuda:3' / 3 / torch.device -> index."""
+    import os
+
+    if device is None:
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    if isinstance(device, (int, np.integer)):
+        return int(device)
+    s = str(device)
+    if ":" in s:
+        return int(s.split(":")[1])
+    if s in ("cuda", "hip"):
+        return 0
+    return int(s)

@@ -1,0 +1,190 @@
+/*
+ * mi355env.h -- C ABI of libmi355env.so, the MI355X (gfx950) lockstep vector-environment engine.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json: one call steps / resets all
+ * `num_envs` sub-environments of a gymnasium.vector.VectorEnv on the GPU.  Plain pointers and sizes only;
+ * no torch / numpy types.  Every entry point states the reference interface it replaces (paths relative
+ * to the reference tree, gymnasium v1.4.0).
+ *
+ * Threading contract (same as the reference's SyncVectorEnv, which is single-threaded and not re-entrant):
+ * one mi_vecenv may be used from one host thread at a time.  All work is enqueued on the env's HIP stream
+ * (mi_set_stream); calls taking MI_HOST pointers synchronise that stream before returning, calls taking
+ * MI_DEVICE pointers only enqueue.
+ *
+ * Errors: every function returns MI_OK (0) or a negative mi_status; mi_last_error() gives the message of
+ * the last failure on the calling thread (the Python shim raises it as an exception, mirroring the
+ * reference's AssertionError / ValueError / gymnasium.error.Error behaviour one level up).
+ */
+#ifndef MI355ENV_H
+#define MI355ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355ENV_ABI_VERSION 1
+
+typedef enum mi_status {
+    MI_OK = 0,
+    MI_ERR_INVALID_ARGUMENT = -1,
+    MI_ERR_NO_DEVICE = -2,     /* no HIP device visible: the engine has NO CPU fallback */
+    MI_ERR_HIP = -3,           /* a HIP runtime call failed; see mi_last_error() */
+    MI_ERR_UNSUPPORTED = -4,
+    MI_ERR_STATE = -5          /* e.g. step before reset/seed */
+} mi_status;
+
+/* Sub-environment dynamics.  Each value replaces the scalar env class named beside it. */
+typedef enum mi_env_kind {
+    MI_ENV_CARTPOLE = 0,               /* envs/classic_control/cartpole.py:119-247 (CartPole-v1)                */
+    MI_ENV_PENDULUM = 1,               /* envs/classic_control/pendulum.py:102-171 (Pendulum-v1)                */
+    MI_ENV_ACROBOT = 2,                /* envs/classic_control/acrobot.py:172-279,375-461 (Acrobot-v1)          */
+    MI_ENV_MOUNTAIN_CAR = 3,           /* envs/classic_control/mountain_car.py:108-170 (MountainCar-v0)         */
+    MI_ENV_MOUNTAIN_CAR_CONTINUOUS = 4, /* envs/classic_control/continuous_mountain_car.py:116-194              */
+    MI_ENV_KIND_COUNT = 5
+} mi_env_kind;
+
+/* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */
+typedef enum mi_autoreset_mode {
+    MI_AUTORESET_NEXT_STEP = 0,
+    MI_AUTORESET_SAME_STEP = 1,
+    MI_AUTORESET_DISABLED = 2
+} mi_autoreset_mode;
+
+typedef enum mi_mem_location { MI_HOST = 0, MI_DEVICE = 1 } mi_mem_location;
+
+/* Element types of the action / observation rows (mi_layout). */
+typedef enum mi_dtype { MI_F32 = 0, MI_F64 = 1, MI_I64 = 2 } mi_dtype;
+
+/*
+ * Construction parameters = the kwargs the reference passes to the scalar env constructor through
+ * make_vec(**kwargs) (envs/registration.py:957-963) plus the TimeLimit and vectoriser settings.
+ *   params[] per kind:
+ *     CARTPOLE                 params[0] = sutton_barto_reward (0/1)          cartpole.py:119-121
+ *     PENDULUM                 params[0] = g (default 10.0)                   pendulum.py:102
+ *     MOUNTAIN_CAR(_CONTINUOUS) params[0] = goal_velocity (default 0)         mountain_car.py:108
+ */
+typedef struct mi_config {
+    int32_t struct_size;         /* = sizeof(mi_config) */
+    int32_t kind;                /* mi_env_kind */
+    int32_t num_envs;            /* N >= 1 (sub-environments owned by THIS device / rank) */
+    int32_t max_episode_steps;   /* TimeLimit (wrappers/common.py:116-150); <= 0 disables truncation */
+    int32_t autoreset_mode;      /* mi_autoreset_mode */
+    int32_t reserved[3];
+    double params[8];
+} mi_config;
+
+typedef struct mi_layout {
+    int32_t obs_dim;      /* observation row length (elements) */
+    int32_t obs_dtype;    /* mi_dtype */
+    int32_t act_dim;      /* action row length; discrete envs: 1 element of MI_I64 per env */
+    int32_t act_dtype;    /* mi_dtype */
+    int32_t state_dim;    /* physics state row length for mi_get_state/mi_set_state (float64) */
+    int32_t reserved[3];
+} mi_layout;
+
+/*
+ * Buffers of one step() call, all row-major [num_envs][dim].  Pointers are all host or all device
+ * (mi_mem_location).  Nullable members are skipped.
+ *   actions          in   [N][act_dim] act_dtype     (i64 for Discrete -- what iterate(MultiDiscrete) yields)
+ *   obs              out  [N][obs_dim] obs_dtype
+ *   reward           out  [N] f64                     (sync_vector_env.py:171)
+ *   terminated       out  [N] u8 0/1                  (np.bool_ compatible)
+ *   truncated        out  [N] u8 0/1
+ *   final_obs        out  [N][obs_dim]  SAME_STEP only: rows of envs that finished this step (others untouched)
+ *   episode_return   out  [N] f64      vector RecordEpisodeStatistics "r" (wrappers/vector/common.py:156-235):
+ *   episode_length   out  [N] i32      "l"; both 0 where the env did not finish an episode this step
+ */
+typedef struct mi_step_io {
+    const void *actions;
+    void *obs;
+    double *reward;
+    uint8_t *terminated;
+    uint8_t *truncated;
+    void *final_obs;
+    double *episode_return;
+    int32_t *episode_length;
+} mi_step_io;
+
+/* Buffers of one fused rollout() call: T consecutive step()s in one launch, time-major [T][N][dim].
+ * Any output pointer may be NULL (not materialised).  Device pointers only. */
+typedef struct mi_rollout_io {
+    const void *actions_in;   /* [T][N][act_dim] or NULL => sample on device from the action stream */
+    void *actions_out;        /* [T][N][act_dim] the sampled actions (NULL to skip)                    */
+    void *obs;                /* [T][N][obs_dim] */
+    double *reward;           /* [T][N] */
+    uint8_t *terminated;      /* [T][N] */
+    uint8_t *truncated;       /* [T][N] */
+} mi_rollout_io;
+
+/* Running totals kept on device (the multi-GPU metric all-reduce operates on these three numbers). */
+typedef struct mi_stats {
+    uint64_t env_steps;       /* sub-env steps that advanced dynamics (utils/performance.py:88-90 counting) */
+    uint64_t reset_steps;     /* NEXT_STEP autoreset steps (not counted as env steps)                       */
+    uint64_t episodes;        /* finished episodes                                                          */
+    double return_sum;        /* sum of finished-episode returns                                            */
+    uint64_t length_sum;      /* sum of finished-episode lengths                                            */
+} mi_stats;
+
+typedef struct mi_vecenv mi_vecenv;
+
+/* Library / device ----------------------------------------------------------------------------------- */
+int mi_abi_version(void);
+const char *mi_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never an error). */
+int mi_device_count(void);
+
+/* Lifetime.  Replaces SyncVectorEnv.__init__ (vector/sync_vector_env.py:76-185) / the vector_entry_point
+ * creator call (envs/registration.py:963).  Fails with MI_ERR_NO_DEVICE when no GPU is present. */
+int mi_create(const mi_config *cfg, int device, mi_vecenv **out);
+/* Replaces VectorEnv.close_extras (vector/vector_env.py:238-240). */
+void mi_destroy(mi_vecenv *env);
+int mi_get_layout(const mi_vecenv *env, mi_layout *out);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL = own stream. */
+int mi_set_stream(mi_vecenv *env, void *hip_stream);
+int mi_synchronize(mi_vecenv *env);
+
+/* Seeding.  Replaces Env.reset(seed=...) -> seeding.np_random (core.py:157-159, utils/seeding.py:10-42)
+ * with the SyncVectorEnv fan-out seed+i (vector/sync_vector_env.py:207-208).
+ *   mi_seed:          pcg[N][4] = {state_hi, state_lo, inc_hi, inc_lo} of each env's PCG64 (host pointer);
+ *                     mask (host, nullable) selects which envs are re-seeded.
+ *   mi_seed_sequence: env i <- PCG64(SeedSequence(base_seed + first_index + i)) computed on device. */
+int mi_seed(mi_vecenv *env, const uint64_t *pcg, const uint8_t *mask);
+int mi_seed_sequence(mi_vecenv *env, uint64_t base_seed, uint64_t first_index, const uint8_t *mask);
+
+/* Replaces SyncVectorEnv.reset (vector/sync_vector_env.py:187-264) incl. options["reset_mask"] (:214-246)
+ * and the classic-control reset options (envs/classic_control/utils.py:17-46; pendulum.py:151-162):
+ *   bounds (host, nullable) = {low, high}  (Pendulum: {x_init, y_init}).
+ * mask/obs are host or device pointers per `loc`; rows with mask==0 are not written. */
+int mi_reset(mi_vecenv *env, const uint8_t *mask, const double *bounds, void *obs, int loc);
+
+/* Replaces SyncVectorEnv.step (vector/sync_vector_env.py:266-337) with TimeLimit (wrappers/common.py:129-133)
+ * and the scalar env's step() folded into one kernel launch. */
+int mi_step(mi_vecenv *env, const mi_step_io *io, int loc);
+
+/* Random policy on device: the action space's generator (spaces/space.py:112-122 Space.seed), given as the
+ * PCG64 {state_hi,state_lo,inc_hi,inc_lo}.  rollout then reproduces
+ *   for t in range(T): step(action_space.sample())   (spaces/multi_discrete.py:176-178, spaces/box.py:463-465)
+ * bit-for-bit in a single launch. */
+int mi_action_seed(mi_vecenv *env, const uint64_t pcg[4]);
+int mi_rollout(mi_vecenv *env, int T, const mi_rollout_io *io);
+
+/* Bookkeeping ------------------------------------------------------------------------------------------ */
+int mi_get_stats(mi_vecenv *env, mi_stats *out);     /* synchronises */
+int mi_reset_stats(mi_vecenv *env);
+/* Per-env flag bits of mi_get_state/mi_set_state. */
+#define MI_FLAG_NEEDS_RESET 1u /* the env finished last step (SyncVectorEnv._autoreset_envs, sync_vector_env.py:329) */
+#define MI_FLAG_STATE_F32 2u   /* MountainCarContinuous: state currently held as float32 (continuous_mountain_car.py:178) */
+/* Physics state rows [N][state_dim] float64 (host pointers); checkpoint/resume + teacher-forced tests.
+ * Replaces poking env.unwrapped.state (tests/envs/test_env_implementation.py:255-321 compares it). */
+int mi_get_state(mi_vecenv *env, double *state, int32_t *elapsed_steps, uint8_t *flags);
+int mi_set_state(mi_vecenv *env, const double *state, const int32_t *elapsed_steps, const uint8_t *flags);
+/* Per-env PCG64 words, same layout as mi_seed (host pointer). */
+int mi_get_rng(mi_vecenv *env, uint64_t *pcg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355ENV_H */

@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ FROM THE REFERENCE ITSELF.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports gymnasium 1.4.0 from /root/reference (NumPy >= 2 required: the classic-control envs depend on NEP-50
+weak-scalar promotion) and records
+
+  rng_golden.npz            NumPy SeedSequence/PCG64/uniform known answers (utils/seeding.py:39-41)
+  rollout_<env>.npz         gym.make_vec(id, 8, "sync") trajectories, NEXT_STEP autoreset, random policy from
+                            action_space.seed(...) (vector/sync_vector_env.py:187-337), per-step scalar-env state
+  modes_cartpole.npz        SAME_STEP / DISABLED autoreset trajectories incl. final_obs and reset_mask
+  options.npz               reset(options=...) bounds, seed lists
+  episode_stats.npz         wrappers.vector.RecordEpisodeStatistics r / l
+  teacher_<env>.npz         teacher-forced single steps from random (state, action) pairs
+  config1_cartpole.npz      BASELINE.json configs[0]: CartPole-v1, Sync, 4 envs, 1000 steps, seed 0
+
+Nothing here is read at run time by the product; tests compare the oracle (oracle/) and the HIP engine to it.
+"""
+import os
+import sys
+
+REF = os.environ.get("GYM_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+
+import gymnasium as gym  # noqa: E402
+from gymnasium.vector import AutoresetMode  # noqa: E402
+
+assert int(np.__version__.split(".")[0]) >= 2, "golden vectors must be generated with NumPy >= 2"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+ENVS = {
+    "cartpole": ("CartPole-v1", 600),
+    "pendulum": ("Pendulum-v1", 450),
+    "acrobot": ("Acrobot-v1", 1100),
+    "mountaincar": ("MountainCar-v0", 450),
+    "mountaincar_continuous": ("MountainCarContinuous-v0", 2100),
+}
+
+
+def pcg_words(gen):
+    st = gen.bit_generator.state["state"]
+    s, i = st["state"], st["inc"]
+    m = (1 << 64) - 1
+    return np.array([s >> 64, s & m, i >> 64, i & m], dtype=np.uint64)
+
+
+def scalar_states(vec):
+    out = []
+    for e in vec.envs:
+        s = e.unwrapped.state
+        out.append(np.asarray(s, dtype=np.float64).ravel())
+    return np.stack(out)
+
+
+def state_is_f32(vec):
+    return np.array([getattr(e.unwrapped.state, "dtype", None) == np.float32 for e in vec.envs])
+
+
+def rollout(env_id, n, T, seed, aseed, **vector_kwargs):
+    vec = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync", vector_kwargs=vector_kwargs or None)
+    obs0, _ = vec.reset(seed=seed)
+    vec.action_space.seed(aseed)
+    rec = dict(obs0=obs0, state0=scalar_states(vec), actions=[], obs=[], reward=[], term=[], trunc=[], state=[],
+               f32=[], final_obs=[], final_mask=[])
+    for _ in range(T):
+        a = vec.action_space.sample()
+        o, r, te, tr, info = vec.step(a)
+        rec["actions"].append(a), rec["obs"].append(o), rec["reward"].append(r)
+        rec["term"].append(te), rec["trunc"].append(tr), rec["state"].append(scalar_states(vec))
+        rec["f32"].append(state_is_f32(vec))
+        fo = np.zeros_like(o)
+        fm = np.zeros(n, dtype=bool)
+        if "final_obs" in info:
+            fm = info["_final_obs"].copy()
+            for i in np.where(fm)[0]:
+                fo[i] = info["final_obs"][i]
+        rec["final_obs"].append(fo), rec["final_mask"].append(fm)
+    vec.close()
+    return {k: (np.stack(v) if isinstance(v, list) else v) for k, v in rec.items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def make_rng():
+    seeds = [0, 1, 2, 3, 42, 123, 65535, 65536, 2**31, 2**32 - 1, 2**32, 2**32 + 5, 2**40 + 17, 2**63 - 1, 2**64 - 1]
+    words, raw, uni, ss = [], [], [], []
+    for s in seeds:
+        g, _ = gym.utils.seeding.np_random(s)
+        words.append(pcg_words(g))
+        ss.append(np.random.SeedSequence(s).generate_state(4, np.uint64))
+        g2, _ = gym.utils.seeding.np_random(s)
+        raw.append(g2.bit_generator.random_raw(8))
+        g3, _ = gym.utils.seeding.np_random(s)
+        uni.append(np.concatenate([g3.uniform(-0.05, 0.05, size=(4,)), g3.uniform([-np.pi, -1.0], [np.pi, 1.0]), g3.random(2)]))
+    save("rng_golden.npz", seeds=np.array(seeds, dtype=np.uint64), pcg=np.stack(words), seedseq=np.stack(ss),
+         raw=np.stack(raw), uniform=np.stack(uni))
+
+
+def make_rollouts():
+    for key, (env_id, T) in ENVS.items():
+        rec = rollout(env_id, 8, T, seed=7, aseed=11)
+        save(f"rollout_{key}.npz", **rec)
+
+
+def make_config1():
+    rec = rollout("CartPole-v1", 4, 1000, seed=0, aseed=0)
+    assert rec["reward"].sum() == 3819.0 and rec["term"].sum() == 181
+    save("config1_cartpole.npz", obs0=rec["obs0"], actions=rec["actions"], obs=rec["obs"], reward=rec["reward"],
+         term=rec["term"], trunc=rec["trunc"])
+    # Appendix C of SURVEY.md for the other ids (sum of rewards, #terminated, #truncated, final obs[0])
+    summ = {}
+    for key, (env_id, T) in {"pendulum": ("Pendulum-v1", 450), "acrobot": ("Acrobot-v1", 1100),
+                             "mountaincar_continuous": ("MountainCarContinuous-v0", 2100),
+                             "mountaincar": ("MountainCar-v0", 450)}.items():
+        r = rollout(env_id, 4, T, seed=0, aseed=0)
+        summ[key] = np.array([r["reward"].sum(), r["term"].sum(), r["trunc"].sum()] + list(r["obs"][-1][0]), dtype=np.float64)
+    save("appendix_c.npz", **summ)
+
+
+def make_modes():
+    out = {}
+    for mode in ("SameStep", "Disabled"):
+        n, T = 6, 300
+        vec = gym.make_vec("CartPole-v1", num_envs=n, vectorization_mode="sync", vector_kwargs={"autoreset_mode": mode})
+        obs0, _ = vec.reset(seed=3)
+        vec.action_space.seed(5)
+        A, O, R, TE, TR, FO, FM, RM = [], [], [], [], [], [], [], []
+        for _ in range(T):
+            a = vec.action_space.sample()
+            o, r, te, tr, info = vec.step(a)
+            fo, fm = np.zeros_like(o), np.zeros(n, dtype=bool)
+            if "final_obs" in info:
+                fm = info["_final_obs"].copy()
+                for i in np.where(fm)[0]:
+                    fo[i] = info["final_obs"][i]
+            rm = np.zeros(n, dtype=bool)
+            if mode == "Disabled":
+                rm = np.logical_or(te, tr)
+                if rm.any():
+                    # the user resets finished sub-envs explicitly (sync_vector_env.py:214-246)
+                    o2, _ = vec.reset(options={"reset_mask": rm.copy()})
+                    o = o2  # what the caller holds after the masked reset
+            A.append(a), O.append(o), R.append(r), TE.append(te), TR.append(tr), FO.append(fo), FM.append(fm), RM.append(rm)
+        vec.close()
+        for k, v in dict(obs0=obs0, actions=A, obs=O, reward=R, term=TE, trunc=TR, final_obs=FO, final_mask=FM, reset_mask=RM).items():
+            out[f"{mode}_{k}"] = np.stack(v) if isinstance(v, list) else v
+    save("modes_cartpole.npz", **out)
+
+
+def make_options():
+    out = {}
+    v = gym.make_vec("CartPole-v1", num_envs=5, vectorization_mode="sync")
+    out["cartpole_bounds"], _ = v.reset(seed=123, options={"low": -0.1, "high": 0.1})
+    out["cartpole_seedlist"], _ = v.reset(seed=[5, 9, 1, 1000000, 77])
+    v.close()
+    v = gym.make_vec("Pendulum-v1", num_envs=5, vectorization_mode="sync")
+    out["pendulum_init"], _ = v.reset(seed=123, options={"x_init": 1.0, "y_init": 0.5})
+    out["pendulum_default"], _ = v.reset(seed=42)  # doctest vector/sync_vector_env.py:40-57 uses seed=42
+    v.close()
+    v = gym.make_vec("Acrobot-v1", num_envs=5, vectorization_mode="sync")
+    out["acrobot_bounds"], _ = v.reset(seed=123, options={"low": -0.2, "high": 0.3})
+    v.close()
+    for key, env_id in (("mountaincar", "MountainCar-v0"), ("mountaincar_continuous", "MountainCarContinuous-v0")):
+        v = gym.make_vec(env_id, num_envs=5, vectorization_mode="sync")
+        out[f"{key}_bounds"], _ = v.reset(seed=123, options={"low": -0.55, "high": -0.45})
+        v.close()
+    # kwargs through make_vec: sutton_barto_reward, g, goal_velocity
+    v = gym.make_vec("CartPole-v1", num_envs=3, vectorization_mode="sync", sutton_barto_reward=True)
+    v.reset(seed=2)
+    v.action_space.seed(2)
+    R = []
+    for _ in range(120):
+        _, r, _, _, _ = v.step(v.action_space.sample())
+        R.append(r)
+    out["cartpole_sutton_reward"] = np.stack(R)
+    v.close()
+    v = gym.make_vec("Pendulum-v1", num_envs=3, vectorization_mode="sync", g=9.81)
+    v.reset(seed=2)
+    v.action_space.seed(2)
+    O, R = [], []
+    for _ in range(50):
+        o, r, _, _, _ = v.step(v.action_space.sample())
+        O.append(o), R.append(r)
+    out["pendulum_g981_obs"], out["pendulum_g981_reward"] = np.stack(O), np.stack(R)
+    v.close()
+    save("options.npz", **out)
+
+
+def make_episode_stats():
+    from gymnasium.wrappers.vector import RecordEpisodeStatistics
+    out = {}
+    for mode in ("NextStep", "SameStep"):
+        vec = gym.make_vec("CartPole-v1", num_envs=6, vectorization_mode="sync", vector_kwargs={"autoreset_mode": mode})
+        vec = RecordEpisodeStatistics(vec)
+        vec.reset(seed=3)
+        vec.action_space.seed(5)
+        Rr, Ll, M = [], [], []
+        for _ in range(300):
+            _, _, _, _, info = vec.step(vec.action_space.sample())
+            if "episode" in info:
+                Rr.append(info["episode"]["r"]), Ll.append(info["episode"]["l"]), M.append(info["_episode"])
+            else:
+                Rr.append(np.zeros(6)), Ll.append(np.zeros(6, dtype=int)), M.append(np.zeros(6, dtype=bool))
+        out[f"{mode}_r"], out[f"{mode}_l"], out[f"{mode}_mask"] = np.stack(Rr), np.stack(Ll), np.stack(M)
+        vec.close()
+    save("episode_stats.npz", **out)
+
+
+def make_teacher():
+    """Teacher-forced single steps: poke env.unwrapped.state, step once, record everything."""
+    rng = np.random.default_rng(2024)
+    M = 3000
+
+    def run(env_id, states, actions, f32_state=None, tuple_state=False):
+        env = gym.make(env_id).unwrapped
+        env.reset(seed=0)
+        ns, ob, rw, te = [], [], [], []
+        for k in range(len(states)):
+            s = states[k]
+            if f32_state is not None and f32_state[k]:
+                env.state = np.array(s, dtype=np.float32)
+            elif tuple_state:
+                env.state = (np.float64(s[0]), np.float64(s[1]))
+            else:
+                env.state = np.array(s, dtype=np.float64)
+            if hasattr(env, "steps_beyond_terminated"):
+                env.steps_beyond_terminated = None
+            o, r, t, _, _ = env.step(actions[k])
+            ns.append(np.asarray(env.state, dtype=np.float64).ravel()), ob.append(o), rw.append(r), te.append(t)
+        return np.stack(ns), np.stack(ob), np.array(rw, dtype=np.float64), np.array(te, dtype=bool)
+
+    # CartPole: around and beyond the thresholds
+    s = np.stack([rng.uniform(-2.6, 2.6, M), rng.uniform(-3, 3, M), rng.uniform(-0.25, 0.25, M), rng.uniform(-3.5, 3.5, M)], 1)
+    a = rng.integers(0, 2, M)
+    ns, ob, rw, te = run("CartPole-v1", s, a)
+    save("teacher_cartpole.npz", state=s, action=a, next_state=ns, obs=ob, reward=rw, term=te)
+    # Pendulum: large unwrapped angles, speeds at the clip, actions beyond the torque limit
+    s = np.stack([rng.uniform(-40, 40, M), rng.uniform(-8, 8, M)], 1)
+    a = rng.uniform(-3, 3, (M, 1)).astype(np.float32)
+    ns, ob, rw, te = run("Pendulum-v1", s, a)
+    save("teacher_pendulum.npz", state=s, action=a, next_state=ns, obs=ob, reward=rw, term=te)
+    # Acrobot: whole state box (wrap loops, velocity bounds, termination)
+    s = np.stack([rng.uniform(-np.pi, np.pi, M), rng.uniform(-np.pi, np.pi, M), rng.uniform(-4 * np.pi, 4 * np.pi, M),
+                  rng.uniform(-9 * np.pi, 9 * np.pi, M)], 1)
+    a = rng.integers(0, 3, M)
+    ns, ob, rw, te = run("Acrobot-v1", s, a)
+    save("teacher_acrobot.npz", state=s, action=a, next_state=ns, obs=ob, reward=rw, term=te)
+    # MountainCar: walls and goal
+    s = np.stack([rng.uniform(-1.2, 0.6, M), rng.uniform(-0.07, 0.07, M)], 1)
+    s[: M // 10, 0] = rng.choice([-1.2, -1.1995, 0.4995, 0.5, 0.6], M // 10)
+    a = rng.integers(0, 3, M)
+    ns, ob, rw, te = run("MountainCar-v0", s, a, tuple_state=True)
+    save("teacher_mountaincar.npz", state=s, action=a, next_state=ns, obs=ob, reward=rw, term=te)
+    # MountainCarContinuous: float32-held state (normal case) and float64-held state (first step after reset),
+    # actions partly outside [-1, 1] (Python-float force path)
+    s = np.stack([rng.uniform(-1.2, 0.6, M), rng.uniform(-0.07, 0.07, M)], 1)
+    s[: M // 10, 0] = rng.choice([-1.2, -1.1995, 0.4495, 0.45, 0.6], M // 10)
+    f32 = rng.random(M) < 0.7
+    s[f32] = s[f32].astype(np.float32).astype(np.float64)
+    a = rng.uniform(-1.3, 1.3, (M, 1)).astype(np.float32)
+    ns, ob, rw, te = run("MountainCarContinuous-v0", s, a, f32_state=f32)
+    save("teacher_mountaincar_continuous.npz", state=s, f32=f32, action=a, next_state=ns, obs=ob, reward=rw, term=te)
+
+
+def make_action_samples():
+    out = {}
+    for key, (env_id, _) in ENVS.items():
+        vec = gym.make_vec(env_id, num_envs=8, vectorization_mode="sync")
+        vec.action_space.seed(11)
+        out[f"{key}_pcg"] = pcg_words(vec.action_space.np_random)
+        out[key] = np.stack([vec.action_space.sample() for _ in range(4)])
+        vec.close()
+    save("action_samples.npz", **out)
+
+
+if __name__ == "__main__":
+    print("reference gymnasium", gym.__version__, "numpy", np.__version__)
+    make_rng()
+    make_rollouts()
+    make_config1()
+    make_modes()
+    make_options()
+    make_episode_stats()
+    make_teacher()
+    make_action_samples()
