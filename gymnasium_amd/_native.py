@@ -121,6 +121,13 @@ def load_library() -> NativeLib:
             raise ImportError(
                 f"{path} is missing: the HIP engine has not been built. Run `python -m gymnasium_amd.csrc.build` "
                 "(needs hipcc, --offload-arch=gfx950). gymnasium_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If it is
+        # going to be used at all it must be the copy that gets loaded first, so that libmi355env.so binds to it too;
+        # two HIP runtimes in one process cannot both open the GPU ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _LIB = NativeLib(path, "mi_")
     return _LIB
 

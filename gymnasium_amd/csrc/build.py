@@ -1,0 +1,40 @@
+"""Build libmi355env.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m gymnasium_amd.csrc.build [--force]
+
+Flags that matter for parity: -ffp-contract=off (hipcc's device default is `fast`, which would fuse a*b+c into FMAs
+the CPU reference does not perform) and no -ffast-math.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["engine.hip"]
+HEADERS = ["envs_classic.h", "pcg64_dev.h", os.path.join("..", "..", "include", "mi355env.h")]
+OUT = os.path.join(HERE, "libmi355env.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS + ["build.py"])
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=HERE)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

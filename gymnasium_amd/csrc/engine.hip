@@ -1,0 +1,811 @@
+// engine.hip -- libmi355env.so: lockstep vector-environment kernels for MI355X (gfx950) and the C ABI of
+// include/mi355env.h.
+//
+// Execution model: one sub-environment per lane, 256-thread workgroups (4 wavefronts of 64, one per SIMD of a CU);
+// at num_envs = 65536 the grid is 256 workgroups = one per CU.  Sub-environment state is struct-of-arrays in HBM
+// (component-major float64, so a wavefront's 64 loads of one component are one contiguous 512-byte segment), the
+// API-typed outputs (obs rows, reward, flags) are written straight from registers as contiguous per-wavefront
+// segments.  TimeLimit, the autoreset state machine, the per-env PCG64 streams and the episode-return bookkeeping
+// all live on device; a step() is ONE kernel launch, a rollout(T) is ONE launch for T steps with the state held
+// in registers in between.  There is no CPU fallback anywhere in this file.
+//
+// Reference semantics reproduced (paths relative to the reference tree):
+//   vector/sync_vector_env.py:187-337  SyncVectorEnv.reset/step incl. NEXT_STEP / SAME_STEP / DISABLED autoreset
+//   wrappers/common.py:116-150         TimeLimit
+//   wrappers/vector/common.py:156-235  RecordEpisodeStatistics (r, l)
+//   envs/classic_control/*.py          dynamics (envs_classic.h)
+//   utils/seeding.py:10-42             per-env Generator(PCG64(SeedSequence(seed + i))) (pcg64_dev.h)
+//   spaces/multi_discrete.py:176-178, spaces/box.py:463-465   action_space.sample() (rollout with on-device policy)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/mi355env.h"
+#include "envs_classic.h"
+#include "pcg64_dev.h"
+
+using namespace mi;
+
+namespace {
+
+constexpr int kBlock = 256;  // 4 wavefronts: one per SIMD of a CU
+constexpr int kErrInvalidAction = 1, kErrDisabledStepped = 2;
+constexpr uint32_t kFlagShift = 30, kElapsedMask = (1u << kFlagShift) - 1u;
+
+// Device view of one vector environment (passed by value as a kernel argument).
+struct DevEnv {
+    double *state;       // [S][N]   physics state, component-major
+    uint32_t *meta;      // [N]      TimeLimit elapsed steps (bits 0..29) | flags (bits 30..31)
+    uint64_t *rng;       // [4][N]   PCG64 {state_hi, state_lo, inc_hi, inc_lo}
+    double *ep_ret;      // [N]      running episode return
+    int32_t *ep_len;     // [N]      running episode length
+    uint64_t *blk_count; // [grid][4] per-workgroup totals: env_steps, reset_steps, episodes, length_sum
+    double *blk_ret;     // [grid]    per-workgroup sum of finished-episode returns
+    int *error;          // sticky device error word
+    int N;
+    int max_steps;
+    EnvParams P;
+};
+
+struct LaneStats {
+    uint32_t env_steps, reset_steps, episodes;
+    uint64_t length_sum;
+    double return_sum;
+};
+
+template <class E>
+struct Lane {
+    double s[E::S];
+    uint32_t elapsed, flags;
+    double ep_ret;
+    int32_t ep_len;
+};
+
+template <class E>
+MI_DEV void load_lane(const DevEnv &d, int i, Lane<E> &L) {
+#pragma unroll
+    for (int k = 0; k < E::S; k++) L.s[k] = d.state[(size_t)k * d.N + i];
+    const uint32_t m = d.meta[i];
+    L.elapsed = m & kElapsedMask, L.flags = m >> kFlagShift;
+    L.ep_ret = d.ep_ret[i], L.ep_len = d.ep_len[i];
+}
+template <class E>
+MI_DEV void store_lane(const DevEnv &d, int i, const Lane<E> &L) {
+#pragma unroll
+    for (int k = 0; k < E::S; k++) d.state[(size_t)k * d.N + i] = L.s[k];
+    d.meta[i] = (L.elapsed & kElapsedMask) | (L.flags << kFlagShift);
+    d.ep_ret[i] = L.ep_ret, d.ep_len[i] = L.ep_len;
+}
+MI_DEV Pcg64 load_rng(const DevEnv &d, int i) {
+    Pcg64 r;
+    r.state = make_u128(d.rng[i], d.rng[(size_t)d.N + i]);
+    r.inc = make_u128(d.rng[(size_t)2 * d.N + i], d.rng[(size_t)3 * d.N + i]);
+    return r;
+}
+MI_DEV void store_rng_state(const DevEnv &d, int i, const Pcg64 &r) {
+    d.rng[i] = (uint64_t)(r.state >> 64), d.rng[(size_t)d.N + i] = (uint64_t)r.state;
+}
+
+// Reset of one lane from its own stream, with the reference's default bounds (autoreset: reset() has no options).
+template <class E>
+MI_DEV void lane_autoreset(const DevEnv &d, int i, Lane<E> &L) {
+    Pcg64 rng = load_rng(d, i);
+    double b0, b1;
+    E::default_bounds(b0, b1);
+    E::reset(rng, L.s, L.flags, b0, b1);
+    store_rng_state(d, i, rng);
+    L.elapsed = 0;  // TimeLimit.reset (wrappers/common.py:149)
+    L.ep_ret = 0.0, L.ep_len = 0;
+}
+
+template <class E>
+struct StepOut {
+    float obs[E::OBS];
+    float final_obs[E::OBS];
+    double reward, ep_ret;
+    int32_t ep_len;
+    bool terminated, truncated, has_final;
+};
+
+// One lockstep step of one sub-environment: sync_vector_env.py:277-329 + TimeLimit + RecordEpisodeStatistics.
+template <class E, int MODE>
+MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, StepOut<E> &o, LaneStats &st) {
+    bool te = false, tr = false;
+    double rew = 0.0;
+    o.has_final = false;
+    if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
+        // :279-284 the step after a finished episode resets, ignores the action, returns reward 0 / not done
+        lane_autoreset<E>(d, i, L);
+        st.reset_steps++;
+    } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
+        // :295 `assert not self._autoreset_envs[i]`: report through the sticky error word, leave the lane untouched
+        *d.error = kErrDisabledStepped;
+        E::obs(L.s, L.flags, o.obs);
+        o.reward = 0.0, o.terminated = false, o.truncated = false, o.ep_ret = 0.0, o.ep_len = 0;
+        return;
+    } else {
+        if (!E::valid(a)) {
+            *d.error = kErrInvalidAction;
+            a = (typename E::Act)0;
+        }
+        E::step(L.s, L.flags, a, d.P, rew, te);
+        L.elapsed += 1;  // TimeLimit.step (wrappers/common.py:129-133)
+        tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;
+        L.ep_ret += rew, L.ep_len += 1;
+        st.env_steps++;
+    }
+    const bool done = te || tr;
+    o.ep_ret = done ? L.ep_ret : 0.0;
+    o.ep_len = done ? L.ep_len : 0;
+    if (done) {
+        st.episodes++;
+        st.return_sum += L.ep_ret;
+        st.length_sum += (uint64_t)L.ep_len;
+    }
+    if (MODE == MI_AUTORESET_SAME_STEP && done) {
+        // :302-319 final_obs, then reset within the same step
+        E::obs(L.s, L.flags, o.final_obs);
+        o.has_final = true;
+        lane_autoreset<E>(d, i, L);
+    }
+    E::obs(L.s, L.flags, o.obs);
+    o.reward = rew, o.terminated = te, o.truncated = tr;
+    if (done && MODE != MI_AUTORESET_SAME_STEP)
+        L.flags |= kNeedsReset;  // _autoreset_envs (:329)
+    else
+        L.flags &= ~kNeedsReset;
+}
+
+template <int W>
+MI_DEV void store_row(float *dst, const float *src) {
+    if (W == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+    } else if (W == 2) {
+        *reinterpret_cast<float2 *>(dst) = make_float2(src[0], src[1]);
+    } else if (W == 6) {
+        float2 *p = reinterpret_cast<float2 *>(dst);
+        p[0] = make_float2(src[0], src[1]), p[1] = make_float2(src[2], src[3]), p[2] = make_float2(src[4], src[5]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; k++) dst[k] = src[k];
+    }
+}
+
+MI_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+MI_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor((int)v, off, 64);
+    return v;
+}
+MI_DEV uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint64_t)__shfl_xor((long long)v, off, 64);
+    return v;
+}
+
+// Per-workgroup totals: wavefront butterflies, 4 partials through LDS, one plain read-modify-write of the
+// workgroup's own slot (no atomics: 1024 same-address atomics would cost more than the whole step).
+MI_DEV void block_accumulate(const DevEnv &d, const LaneStats &st) {
+    __shared__ uint64_t sh_c[4][kBlock / 64];
+    __shared__ double sh_r[kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c0 = wave_sum(st.env_steps), c1 = wave_sum(st.reset_steps), c2 = wave_sum(st.episodes);
+    // c2 is wavefront-uniform: the two wide reductions are skipped by wavefronts in which no episode finished
+    const uint64_t c3 = c2 ? wave_sum(st.length_sum) : 0;
+    const double r = c2 ? wave_sum(st.return_sum) : 0.0;
+    if (lane == 0) sh_c[0][wave] = c0, sh_c[1][wave] = c1, sh_c[2][wave] = c2, sh_c[3][wave] = c3, sh_r[wave] = r;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sh_c[threadIdx.x][w];
+        if (t) d.blk_count[(size_t)blockIdx.x * 4 + threadIdx.x] += t;
+    } else if (threadIdx.x == 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sh_r[w];
+        if (t != 0.0) d.blk_ret[blockIdx.x] += t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------
+
+struct StepPtrs {
+    const void *actions;
+    float *obs;
+    double *reward;
+    uint8_t *terminated, *truncated;
+    float *final_obs;
+    double *ep_ret;
+    int32_t *ep_len;
+};
+
+template <class E, int MODE>
+__global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        Lane<E> L;
+        load_lane<E>(d, i, L);
+        const typename E::Act a = static_cast<const typename E::Act *>(io.actions)[i];
+        StepOut<E> o;
+        lane_step<E, MODE>(d, i, L, a, o, st);
+        store_lane<E>(d, i, L);
+        if (io.obs) store_row<E::OBS>(io.obs + (size_t)i * E::OBS, o.obs);
+        if (io.reward) io.reward[i] = o.reward;
+        if (io.terminated) io.terminated[i] = o.terminated;
+        if (io.truncated) io.truncated[i] = o.truncated;
+        if (MODE == MI_AUTORESET_SAME_STEP && io.final_obs && o.has_final)
+            store_row<E::OBS>(io.final_obs + (size_t)i * E::OBS, o.final_obs);
+        if (io.ep_ret) io.ep_ret[i] = o.ep_ret;
+        if (io.ep_len) io.ep_len[i] = o.ep_len;
+    }
+    block_accumulate(d, st);
+}
+
+template <class E>
+__global__ __launch_bounds__(kBlock) void reset_kernel(DevEnv d, const uint8_t *mask, int has_bounds, double b0, double b1,
+                                                       float *obs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.N) return;
+    if (mask && !mask[i]) return;
+    Lane<E> L;
+    load_lane<E>(d, i, L);
+    Pcg64 rng = load_rng(d, i);
+    if (!has_bounds) E::default_bounds(b0, b1);
+    L.flags &= ~kNeedsReset;
+    E::reset(rng, L.s, L.flags, b0, b1);
+    store_rng_state(d, i, rng);
+    L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+    store_lane<E>(d, i, L);
+    if (obs) {
+        float o[E::OBS];
+        E::obs(L.s, L.flags, o);
+        store_row<E::OBS>(obs + (size_t)i * E::OBS, o);
+    }
+}
+
+// Action stream of the batched action space: ONE PCG64 generator drawn in sub-environment index order, so lane i
+// consumes draw number t*N + i of the stream at step t.  jump[j] advances by 2^j draws; jump_n advances by N.
+struct ActionStream {
+    uint64_t state_hi, state_lo, inc_hi, inc_lo;
+    const PcgJump *pow2;  // [64] device
+    PcgJump jump_n;
+};
+
+struct RolloutPtrs {
+    const void *actions_in;
+    void *actions_out;
+    float *obs;
+    double *reward;
+    uint8_t *terminated, *truncated;
+};
+
+template <class E, int MODE, bool SAMPLE>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        Lane<E> L;
+        load_lane<E>(d, i, L);
+        u128 astate = 0;
+        const u128 ainc = make_u128(as.inc_hi, as.inc_lo);
+        if (SAMPLE) {
+            // skip ahead by (i + 1) draws: one affine map per set bit of (i + 1)
+            astate = make_u128(as.state_hi, as.state_lo);
+            uint32_t delta = (uint32_t)i + 1u;
+            for (int j = 0; delta; j++, delta >>= 1)
+                if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
+        }
+        (void)ainc;
+        const size_t N = (size_t)d.N;
+        for (int t = 0; t < T; t++) {
+            typename E::Act a;
+            if (SAMPLE) {
+                const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate;
+                const uint64_t x = hi ^ lo;
+                const unsigned rot = (unsigned)(hi >> 58);
+                const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+                a = E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
+                astate = as.jump_n.mult * astate + as.jump_n.plus;
+                if (io.actions_out) static_cast<typename E::Act *>(io.actions_out)[t * N + i] = a;
+            } else {
+                a = static_cast<const typename E::Act *>(io.actions_in)[t * N + i];
+            }
+            StepOut<E> o;
+            lane_step<E, MODE>(d, i, L, a, o, st);
+            if (io.obs) store_row<E::OBS>(io.obs + (t * N + i) * E::OBS, o.obs);
+            if (io.reward) io.reward[t * N + i] = o.reward;
+            if (io.terminated) io.terminated[t * N + i] = o.terminated;
+            if (io.truncated) io.truncated[t * N + i] = o.truncated;
+        }
+        store_lane<E>(d, i, L);
+    }
+    block_accumulate(d, st);
+}
+
+__global__ void seed_words_kernel(DevEnv d, const uint64_t *words, const uint8_t *mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N || (mask && !mask[i])) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) d.rng[(size_t)k * d.N + i] = words[(size_t)4 * i + k];
+}
+
+__global__ void seed_sequence_kernel(DevEnv d, uint64_t first_seed, const uint8_t *mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N || (mask && !mask[i])) return;
+    uint64_t w[4];
+    seed_sequence_words(first_seed + (uint64_t)i, w);
+    Pcg64 r;
+    r.srandom(w);
+    d.rng[i] = (uint64_t)(r.state >> 64), d.rng[(size_t)d.N + i] = (uint64_t)r.state;
+    d.rng[(size_t)2 * d.N + i] = (uint64_t)(r.inc >> 64), d.rng[(size_t)3 * d.N + i] = (uint64_t)r.inc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            snprintf(g_err, sizeof g_err, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)MI_ERR_HIP;                                                                       \
+        }                                                                                                 \
+    } while (0)
+
+const mi_layout kLayouts[MI_ENV_KIND_COUNT] = {
+    {CartPole::OBS, MI_F32, 1, MI_I64, CartPole::S, {0, 0, 0}},
+    {Pendulum::OBS, MI_F32, 1, MI_F32, Pendulum::S, {0, 0, 0}},
+    {Acrobot::OBS, MI_F32, 1, MI_I64, Acrobot::S, {0, 0, 0}},
+    {MountainCar::OBS, MI_F32, 1, MI_I64, MountainCar::S, {0, 0, 0}},
+    {MountainCarContinuous::OBS, MI_F32, 1, MI_F32, MountainCarContinuous::S, {0, 0, 0}},
+};
+const int kNumActions[MI_ENV_KIND_COUNT] = {2, 0, 3, 3, 0};
+
+}  // namespace
+
+struct mi_vecenv {
+    mi_config cfg;
+    mi_layout lay;
+    int device;
+    hipStream_t stream, own_stream;
+    DevEnv d;
+    int grid;
+    bool seeded, was_reset, act_seeded;
+    Pcg64 act_rng;          // host copy of the action-space generator
+    PcgJump *d_pow2;        // [64] device jump table for act_rng.inc
+    PcgJump jump_n;
+    // staging for the MI_HOST entry points
+    void *d_actions;
+    float *d_obs, *d_final;
+    double *d_reward, *d_epret;
+    uint8_t *d_term, *d_trunc, *d_mask;
+    int32_t *d_eplen;
+    uint64_t *d_words;
+    size_t act_bytes, obs_bytes;
+};
+
+namespace {
+
+template <class F>
+int dispatch_kind(int kind, F &&f) {
+    switch (kind) {
+    case MI_ENV_CARTPOLE: return f(CartPole());
+    case MI_ENV_PENDULUM: return f(Pendulum());
+    case MI_ENV_ACROBOT: return f(Acrobot());
+    case MI_ENV_MOUNTAIN_CAR: return f(MountainCar());
+    case MI_ENV_MOUNTAIN_CAR_CONTINUOUS: return f(MountainCarContinuous());
+    }
+    return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
+}
+
+int check_device_error(mi_vecenv *v) {
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, v->d.error, sizeof err, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (!err) return MI_OK;
+    HIP_TRY(hipMemsetAsync(v->d.error, 0, sizeof(int), v->stream));
+    if (err == kErrInvalidAction) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
+    return fail(MI_ERR_STATE, "DISABLED autoreset: a finished sub-environment was stepped without reset");
+}
+
+template <class E>
+int launch_step(mi_vecenv *v, const StepPtrs &p) {
+    switch (v->cfg.autoreset_mode) {
+    case MI_AUTORESET_NEXT_STEP:
+        hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_NEXT_STEP>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p);
+        break;
+    case MI_AUTORESET_SAME_STEP:
+        hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_SAME_STEP>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p);
+        break;
+    default:
+        hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_DISABLED>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p);
+        break;
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+template <class E>
+int launch_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample) {
+    const dim3 g(v->grid), b(kBlock);
+    if (v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP) {
+        if (sample)
+            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
+        else
+            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
+    } else {
+        if (sample)
+            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
+        else
+            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int set_device(const mi_vecenv *v) {
+    HIP_TRY(hipSetDevice(v->device));
+    return MI_OK;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int mi_abi_version(void) { return MI355ENV_ABI_VERSION; }
+const char *mi_last_error(void) { return g_err; }
+
+int mi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mi_config)) return fail(MI_ERR_INVALID_ARGUMENT, "bad mi_config");
+    if (cfg->kind < 0 || cfg->kind >= MI_ENV_KIND_COUNT) return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
+    if (cfg->num_envs < 1) return fail(MI_ERR_INVALID_ARGUMENT, "num_envs must be >= 1");
+    if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2) return fail(MI_ERR_INVALID_ARGUMENT, "bad autoreset mode");
+    if (cfg->max_episode_steps > (int)kElapsedMask) return fail(MI_ERR_INVALID_ARGUMENT, "max_episode_steps too large");
+    const int ndev = mi_device_count();
+    if (ndev == 0)
+        return fail(MI_ERR_NO_DEVICE, "no HIP device visible: libmi355env runs on MI355X (gfx950) only and has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MI_ERR_INVALID_ARGUMENT, "device index out of range");
+    mi_vecenv *v = new (std::nothrow) mi_vecenv();
+    if (!v) return fail(MI_ERR_HIP, "out of host memory");
+    memset(v, 0, sizeof *v);
+    v->cfg = *cfg, v->lay = kLayouts[cfg->kind], v->device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&v->own_stream, hipStreamNonBlocking));
+    v->stream = v->own_stream;
+    const size_t N = (size_t)cfg->num_envs;
+    v->grid = (int)((N + kBlock - 1) / kBlock);
+    DevEnv &d = v->d;
+    d.N = cfg->num_envs, d.max_steps = cfg->max_episode_steps;
+    for (int k = 0; k < 8; k++) d.P.p[k] = cfg->params[k];
+    HIP_TRY(hipMalloc(&d.state, sizeof(double) * v->lay.state_dim * N));
+    HIP_TRY(hipMalloc(&d.meta, sizeof(uint32_t) * N));
+    HIP_TRY(hipMalloc(&d.rng, sizeof(uint64_t) * 4 * N));
+    HIP_TRY(hipMalloc(&d.ep_ret, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&d.ep_len, sizeof(int32_t) * N));
+    HIP_TRY(hipMalloc(&d.blk_count, sizeof(uint64_t) * 4 * v->grid));
+    HIP_TRY(hipMalloc(&d.blk_ret, sizeof(double) * v->grid));
+    HIP_TRY(hipMalloc(&d.error, sizeof(int)));
+    HIP_TRY(hipMalloc(&v->d_pow2, sizeof(PcgJump) * 64));
+    HIP_TRY(hipMemsetAsync(d.state, 0, sizeof(double) * v->lay.state_dim * N, v->stream));
+    HIP_TRY(hipMemsetAsync(d.meta, 0, sizeof(uint32_t) * N, v->stream));
+    HIP_TRY(hipMemsetAsync(d.rng, 0, sizeof(uint64_t) * 4 * N, v->stream));
+    HIP_TRY(hipMemsetAsync(d.ep_ret, 0, sizeof(double) * N, v->stream));
+    HIP_TRY(hipMemsetAsync(d.ep_len, 0, sizeof(int32_t) * N, v->stream));
+    HIP_TRY(hipMemsetAsync(d.blk_count, 0, sizeof(uint64_t) * 4 * v->grid, v->stream));
+    HIP_TRY(hipMemsetAsync(d.blk_ret, 0, sizeof(double) * v->grid, v->stream));
+    HIP_TRY(hipMemsetAsync(d.error, 0, sizeof(int), v->stream));
+    v->act_bytes = N * (v->lay.act_dtype == MI_I64 ? 8 : 4) * v->lay.act_dim;
+    v->obs_bytes = N * sizeof(float) * v->lay.obs_dim;
+    HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes));
+    HIP_TRY(hipMalloc(&v->d_obs, v->obs_bytes));
+    HIP_TRY(hipMalloc(&v->d_final, v->obs_bytes));
+    HIP_TRY(hipMalloc(&v->d_reward, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&v->d_epret, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&v->d_eplen, sizeof(int32_t) * N));
+    HIP_TRY(hipMalloc(&v->d_term, N));
+    HIP_TRY(hipMalloc(&v->d_trunc, N));
+    HIP_TRY(hipMalloc(&v->d_mask, N));
+    HIP_TRY(hipMalloc(&v->d_words, sizeof(uint64_t) * 4 * N));
+    HIP_TRY(hipMemsetAsync(v->d_obs, 0, v->obs_bytes, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    *out = v;
+    return MI_OK;
+}
+
+void mi_destroy(mi_vecenv *v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    (void)hipStreamSynchronize(v->stream);
+    void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d.error,
+                    v->d_pow2, v->d_actions, v->d_obs, v->d_final, v->d_reward, v->d_epret, v->d_eplen, v->d_term,
+                    v->d_trunc, v->d_mask, v->d_words};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
+    delete v;
+}
+
+int mi_get_layout(const mi_vecenv *v, mi_layout *out) {
+    if (!v || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    *out = v->lay;
+    return MI_OK;
+}
+
+int mi_set_stream(mi_vecenv *v, void *hip_stream) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    hipStream_t s = (hipStream_t)hip_stream;  // NULL is the legacy default stream (torch's default current stream)
+    if (s != v->stream) {
+        if (set_device(v)) return MI_ERR_HIP;
+        HIP_TRY(hipStreamSynchronize(v->stream));  // order the hand-over between streams
+        v->stream = s;
+    }
+    return MI_OK;
+}
+
+int mi_synchronize(mi_vecenv *v) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (set_device(v)) return MI_ERR_HIP;
+    return check_device_error(v);
+}
+
+static int upload_mask(mi_vecenv *v, const uint8_t *mask, const uint8_t **d_mask) {
+    *d_mask = nullptr;
+    if (!mask) return MI_OK;
+    HIP_TRY(hipMemcpyAsync(v->d_mask, mask, (size_t)v->cfg.num_envs, hipMemcpyHostToDevice, v->stream));
+    *d_mask = v->d_mask;
+    return MI_OK;
+}
+
+int mi_seed(mi_vecenv *v, const uint64_t *pcg, const uint8_t *mask) {
+    if (!v || !pcg) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (set_device(v)) return MI_ERR_HIP;
+    const uint8_t *dm;
+    if (int rc = upload_mask(v, mask, &dm)) return rc;
+    HIP_TRY(hipMemcpyAsync(v->d_words, pcg, sizeof(uint64_t) * 4 * (size_t)v->cfg.num_envs, hipMemcpyHostToDevice, v->stream));
+    hipLaunchKernelGGL(seed_words_kernel, dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, (const uint64_t *)v->d_words, dm);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(v->stream));  // the host buffers may be reused by the caller
+    v->seeded = true;
+    return MI_OK;
+}
+
+int mi_seed_sequence(mi_vecenv *v, uint64_t base_seed, uint64_t first_index, const uint8_t *mask) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (set_device(v)) return MI_ERR_HIP;
+    const uint8_t *dm;
+    if (int rc = upload_mask(v, mask, &dm)) return rc;
+    hipLaunchKernelGGL(seed_sequence_kernel, dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, base_seed + first_index, dm);
+    HIP_TRY(hipGetLastError());
+    if (mask) HIP_TRY(hipStreamSynchronize(v->stream));
+    v->seeded = true;
+    return MI_OK;
+}
+
+int mi_get_rng(mi_vecenv *v, uint64_t *pcg) {
+    if (!v || !pcg) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (set_device(v)) return MI_ERR_HIP;
+    const size_t N = (size_t)v->cfg.num_envs;
+    std::vector<uint64_t> soa(4 * N);
+    HIP_TRY(hipMemcpyAsync(soa.data(), v->d.rng, sizeof(uint64_t) * 4 * N, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    for (size_t i = 0; i < N; i++)
+        for (int k = 0; k < 4; k++) pcg[4 * i + k] = soa[k * N + i];
+    return MI_OK;
+}
+
+int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs, int loc) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (!v->seeded) return fail(MI_ERR_STATE, "reset before seeding");
+    if (set_device(v)) return MI_ERR_HIP;
+    const uint8_t *dm = mask;
+    float *dobs = (float *)obs;
+    if (loc == MI_HOST) {
+        if (int rc = upload_mask(v, mask, &dm)) return rc;
+        dobs = v->d_obs;  // persistent: rows of un-reset sub-envs keep their last observation (sync_vector_env.py:261)
+    }
+    const int has_bounds = bounds != nullptr;
+    const double b0 = has_bounds ? bounds[0] : 0.0, b1 = has_bounds ? bounds[1] : 0.0;
+    int rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int {
+        using E = decltype(env);
+        hipLaunchKernelGGL((reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, has_bounds, b0, b1, dobs);
+        HIP_TRY(hipGetLastError());
+        return (int)MI_OK;
+    });
+    if (rc) return rc;
+    v->was_reset = true;
+    if (loc == MI_HOST) {
+        if (obs) HIP_TRY(hipMemcpyAsync(obs, v->d_obs, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
+        HIP_TRY(hipStreamSynchronize(v->stream));
+    }
+    return MI_OK;
+}
+
+int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
+    if (!v || !io) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (!v->was_reset) return fail(MI_ERR_STATE, "step before reset");
+    if (!io->actions) return fail(MI_ERR_INVALID_ARGUMENT, "actions is NULL");
+    if (set_device(v)) return MI_ERR_HIP;
+    const size_t N = (size_t)v->cfg.num_envs;
+    StepPtrs p;
+    if (loc == MI_HOST) {
+        // validate before anything is mutated (cartpole.py:165-167 asserts action_space.contains(action))
+        const int na = kNumActions[v->cfg.kind];
+        if (na) {
+            const int64_t *a = (const int64_t *)io->actions;
+            for (size_t i = 0; i < N; i++)
+                if (a[i] < 0 || a[i] >= na) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
+        }
+        HIP_TRY(hipMemcpyAsync(v->d_actions, io->actions, v->act_bytes, hipMemcpyHostToDevice, v->stream));
+        p.actions = v->d_actions;
+        p.obs = v->d_obs, p.reward = v->d_reward, p.terminated = v->d_term, p.truncated = v->d_trunc;
+        p.final_obs = io->final_obs ? v->d_final : nullptr;
+        p.ep_ret = io->episode_return ? v->d_epret : nullptr;
+        p.ep_len = io->episode_length ? v->d_eplen : nullptr;
+    } else {
+        p.actions = io->actions;
+        p.obs = (float *)io->obs, p.reward = io->reward, p.terminated = io->terminated, p.truncated = io->truncated;
+        p.final_obs = (float *)io->final_obs, p.ep_ret = io->episode_return, p.ep_len = io->episode_length;
+    }
+    int rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
+    if (rc) return rc;
+    if (loc == MI_HOST) {
+        if (io->obs) HIP_TRY(hipMemcpyAsync(io->obs, v->d_obs, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
+        if (io->reward) HIP_TRY(hipMemcpyAsync(io->reward, v->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost, v->stream));
+        if (io->terminated) HIP_TRY(hipMemcpyAsync(io->terminated, v->d_term, N, hipMemcpyDeviceToHost, v->stream));
+        if (io->truncated) HIP_TRY(hipMemcpyAsync(io->truncated, v->d_trunc, N, hipMemcpyDeviceToHost, v->stream));
+        if (io->final_obs) HIP_TRY(hipMemcpyAsync(io->final_obs, v->d_final, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
+        if (io->episode_return)
+            HIP_TRY(hipMemcpyAsync(io->episode_return, v->d_epret, sizeof(double) * N, hipMemcpyDeviceToHost, v->stream));
+        if (io->episode_length)
+            HIP_TRY(hipMemcpyAsync(io->episode_length, v->d_eplen, sizeof(int32_t) * N, hipMemcpyDeviceToHost, v->stream));
+        return check_device_error(v);  // synchronises
+    }
+    return MI_OK;
+}
+
+int mi_action_seed(mi_vecenv *v, const uint64_t pcg[4]) {
+    if (!v || !pcg) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (set_device(v)) return MI_ERR_HIP;
+    const u128 inc = make_u128(pcg[2], pcg[3]);
+    const bool same_inc = v->act_seeded && v->act_rng.inc == inc;
+    v->act_rng.state = make_u128(pcg[0], pcg[1]);
+    v->act_rng.inc = inc;
+    if (!same_inc) {
+        PcgJump tab[64];
+        for (int j = 0; j < 64; j++) tab[j] = pcg_jump(inc, (u128)1 << j);
+        HIP_TRY(hipMemcpyAsync(v->d_pow2, tab, sizeof tab, hipMemcpyHostToDevice, v->stream));
+        HIP_TRY(hipStreamSynchronize(v->stream));
+        v->jump_n = pcg_jump(inc, (u128)v->cfg.num_envs * (u128)v->lay.act_dim);
+    }
+    v->act_seeded = true;
+    return MI_OK;
+}
+
+int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
+    if (!v || !io) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (!v->was_reset) return fail(MI_ERR_STATE, "rollout before reset");
+    if (T < 0) return fail(MI_ERR_INVALID_ARGUMENT, "T must be >= 0");
+    if (v->cfg.autoreset_mode == MI_AUTORESET_DISABLED) return fail(MI_ERR_UNSUPPORTED, "rollout needs an autoreset mode");
+    const bool sample = io->actions_in == nullptr;
+    if (sample && !v->act_seeded) return fail(MI_ERR_STATE, "rollout without actions needs mi_action_seed");
+    if (T == 0) return MI_OK;
+    if (set_device(v)) return MI_ERR_HIP;
+    RolloutPtrs p = {io->actions_in, io->actions_out, (float *)io->obs, io->reward, io->terminated, io->truncated};
+    ActionStream as;
+    memset(&as, 0, sizeof as);
+    if (sample) {
+        as.state_hi = (uint64_t)(v->act_rng.state >> 64), as.state_lo = (uint64_t)v->act_rng.state;
+        as.inc_hi = (uint64_t)(v->act_rng.inc >> 64), as.inc_lo = (uint64_t)v->act_rng.inc;
+        as.pow2 = v->d_pow2, as.jump_n = v->jump_n;
+    }
+    int rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
+    if (rc) return rc;
+    if (sample) {  // the host copy of the generator moves past the T*N draws the kernel consumes
+        const PcgJump j = pcg_jump(v->act_rng.inc, (u128)T * (u128)v->cfg.num_envs * (u128)v->lay.act_dim);
+        v->act_rng.state = j.mult * v->act_rng.state + j.plus;
+    }
+    return MI_OK;
+}
+
+int mi_get_stats(mi_vecenv *v, mi_stats *out) {
+    if (!v || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (set_device(v)) return MI_ERR_HIP;
+    std::vector<uint64_t> c(4 * (size_t)v->grid);
+    std::vector<double> r((size_t)v->grid);
+    HIP_TRY(hipMemcpyAsync(c.data(), v->d.blk_count, sizeof(uint64_t) * c.size(), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(r.data(), v->d.blk_ret, sizeof(double) * r.size(), hipMemcpyDeviceToHost, v->stream));
+    if (int rc = check_device_error(v)) return rc;
+    memset(out, 0, sizeof *out);
+    for (int b = 0; b < v->grid; b++) {
+        out->env_steps += c[4 * b], out->reset_steps += c[4 * b + 1], out->episodes += c[4 * b + 2];
+        out->length_sum += c[4 * b + 3], out->return_sum += r[b];
+    }
+    return MI_OK;
+}
+
+int mi_reset_stats(mi_vecenv *v) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (set_device(v)) return MI_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(v->d.blk_count, 0, sizeof(uint64_t) * 4 * v->grid, v->stream));
+    HIP_TRY(hipMemsetAsync(v->d.blk_ret, 0, sizeof(double) * v->grid, v->stream));
+    return MI_OK;
+}
+
+int mi_get_state(mi_vecenv *v, double *state, int32_t *elapsed, uint8_t *flags) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (set_device(v)) return MI_ERR_HIP;
+    const size_t N = (size_t)v->cfg.num_envs, S = (size_t)v->lay.state_dim;
+    std::vector<double> soa(S * N);
+    std::vector<uint32_t> meta(N);
+    HIP_TRY(hipMemcpyAsync(soa.data(), v->d.state, sizeof(double) * S * N, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(meta.data(), v->d.meta, sizeof(uint32_t) * N, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    for (size_t i = 0; i < N; i++) {
+        if (state)
+            for (size_t k = 0; k < S; k++) state[i * S + k] = soa[k * N + i];
+        if (elapsed) elapsed[i] = (int32_t)(meta[i] & kElapsedMask);
+        if (flags) flags[i] = (uint8_t)(meta[i] >> kFlagShift);
+    }
+    return MI_OK;
+}
+
+int mi_set_state(mi_vecenv *v, const double *state, const int32_t *elapsed, const uint8_t *flags) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (set_device(v)) return MI_ERR_HIP;
+    const size_t N = (size_t)v->cfg.num_envs, S = (size_t)v->lay.state_dim;
+    if (state) {
+        std::vector<double> soa(S * N);
+        for (size_t i = 0; i < N; i++)
+            for (size_t k = 0; k < S; k++) soa[k * N + i] = state[i * S + k];
+        HIP_TRY(hipMemcpyAsync(v->d.state, soa.data(), sizeof(double) * S * N, hipMemcpyHostToDevice, v->stream));
+        HIP_TRY(hipStreamSynchronize(v->stream));
+    }
+    if (elapsed || flags) {
+        std::vector<uint32_t> meta(N);
+        HIP_TRY(hipMemcpyAsync(meta.data(), v->d.meta, sizeof(uint32_t) * N, hipMemcpyDeviceToHost, v->stream));
+        HIP_TRY(hipStreamSynchronize(v->stream));
+        for (size_t i = 0; i < N; i++) {
+            uint32_t e = meta[i] & kElapsedMask, f = meta[i] >> kFlagShift;
+            if (elapsed) e = (uint32_t)elapsed[i] & kElapsedMask;
+            if (flags) f = flags[i] & 3u;
+            meta[i] = e | (f << kFlagShift);
+        }
+        HIP_TRY(hipMemcpyAsync(v->d.meta, meta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice, v->stream));
+        HIP_TRY(hipStreamSynchronize(v->stream));
+    }
+    v->was_reset = true;
+    return MI_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,317 @@
+// envs_classic.h -- per-lane dynamics of the five classic-control environments for gfx950.
+//
+// One sub-environment per lane; the state lives in registers for the duration of a step (or of a whole fused
+// rollout).  Arithmetic follows the reference expression by expression, in float64 except where NumPy-2 weak-scalar
+// promotion makes the reference round to float32.  The translation unit is compiled with
+// -ffp-contract=off so that no a*b+c is fused: the reference rounds every product.
+//
+// Differences from the CPU reference that remain (and are covered by the stated tolerance rtol=atol=1e-5,
+// gymnasium/utils/env_checker.py:68): ocml sin/cos/fmod instead of glibc's (<= 1-2 ulp), and x*x where NumPy's
+// scalar `**2` calls libm pow (x*x is the correctly rounded value; glibc pow is within 1 ulp of it).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pcg64_dev.h"
+
+namespace mi {
+
+#define MI_DEV __device__ __forceinline__
+
+constexpr double kPi = 3.141592653589793;
+
+enum : uint32_t { kNeedsReset = 1u, kStateF32 = 2u };
+
+struct EnvParams {
+    double p[8];
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// CartPole-v1: gymnasium/envs/classic_control/cartpole.py:119-247
+// ---------------------------------------------------------------------------------------------------------
+struct CartPole {
+    static constexpr int S = 4, OBS = 4, N_ACTIONS = 2;
+    static constexpr bool DISCRETE = true;
+    typedef int64_t Act;
+
+    static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.05, b1 = 0.05; }
+
+    // cartpole.py:242  state = np_random.uniform(low, high, size=(4,))
+    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
+        const double range = b1 - b0;
+#pragma unroll
+        for (int k = 0; k < S; k++) s[k] = rng.uniform(b0, range);
+        (void)flags;
+    }
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
+#pragma unroll
+        for (int k = 0; k < OBS; k++) o[k] = (float)s[k];
+    }
+    static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
+    static MI_DEV Act sample(double u) { return (Act)(u * 2.0); }  // (random(N) * nvec).astype(int64)
+
+    // cartpole.py:164-226: explicit Euler with the OLD velocities, all float64.
+    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
+        const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+        const double total_mass = masspole + masscart;
+        const double polemass_length = masspole * length;
+        const double theta_threshold = 12 * 2 * kPi / 360;
+        const double x_threshold = 2.4;
+        double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+        const double force = action == 1 ? force_mag : -force_mag;
+        double sintheta, costheta;
+        sincos(theta, &sintheta, &costheta);
+        const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+        const double thetaacc = (gravity * sintheta - costheta * temp) /
+                                (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+        const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+        x = x + tau * x_dot;
+        x_dot = x_dot + tau * xacc;
+        theta = theta + tau * theta_dot;
+        theta_dot = theta_dot + tau * thetaacc;
+        s[0] = x, s[1] = x_dot, s[2] = theta, s[3] = theta_dot;
+        terminated = x < -x_threshold || x > x_threshold || theta < -theta_threshold || theta > theta_threshold;
+        const bool sutton_barto = P.p[0] != 0.0;
+        reward = terminated ? (sutton_barto ? -1.0 : 1.0) : (sutton_barto ? 0.0 : 1.0);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Pendulum-v1: gymnasium/envs/classic_control/pendulum.py:102-171,281-282
+// ---------------------------------------------------------------------------------------------------------
+struct Pendulum {
+    static constexpr int S = 2, OBS = 3;
+    static constexpr bool DISCRETE = false;
+    typedef float Act;
+
+    static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
+
+    // pendulum.py:149-167: high = [x_init, y_init], low = -high, uniform(low, high) -> theta, thetadot
+    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &, double x_init, double y_init) {
+        s[0] = rng.uniform(-x_init, x_init - (-x_init));
+        s[1] = rng.uniform(-y_init, y_init - (-y_init));
+    }
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
+        double sn, cs;
+        sincos(s[0], &sn, &cs);
+        o[0] = (float)cs, o[1] = (float)sn, o[2] = (float)s[1];
+    }
+    static MI_DEV bool valid(Act) { return true; }
+    static MI_DEV Act sample(double u) { return (Act)(-2.0 + (2.0 - (-2.0)) * u); }  // Box.sample: uniform(low, high).astype(f32)
+
+    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
+        const double max_speed = 8, max_torque = 2.0, dt = 0.05, m = 1.0, l = 1.0;
+        const double g = P.p[0];
+        const double th = s[0], thdot = s[1];
+        float u = action;  // np.clip(u, -2, 2)[0] stays np.float32
+        u = u < (float)-max_torque ? (float)-max_torque : u;
+        u = u > (float)max_torque ? (float)max_torque : u;
+        // angle_normalize: ((x + pi) % (2 pi)) - pi with Python floor-modulo
+        double md = fmod(th + kPi, 2 * kPi);
+        if (md != 0.0) {
+            if (md < 0.0) md += 2 * kPi;
+        } else {
+            md = 0.0;
+        }
+        const double an = md - kPi;
+        const float cu = 0.001f * (u * u);            // float32: 0.001 * (u ** 2)
+        const double costs = an * an + 0.1 * (thdot * thdot) + (double)cu;
+        const float tu = (float)(3.0 / (m * (l * l))) * u;  // float32: 3.0 / (m l^2) * u
+        double sn = sin(th);
+        double newthdot = thdot + (3 * g / (2 * l) * sn + (double)tu) * dt;
+        newthdot = newthdot < -max_speed ? -max_speed : newthdot;
+        newthdot = newthdot > max_speed ? max_speed : newthdot;
+        const double newth = th + newthdot * dt;
+        s[0] = newth, s[1] = newthdot;
+        reward = -costs;
+        terminated = false;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Acrobot-v1: gymnasium/envs/classic_control/acrobot.py:172-279,375-461
+// ---------------------------------------------------------------------------------------------------------
+struct Acrobot {
+    static constexpr int S = 4, OBS = 6, N_ACTIONS = 3;
+    static constexpr bool DISCRETE = true;
+    typedef int64_t Act;
+
+    static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.1, b1 = 0.1; }
+
+    // acrobot.py:185-200: uniform(low, high, size=(4,)).astype(np.float32)
+    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
+        const double range = b1 - b0;
+#pragma unroll
+        for (int k = 0; k < S; k++) s[k] = (double)(float)rng.uniform(b0, range);
+        flags |= kStateF32;
+    }
+    // acrobot.py:232-237 (after a reset NumPy evaluates these in float32; we return the correctly rounded value)
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
+        double s1, c1, s2, c2;
+        sincos(s[0], &s1, &c1);
+        sincos(s[1], &s2, &c2);
+        o[0] = (float)c1, o[1] = (float)s1, o[2] = (float)c2, o[3] = (float)s2, o[4] = (float)s[2], o[5] = (float)s[3];
+    }
+    static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
+    static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }
+
+    // acrobot.py:244-279, "book" dynamics; y = (theta1, theta2, dtheta1, dtheta2), a = torque
+    static MI_DEV void dsdt(const double y[4], double a, double d[4]) {
+        const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
+        const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+        double s2, c2;
+        sincos(theta2, &s2, &c2);
+        const double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
+        const double d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+        const double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - kPi / 2.0);
+        const double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+                            (m1 * lc1 + m2 * l1) * g * cos(theta1 - kPi / 2) + phi2;
+        const double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                                (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+        const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+        d[0] = dtheta1, d[1] = dtheta2, d[2] = ddtheta1, d[3] = ddtheta2;
+    }
+    static MI_DEV double wrap(double x, double m, double M) {
+        const double diff = M - m;
+        while (x > M) x = x - diff;
+        while (x < m) x = x + diff;
+        return x;
+    }
+    static MI_DEV double bound(double x, double m, double M) {
+        const double t = (m > x) ? m : x;
+        return (M < t) ? M : t;
+    }
+    // acrobot.py:202-230 with rk4 (:415-461) over t = [0, 0.2]; the torque component has derivative 0
+    static MI_DEV void step(double s[S], uint32_t &flags, Act action, const EnvParams &, double &reward, bool &terminated) {
+        const double dt = 0.2 - 0, dt2 = dt / 2.0, dt6 = dt / 6.0;
+        const double a = action == 0 ? -1.0 : (action == 1 ? 0.0 : 1.0);
+        double k1[4], k2[4], k3[4], k4[4], t[4];
+        dsdt(s, a, k1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = s[i] + dt2 * k1[i];
+        dsdt(t, a, k2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = s[i] + dt2 * k2[i];
+        dsdt(t, a, k3);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = s[i] + dt * k3[i];
+        dsdt(t, a, k4);
+        double ns[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) ns[i] = s[i] + dt6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        ns[0] = wrap(ns[0], -kPi, kPi);
+        ns[1] = wrap(ns[1], -kPi, kPi);
+        ns[2] = bound(ns[2], -4 * kPi, 4 * kPi);
+        ns[3] = bound(ns[3], -9 * kPi, 9 * kPi);
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[i] = ns[i];
+        flags &= ~kStateF32;
+        terminated = (-cos(ns[0]) - cos(ns[1] + ns[0])) > 1.0;
+        reward = terminated ? 0.0 : -1.0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// MountainCar-v0: gymnasium/envs/classic_control/mountain_car.py:108-170
+// ---------------------------------------------------------------------------------------------------------
+struct MountainCar {
+    static constexpr int S = 2, OBS = 2, N_ACTIONS = 3;
+    static constexpr bool DISCRETE = true;
+    typedef int64_t Act;
+
+    static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
+    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
+        s[0] = rng.uniform(b0, b1 - b0);
+        s[1] = 0.0;
+        flags &= ~kStateF32;
+    }
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) { o[0] = (float)s[0], o[1] = (float)s[1]; }
+    static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
+    static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }
+
+    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
+        const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5;
+        const double force = 0.001, gravity = 0.0025;
+        double position = s[0], velocity = s[1];
+        velocity += (double)(action - 1) * force + cos(3 * position) * (-gravity);
+        velocity = velocity < -max_speed ? -max_speed : velocity;
+        velocity = velocity > max_speed ? max_speed : velocity;
+        position += velocity;
+        position = position < min_position ? min_position : position;
+        position = position > max_position ? max_position : position;
+        if (position == min_position && velocity < 0) velocity = 0;
+        s[0] = position, s[1] = velocity;
+        terminated = position >= goal_position && velocity >= P.p[0];
+        reward = -1.0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// MountainCarContinuous-v0: gymnasium/envs/classic_control/continuous_mountain_car.py:116-194
+// The state is a float64 array right after reset and a float32 array from the first step on (":178"); NumPy-2
+// promotion then makes most of the update float32 arithmetic.
+// ---------------------------------------------------------------------------------------------------------
+struct MountainCarContinuous {
+    static constexpr int S = 2, OBS = 2;
+    static constexpr bool DISCRETE = false;
+    typedef float Act;
+
+    static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
+    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
+        s[0] = rng.uniform(b0, b1 - b0);
+        s[1] = 0.0;
+        flags &= ~kStateF32;
+    }
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) { o[0] = (float)s[0], o[1] = (float)s[1]; }
+    static MI_DEV bool valid(Act) { return true; }
+    static MI_DEV Act sample(double u) { return (Act)(-1.0 + (1.0 - (-1.0)) * u); }
+
+    static MI_DEV void step(double s[S], uint32_t &flags, Act a0, const EnvParams &P, double &reward, bool &terminated) {
+        const double min_action = -1.0, max_action = 1.0, min_position = -1.2, max_position = 0.6, max_speed = 0.07;
+        const double goal_position = 0.45, power = 0.0015, goal_velocity = P.p[0];
+        // force = min(max(action[0], -1.0), 1.0): an np.float32 unless out of range, then the Python float bound
+        bool force_is_py = false;
+        double force_py = 0.0;
+        if (min_action > (double)a0) force_is_py = true, force_py = min_action;
+        if (!force_is_py && max_action < (double)a0) force_is_py = true, force_py = max_action;
+        double position, velocity;
+        if (flags & kStateF32) {
+            float p = (float)s[0], v = (float)s[1];
+            const float three_p = 3.0f * p;
+            const double g = 0.0025 * cos((double)three_p);
+            if (force_is_py)
+                v = v + (float)(force_py * power - g);
+            else
+                v = v + ((a0 * (float)power) - (float)g);
+            v = v > (float)max_speed ? (float)max_speed : v;
+            v = v < (float)-max_speed ? (float)-max_speed : v;
+            p = p + v;
+            p = p > (float)max_position ? (float)max_position : p;
+            p = p < (float)min_position ? (float)min_position : p;
+            if (p == (float)min_position && v < 0) v = 0;
+            terminated = p >= (float)goal_position && v >= (float)goal_velocity;
+            position = p, velocity = v;
+        } else {
+            double p = s[0], v = s[1];
+            const double g = 0.0025 * cos(3 * p);
+            if (force_is_py)
+                v = v + (force_py * power - g);
+            else
+                v = v + (double)((a0 * (float)power) - (float)g);
+            v = v > max_speed ? max_speed : v;
+            v = v < -max_speed ? -max_speed : v;
+            p = p + v;
+            p = p > max_position ? max_position : p;
+            p = p < min_position ? min_position : p;
+            if (p == min_position && v < 0) v = 0;
+            terminated = p >= goal_position && v >= goal_velocity;
+            position = (double)(float)p, velocity = (double)(float)v;
+        }
+        const double a_d = (double)a0;
+        reward = (terminated ? 100.0 : 0.0) - (a_d * a_d) * 0.1;  // math.pow(action[0], 2) * 0.1 (exact in double)
+        s[0] = position, s[1] = velocity;
+        flags |= kStateF32;
+    }
+};
+
+}  // namespace mi

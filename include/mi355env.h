@@ -142,7 +142,9 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out);
 /* Replaces VectorEnv.close_extras (vector/vector_env.py:238-240). */
 void mi_destroy(mi_vecenv *env);
 int mi_get_layout(const mi_vecenv *env, mi_layout *out);
-/* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL = own stream. */
+/* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work.  NULL means the legacy
+ * default stream (what torch.cuda.current_stream().cuda_stream is by default).  Until this is called the env
+ * uses a private non-blocking stream created by mi_create. */
 int mi_set_stream(mi_vecenv *env, void *hip_stream);
 int mi_synchronize(mi_vecenv *env);
 

@@ -1,0 +1,69 @@
+"""CPU checks of the boundary: the library loads, exports every symbol include/mi355env.h declares, refuses to run
+without a GPU (no CPU fallback), and the ctypes structs match the header's layout."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "mi355env.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gymnasium_amd import _native
+
+    lib = _native.load_library()
+    declared = header_functions()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib.dll, name), f"{name} declared in include/mi355env.h but not exported"
+    assert sorted("mi_" + s for s in _native.SYMBOLS) == declared
+    assert lib.abi_version() == _native.ABI_VERSION
+
+
+def test_oracle_exports_the_same_abi(oracle_factory):
+    from gymnasium_amd import _native
+    from oracle import oracle
+
+    lib = oracle.load()
+    for s in _native.SYMBOLS:
+        assert hasattr(lib.dll, "orc_" + s)
+
+
+def test_struct_layouts_match_header():
+    from gymnasium_amd import _native as n
+
+    assert ctypes.sizeof(n.MiConfig) == 8 * 4 + 8 * 8
+    assert ctypes.sizeof(n.MiLayout) == 8 * 4
+    assert ctypes.sizeof(n.MiStepIO) == 8 * 8
+    assert ctypes.sizeof(n.MiRolloutIO) == 6 * 8
+    assert ctypes.sizeof(n.MiStats) == 5 * 8
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must fail loudly; it must never route through the oracle."""
+    import gymnasium_amd
+    from gymnasium_amd import _native
+
+    lib = _native.load_library()
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_native.NativeError) as e:
+        gymnasium_amd.make_vec("CartPole-v1", num_envs=4)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    # the package never imports the oracle
+    import sys
+
+    assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules if "gymnasium_amd" in getattr(sys.modules[m], "__name__", "") )
+    src = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gymnasium_amd")):
+        src += [os.path.join(dirpath, f) for f in files if f.endswith((".py", ".hip", ".h", ".cpp"))]
+    for f in src:
+        text = open(f).read()
+        assert "liboracle" not in text and "import oracle" not in text and "from oracle" not in text, f
