@@ -67,10 +67,11 @@ def test_fused_rollout_equals_stepping(key):
 
 # Free-running whole episodes.  CartPole / MountainCar x2 / Pendulum hold the 1e-5 tolerance for the whole episode.
 # Acrobot is a chaotic double pendulum: the <= 1-2 ulp (1e-16) difference between ocml's and glibc's sin/cos is
-# amplified exponentially along a free-running trajectory (measured: up to 1.3e-5 after ~360 steps in the worst of
-# 4096 sub-envs), so its free-running bound is 2e-4 and the 1e-5 bound is checked with the GPU state re-synchronised
-# to the oracle every 100 steps (test_acrobot_windowed_vs_oracle) and per step (teacher-forced tests, 1e-10).
-@pytest.mark.parametrize("key,T,tol", [("cartpole", 520, 1e-5), ("pendulum", 210, 1e-5), ("acrobot", 510, 2e-4),
+# amplified exponentially along a free-running trajectory (measured over 4096 sub-envs: worst |obs diff| 1.3e-5 at
+# step 362, 3.1e-4 at step 405), so it is compared free-running for 200 steps, and for the whole 500-step episode
+# with the GPU state re-synchronised to the oracle every 100 steps (test_acrobot_windowed_vs_oracle); per-step
+# agreement is checked at 1e-10 by the teacher-forced tests.  Flags must match exactly in every case.
+@pytest.mark.parametrize("key,T,tol", [("cartpole", 520, 1e-5), ("pendulum", 210, 1e-5), ("acrobot", 200, 1e-5),
                                        ("mountaincar", 210, 1e-5), ("mountaincar_continuous", 1010, 1e-5)])
 def test_full_episode_vs_oracle(key, T, tol, oracle_factory):
     """4096 sub-envs, at least one full episode each, same seeds and actions on GPU and oracle."""
