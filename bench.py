@@ -135,13 +135,11 @@ def main():
     elapsed = time.perf_counter() - t0
     st = env.statistics()
     kernel_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(K)]
-    totals = torch.tensor([float(st["env_steps"]), float(st["episodes"]), st["return_sum"], elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = totals[3:].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(totals[:3], op=dist.ReduceOp.SUM)  # the only collective: 24 bytes over RCCL/xGMI
-        elapsed = float(tmax[0])
-    env_steps, episodes, return_sum = float(totals[0]), float(totals[1]), float(totals[2])
+    from gymnasium_amd import distributed as gd
+
+    red = gd.reduce_statistics(st, elapsed_s=elapsed, device=dev)  # the only collective: a few dozen bytes over RCCL/xGMI
+    elapsed = red["elapsed_s"]
+    env_steps, episodes, return_sum = float(red["env_steps"]), float(red["episodes"]), float(red["return_sum"])
 
     result = None
     if rank == 0:

@@ -1,0 +1,53 @@
+"""Multi-GPU layout of the vector-env path: sub-environments shard across ranks, nothing else does.
+
+The reference has no distributed backend at all (AsyncVectorEnv is one OS process per env over pipes,
+vector/async_vector_env.py:252-277).  Sub-environments never interact (vector/sync_vector_env.py:277-323 touches only
+index i), so the N>1 path is: one process per GPU, rank r owns a contiguous block of global env indices, env g keeps
+seed ``seed + g`` whatever the world size, and the ONLY collective is the final metric reduction (a few dozen bytes
+over RCCL/xGMI; backend "nccl" on ROCm, "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+
+
+def rank_info():
+    """(rank, local_rank, world_size) from the torchrun environment (defaults: single process)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(total_envs: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of global env indices owned by ``rank``.  Blocks differ by at most one
+    env when ``world`` does not divide ``total_envs``."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    base, rem = divmod(int(total_envs), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+STAT_KEYS = ("env_steps", "reset_steps", "episodes", "length_sum", "return_sum")
+
+
+def reduce_statistics(stats: dict, elapsed_s: float | None = None, device=None) -> dict:
+    """Sum the per-rank ``VectorEnv.statistics()`` over all ranks (one all_reduce) and take the MAX of ``elapsed_s``.
+
+    Works on whatever backend the default process group uses; a no-op without an initialised group."""
+    import torch
+    import torch.distributed as dist
+
+    out = {k: stats[k] for k in STAT_KEYS}
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if elapsed_s is not None:
+            out["elapsed_s"] = float(elapsed_s)
+        return out
+    # integers are exact in float64 up to 2^53 -- env-step counts of any realistic run
+    t = torch.tensor([float(stats[k]) for k in STAT_KEYS], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    for k, v in zip(STAT_KEYS, t.tolist()):
+        out[k] = v if k == "return_sum" else int(round(v))
+    if elapsed_s is not None:
+        e = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        out["elapsed_s"] = float(e[0])
+    return out
