@@ -36,11 +36,12 @@ struct CartPole {
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.05, b1 = 0.05; }
 
-    // cartpole.py:242  state = np_random.uniform(low, high, size=(4,))
-    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
+    // cartpole.py:242  state = np_random.uniform(low, high, size=(4,)); u[k] are the stream's next_double() values
+    static constexpr int NDRAWS = 4;
+    static MI_DEV void reset_u(const double u[NDRAWS], double s[S], uint32_t &flags, double b0, double b1) {
         const double range = b1 - b0;
 #pragma unroll
-        for (int k = 0; k < S; k++) s[k] = rng.uniform(b0, range);
+        for (int k = 0; k < S; k++) s[k] = b0 + range * u[k];
         (void)flags;
     }
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
@@ -87,9 +88,10 @@ struct Pendulum {
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
 
     // pendulum.py:149-167: high = [x_init, y_init], low = -high, uniform(low, high) -> theta, thetadot
-    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &, double x_init, double y_init) {
-        s[0] = rng.uniform(-x_init, x_init - (-x_init));
-        s[1] = rng.uniform(-y_init, y_init - (-y_init));
+    static constexpr int NDRAWS = 2;
+    static MI_DEV void reset_u(const double u[NDRAWS], double s[S], uint32_t &, double x_init, double y_init) {
+        s[0] = -x_init + (x_init - (-x_init)) * u[0];
+        s[1] = -y_init + (y_init - (-y_init)) * u[1];
     }
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
         double sn, cs;
@@ -139,10 +141,11 @@ struct Acrobot {
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.1, b1 = 0.1; }
 
     // acrobot.py:185-200: uniform(low, high, size=(4,)).astype(np.float32)
-    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
+    static constexpr int NDRAWS = 4;
+    static MI_DEV void reset_u(const double u[NDRAWS], double s[S], uint32_t &flags, double b0, double b1) {
         const double range = b1 - b0;
 #pragma unroll
-        for (int k = 0; k < S; k++) s[k] = (double)(float)rng.uniform(b0, range);
+        for (int k = 0; k < S; k++) s[k] = (double)(float)(b0 + range * u[k]);
         flags |= kStateF32;
     }
     // acrobot.py:232-237 (after a reset NumPy evaluates these in float32; we return the correctly rounded value)
@@ -220,8 +223,9 @@ struct MountainCar {
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
-    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
-        s[0] = rng.uniform(b0, b1 - b0);
+    static constexpr int NDRAWS = 1;
+    static MI_DEV void reset_u(const double u[NDRAWS], double s[S], uint32_t &flags, double b0, double b1) {
+        s[0] = b0 + (b1 - b0) * u[0];
         s[1] = 0.0;
         flags &= ~kStateF32;
     }
@@ -257,8 +261,9 @@ struct MountainCarContinuous {
     typedef float Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
-    static MI_DEV void reset(Pcg64 &rng, double s[S], uint32_t &flags, double b0, double b1) {
-        s[0] = rng.uniform(b0, b1 - b0);
+    static constexpr int NDRAWS = 1;
+    static MI_DEV void reset_u(const double u[NDRAWS], double s[S], uint32_t &flags, double b0, double b1) {
+        s[0] = b0 + (b1 - b0) * u[0];
         s[1] = 0.0;
         flags &= ~kStateF32;
     }

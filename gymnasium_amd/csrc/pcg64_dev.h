@@ -22,12 +22,21 @@ typedef unsigned __int128 u128;
 
 MI_HD u128 make_u128(uint64_t hi, uint64_t lo) { return ((u128)hi << 64) | (u128)lo; }
 MI_HD u128 pcg_mult() { return make_u128(0x2360ED051FC65DA4ULL, 0x4385DF649FCCF645ULL); }
+// Multiplicative inverse of pcg_mult() mod 2^128 (Newton: x <- x (2 - a x) doubles the number of correct low bits).
+MI_HD constexpr u128 pcg_mult_inverse() {
+    const u128 a = ((u128)0x2360ED051FC65DA4ULL << 64) | (u128)0x4385DF649FCCF645ULL;
+    u128 x = a;  // a * a == 1 (mod 8) for odd a: 3 correct bits
+    for (int it = 0; it < 7; it++) x = x * ((u128)2 - a * x);
+    return x;
+}
+static_assert(pcg_mult_inverse() * (((u128)0x2360ED051FC65DA4ULL << 64) | (u128)0x4385DF649FCCF645ULL) == (u128)1, "inverse");
 
 struct Pcg64 {
     u128 state;
     u128 inc;
 
     MI_HD void step() { state = state * pcg_mult() + inc; }
+    MI_HD void unstep() { state = (state - inc) * pcg_mult_inverse(); }  // exact inverse of step()
     MI_HD uint64_t next64() {
         step();
         uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;

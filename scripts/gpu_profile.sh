@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats + separate PMC passes for one bench.py configuration, then
+# summarise into gpurun_out/<tag>.txt (copy the summary to profiles/ afterwards).
+#   scripts/gpu_profile.sh <tag> [bench.py args...]
+set -u
+TAG=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+CMD="python $ROOT/bench.py --steps 20 --warmup 3 --no-api --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -- $CMD > "$OUT/${TAG}_stats.log" 2>&1
+PMC=()
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d "$OUT/${TAG}_$C" -- $CMD > "$OUT/${TAG}_$C.log" 2>&1 && PMC+=("$OUT/${TAG}_$C")
+done
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace \
+  -d "$OUT/${TAG}_SQ" -- $CMD > "$OUT/${TAG}_SQ.log" 2>&1 && PMC+=("$OUT/${TAG}_SQ")
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS --kernel-trace \
+  -d "$OUT/${TAG}_SQ2" -- $CMD > "$OUT/${TAG}_SQ2.log" 2>&1 && PMC+=("$OUT/${TAG}_SQ2")
+cd "$ROOT"
+python scripts/rocpd_summary.py --stats "$OUT/${TAG}_stats" --pmc "${PMC[@]}" --cmd "$CMD" -o "$OUT/${TAG}.txt" > /dev/null
+# keep the merge-back small: the raw databases are not needed once summarised
+rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_FETCH_SIZE" "$OUT/${TAG}_WRITE_SIZE" "$OUT/${TAG}_SQ" "$OUT/${TAG}_SQ2"
+tail -n +1 "$OUT/${TAG}.txt" | grep -i "rollout_kernel\|mj_" | head -40

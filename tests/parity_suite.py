@@ -293,12 +293,12 @@ def _dummy_factory(kind, num_envs, *a):
     return _E()
 
 
-def check_rollout_fused(key, factory, n=64, T=40):
+def check_rollout_fused(key, factory, n=64, T=40, **kw):
     """rollout(T) with on-device action sampling == T x step(action_space.sample()) on the same backend."""
     import torch
 
-    a = make(key, n, factory, output="torch")
-    b = make(key, n, factory, output="torch")
+    a = make(key, n, factory, output="torch", **kw)
+    b = make(key, n, factory, output="torch", **kw)
     a.reset(seed=5), b.reset(seed=5)
     a.action_space.seed(9), b.action_space.seed(9)
     out = a.rollout(T)

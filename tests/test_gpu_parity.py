@@ -65,6 +65,15 @@ def test_fused_rollout_equals_stepping(key):
     ps.check_rollout_fused(key, None)
 
 
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep"])
+@pytest.mark.parametrize("max_steps,T", [(1, 19), (2, 37), (3, 8), (7, 45)])
+def test_fused_rollout_short_episodes(mode, max_steps, T):
+    """Episodes shorter than the rollout kernel's reset-queue refill period: the on-demand draw path, the queue and the
+    hand-back of unconsumed draws (Pcg64::unstep) must leave trajectories and generator states exactly as stepping does."""
+    for key in ("cartpole", "pendulum", "mountaincar"):
+        ps.check_rollout_fused(key, None, n=192, T=T, max_episode_steps=max_steps, autoreset_mode=mode)
+
+
 # Free-running whole episodes.  CartPole / MountainCar x2 / Pendulum hold the 1e-5 tolerance for the whole episode.
 # Acrobot is a chaotic double pendulum: the <= 1-2 ulp (1e-16) difference between ocml's and glibc's sin/cos is
 # amplified exponentially along a free-running trajectory (measured over 4096 sub-envs: worst |obs diff| 1.3e-5 at
