@@ -97,10 +97,19 @@ MI_DEV void store_rng_state(const DevEnv &d, int i, const Pcg64 &r) {
 // every kRefillPeriod steps and a reset merely moves the queued values into the state.  The stream order is
 // unchanged (the env's generator is consumed by resets only), and unconsumed draws are handed back at the end of
 // the launch (Pcg64::unstep), so the generator state in HBM is always exactly the reference's.
+// The generator itself is held in registers for the whole launch: a loop without global loads also keeps the
+// compiler from draining the store queue (s_waitcnt vmcnt(0)) on every iteration -- loads and stores share one
+// in-order counter on gfx950.
 template <class E>
 struct ResetQueue {
     double u[E::NDRAWS];
     bool have;
+    Pcg64 rng;
+    MI_DEV void refill() {
+#pragma unroll
+        for (int k = 0; k < E::NDRAWS; k++) u[k] = rng.next_double();
+        have = true;
+    }
 };
 constexpr int kRefillPeriod = 8;
 
@@ -116,7 +125,8 @@ MI_DEV void draw_reset_values(const DevEnv &d, int i, double u[E::NDRAWS]) {
 template <class E>
 MI_DEV void lane_autoreset(const DevEnv &d, int i, Lane<E> &L, ResetQueue<E> *q) {
     double u[E::NDRAWS];
-    if (q && q->have) {
+    if (q) {
+        if (!q->have) q->refill();  // rare: two episode ends within one refill period
 #pragma unroll
         for (int k = 0; k < E::NDRAWS; k++) u[k] = q->u[k];
         q->have = false;
@@ -187,6 +197,53 @@ MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, Ste
         L.flags |= kNeedsReset;  // _autoreset_envs (:329)
     else
         L.flags &= ~kNeedsReset;
+}
+
+// NEXT_STEP step of one lane inside a fused rollout, written without divergent control flow: a wavefront that runs
+// alone on its SIMD pays an issue slot for every s_and_saveexec / s_cbranch and a refetch for every taken branch,
+// and with 64 CartPoles per wavefront some lane is in its autoreset step on ~95 % of the steps anyway.  So every
+// lane integrates (a finished episode's state is finite; the result is discarded) and the autoreset lanes SELECT the
+// queued reset values instead.  Same results as lane_step<E, NEXT_STEP>.
+template <class E, bool CHECK_ACTION>
+MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, StepOut<E> &o, LaneStats &st, ResetQueue<E> &q) {
+    const bool resetting = (L.flags & kNeedsReset) != 0;
+    if (__builtin_expect(resetting && !q.have, 0)) q.refill();  // rare: two episode ends within one refill period
+    if (CHECK_ACTION && !resetting && !E::valid(a)) {
+        *d.error = kErrInvalidAction;
+        a = (typename E::Act)0;
+    }
+    // the reset candidate (sync_vector_env.py:279-284)
+    double rs[E::S], b0, b1;
+    uint32_t rflags = L.flags & ~kNeedsReset;
+    E::default_bounds(b0, b1);
+    E::reset_u(q.u, rs, rflags, b0, b1);
+    // the step candidate
+    double rew;
+    bool te;
+    uint32_t sflags = L.flags;
+    E::step(L.s, sflags, a, d.P, rew, te);
+    const uint32_t elapsed = L.elapsed + 1;  // TimeLimit.step (wrappers/common.py:129-133)
+    const bool tr = d.max_steps > 0 && (int)elapsed >= d.max_steps;
+    const double ep_ret = L.ep_ret + rew;
+    const int32_t ep_len = L.ep_len + 1;
+    const bool done = !resetting && (te || tr);
+#pragma unroll
+    for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
+    L.flags = resetting ? rflags : (done ? (sflags | kNeedsReset) : sflags);
+    L.elapsed = resetting ? 0u : elapsed;
+    L.ep_ret = resetting ? 0.0 : ep_ret;
+    L.ep_len = resetting ? 0 : ep_len;
+    q.have = q.have && !resetting;
+    st.reset_steps += resetting ? 1u : 0u;
+    st.env_steps += resetting ? 0u : 1u;
+    st.episodes += done ? 1u : 0u;
+    st.return_sum += done ? ep_ret : 0.0;
+    st.length_sum += done ? (uint64_t)ep_len : 0ull;
+    E::obs(L.s, L.flags, o.obs);
+    o.reward = resetting ? 0.0 : rew;
+    o.terminated = !resetting && te, o.truncated = !resetting && tr;
+    o.ep_ret = done ? ep_ret : 0.0, o.ep_len = done ? ep_len : 0;
+    o.has_final = false;
 }
 
 template <int W>
@@ -320,7 +377,9 @@ struct RolloutPtrs {
     uint8_t *terminated, *truncated;
 };
 
-template <class E, int MODE, bool SAMPLE>
+// FULL: every trajectory output is materialised -- the per-store null checks (five taken branches per step for a
+// wavefront that runs alone on its SIMD) disappear from the loop.
+template <class E, int MODE, bool SAMPLE, bool FULL>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
@@ -340,11 +399,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
         const size_t N = (size_t)d.N;
         ResetQueue<E> q;
         q.have = false;
+        q.rng = load_rng(d, i);
         for (int t = 0; t < T; t++) {
-            if ((t & (kRefillPeriod - 1)) == 0 && !q.have) {
-                draw_reset_values<E>(d, i, q.u);
-                q.have = true;
-            }
+            if ((t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
             typename E::Act a;
             if (SAMPLE) {
                 const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate;
@@ -353,24 +410,26 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
                 const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
                 a = E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
                 astate = as.jump_n.mult * astate + as.jump_n.plus;
-                if (io.actions_out) static_cast<typename E::Act *>(io.actions_out)[t * N + i] = a;
+                if (FULL || io.actions_out) static_cast<typename E::Act *>(io.actions_out)[t * N + i] = a;
             } else {
                 a = static_cast<const typename E::Act *>(io.actions_in)[t * N + i];
             }
             StepOut<E> o;
-            lane_step<E, MODE>(d, i, L, a, o, st, &q);
-            if (io.obs) store_row<E::OBS>(io.obs + (t * N + i) * E::OBS, o.obs);
-            if (io.reward) io.reward[t * N + i] = o.reward;
-            if (io.terminated) io.terminated[t * N + i] = o.terminated;
-            if (io.truncated) io.truncated[t * N + i] = o.truncated;
+            if (MODE == MI_AUTORESET_NEXT_STEP)
+                lane_step_fused<E, !SAMPLE>(d, L, a, o, st, q);
+            else
+                lane_step<E, MODE>(d, i, L, a, o, st, &q);
+            if (FULL || io.obs) store_row<E::OBS>(io.obs + (t * N + i) * E::OBS, o.obs);
+            if (FULL || io.reward) io.reward[t * N + i] = o.reward;
+            if (FULL || io.terminated) io.terminated[t * N + i] = o.terminated;
+            if (FULL || io.truncated) io.truncated[t * N + i] = o.truncated;
         }
         store_lane<E>(d, i, L);
         if (q.have) {  // hand the unconsumed draws back to the env's generator
-            Pcg64 rng = load_rng(d, i);
 #pragma unroll
-            for (int k = 0; k < E::NDRAWS; k++) rng.unstep();
-            store_rng_state(d, i, rng);
+            for (int k = 0; k < E::NDRAWS; k++) q.rng.unstep();
         }
+        store_rng_state(d, i, q.rng);
     }
     block_accumulate(d, st);
 }
@@ -486,20 +545,25 @@ int launch_step(mi_vecenv *v, const StepPtrs &p) {
     return MI_OK;
 }
 
+template <class E, int MODE, bool SAMPLE, bool FULL>
+void launch_rollout_variant(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T) {
+    hipLaunchKernelGGL((rollout_kernel<E, MODE, SAMPLE, FULL>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p, as, T);
+}
+
 template <class E>
 int launch_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample) {
-    const dim3 g(v->grid), b(kBlock);
-    if (v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP) {
-        if (sample)
-            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
-        else
-            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
-    } else {
-        if (sample)
-            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
-        else
-            hipLaunchKernelGGL((rollout_kernel<E, MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
-    }
+    const bool next_step = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
+    const bool full = p.obs && p.reward && p.terminated && p.truncated && (!sample || p.actions_out);
+    if (next_step && sample && full)  // the collector's configuration (bench.py)
+        launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, true>(v, p, as, T);
+    else if (next_step && sample)
+        launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, false>(v, p, as, T);
+    else if (next_step)
+        launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, false, false>(v, p, as, T);
+    else if (sample)
+        launch_rollout_variant<E, MI_AUTORESET_SAME_STEP, true, false>(v, p, as, T);
+    else
+        launch_rollout_variant<E, MI_AUTORESET_SAME_STEP, false, false>(v, p, as, T);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }

