@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
                 const uint64_t x = hi ^ lo;
                 const unsigned rot = (unsigned)(hi >> 58);
                 const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
-                a = E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
+                a = E::SAMPLE_FROM_BITS ? E::sample_bits(out) : E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
                 astate = as.jump_n.mult * astate + as.jump_n.plus;
                 if (FULL || io.actions_out) static_cast<typename E::Act *>(io.actions_out)[t * N + i] = a;
             } else {

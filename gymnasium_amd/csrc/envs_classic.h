@@ -93,10 +93,14 @@ struct CartPole {
     }
     static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
     static MI_DEV Act sample(double u) { return (Act)(u * 2.0); }  // (random(N) * nvec).astype(int64)
+    // the same value straight from the 64 random bits: u = (bits >> 11) * 2^-53, and u * 2.0 is exact, so
+    // floor(u * 2) is the top bit
+    static constexpr bool SAMPLE_FROM_BITS = true;
+    static MI_DEV Act sample_bits(uint64_t bits) { return (Act)(bits >> 63); }
 
     // cartpole.py:164-226: explicit Euler with the OLD velocities, all float64.
     static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
-        const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+        const double gravity = 9.8, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
         const double polemass_length = masspole * length;
         const double theta_threshold = 12 * 2 * kPi / 360;
         const double x_threshold = 2.4;
@@ -142,6 +146,8 @@ struct Pendulum {
     }
     static MI_DEV bool valid(Act) { return true; }
     static MI_DEV Act sample(double u) { return (Act)(-2.0 + (2.0 - (-2.0)) * u); }  // Box.sample: uniform(low, high).astype(f32)
+    static constexpr bool SAMPLE_FROM_BITS = false;
+    static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
     static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
         const double max_speed = 8, max_torque = 2.0, dt = 0.05, m = 1.0, l = 1.0;
@@ -198,7 +204,9 @@ struct Acrobot {
         o[0] = (float)c1, o[1] = (float)s1, o[2] = (float)c2, o[3] = (float)s2, o[4] = (float)s[2], o[5] = (float)s[3];
     }
     static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
-    static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }
+    static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }  // u * 3.0 rounds: not reducible to integer arithmetic
+    static constexpr bool SAMPLE_FROM_BITS = false;
+    static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
     // acrobot.py:244-279, "book" dynamics; y = (theta1, theta2, dtheta1, dtheta2), a = torque
     static MI_DEV void dsdt(const double y[4], double a, double d[4]) {
@@ -273,7 +281,9 @@ struct MountainCar {
     }
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) { o[0] = (float)s[0], o[1] = (float)s[1]; }
     static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
-    static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }
+    static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }  // u * 3.0 rounds: not reducible to integer arithmetic
+    static constexpr bool SAMPLE_FROM_BITS = false;
+    static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
     static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
         const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5;
@@ -312,6 +322,8 @@ struct MountainCarContinuous {
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) { o[0] = (float)s[0], o[1] = (float)s[1]; }
     static MI_DEV bool valid(Act) { return true; }
     static MI_DEV Act sample(double u) { return (Act)(-1.0 + (1.0 - (-1.0)) * u); }
+    static constexpr bool SAMPLE_FROM_BITS = false;
+    static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
     static MI_DEV void step(double s[S], uint32_t &flags, Act a0, const EnvParams &P, double &reward, bool &terminated) {
         const double min_action = -1.0, max_action = 1.0, min_position = -1.2, max_position = 0.6, max_speed = 0.07;
