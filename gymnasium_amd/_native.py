@@ -15,9 +15,10 @@ MI_OK = 0
 MI_HOST, MI_DEVICE = 0, 1
 MI_F32, MI_F64, MI_I64 = 0, 1, 2
 FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4}
+ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
+             "half_cheetah": 5, "ant": 6, "humanoid": 7}
 AUTORESET = {"NextStep": 0, "SameStep": 1, "Disabled": 2}
 NP_DTYPES = {MI_F32: np.float32, MI_F64: np.float64, MI_I64: np.int64}
 
@@ -31,18 +32,18 @@ SYMBOLS = [
 
 class MiConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("kind", C.c_int32), ("num_envs", C.c_int32), ("max_episode_steps", C.c_int32),
-                ("autoreset_mode", C.c_int32), ("reserved", C.c_int32 * 3), ("params", C.c_double * 8)]
+                ("autoreset_mode", C.c_int32), ("reserved", C.c_int32 * 3), ("params", C.c_double * 16)]
 
 
 class MiLayout(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("obs_dtype", C.c_int32), ("act_dim", C.c_int32), ("act_dtype", C.c_int32),
-                ("state_dim", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("state_dim", C.c_int32), ("info_dim", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class MiStepIO(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
                 ("truncated", C.c_void_p), ("final_obs", C.c_void_p), ("episode_return", C.c_void_p),
-                ("episode_length", C.c_void_p)]
+                ("episode_length", C.c_void_p), ("info", C.c_void_p)]
 
 
 class MiRolloutIO(C.Structure):
@@ -178,7 +179,7 @@ class Engine:
         self.num_envs = int(num_envs)
         lay = MiLayout()
         lib.check(lib.get_layout(handle, C.byref(lay)))
-        self.obs_dim, self.act_dim, self.state_dim = lay.obs_dim, lay.act_dim, lay.state_dim
+        self.obs_dim, self.act_dim, self.state_dim, self.info_dim = lay.obs_dim, lay.act_dim, lay.state_dim, lay.info_dim
         self.obs_dtype, self.act_dtype = NP_DTYPES[lay.obs_dtype], NP_DTYPES[lay.act_dtype]
         self._step_io = MiStepIO()
         self._rollout_io = MiRolloutIO()
@@ -207,11 +208,11 @@ class Engine:
         self.lib.check(self.lib.reset(self.handle, _ptr(mask), _ptr(b), _ptr(obs), loc))
 
     def step(self, actions, obs, reward, terminated, truncated, final_obs=None, episode_return=None,
-             episode_length=None, loc=MI_HOST):
+             episode_length=None, loc=MI_HOST, info=None):
         io = self._step_io
         io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
         io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
-        io.episode_return, io.episode_length = _ptr(episode_return), _ptr(episode_length)
+        io.episode_return, io.episode_length, io.info = _ptr(episode_return), _ptr(episode_length), _ptr(info)
         self.lib.check(self.lib.step(self.handle, C.byref(io), loc))
 
     def action_seed(self, words):

@@ -472,14 +472,15 @@ int fail(int code, const char *fmt, const char *detail = "") {
         }                                                                                                 \
     } while (0)
 
-const mi_layout kLayouts[MI_ENV_KIND_COUNT] = {
-    {CartPole::OBS, MI_F32, 1, MI_I64, CartPole::S, {0, 0, 0}},
-    {Pendulum::OBS, MI_F32, 1, MI_F32, Pendulum::S, {0, 0, 0}},
-    {Acrobot::OBS, MI_F32, 1, MI_I64, Acrobot::S, {0, 0, 0}},
-    {MountainCar::OBS, MI_F32, 1, MI_I64, MountainCar::S, {0, 0, 0}},
-    {MountainCarContinuous::OBS, MI_F32, 1, MI_F32, MountainCarContinuous::S, {0, 0, 0}},
+constexpr int kClassicKinds = 5;
+const mi_layout kLayouts[kClassicKinds] = {
+    {CartPole::OBS, MI_F32, 1, MI_I64, CartPole::S, 0, {0, 0}},
+    {Pendulum::OBS, MI_F32, 1, MI_F32, Pendulum::S, 0, {0, 0}},
+    {Acrobot::OBS, MI_F32, 1, MI_I64, Acrobot::S, 0, {0, 0}},
+    {MountainCar::OBS, MI_F32, 1, MI_I64, MountainCar::S, 0, {0, 0}},
+    {MountainCarContinuous::OBS, MI_F32, 1, MI_F32, MountainCarContinuous::S, 0, {0, 0}},
 };
-const int kNumActions[MI_ENV_KIND_COUNT] = {2, 0, 3, 3, 0};
+const int kNumActions[MI_ENV_KIND_COUNT] = {2, 0, 3, 3, 0, 0, 0, 0};
 
 }  // namespace
 
@@ -593,6 +594,7 @@ int mi_device_count(void) {
 int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mi_config)) return fail(MI_ERR_INVALID_ARGUMENT, "bad mi_config");
     if (cfg->kind < 0 || cfg->kind >= MI_ENV_KIND_COUNT) return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
+    if (cfg->kind >= kClassicKinds) return fail(MI_ERR_UNSUPPORTED, "MuJoCo kinds are served by the mjx engine (not built into this library yet)");
     if (cfg->num_envs < 1) return fail(MI_ERR_INVALID_ARGUMENT, "num_envs must be >= 1");
     if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2) return fail(MI_ERR_INVALID_ARGUMENT, "bad autoreset mode");
     if (cfg->max_episode_steps > (int)kElapsedMask) return fail(MI_ERR_INVALID_ARGUMENT, "max_episode_steps too large");
@@ -611,7 +613,7 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     v->grid = (int)((N + kBlock - 1) / kBlock);
     DevEnv &d = v->d;
     d.N = cfg->num_envs, d.max_steps = cfg->max_episode_steps;
-    for (int k = 0; k < 8; k++) d.P.p[k] = cfg->params[k];
+    for (int k = 0; k < 16; k++) d.P.p[k] = cfg->params[k];
     HIP_TRY(hipMalloc(&d.state, sizeof(double) * v->lay.state_dim * N));
     HIP_TRY(hipMalloc(&d.meta, sizeof(uint32_t) * N));
     HIP_TRY(hipMalloc(&d.rng, sizeof(uint64_t) * 4 * N));

@@ -62,7 +62,7 @@ MI_DEV double div_by_constant(double x, C) {
 }
 
 struct EnvParams {
-    double p[8];
+    double p[16];
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1,0 +1,146 @@
+"""HalfCheetah-v5 / Ant-v5 / Humanoid-v5 as lockstep MI355X vector environments.
+
+Each class is the ``vector_entry_point`` creator for one id; its constructor takes the kwargs of the reference's scalar env
+(``make_vec`` forwards them verbatim, envs/registration.py:957-963) and describes the same spaces:
+
+  HalfCheetahVectorEnv   envs/mujoco/half_cheetah_v5.py:153-218   obs float64[17],  action float32[6]  in [-1, 1]
+  AntVectorEnv           envs/mujoco/ant_v5.py:228-321            obs float64[105], action float32[8]  in [-1, 1]
+  HumanoidVectorEnv      envs/mujoco/humanoid_v5.py:307-411       obs float64[348], action float32[17] in [-0.4, 0.4]
+
+Observation space: Box(-inf, inf, (obs_size,), float64); action space: Box(ctrlrange, float32) (mujoco_env.py:113-117).
+The robots themselves are gymnasium_amd/envs/mujoco/models.py (a transcription of the reference's MJCF assets); the
+physics runs in gymnasium_amd/csrc (HIP).  Nothing here computes a step.  rendering / xml_file overrides are not
+supported (GPU-resident lanes): ``xml_file`` other than the stock asset raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ...gym_api import error, spaces
+from ...vector.hip_vector_env import HipVectorEnv
+
+
+class _MujocoVectorEnv(HipVectorEnv):
+    STOCK_XML = ""
+    NQ = NV = NU = NBODY = 0
+    CTRL_LOW = CTRL_HIGH = 0.0
+
+    def _check_common(self, xml_file, frame_skip, kwargs):
+        if xml_file != self.STOCK_XML:
+            raise error.Error(f"gymnasium_amd runs the stock {self.STOCK_XML} model compiled into the engine; got xml_file={xml_file!r}")
+        for k in ("default_camera_config", "width", "height", "camera_id", "camera_name", "max_geom", "visual_options"):
+            kwargs.pop(k, None)  # rendering-only arguments of MujocoEnv (mujoco_env.py:38-55)
+        self.frame_skip = int(frame_skip)
+
+    def _single_spaces(self):
+        obs = spaces.Box(low=-np.inf, high=np.inf, shape=(self._obs_size(),), dtype=np.float64)
+        low = np.full(self.NU, self.CTRL_LOW, dtype=np.float32)
+        high = np.full(self.NU, self.CTRL_HIGH, dtype=np.float32)
+        return obs, spaces.Box(low=low, high=high, dtype=np.float32)
+
+    def _parse_reset_options(self, options):
+        return None  # MujocoEnv.reset ignores options (mujoco_env.py:172-187)
+
+
+class HalfCheetahVectorEnv(_MujocoVectorEnv):
+    KIND = "half_cheetah"
+    DEFAULT_MAX_EPISODE_STEPS = 1000
+    STOCK_XML = "half_cheetah.xml"
+    NQ, NV, NU, NBODY = 9, 9, 6, 8
+    CTRL_LOW, CTRL_HIGH = -1.0, 1.0
+    INFO_KEYS = ("x_position", "x_velocity", "reward_forward", "reward_ctrl")
+    N_RESET_INFO_KEYS = 1
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "half_cheetah.xml", frame_skip: int = 5,
+                 forward_reward_weight: float = 1.0, ctrl_cost_weight: float = 0.1, reset_noise_scale: float = 0.1,
+                 exclude_current_positions_from_observation: bool = True, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._params = (forward_reward_weight, ctrl_cost_weight, reset_noise_scale, float(bool(exclude_current_positions_from_observation)),
+                        float(frame_skip))
+        self._exclude = bool(exclude_current_positions_from_observation)
+        self.observation_structure = {"skipped_qpos": 1 * self._exclude, "qpos": self.NQ - 1 * self._exclude, "qvel": self.NV}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return self.NQ + self.NV - self._exclude
+
+    def _engine_params(self):
+        return self._params
+
+
+class AntVectorEnv(_MujocoVectorEnv):
+    KIND = "ant"
+    DEFAULT_MAX_EPISODE_STEPS = 1000
+    STOCK_XML = "ant.xml"
+    NQ, NV, NU, NBODY = 15, 14, 8, 14
+    CTRL_LOW, CTRL_HIGH = -1.0, 1.0
+    INFO_KEYS = ("x_position", "y_position", "distance_from_origin", "x_velocity", "y_velocity", "reward_forward", "reward_ctrl",
+                 "reward_contact", "reward_survive")
+    N_RESET_INFO_KEYS = 3
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "ant.xml", frame_skip: int = 5,
+                 forward_reward_weight: float = 1, ctrl_cost_weight: float = 0.5, contact_cost_weight: float = 5e-4,
+                 healthy_reward: float = 1.0, main_body: int | str = 1, terminate_when_unhealthy: bool = True,
+                 healthy_z_range=(0.2, 1.0), contact_force_range=(-1.0, 1.0), reset_noise_scale: float = 0.1,
+                 exclude_current_positions_from_observation: bool = True, include_cfrc_ext_in_observation: bool = True, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        if main_body not in (1, "torso"):
+            raise error.Error("gymnasium_amd Ant tracks the torso (main_body=1) only")
+        self._exclude, self._cfrc = bool(exclude_current_positions_from_observation), bool(include_cfrc_ext_in_observation)
+        self._params = (forward_reward_weight, ctrl_cost_weight, reset_noise_scale, float(self._exclude), float(frame_skip),
+                        contact_cost_weight, healthy_reward, float(bool(terminate_when_unhealthy)), healthy_z_range[0], healthy_z_range[1],
+                        contact_force_range[0], contact_force_range[1], float(self._cfrc))
+        self.observation_structure = {"skipped_qpos": 2 * self._exclude, "qpos": self.NQ - 2 * self._exclude, "qvel": self.NV,
+                                      "cfrc_ext": 6 * (self.NBODY - 1) * self._cfrc}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return self.NQ + self.NV - 2 * self._exclude + 6 * (self.NBODY - 1) * self._cfrc
+
+    def _engine_params(self):
+        return self._params
+
+
+class HumanoidVectorEnv(_MujocoVectorEnv):
+    KIND = "humanoid"
+    DEFAULT_MAX_EPISODE_STEPS = 1000
+    STOCK_XML = "humanoid.xml"
+    NQ, NV, NU, NBODY = 24, 23, 17, 14
+    CTRL_LOW, CTRL_HIGH = -0.4, 0.4
+    INFO_KEYS = AntVectorEnv.INFO_KEYS
+    N_RESET_INFO_KEYS = 3
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "humanoid.xml", frame_skip: int = 5,
+                 forward_reward_weight: float = 1.25, ctrl_cost_weight: float = 0.1, contact_cost_weight: float = 5e-7,
+                 contact_cost_range=(-np.inf, 10.0), healthy_reward: float = 5.0, terminate_when_unhealthy: bool = True,
+                 healthy_z_range=(1.0, 2.0), reset_noise_scale: float = 1e-2, exclude_current_positions_from_observation: bool = True,
+                 include_cinert_in_observation: bool = True, include_cvel_in_observation: bool = True,
+                 include_qfrc_actuator_in_observation: bool = True, include_cfrc_ext_in_observation: bool = True, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._exclude = bool(exclude_current_positions_from_observation)
+        inc = [bool(include_cinert_in_observation), bool(include_cvel_in_observation), bool(include_qfrc_actuator_in_observation),
+               bool(include_cfrc_ext_in_observation)]
+        self._inc = inc
+        self._params = (forward_reward_weight, ctrl_cost_weight, reset_noise_scale, float(self._exclude), float(frame_skip),
+                        contact_cost_weight, healthy_reward, float(bool(terminate_when_unhealthy)), healthy_z_range[0], healthy_z_range[1],
+                        contact_cost_range[0], contact_cost_range[1], *[float(x) for x in inc])
+        nb1 = self.NBODY - 1
+        self.observation_structure = {"skipped_qpos": 2 * self._exclude, "qpos": self.NQ - 2 * self._exclude, "qvel": self.NV,
+                                      "cinert": 10 * nb1 * inc[0], "cvel": 6 * nb1 * inc[1], "qfrc_actuator": (self.NV - 6) * inc[2],
+                                      "cfrc_ext": 6 * nb1 * inc[3], "ten_length": 0, "ten_velocity": 0}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        nb1, inc = self.NBODY - 1, self._inc
+        return self.NQ + self.NV - 2 * self._exclude + 10 * nb1 * inc[0] + 6 * nb1 * inc[1] + (self.NV - 6) * inc[2] + 6 * nb1 * inc[3]
+
+    def _engine_params(self):
+        return self._params
+
+
+# id -> (creator, max_episode_steps, reward_threshold): gymnasium/envs/__init__.py:283-288, 353-358, 370-374
+ENV_TABLE = {
+    "HalfCheetah-v5": (HalfCheetahVectorEnv, 1000, 4800.0),
+    "Ant-v5": (AntVectorEnv, 1000, 6000.0),
+    "Humanoid-v5": (HumanoidVectorEnv, 1000, None),
+}

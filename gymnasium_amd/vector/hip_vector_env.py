@@ -59,6 +59,8 @@ class HipVectorEnv(VectorEnv):
 
     KIND: str = ""
     DEFAULT_MAX_EPISODE_STEPS: int | None = None
+    INFO_KEYS: tuple = ()        # names of the engine's info columns (MuJoCo envs); the first N_RESET_INFO_KEYS are also
+    N_RESET_INFO_KEYS: int = 0   # what the scalar env's reset() reports (_get_reset_info), i.e. valid on autoreset steps
     metadata: dict[str, Any] = {"render_modes": [], "autoreset_mode": AutoresetMode.NEXT_STEP}
 
     # -- to be provided by subclasses ------------------------------------------------------------------
@@ -125,11 +127,13 @@ class HipVectorEnv(VectorEnv):
             self._torch = torch
             dev = torch.device("cuda", self._device_index)
             self._tdev = dev
-            self._obs = torch.zeros((N, eng.obs_dim), dtype=torch.float32, device=dev)
+            self._obs_tdtype = torch.float64 if eng.obs_dtype is np.float64 else torch.float32
+            self._obs = torch.zeros((N, eng.obs_dim), dtype=self._obs_tdtype, device=dev)
             self._rew = torch.zeros((N,), dtype=torch.float64, device=dev)
             self._term = torch.zeros((N,), dtype=torch.bool, device=dev)
             self._trunc = torch.zeros((N,), dtype=torch.bool, device=dev)
-            self._final = torch.zeros((N, eng.obs_dim), dtype=torch.float32, device=dev) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
+            self._final = torch.zeros((N, eng.obs_dim), dtype=self._obs_tdtype, device=dev) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
+            self._info = torch.zeros((N, eng.info_dim), dtype=torch.float64, device=dev) if eng.info_dim else None
             self._ep_r = torch.zeros((N,), dtype=torch.float64, device=dev) if self.record_episode_statistics else None
             self._ep_l = torch.zeros((N,), dtype=torch.int32, device=dev) if self.record_episode_statistics else None
             self._loc = _native.MI_DEVICE
@@ -139,6 +143,7 @@ class HipVectorEnv(VectorEnv):
             self._term = np.zeros((N,), dtype=np.bool_)
             self._trunc = np.zeros((N,), dtype=np.bool_)
             self._final = np.zeros((N, eng.obs_dim), dtype=eng.obs_dtype) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
+            self._info = np.zeros((N, eng.info_dim), dtype=np.float64) if eng.info_dim else None
             self._ep_r = np.zeros((N,), dtype=np.float64) if self.record_episode_statistics else None
             self._ep_l = np.zeros((N,), dtype=np.int32) if self.record_episode_statistics else None
             self._loc = _native.MI_HOST
@@ -227,6 +232,7 @@ class HipVectorEnv(VectorEnv):
         else:
             self._engine.reset(mask, bounds, self._obs, _native.MI_HOST)
         self._has_reset = True
+        self._was_done = np.zeros(self.num_envs, dtype=np.bool_)
         if self.record_episode_statistics:
             now = time.perf_counter()
             if mask is None:
@@ -270,7 +276,7 @@ class HipVectorEnv(VectorEnv):
         self._bind_stream()
         try:
             self._engine.step(aptr, self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc),
-                              self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc)
+                              self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc, self._p(self._info))
         except _native.NativeError as e:
             if e.code == -1:  # MI_ERR_INVALID_ARGUMENT: action outside the space (cartpole.py:165-167 asserts)
                 raise AssertionError(e.message) from e
@@ -284,6 +290,18 @@ class HipVectorEnv(VectorEnv):
     def _build_infos(self) -> dict:
         infos: dict[str, Any] = {}
         need_final = self.autoreset_mode == AutoresetMode.SAME_STEP
+        if self.INFO_KEYS and self._info is not None:
+            # VectorEnv._add_info (vector_env.py:277-338): one array per key plus a `_key` mask of the envs that supplied
+            # it; an env in its NEXT_STEP autoreset step supplies only its reset info (sync_vector_env.py:279-284)
+            info = self._info.cpu().numpy() if self.output == "torch" else self._info
+            stepping = ~self._was_done if self.autoreset_mode == AutoresetMode.NEXT_STEP else np.ones(self.num_envs, dtype=np.bool_)
+            for k, name in enumerate(self.INFO_KEYS):
+                infos[name] = info[:, k].copy()
+                infos["_" + name] = np.ones(self.num_envs, dtype=np.bool_) if k < self.N_RESET_INFO_KEYS else stepping.copy()
+            if self.output == "torch":
+                self._was_done = (self._term | self._trunc).cpu().numpy()
+            else:
+                self._was_done = np.logical_or(self._term, self._trunc)
         if not need_final and not self.record_episode_statistics:
             return infos
         if self.output == "torch":
@@ -344,7 +362,7 @@ class HipVectorEnv(VectorEnv):
             eng.action_seed(_native.pcg_words(self.action_space.np_random))
             if return_actions:
                 a_out = t.empty(act_shape, dtype=act_dtype, device=dev)
-        obs = t.empty((T, N, eng.obs_dim), dtype=t.float32, device=dev)
+        obs = t.empty((T, N, eng.obs_dim), dtype=self._obs_tdtype, device=dev)
         rew = t.empty((T, N), dtype=t.float64, device=dev)
         term = t.empty((T, N), dtype=t.bool, device=dev)
         trunc = t.empty((T, N), dtype=t.bool, device=dev)

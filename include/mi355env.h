@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355ENV_ABI_VERSION 1
+#define MI355ENV_ABI_VERSION 2
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -43,7 +43,11 @@ typedef enum mi_env_kind {
     MI_ENV_ACROBOT = 2,                /* envs/classic_control/acrobot.py:172-279,375-461 (Acrobot-v1)          */
     MI_ENV_MOUNTAIN_CAR = 3,           /* envs/classic_control/mountain_car.py:108-170 (MountainCar-v0)         */
     MI_ENV_MOUNTAIN_CAR_CONTINUOUS = 4, /* envs/classic_control/continuous_mountain_car.py:116-194              */
-    MI_ENV_KIND_COUNT = 5
+    /* MuJoCo family: the env class + MujocoEnv (envs/mujoco/mujoco_env.py:35-229) + the `mujoco` physics it calls  */
+    MI_ENV_HALF_CHEETAH = 5,           /* envs/mujoco/half_cheetah_v5.py:153-281 + assets/half_cheetah.xml     */
+    MI_ENV_ANT = 6,                    /* envs/mujoco/ant_v5.py:228-428 + assets/ant.xml                       */
+    MI_ENV_HUMANOID = 7,               /* envs/mujoco/humanoid_v5.py:307-541 + assets/humanoid.xml             */
+    MI_ENV_KIND_COUNT = 8
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */
@@ -65,6 +69,14 @@ typedef enum mi_dtype { MI_F32 = 0, MI_F64 = 1, MI_I64 = 2 } mi_dtype;
  *     CARTPOLE                 params[0] = sutton_barto_reward (0/1)          cartpole.py:119-121
  *     PENDULUM                 params[0] = g (default 10.0)                   pendulum.py:102
  *     MOUNTAIN_CAR(_CONTINUOUS) params[0] = goal_velocity (default 0)         mountain_car.py:108
+ *     HALF_CHEETAH / ANT / HUMANOID (constructor kwargs of half_cheetah_v5.py:153-164, ant_v5.py:228-245,
+ *     humanoid_v5.py:307-326; all three share slots 0-4, the last two share 5-11):
+ *       [0] forward_reward_weight  [1] ctrl_cost_weight  [2] reset_noise_scale
+ *       [3] exclude_current_positions_from_observation (0/1)  [4] frame_skip
+ *       [5] contact_cost_weight  [6] healthy_reward  [7] terminate_when_unhealthy (0/1)  [8],[9] healthy_z_range
+ *       [10],[11] ANT: contact_force_range / HUMANOID: contact_cost_range
+ *       [12] ANT: include_cfrc_ext_in_observation / HUMANOID: include_cinert_in_observation
+ *       [13],[14],[15] HUMANOID: include_cvel / include_qfrc_actuator / include_cfrc_ext _in_observation
  */
 typedef struct mi_config {
     int32_t struct_size;         /* = sizeof(mi_config) */
@@ -73,7 +85,7 @@ typedef struct mi_config {
     int32_t max_episode_steps;   /* TimeLimit (wrappers/common.py:116-150); <= 0 disables truncation */
     int32_t autoreset_mode;      /* mi_autoreset_mode */
     int32_t reserved[3];
-    double params[8];
+    double params[16];
 } mi_config;
 
 typedef struct mi_layout {
@@ -82,7 +94,11 @@ typedef struct mi_layout {
     int32_t act_dim;      /* action row length; discrete envs: 1 element of MI_I64 per env */
     int32_t act_dtype;    /* mi_dtype */
     int32_t state_dim;    /* physics state row length for mi_get_state/mi_set_state (float64) */
-    int32_t reserved[3];
+    int32_t info_dim;     /* per-env info row length (float64), 0 for classic control; MuJoCo columns:
+                             HALF_CHEETAH: x_position, x_velocity, reward_forward, reward_ctrl   (half_cheetah_v5.py:230,241-246)
+                             ANT / HUMANOID: x_position, y_position, distance_from_origin, x_velocity, y_velocity,
+                                             reward_forward, reward_ctrl, reward_contact, reward_survive (ant_v5.py:359-366,384-389) */
+    int32_t reserved[2];
 } mi_layout;
 
 /*
@@ -96,6 +112,7 @@ typedef struct mi_layout {
  *   final_obs        out  [N][obs_dim]  SAME_STEP only: rows of envs that finished this step (others untouched)
  *   episode_return   out  [N] f64      vector RecordEpisodeStatistics "r" (wrappers/vector/common.py:156-235):
  *   episode_length   out  [N] i32      "l"; both 0 where the env did not finish an episode this step
+ *   info             out  [N][info_dim] f64   the numeric entries of the scalar env's info dict (layout.info_dim columns)
  */
 typedef struct mi_step_io {
     const void *actions;
@@ -106,6 +123,7 @@ typedef struct mi_step_io {
     void *final_obs;
     double *episode_return;
     int32_t *episode_length;
+    double *info;
 } mi_step_io;
 
 /* Buffers of one fused rollout() call: T consecutive step()s in one launch, time-major [T][N][dim].
@@ -179,6 +197,8 @@ int mi_reset_stats(mi_vecenv *env);
 /* Per-env flag bits of mi_get_state/mi_set_state. */
 #define MI_FLAG_NEEDS_RESET 1u /* the env finished last step (SyncVectorEnv._autoreset_envs, sync_vector_env.py:329) */
 #define MI_FLAG_STATE_F32 2u   /* MountainCarContinuous: state currently held as float32 (continuous_mountain_car.py:178) */
+/* MuJoCo kinds: a state row is [qpos(nq), qvel(nv), qacc_warmstart(nv), tracked_x, tracked_y] -- the Cartesian position
+ * the next step's velocity reward is differenced against comes from the last forward pass and lags qpos. */
 /* Physics state rows [N][state_dim] float64 (host pointers); checkpoint/resume + teacher-forced tests.
  * Replaces poking env.unwrapped.state (tests/envs/test_env_implementation.py:255-321 compares it). */
 int mi_get_state(mi_vecenv *env, double *state, int32_t *elapsed_steps, uint8_t *flags);

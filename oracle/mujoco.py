@@ -1,0 +1,101 @@
+"""ctypes access to the MuJoCo-pipeline oracle (oracle/mujoco_core.c).  TEST INFRASTRUCTURE, PARITY UNPINNED.
+
+    model = OracleModel("ant")          # compiles the model description, hands the blob to C
+    data = model.make_data()
+    data.set_state(qpos, qvel, ctrl); data.forward(); data.get("qM") ...
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from gymnasium_amd.envs.mujoco import compiler
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+_DLL = None
+
+
+def model_blob(m) -> np.ndarray:
+    """Serialise a CompiledModel in the order mjo_model_from_blob (mujoco_core.c) reads it."""
+    parts = [[m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, len(m.pair_geom1), 1 if m.integrator == "RK4" else 0,
+              1 if m.solver == "PGS" else 0, m.iterations, m.timestep], m.gravity, [m.meaninertia],
+             m.body_parentid, m.body_rootid, m.body_jntadr, m.body_jntnum, m.body_dofadr, m.body_dofnum,
+             m.body_pos, m.body_quat, m.body_mass, m.body_ipos, m.body_inertia, m.body_invweight0,
+             m.jnt_type, m.jnt_qposadr, m.jnt_dofadr, m.jnt_bodyid, m.jnt_limited,
+             m.jnt_pos, m.jnt_axis, m.jnt_range, m.jnt_stiffness, m.jnt_margin, m.jnt_solref, m.jnt_solimp,
+             m.dof_bodyid, m.dof_jntid, m.dof_parentid, m.dof_armature, m.dof_damping, m.dof_invweight0,
+             m.qpos0, m.qpos_spring, m.geom_type, m.geom_bodyid, m.geom_size, m.geom_pos, m.geom_mat,
+             m.pair_geom1, m.pair_geom2, m.pair_condim, m.pair_friction, m.pair_margin, m.pair_solref, m.pair_solimp,
+             m.actuator_dofadr, m.actuator_gear, m.actuator_ctrlrange]
+    return np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts])
+
+
+def dll():
+    global _DLL
+    if _DLL is None:
+        from oracle import oracle
+
+        oracle.build()
+        _DLL = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        _DLL.orc_mj_model_create.restype, _DLL.orc_mj_model_create.argtypes = vp, [vp, C.c_int]
+        _DLL.orc_mj_data_create.restype, _DLL.orc_mj_data_create.argtypes = vp, [vp]
+        for name, args in (("model_destroy", [vp]), ("data_destroy", [vp]), ("reset", [vp, vp]), ("set_state", [vp] * 5),
+                           ("forward", [vp, vp]), ("step", [vp, vp, C.c_int]), ("rne_post_constraint", [vp, vp])):
+            fn = getattr(_DLL, "orc_mj_" + name)
+            fn.restype, fn.argtypes = None, args
+        _DLL.orc_mj_get.restype, _DLL.orc_mj_get.argtypes = C.c_int, [vp, vp, C.c_char_p, vp, C.c_int]
+    return _DLL
+
+
+class OracleModel:
+    def __init__(self, name_or_model):
+        self.m = compiler.compile_model(name_or_model) if isinstance(name_or_model, str) else name_or_model
+        blob = model_blob(self.m)
+        self.handle = dll().orc_mj_model_create(blob.ctypes.data, len(blob))
+        if not self.handle:
+            raise RuntimeError("oracle rejected the model blob")
+
+    def make_data(self):
+        return OracleData(self)
+
+
+class OracleData:
+    def __init__(self, model):
+        self.model = model
+        self.handle = dll().orc_mj_data_create(model.handle)
+        self._buf = np.zeros(65536)
+
+    def reset(self):
+        dll().orc_mj_reset(self.model.handle, self.handle)
+
+    def set_state(self, qpos=None, qvel=None, ctrl=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (qpos, qvel, ctrl)]
+        dll().orc_mj_set_state(self.model.handle, self.handle, *[None if a is None else a.ctypes.data for a in arrs])
+
+    def forward(self):
+        dll().orc_mj_forward(self.model.handle, self.handle)
+
+    def step(self, n=1):
+        dll().orc_mj_step(self.model.handle, self.handle, n)
+
+    def rne_post_constraint(self):
+        dll().orc_mj_rne_post_constraint(self.model.handle, self.handle)
+
+    def get(self, name):
+        n = dll().orc_mj_get(self.model.handle, self.handle, name.encode(), self._buf.ctypes.data, len(self._buf))
+        if n < 0:
+            raise KeyError(name)
+        out = self._buf[:n].copy()
+        m = self.model.m
+        if name in ("ncon", "nefc", "solver_iter"):
+            return int(out[0])
+        if name == "contact":
+            return out.reshape(-1, 17)
+        if name in ("qM", "efc_J"):
+            return out.reshape(-1, m.nv)
+        width = {"xpos": 3, "xquat": 4, "xmat": 9, "xipos": 3, "xanchor": 3, "xaxis": 3, "geom_xpos": 3, "geom_xmat": 9, "subtree_com": 3,
+                 "cinert": 10, "cdof": 6, "cvel": 6, "cdof_dot": 6, "cfrc_ext": 6, "efc_KBIP": 4}.get(name)
+        return out.reshape(-1, width) if width else out

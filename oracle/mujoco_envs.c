@@ -1,0 +1,259 @@
+/*
+ * mujoco_envs.c -- TEST INFRASTRUCTURE (CPU oracle).  The reference's Python glue around `mujoco` for
+ * HalfCheetah-v5 / Ant-v5 / Humanoid-v5 restated in C on top of mujoco_core.c (PARITY UNPINNED for the physics, see
+ * mujoco_core.h; the glue arithmetic -- NumPy reductions, float32 promotion, reset-noise streams -- is pinned on NumPy by
+ * tests/test_mujoco_oracle.py).
+ *
+ *   step / reward / termination / obs / reset_model:
+ *     gymnasium/envs/mujoco/half_cheetah_v5.py:220-281   ant_v5.py:327-428   humanoid_v5.py:413-541 (mass_center :17-21)
+ *   do_simulation = ctrl copy -> mj_step(frame_skip) -> mj_rnePostConstraint:  mujoco_env.py:144-155,193-202
+ *   reset = mj_resetData -> reset_model (noise) -> set_state -> mj_forward:     mujoco_env.py:132-142,172-187
+ */
+#include "mujoco_envs.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../gymnasium_amd/csrc/ziggurat_tables.h"
+
+static const uint64_t KI[256] = {MI_ZIG_KI_VALUES};
+static const double WI[256] = {MI_ZIG_WI_VALUES};
+static const double FI[256] = {MI_ZIG_FI_VALUES};
+
+/* numpy/random/src/distributions/distributions.c random_standard_normal (ziggurat, 256 layers) */
+double orc_standard_normal(orc_pcg64 *rng) {
+    for (;;) {
+        uint64_t r = orc_pcg64_next64(rng);
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 0x1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * WI[idx];
+        if (sign) x = -x;
+        if (rabs < KI[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -MI_ZIG_INV_R * log1p(-orc_pcg64_double(rng));
+                double yy = -log1p(-orc_pcg64_double(rng));
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 0x1) ? -(MI_ZIG_R + xx) : MI_ZIG_R + xx;
+            }
+        } else {
+            if ((FI[idx - 1] - FI[idx]) * orc_pcg64_double(rng) + FI[idx] < exp(-0.5 * x * x)) return x;
+        }
+    }
+}
+
+/* np.sum over a contiguous array = NumPy's pairwise_sum over all n elements (numpy/_core/src/umath/loops_utils.h.src:
+ * plain loop below 8 elements, 8 interleaved accumulators up to 128, recursion above); order determined empirically
+ * against NumPy 2.2 in tests/test_mujoco_oracle.py */
+static double pairwise_f64(const double *a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_f64(a, n2) + pairwise_f64(a + n2, n - n2);
+    }
+}
+double orc_np_sum_f64(const double *a, int n) { return pairwise_f64(a, n); }
+static float pairwise_f32(const float *a, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    } else {
+        float r[8];
+        int i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+}
+float orc_np_sum_f32(const float *a, int n) { return pairwise_f32(a, n); }
+
+/* ---- model registry (filled by oracle/oracle.py at load time) -------------------------------------------------- */
+static mjo_model *g_models[3];
+__attribute__((visibility("default"))) int orc_mj_register_model(int which, const double *blob, int n) {
+    if (which < 0 || which > 2) return -1;
+    if (!g_models[which]) g_models[which] = (mjo_model *)malloc(sizeof(mjo_model));
+    return mjo_model_from_blob(g_models[which], blob, n);
+}
+const mjo_model *orc_mj_model(int which) { return which >= 0 && which < 3 ? g_models[which] : 0; }
+
+/* ---- layout ----------------------------------------------------------------------------------------------------- */
+int orc_mjenv_obs_dim(int which, const double *P) {
+    const mjo_model *m = g_models[which];
+    int excl = P[3] != 0.0;
+    if (which == ORC_MJ_HALF_CHEETAH) return m->nq - (excl ? 1 : 0) + m->nv;
+    if (which == ORC_MJ_ANT) return m->nq - (excl ? 2 : 0) + m->nv + (P[12] != 0.0 ? 6 * (m->nbody - 1) : 0);
+    return m->nq - (excl ? 2 : 0) + m->nv + (P[12] != 0.0 ? 10 * (m->nbody - 1) : 0) + (P[13] != 0.0 ? 6 * (m->nbody - 1) : 0) +
+           (P[14] != 0.0 ? m->nv - 6 : 0) + (P[15] != 0.0 ? 6 * (m->nbody - 1) : 0);
+}
+int orc_mjenv_info_dim(int which) { return which == ORC_MJ_HALF_CHEETAH ? 4 : 9; }
+int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
+
+/* ---- per-env glue ----------------------------------------------------------------------------------------------- */
+orc_mjenv *orc_mjenv_create(int which) {
+    orc_mjenv *e = (orc_mjenv *)calloc(1, sizeof *e);
+    e->which = which, e->m = g_models[which];
+    mjo_reset_data(e->m, &e->d);
+    return e;
+}
+
+static void mass_center_xy(const orc_mjenv *e, double out[2]) { /* humanoid_v5.py:17-21 (einsum then divide) */
+    const mjo_model *m = e->m;
+    double num[2] = {0, 0}, den = 0;
+    for (int b = 0; b < m->nbody; b++) num[0] += m->body_mass[b] * e->d.xipos[b][0], num[1] += m->body_mass[b] * e->d.xipos[b][1];
+    den = orc_np_sum_f64(m->body_mass, m->nbody);
+    out[0] = num[0] / den, out[1] = num[1] / den;
+}
+
+/* the position the env differentiates to get its velocity reward, read from the LAST forward pass (the reference reads
+ * data.qpos / data.body().xpos / data.xipos after mj_step, and those Cartesian quantities lag qpos by one sub-step) */
+static void tracked_xy(const orc_mjenv *e, double out[2]) {
+    if (e->which == ORC_MJ_HALF_CHEETAH)
+        out[0] = e->d.qpos[0], out[1] = 0;
+    else if (e->which == ORC_MJ_ANT)
+        out[0] = e->d.xpos[1][0], out[1] = e->d.xpos[1][1]; /* main_body = 1 (torso) */
+    else
+        mass_center_xy(e, out);
+}
+
+void orc_mjenv_obs(const orc_mjenv *e, const double *P, double *o) {
+    const mjo_model *m = e->m;
+    const mjo_data *d = &e->d;
+    int skip = P[3] != 0.0 ? (e->which == ORC_MJ_HALF_CHEETAH ? 1 : 2) : 0, n = 0;
+    for (int k = skip; k < m->nq; k++) o[n++] = d->qpos[k];
+    for (int k = 0; k < m->nv; k++) o[n++] = d->qvel[k];
+    if (e->which == ORC_MJ_ANT && P[12] != 0.0) {
+        for (int b = 1; b < m->nbody; b++)
+            for (int k = 0; k < 6; k++) {
+                double f = d->cfrc_ext[b][k];
+                o[n++] = f < P[10] ? P[10] : (f > P[11] ? P[11] : f); /* np.clip(cfrc_ext, lo, hi) ant_v5.py:327-332 */
+            }
+    } else if (e->which == ORC_MJ_HUMANOID) {
+        if (P[12] != 0.0)
+            for (int b = 1; b < m->nbody; b++)
+                for (int k = 0; k < 10; k++) o[n++] = d->cinert[b][k];
+        if (P[13] != 0.0)
+            for (int b = 1; b < m->nbody; b++)
+                for (int k = 0; k < 6; k++) o[n++] = d->cvel[b][k];
+        if (P[14] != 0.0)
+            for (int k = 6; k < m->nv; k++) o[n++] = d->qfrc_actuator[k];
+        if (P[15] != 0.0)
+            for (int b = 1; b < m->nbody; b++)
+                for (int k = 0; k < 6; k++) o[n++] = d->cfrc_ext[b][k];
+    }
+}
+
+void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
+    const mjo_model *m = e->m;
+    double scale = P[2], qpos[MJO_MAXQ], qvel[MJO_MAXV];
+    mjo_reset_data(m, &e->d); /* mj_resetData */
+    /* qpos = init_qpos + uniform(-s, s, nq): Generator.uniform = low + (high - low) * next_double */
+    for (int k = 0; k < m->nq; k++) qpos[k] = m->qpos0[k] + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
+    if (e->which == ORC_MJ_HUMANOID) /* humanoid_v5.py:526-528: uniform noise on the velocities too */
+        for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
+    else /* init_qvel + scale * standard_normal(nv) */
+        for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + scale * orc_standard_normal(rng);
+    memcpy(e->d.qpos, qpos, sizeof(double) * m->nq), memcpy(e->d.qvel, qvel, sizeof(double) * m->nv);
+    mjo_forward(m, &e->d); /* set_state -> mj_forward */
+    e->has_override = 0;
+    /* cfrc_ext stays zero after mj_resetData until the first mj_rnePostConstraint (the reset observation shows zeros) */
+}
+
+void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *reward, int *terminated, double *info) {
+    const mjo_model *m = e->m;
+    mjo_data *d = &e->d;
+    const int nu = m->nu, frame_skip = (int)P[4];
+    double before[2], after[2];
+    if (e->has_override)
+        before[0] = e->track_override[0], before[1] = e->track_override[1], e->has_override = 0;
+    else
+        tracked_xy(e, before);
+    for (int u = 0; u < nu; u++) d->ctrl[u] = (double)action[u];
+    mjo_step(m, d, frame_skip);
+    mjo_rne_post_constraint(m, d);
+    tracked_xy(e, after);
+    const double dt = m->timestep * frame_skip;
+    const double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
+    const double forward_reward = e->which == ORC_MJ_ANT ? xv * P[0] : P[0] * xv;
+    if (e->which == ORC_MJ_HALF_CHEETAH) {
+        /* control_cost: weight * np.sum(np.square(action)) with a float32 action -> float32 (NEP 50) */
+        float sq[MJO_MAXU];
+        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
+        float ctrl_cost = (float)P[1] * orc_np_sum_f32(sq, nu);
+        *reward = forward_reward - (double)ctrl_cost;
+        *terminated = 0;
+        info[0] = d->qpos[0], info[1] = xv, info[2] = forward_reward, info[3] = -(double)ctrl_cost;
+        return;
+    }
+    int healthy;
+    double ctrl_cost, contact_cost;
+    if (e->which == ORC_MJ_ANT) {
+        int finite = 1;
+        for (int k = 0; k < m->nq; k++) finite &= isfinite(d->qpos[k]) != 0;
+        for (int k = 0; k < m->nv; k++) finite &= isfinite(d->qvel[k]) != 0;
+        healthy = finite && P[8] <= d->qpos[2] && d->qpos[2] <= P[9];
+        float sq[MJO_MAXU];
+        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
+        ctrl_cost = (double)((float)P[1] * orc_np_sum_f32(sq, nu));
+        double c2[6 * MJO_MAXB];
+        for (int b = 0; b < m->nbody; b++)
+            for (int k = 0; k < 6; k++) {
+                double f = d->cfrc_ext[b][k];
+                f = f < P[10] ? P[10] : (f > P[11] ? P[11] : f);
+                c2[6 * b + k] = f * f;
+            }
+        contact_cost = P[5] * orc_np_sum_f64(c2, 6 * m->nbody);
+    } else {
+        healthy = P[8] < d->qpos[2] && d->qpos[2] < P[9];
+        double sq[MJO_MAXU], c2[6 * MJO_MAXB];
+        for (int u = 0; u < nu; u++) sq[u] = d->ctrl[u] * d->ctrl[u]; /* np.square(self.data.ctrl): float64 */
+        ctrl_cost = P[1] * orc_np_sum_f64(sq, nu);
+        for (int b = 0; b < m->nbody; b++)
+            for (int k = 0; k < 6; k++) c2[6 * b + k] = d->cfrc_ext[b][k] * d->cfrc_ext[b][k];
+        contact_cost = P[5] * orc_np_sum_f64(c2, 6 * m->nbody);
+        contact_cost = contact_cost < P[10] ? P[10] : (contact_cost > P[11] ? P[11] : contact_cost);
+    }
+    const double healthy_reward = healthy ? P[6] : 0.0; /* is_healthy * healthy_reward */
+    const double rewards = forward_reward + healthy_reward, costs = ctrl_cost + contact_cost;
+    *reward = rewards - costs;
+    *terminated = !healthy && P[7] != 0.0;
+    info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = sqrt(d->qpos[0] * d->qpos[0] + d->qpos[1] * d->qpos[1]);
+    info[3] = xv, info[4] = yv, info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
+}
+
+/* checkpoint row: qpos, qvel, qacc_warmstart, tracked xy of the last forward pass */
+void orc_mjenv_get_state(const orc_mjenv *e, double *s) {
+    const mjo_model *m = e->m;
+    memcpy(s, e->d.qpos, sizeof(double) * m->nq), memcpy(s + m->nq, e->d.qvel, sizeof(double) * m->nv);
+    memcpy(s + m->nq + m->nv, e->d.qacc_warmstart, sizeof(double) * m->nv);
+    if (e->has_override)
+        s[m->nq + 2 * m->nv] = e->track_override[0], s[m->nq + 2 * m->nv + 1] = e->track_override[1];
+    else
+        tracked_xy(e, s + m->nq + 2 * m->nv);
+}
+void orc_mjenv_set_state(orc_mjenv *e, const double *s) {
+    const mjo_model *m = e->m;
+    memcpy(e->d.qpos, s, sizeof(double) * m->nq), memcpy(e->d.qvel, s + m->nq, sizeof(double) * m->nv);
+    mjo_forward(m, &e->d);
+    memcpy(e->d.qacc_warmstart, s + m->nq + m->nv, sizeof(double) * m->nv);
+    /* the Cartesian position the next step differentiates against is the checkpointed (lagging) one, not the fresh one */
+    e->track_override[0] = s[m->nq + 2 * m->nv], e->track_override[1] = s[m->nq + 2 * m->nv + 1], e->has_override = 1;
+}

@@ -15,7 +15,7 @@ _LIB = None
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(HERE, f) for f in ("classic_control.c", "pcg64.h", "Makefile")] + [os.path.join(HERE, "..", "include", "mi355env.h")]
+    src = [os.path.join(HERE, f) for f in ("classic_control.c", "mujoco_core.c", "mujoco_core.h", "mujoco_api.c", "mujoco_envs.c", "mujoco_envs.h", "pcg64.h", "Makefile")] + [os.path.join(HERE, "..", "include", "mi355env.h")]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src if os.path.exists(s))
     if stale:
         subprocess.run(["make", "-C", HERE, "-s", "-B"], check=True)
@@ -26,7 +26,23 @@ def load() -> _native.NativeLib:
     global _LIB
     if _LIB is None:
         _LIB = _native.NativeLib(build(), "orc_")
+        _register_mujoco_models(_LIB)
     return _LIB
+
+
+def _register_mujoco_models(lib):
+    """Hand the compiled robot models (gymnasium_amd/envs/mujoco/compiler.py) to the oracle's MuJoCo-pipeline restatement."""
+    import ctypes
+
+    from gymnasium_amd.envs.mujoco import compiler
+    from oracle import mujoco as omj
+
+    fn = lib.dll.orc_mj_register_model
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    for which, name in enumerate(("half_cheetah", "ant", "humanoid")):
+        blob = omj.model_blob(compiler.compile_model(name))
+        rc = fn(which, blob.ctypes.data, len(blob))
+        assert rc == 0, f"oracle rejected the {name} model blob (rc={rc})"
 
 
 def engine_factory(kind, num_envs, max_episode_steps, autoreset_mode, params, device):

@@ -285,7 +285,7 @@ def _dummy_factory(kind, num_envs, *a):
         act_dtype = np.int64 if kind in ("cartpole", "acrobot", "mountain_car") else np.float32
         obs_dtype = np.float32
         obs_dim = {"cartpole": 4, "pendulum": 3, "acrobot": 6}.get(kind, 2)
-        act_dim, state_dim = 1, 2
+        act_dim, state_dim, info_dim = 1, 2, 0
 
         def close(self):
             pass

@@ -39,9 +39,9 @@ def test_oracle_exports_the_same_abi(oracle_factory):
 def test_struct_layouts_match_header():
     from gymnasium_amd import _native as n
 
-    assert ctypes.sizeof(n.MiConfig) == 8 * 4 + 8 * 8
+    assert ctypes.sizeof(n.MiConfig) == 8 * 4 + 16 * 8
     assert ctypes.sizeof(n.MiLayout) == 8 * 4
-    assert ctypes.sizeof(n.MiStepIO) == 8 * 8
+    assert ctypes.sizeof(n.MiStepIO) == 9 * 8
     assert ctypes.sizeof(n.MiRolloutIO) == 6 * 8
     assert ctypes.sizeof(n.MiStats) == 5 * 8
 
