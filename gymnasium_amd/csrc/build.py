@@ -11,10 +11,21 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["engine.hip"]
-HEADERS = ["envs_classic.h", "pcg64_dev.h", os.path.join("..", "..", "include", "mi355env.h")]
+HEADERS = ["envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_kernels.h", "ziggurat_tables.h", os.path.join("generated", "mjx_models.h"),
+           os.path.join("..", "..", "include", "mi355env.h")]
 OUT = os.path.join(HERE, "libmi355env.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
+
+
+def generate_models() -> None:
+    """Regenerate generated/mjx_models.h from the model descriptions (only rewritten when its content changes)."""
+    root = os.path.normpath(os.path.join(HERE, "..", ".."))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from gymnasium_amd.envs.mujoco import codegen
+
+    codegen.generate()
 
 
 def needs_build() -> bool:
@@ -25,6 +36,7 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    generate_models()
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -27,6 +27,7 @@
 #include "../../include/mi355env.h"
 #include "envs_classic.h"
 #include "pcg64_dev.h"
+#include "mjx_kernels.h"
 
 using namespace mi;
 
@@ -372,7 +373,7 @@ struct ActionStream {
 struct RolloutPtrs {
     const void *actions_in;
     void *actions_out;
-    float *obs;
+    void *obs;
     double *reward;
     uint8_t *terminated, *truncated;
 };
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
                 lane_step_fused<E, !SAMPLE>(d, L, a, o, st, q);
             else
                 lane_step<E, MODE>(d, i, L, a, o, st, &q);
-            if (FULL || io.obs) store_row<E::OBS>(io.obs + (t * N + i) * E::OBS, o.obs);
+            if (FULL || io.obs) store_row<E::OBS>(static_cast<float *>(io.obs) + (t * N + i) * E::OBS, o.obs);
             if (FULL || io.reward) io.reward[t * N + i] = o.reward;
             if (FULL || io.terminated) io.terminated[t * N + i] = o.terminated;
             if (FULL || io.truncated) io.truncated[t * N + i] = o.truncated;
@@ -430,6 +431,169 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
             for (int k = 0; k < E::NDRAWS; k++) q.rng.unstep();
         }
         store_rng_state(d, i, q.rng);
+    }
+    block_accumulate(d, st);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// MuJoCo-family kernels (mjx_kernels.h): same vectoriser state machine, float64 observations, float32 action rows
+// ---------------------------------------------------------------------------------------------------------
+struct MjStepPtrs {
+    const float *actions;
+    double *obs, *reward;
+    uint8_t *terminated, *truncated;
+    double *final_obs, *ep_ret;
+    int32_t *ep_len;
+    double *info;
+    int obs_dim;
+};
+
+template <class E>
+struct MjLane {
+    double s[E::S];
+    uint32_t elapsed, flags;
+    double ep_ret;
+    int32_t ep_len;
+};
+template <class E>
+MI_DEV void mj_load(const DevEnv &d, int i, MjLane<E> &L) {
+    for (int k = 0; k < E::S; k++) L.s[k] = d.state[(size_t)k * d.N + i];
+    const uint32_t m = d.meta[i];
+    L.elapsed = m & kElapsedMask, L.flags = m >> kFlagShift;
+    L.ep_ret = d.ep_ret[i], L.ep_len = d.ep_len[i];
+}
+template <class E>
+MI_DEV void mj_store(const DevEnv &d, int i, const MjLane<E> &L) {
+    for (int k = 0; k < E::S; k++) d.state[(size_t)k * d.N + i] = L.s[k];
+    d.meta[i] = (L.elapsed & kElapsedMask) | (L.flags << kFlagShift);
+    d.ep_ret[i] = L.ep_ret, d.ep_len[i] = L.ep_len;
+}
+template <class E>
+MI_DEV void mj_autoreset(const DevEnv &d, int i, MjLane<E> &L) {
+    Pcg64 rng = load_rng(d, i);
+    E::reset(rng, L.s, d.P);
+    store_rng_state(d, i, rng);
+    L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+}
+
+// one lockstep step of one MuJoCo sub-environment; obs / info rows are written straight to their destination
+template <class E, int MODE>
+MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *action, double *obs, double *final_obs, double *info,
+                         double &reward, bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st) {
+    te = tr = false, reward = 0.0;
+    if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
+        mj_autoreset<E>(d, i, L);
+        E::write_obs(L.s, nullptr, d.P, obs);
+        if (info) E::reset_info(L.s, info);
+        st.reset_steps++;
+    } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
+        *d.error = kErrDisabledStepped;
+        out_ret = 0.0, out_len = 0;
+        return;
+    } else {
+        E::step(L.s, action, d.P, obs, reward, te, info);
+        L.elapsed += 1;
+        tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;
+        L.ep_ret += reward, L.ep_len += 1;
+        st.env_steps++;
+    }
+    const bool done = te || tr;
+    out_ret = done ? L.ep_ret : 0.0, out_len = done ? L.ep_len : 0;
+    if (done) st.episodes++, st.return_sum += L.ep_ret, st.length_sum += (uint64_t)L.ep_len;
+    if (MODE == MI_AUTORESET_SAME_STEP && done) {
+        if (final_obs)
+            for (int k = 0; k < E::obs_dim(d.P); k++) final_obs[k] = obs[k];
+        mj_autoreset<E>(d, i, L);
+        E::write_obs(L.s, nullptr, d.P, obs);
+    }
+    if (done && MODE != MI_AUTORESET_SAME_STEP)
+        L.flags |= kNeedsReset;
+    else
+        L.flags &= ~kNeedsReset;
+}
+
+template <class E, int MODE>
+__global__ __launch_bounds__(kBlock) void mj_step_kernel(DevEnv d, MjStepPtrs io) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        MjLane<E> L;
+        mj_load<E>(d, i, L);
+        double reward, out_ret;
+        int32_t out_len;
+        bool te, tr;
+        mj_lane_step<E, MODE>(d, i, L, io.actions + (size_t)i * E::NU, io.obs + (size_t)i * io.obs_dim,
+                              io.final_obs ? io.final_obs + (size_t)i * io.obs_dim : nullptr,
+                              io.info ? io.info + (size_t)i * E::INFO : nullptr, reward, te, tr, out_ret, out_len, st);
+        mj_store<E>(d, i, L);
+        if (io.reward) io.reward[i] = reward;
+        if (io.terminated) io.terminated[i] = te;
+        if (io.truncated) io.truncated[i] = tr;
+        if (io.ep_ret) io.ep_ret[i] = out_ret;
+        if (io.ep_len) io.ep_len[i] = out_len;
+    }
+    block_accumulate(d, st);
+}
+
+template <class E>
+__global__ __launch_bounds__(kBlock) void mj_reset_kernel(DevEnv d, const uint8_t *mask, double *obs, int obs_dim) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.N || (mask && !mask[i])) return;
+    MjLane<E> L;
+    mj_load<E>(d, i, L);
+    L.flags &= ~kNeedsReset;
+    mj_autoreset<E>(d, i, L);
+    mj_store<E>(d, i, L);
+    if (obs) E::write_obs(L.s, nullptr, d.P, obs + (size_t)i * obs_dim);
+}
+
+// fused rollout: T steps per launch, Box action space sampled on device from the batched space's single PCG64 stream
+// (draw number (t*N + i)*NU + u belongs to lane i, component u, step t)
+template <class E, int MODE, bool SAMPLE>
+__global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int obs_dim) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        MjLane<E> L;
+        mj_load<E>(d, i, L);
+        u128 astate = 0;
+        const u128 ainc = make_u128(as.inc_hi, as.inc_lo);
+        if (SAMPLE) {
+            astate = make_u128(as.state_hi, as.state_lo);
+            uint64_t delta = (uint64_t)i * E::NU + 1u;
+            for (int j = 0; delta; j++, delta >>= 1)
+                if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
+        }
+        const size_t N = (size_t)d.N;
+        double scratch_obs[128];
+        for (int t = 0; t < T; t++) {
+            float a[E::NU];
+            if (SAMPLE) {
+                for (int u = 0; u < E::NU; u++) {
+                    const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate, x = hi ^ lo;
+                    const unsigned rot = (unsigned)(hi >> 58);
+                    const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+                    const double lo_b = (double)(float)E::Model::actuator_ctrlrange[u][0], hi_b = (double)(float)E::Model::actuator_ctrlrange[u][1];
+                    a[u] = (float)(lo_b + (hi_b - lo_b) * ((double)(out >> 11) * (1.0 / 9007199254740992.0)));
+                    if (u + 1 < E::NU) astate = astate * pcg_mult() + ainc;
+                }
+                astate = as.jump_n.mult * astate + as.jump_n.plus;
+                if (io.actions_out)
+                    for (int u = 0; u < E::NU; u++) static_cast<float *>(io.actions_out)[(t * N + i) * E::NU + u] = a[u];
+            } else {
+                for (int u = 0; u < E::NU; u++) a[u] = static_cast<const float *>(io.actions_in)[(t * N + i) * E::NU + u];
+            }
+            double reward, out_ret;
+            int32_t out_len;
+            bool te, tr;
+            double *obs = io.obs ? static_cast<double *>(io.obs) + (t * N + i) * obs_dim : scratch_obs;
+            mj_lane_step<E, MODE>(d, i, L, a, obs, nullptr, nullptr, reward, te, tr, out_ret, out_len, st);
+            if (io.reward) io.reward[t * N + i] = reward;
+            if (io.terminated) io.terminated[t * N + i] = te;
+            if (io.truncated) io.truncated[t * N + i] = tr;
+        }
+        mj_store<E>(d, i, L);
     }
     block_accumulate(d, st);
 }
@@ -497,12 +661,14 @@ struct mi_vecenv {
     PcgJump jump_n;
     // staging for the MI_HOST entry points
     void *d_actions;
-    float *d_obs, *d_final;
+    void *d_obs, *d_final;
     double *d_reward, *d_epret;
     uint8_t *d_term, *d_trunc, *d_mask;
     int32_t *d_eplen;
     uint64_t *d_words;
     size_t act_bytes, obs_bytes;
+    double *d_info;
+    size_t info_bytes;
 };
 
 namespace {
@@ -517,6 +683,18 @@ int dispatch_kind(int kind, F &&f) {
     case MI_ENV_MOUNTAIN_CAR_CONTINUOUS: return f(MountainCarContinuous());
     }
     return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
+}
+
+typedef mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah> HalfCheetahEnv;
+typedef mjx::MjEnv<mjx::AntModel, mjx::kAnt> AntEnv;
+bool is_mj(int kind) { return kind >= kClassicKinds; }
+template <class F>
+int dispatch_mj(int kind, F &&f) {
+    switch (kind) {
+    case MI_ENV_HALF_CHEETAH: return f(HalfCheetahEnv());
+    case MI_ENV_ANT: return f(AntEnv());
+    }
+    return fail(MI_ERR_UNSUPPORTED, "this MuJoCo kind is not built into the HIP engine yet");
 }
 
 int check_device_error(mi_vecenv *v) {
@@ -594,7 +772,7 @@ int mi_device_count(void) {
 int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mi_config)) return fail(MI_ERR_INVALID_ARGUMENT, "bad mi_config");
     if (cfg->kind < 0 || cfg->kind >= MI_ENV_KIND_COUNT) return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
-    if (cfg->kind >= kClassicKinds) return fail(MI_ERR_UNSUPPORTED, "MuJoCo kinds are served by the mjx engine (not built into this library yet)");
+    if (cfg->kind == MI_ENV_HUMANOID) return fail(MI_ERR_UNSUPPORTED, "Humanoid-v5 is not built into the HIP engine yet");
     if (cfg->num_envs < 1) return fail(MI_ERR_INVALID_ARGUMENT, "num_envs must be >= 1");
     if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2) return fail(MI_ERR_INVALID_ARGUMENT, "bad autoreset mode");
     if (cfg->max_episode_steps > (int)kElapsedMask) return fail(MI_ERR_INVALID_ARGUMENT, "max_episode_steps too large");
@@ -605,7 +783,21 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     mi_vecenv *v = new (std::nothrow) mi_vecenv();
     if (!v) return fail(MI_ERR_HIP, "out of host memory");
     memset(v, 0, sizeof *v);
-    v->cfg = *cfg, v->lay = kLayouts[cfg->kind], v->device = device;
+    v->cfg = *cfg, v->device = device;
+    if (is_mj(cfg->kind)) {
+        mi::EnvParams P;
+        for (int k = 0; k < 16; k++) P.p[k] = cfg->params[k];
+        dispatch_mj(cfg->kind, [&](auto env) -> int {
+            using E = decltype(env);
+            const int skip = P.p[3] != 0.0 ? E::SKIP : 0;
+            const int extra = (cfg->kind == MI_ENV_ANT && P.p[12] != 0.0) ? 6 * (E::NB - 1) : 0;
+            const mi_layout l = {E::NQ + E::NV - skip + extra, MI_F64, E::NU, MI_F32, E::S, E::INFO, {0, 0}};
+            v->lay = l;
+            return (int)MI_OK;
+        });
+    } else {
+        v->lay = kLayouts[cfg->kind];
+    }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&v->own_stream, hipStreamNonBlocking));
     v->stream = v->own_stream;
@@ -632,7 +824,9 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     HIP_TRY(hipMemsetAsync(d.blk_ret, 0, sizeof(double) * v->grid, v->stream));
     HIP_TRY(hipMemsetAsync(d.error, 0, sizeof(int), v->stream));
     v->act_bytes = N * (v->lay.act_dtype == MI_I64 ? 8 : 4) * v->lay.act_dim;
-    v->obs_bytes = N * sizeof(float) * v->lay.obs_dim;
+    v->obs_bytes = N * (v->lay.obs_dtype == MI_F64 ? sizeof(double) : sizeof(float)) * v->lay.obs_dim;
+    v->info_bytes = N * sizeof(double) * (v->lay.info_dim > 0 ? v->lay.info_dim : 1);
+    HIP_TRY(hipMalloc(&v->d_info, v->info_bytes));
     HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes));
     HIP_TRY(hipMalloc(&v->d_obs, v->obs_bytes));
     HIP_TRY(hipMalloc(&v->d_final, v->obs_bytes));
@@ -655,7 +849,7 @@ void mi_destroy(mi_vecenv *v) {
     (void)hipStreamSynchronize(v->stream);
     void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d.error,
                     v->d_pow2, v->d_actions, v->d_obs, v->d_final, v->d_reward, v->d_epret, v->d_eplen, v->d_term,
-                    v->d_trunc, v->d_mask, v->d_words};
+                    v->d_trunc, v->d_mask, v->d_words, v->d_info};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
@@ -735,16 +929,21 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
     if (!v->seeded) return fail(MI_ERR_STATE, "reset before seeding");
     if (set_device(v)) return MI_ERR_HIP;
     const uint8_t *dm = mask;
-    float *dobs = (float *)obs;
+    void *dobs = obs;
     if (loc == MI_HOST) {
         if (int rc = upload_mask(v, mask, &dm)) return rc;
         dobs = v->d_obs;  // persistent: rows of un-reset sub-envs keep their last observation (sync_vector_env.py:261)
     }
     const int has_bounds = bounds != nullptr;
     const double b0 = has_bounds ? bounds[0] : 0.0, b1 = has_bounds ? bounds[1] : 0.0;
-    int rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int {
+    int rc = is_mj(v->cfg.kind) ? dispatch_mj(v->cfg.kind, [&](auto env) -> int {
         using E = decltype(env);
-        hipLaunchKernelGGL((reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, has_bounds, b0, b1, dobs);
+        hipLaunchKernelGGL((mj_reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, (double *)dobs, v->lay.obs_dim);
+        HIP_TRY(hipGetLastError());
+        return (int)MI_OK;
+    }) : dispatch_kind(v->cfg.kind, [&](auto env) -> int {
+        using E = decltype(env);
+        hipLaunchKernelGGL((reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, has_bounds, b0, b1, (float *)dobs);
         HIP_TRY(hipGetLastError());
         return (int)MI_OK;
     });
@@ -774,8 +973,8 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
         }
         HIP_TRY(hipMemcpyAsync(v->d_actions, io->actions, v->act_bytes, hipMemcpyHostToDevice, v->stream));
         p.actions = v->d_actions;
-        p.obs = v->d_obs, p.reward = v->d_reward, p.terminated = v->d_term, p.truncated = v->d_trunc;
-        p.final_obs = io->final_obs ? v->d_final : nullptr;
+        p.obs = (float *)v->d_obs, p.reward = v->d_reward, p.terminated = v->d_term, p.truncated = v->d_trunc;
+        p.final_obs = io->final_obs ? (float *)v->d_final : nullptr;
         p.ep_ret = io->episode_return ? v->d_epret : nullptr;
         p.ep_len = io->episode_length ? v->d_eplen : nullptr;
     } else {
@@ -783,9 +982,29 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
         p.obs = (float *)io->obs, p.reward = io->reward, p.terminated = io->terminated, p.truncated = io->truncated;
         p.final_obs = (float *)io->final_obs, p.ep_ret = io->episode_return, p.ep_len = io->episode_length;
     }
-    int rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
+    double *dinfo = loc == MI_HOST ? (io->info ? v->d_info : nullptr) : io->info;
+    int rc;
+    if (is_mj(v->cfg.kind)) {
+        const MjStepPtrs mp = {(const float *)p.actions, (double *)p.obs, p.reward, p.terminated, p.truncated, (double *)p.final_obs,
+                               p.ep_ret, p.ep_len, dinfo, v->lay.obs_dim};
+        if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
+        rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int {
+            using E = decltype(env);
+            const dim3 g(v->grid), b(kBlock);
+            switch (v->cfg.autoreset_mode) {
+            case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_NEXT_STEP>), g, b, 0, v->stream, v->d, mp); break;
+            case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_SAME_STEP>), g, b, 0, v->stream, v->d, mp); break;
+            default: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_DISABLED>), g, b, 0, v->stream, v->d, mp); break;
+            }
+            HIP_TRY(hipGetLastError());
+            return (int)MI_OK;
+        });
+    } else {
+        rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
+    }
     if (rc) return rc;
     if (loc == MI_HOST) {
+        if (io->info) HIP_TRY(hipMemcpyAsync(io->info, v->d_info, v->info_bytes, hipMemcpyDeviceToHost, v->stream));
         if (io->obs) HIP_TRY(hipMemcpyAsync(io->obs, v->d_obs, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
         if (io->reward) HIP_TRY(hipMemcpyAsync(io->reward, v->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost, v->stream));
         if (io->terminated) HIP_TRY(hipMemcpyAsync(io->terminated, v->d_term, N, hipMemcpyDeviceToHost, v->stream));
@@ -812,7 +1031,8 @@ int mi_action_seed(mi_vecenv *v, const uint64_t pcg[4]) {
         for (int j = 0; j < 64; j++) tab[j] = pcg_jump(inc, (u128)1 << j);
         HIP_TRY(hipMemcpyAsync(v->d_pow2, tab, sizeof tab, hipMemcpyHostToDevice, v->stream));
         HIP_TRY(hipStreamSynchronize(v->stream));
-        v->jump_n = pcg_jump(inc, (u128)v->cfg.num_envs * (u128)v->lay.act_dim);
+        // per step a lane draws act_dim consecutive values, then skips to its slot in the next step's batch
+        v->jump_n = pcg_jump(inc, (u128)v->cfg.num_envs * (u128)v->lay.act_dim - (u128)(v->lay.act_dim - 1));
     }
     v->act_seeded = true;
     return MI_OK;
@@ -827,7 +1047,7 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
     if (sample && !v->act_seeded) return fail(MI_ERR_STATE, "rollout without actions needs mi_action_seed");
     if (T == 0) return MI_OK;
     if (set_device(v)) return MI_ERR_HIP;
-    RolloutPtrs p = {io->actions_in, io->actions_out, (float *)io->obs, io->reward, io->terminated, io->truncated};
+    RolloutPtrs p = {io->actions_in, io->actions_out, io->obs, io->reward, io->terminated, io->truncated};
     ActionStream as;
     memset(&as, 0, sizeof as);
     if (sample) {
@@ -835,7 +1055,26 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
         as.inc_hi = (uint64_t)(v->act_rng.inc >> 64), as.inc_lo = (uint64_t)v->act_rng.inc;
         as.pow2 = v->d_pow2, as.jump_n = v->jump_n;
     }
-    int rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
+    int rc;
+    if (is_mj(v->cfg.kind)) {
+        rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int {
+            using E = decltype(env);
+            const dim3 g(v->grid), b(kBlock);
+            const bool next = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
+            if (next && sample)
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+            else if (next)
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+            else if (sample)
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+            else
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+            HIP_TRY(hipGetLastError());
+            return (int)MI_OK;
+        });
+    } else {
+        rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
+    }
     if (rc) return rc;
     if (sample) {  // the host copy of the generator moves past the T*N draws the kernel consumes
         const PcgJump j = pcg_jump(v->act_rng.inc, (u128)T * (u128)v->cfg.num_envs * (u128)v->lay.act_dim);

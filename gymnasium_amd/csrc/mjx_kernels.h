@@ -1,0 +1,162 @@
+// mjx_kernels.h -- the MuJoCo-family environments as lockstep kernels (included by engine.hip, which owns the C ABI).
+//
+// Per-env glue restated from the reference's Python (one lane = one scalar env):
+//   gymnasium/envs/mujoco/mujoco_env.py:132-155,172-187   set_state / do_simulation / reset
+//   gymnasium/envs/mujoco/half_cheetah_v5.py:220-281      step, _get_rew, _get_obs, reset_model
+//   gymnasium/envs/mujoco/ant_v5.py:327-428               contact_forces, is_healthy, step, _get_rew, _get_obs, reset_model
+// and the vectoriser semantics shared with the classic-control kernels (TimeLimit, autoreset modes, episode statistics).
+// Physics: mjx_core.h.  NumPy arithmetic that the reference inherits (np.sum pairwise order, float32 promotion of the
+// control cost, Generator.uniform / standard_normal streams) is reproduced bit for bit.
+#pragma once
+#include "mjx_core.h"
+#include "ziggurat_tables.h"
+
+namespace mjx {
+
+__device__ const uint64_t kZigKi[256] = {MI_ZIG_KI_VALUES};
+__device__ const double kZigWi[256] = {MI_ZIG_WI_VALUES};
+__device__ const double kZigFi[256] = {MI_ZIG_FI_VALUES};
+
+// numpy random_standard_normal (256-layer ziggurat) on the lane's own PCG64 stream
+MJX_DEV double standard_normal(mi::Pcg64 &rng) {
+    for (;;) {
+        uint64_t r = rng.next64();
+        const int idx = (int)(r & 0xff);
+        r >>= 8;
+        const int sign = (int)(r & 1);
+        const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * kZigWi[idx];
+        if (sign) x = -x;
+        if (rabs < kZigKi[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                const double xx = -MI_ZIG_INV_R * log1p(-rng.next_double());
+                const double yy = -log1p(-rng.next_double());
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(MI_ZIG_R + xx) : MI_ZIG_R + xx;
+            }
+        } else if ((kZigFi[idx - 1] - kZigFi[idx]) * rng.next_double() + kZigFi[idx] < exp(-0.5 * x * x)) {
+            return x;
+        }
+    }
+}
+
+// np.sum of a contiguous array: NumPy's pairwise_sum (plain loop < 8 elements, 8 interleaved accumulators up to 128)
+template <class T, int N>
+MJX_DEV T np_sum(const T *a) {
+    static_assert(N <= 128, "block recursion not needed for these envs");
+    if (N < 8) {
+        T res = 0;
+        for (int i = 0; i < N; i++) res += a[i];
+        return res;
+    }
+    T r[8];
+    for (int i = 0; i < 8; i++) r[i] = a[i];
+    int i = 8;
+    for (; i < N - (N % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < N; i++) res += a[i];
+    return res;
+}
+
+enum MjKind { kHalfCheetah = 0, kAnt = 1 };
+
+template <class M, int KIND>
+struct MjEnv {
+    typedef M Model;
+    static constexpr int NQ = M::NQ, NV = M::NV, NU = M::NU, NB = M::NBODY;
+    static constexpr int S = NQ + 2 * NV + 2;  // state row: qpos, qvel, (warm-start slot, unused by the Newton solver), tracked xy
+    static constexpr int INFO = KIND == kHalfCheetah ? 4 : 9;
+    static constexpr int SKIP = KIND == kHalfCheetah ? 1 : 2;
+
+    static MJX_DEV int obs_dim(const mi::EnvParams &P) {
+        int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
+        if (KIND == kAnt && P.p[12] != 0.0) n += 6 * (NB - 1);
+        return n;
+    }
+
+    // observation of the CURRENT state row with the given external forces (zero right after a reset, mj_resetData)
+    static MJX_DEV void write_obs(const double *s, const double (*cfrc)[6], const mi::EnvParams &P, double *o) {
+        int n = 0;
+        for (int k = (P.p[3] != 0.0 ? SKIP : 0); k < NQ; k++) o[n++] = s[k];
+        for (int k = 0; k < NV; k++) o[n++] = s[NQ + k];
+        if (KIND == kAnt && P.p[12] != 0.0)
+            for (int b = 1; b < NB; b++)
+                for (int k = 0; k < 6; k++) {
+                    const double f = cfrc ? cfrc[b][k] : 0.0;
+                    o[n++] = f < P.p[10] ? P.p[10] : (f > P.p[11] ? P.p[11] : f);
+                }
+    }
+
+    // reset_model: qpos = init_qpos + U(-s, s, nq), qvel = s * standard_normal(nv); set_state; tracked position refreshed
+    static MJX_DEV void reset(mi::Pcg64 &rng, double *s, const mi::EnvParams &P) {
+        const double scale = P.p[2];
+        for (int k = 0; k < NQ; k++) s[k] = M::qpos0[k] + (-scale + (scale - (-scale)) * rng.next_double());
+        for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + scale * standard_normal(rng);
+        for (int k = 0; k < NV; k++) s[NQ + NV + k] = 0.0;
+        // mj_forward at the reset state: the tracked Cartesian position is the free joint's / slider's own coordinate
+        s[NQ + 2 * NV] = s[0], s[NQ + 2 * NV + 1] = KIND == kHalfCheetah ? 0.0 : s[1];
+    }
+
+    static MJX_DEV void step(double *s, const float *action, const mi::EnvParams &P, double *obs, double &reward, bool &terminated,
+                             double *info) {
+        Data<M> d;
+        for (int k = 0; k < NQ; k++) d.qpos[k] = s[k];
+        for (int k = 0; k < NV; k++) d.qvel[k] = s[NQ + k];
+        for (int u = 0; u < NU; u++) d.ctrl[u] = (double)action[u];
+        const double before[2] = {s[NQ + 2 * NV], s[NQ + 2 * NV + 1]};
+        const int frame_skip = (int)P.p[4];
+        for (int f = 0; f < frame_skip; f++) mjx::step<M>(d);
+        // Cartesian quantities of the LAST forward pass (they lag qpos by one sub-step, as in the reference)
+        double after[2];
+        if (KIND == kHalfCheetah)
+            after[0] = d.qpos[0], after[1] = 0.0;
+        else
+            after[0] = d.xpos[1][0], after[1] = d.xpos[1][1];
+        for (int k = 0; k < NQ; k++) s[k] = d.qpos[k];
+        for (int k = 0; k < NV; k++) s[NQ + k] = d.qvel[k];
+        s[NQ + 2 * NV] = after[0], s[NQ + 2 * NV + 1] = after[1];
+        const double dt = M::TIMESTEP * frame_skip;
+        const double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
+        float sq[NU];
+        for (int u = 0; u < NU; u++) sq[u] = action[u] * action[u];
+        const float ctrl_cost_f = (float)P.p[1] * np_sum<float, NU>(sq);  // weight * np.sum(np.square(float32 action)): float32
+        if (KIND == kHalfCheetah) {
+            const double forward_reward = P.p[0] * xv;
+            reward = forward_reward - (double)ctrl_cost_f;
+            terminated = false;
+            write_obs(s, nullptr, P, obs);
+            if (info) info[0] = s[0], info[1] = xv, info[2] = forward_reward, info[3] = -(double)ctrl_cost_f;
+            return;
+        }
+        double cfrc[NB][6];
+        contact_forces<M>(d, cfrc);
+        bool finite = true;
+        for (int k = 0; k < NQ + NV; k++) finite &= isfinite(s[k]);
+        const bool healthy = finite && P.p[8] <= s[2] && s[2] <= P.p[9];
+        double c2[6 * NB];
+        for (int b = 0; b < NB; b++)
+            for (int k = 0; k < 6; k++) {
+                double f = cfrc[b][k];
+                f = f < P.p[10] ? P.p[10] : (f > P.p[11] ? P.p[11] : f);
+                c2[6 * b + k] = f * f;
+            }
+        const double contact_cost = P.p[5] * np_sum<double, 6 * NB>(c2), ctrl_cost = (double)ctrl_cost_f;
+        const double forward_reward = xv * P.p[0], healthy_reward = healthy ? P.p[6] : 0.0;
+        const double rewards = forward_reward + healthy_reward, costs = ctrl_cost + contact_cost;
+        reward = rewards - costs;
+        terminated = !healthy && P.p[7] != 0.0;
+        write_obs(s, cfrc, P, obs);
+        if (info) {
+            info[0] = s[0], info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]), info[3] = xv, info[4] = yv;
+            info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
+        }
+    }
+    static MJX_DEV void reset_info(const double *s, double *info) {
+        for (int k = 0; k < INFO; k++) info[k] = 0.0;
+        info[0] = s[0];
+        if (KIND != kHalfCheetah) info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]);
+    }
+};
+
+}  // namespace mjx
