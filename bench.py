@@ -47,9 +47,9 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0):
     eng = env._engine
     eng.action_seed(_native.pcg_words(env.action_space.np_random))
     T = 4
-    obs = np.zeros((T, num_envs, eng.obs_dim), np.float32)
+    obs = np.zeros((T, num_envs, eng.obs_dim), eng.obs_dtype)
     rew, te, tr = np.zeros((T, num_envs)), np.zeros((T, num_envs), np.bool_), np.zeros((T, num_envs), np.bool_)
-    acts = np.zeros((T, num_envs), dtype=eng.act_dtype)
+    acts = np.zeros((T, num_envs) if eng.act_dtype is np.int64 else (T, num_envs, eng.act_dim), dtype=eng.act_dtype)
     t0 = time.perf_counter()
     eng.rollout(T, None, acts, obs, rew, te, tr)
     per_step = (time.perf_counter() - t0) / T
@@ -104,8 +104,9 @@ def main():
     from gymnasium_amd import _native
 
     act_dtype = torch.int64 if env._discrete else torch.float32
-    acts = torch.empty((inner, N), dtype=act_dtype, device=dev)
-    obs = torch.empty((inner, N, eng.obs_dim), dtype=torch.float32, device=dev)
+    obs_dtype = torch.float64 if eng.obs_dtype is np.float64 else torch.float32
+    acts = torch.empty((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=act_dtype, device=dev)
+    obs = torch.empty((inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
     rew = torch.empty((inner, N), dtype=torch.float64, device=dev)
     te = torch.empty((inner, N), dtype=torch.bool, device=dev)
     tr = torch.empty((inner, N), dtype=torch.bool, device=dev)
@@ -145,7 +146,12 @@ def main():
     if rank == 0:
         value = env_steps / elapsed
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-        bytes_per_launch = (ROLLOUT_BYTES[args.env] * inner + STATE_BYTES[args.env]) * N
+        if args.env in ROLLOUT_BYTES:
+            rollout_b, state_b = ROLLOUT_BYTES[args.env], STATE_BYTES[args.env]
+        else:  # MuJoCo family: float32 action row + float64 obs row + reward + 2 flags per env-step; state row R+W per launch
+            rollout_b = 4 * eng.act_dim + 8 * eng.obs_dim + 8 + 2
+            state_b = 2 * (8 * eng.state_dim + 4 + 8 + 4)
+        bytes_per_launch = (rollout_b * inner + state_b) * N
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -165,14 +171,14 @@ def main():
                        "env": args.env, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
                        "parallelism": f"env-sharded x{world} (no data-path collective)"},
             "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
-            "roofline": {"bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.env in ROLLOUT_BYTES else "mj_rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3},
         }
 
     # ---- secondary numbers (rank 0, N=1 only): per-launch step() API ---------------------------------------
     if rank == 0 and world == 1 and not args.no_api:
-        a_dev = torch.randint(0, 2, (N,), device=dev) if env._discrete else (torch.rand((N, 1), device=dev) * 2 - 1)
+        a_dev = torch.randint(0, 2, (N,), device=dev) if env._discrete else (torch.rand((N, eng.act_dim), device=dev) * 0.8 - 0.4)
         env.copy = False
         for _ in range(20):
             env.step(a_dev)
@@ -189,7 +195,7 @@ def main():
         step_kernel_s = e0.elapsed_time(e1) * 1e-3 / reps
         result["api_step_device"] = {"value": N * reps / dt, "unit": "vector-env lanes/s (incl. autoreset lanes)",
                                      "us_per_step_wall": dt / reps * 1e6, "us_per_step_gpu": step_kernel_s * 1e6,
-                                     "roofline_frac": STEP_BYTES[args.env] * N / step_kernel_s / 1e9 / HBM_PEAK_GBS}
+                                     "roofline_frac": (STEP_BYTES[args.env] * N / step_kernel_s / 1e9 / HBM_PEAK_GBS) if args.env in STEP_BYTES else None}
         env_np = gymnasium_amd.make_vec(args.env, num_envs=N, device=local_rank, copy=False)
         env_np.reset(seed=0)
         env_np.action_space.seed(0)

@@ -470,9 +470,9 @@ MI_DEV void mj_store(const DevEnv &d, int i, const MjLane<E> &L) {
     d.ep_ret[i] = L.ep_ret, d.ep_len[i] = L.ep_len;
 }
 template <class E>
-MI_DEV void mj_autoreset(const DevEnv &d, int i, MjLane<E> &L) {
+MI_DEV void mj_autoreset(const DevEnv &d, int i, MjLane<E> &L, double *obs) {
     Pcg64 rng = load_rng(d, i);
-    E::reset(rng, L.s, d.P);
+    E::reset(rng, L.s, d.P, obs);
     store_rng_state(d, i, rng);
     L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
 }
@@ -483,8 +483,7 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
                          double &reward, bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st) {
     te = tr = false, reward = 0.0;
     if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
-        mj_autoreset<E>(d, i, L);
-        E::write_obs(L.s, nullptr, d.P, obs);
+        mj_autoreset<E>(d, i, L, obs);
         if (info) E::reset_info(L.s, info);
         st.reset_steps++;
     } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
@@ -504,8 +503,7 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
     if (MODE == MI_AUTORESET_SAME_STEP && done) {
         if (final_obs)
             for (int k = 0; k < E::obs_dim(d.P); k++) final_obs[k] = obs[k];
-        mj_autoreset<E>(d, i, L);
-        E::write_obs(L.s, nullptr, d.P, obs);
+        mj_autoreset<E>(d, i, L, obs);
     }
     if (done && MODE != MI_AUTORESET_SAME_STEP)
         L.flags |= kNeedsReset;
@@ -543,9 +541,8 @@ __global__ __launch_bounds__(kBlock) void mj_reset_kernel(DevEnv d, const uint8_
     MjLane<E> L;
     mj_load<E>(d, i, L);
     L.flags &= ~kNeedsReset;
-    mj_autoreset<E>(d, i, L);
+    mj_autoreset<E>(d, i, L, obs ? obs + (size_t)i * obs_dim : nullptr);
     mj_store<E>(d, i, L);
-    if (obs) E::write_obs(L.s, nullptr, d.P, obs + (size_t)i * obs_dim);
 }
 
 // fused rollout: T steps per launch, Box action space sampled on device from the batched space's single PCG64 stream
@@ -566,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtr
                 if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
         }
         const size_t N = (size_t)d.N;
-        double scratch_obs[128];
+        double scratch_obs[E::MAX_OBS];
         for (int t = 0; t < T; t++) {
             float a[E::NU];
             if (SAMPLE) {
@@ -687,12 +684,14 @@ int dispatch_kind(int kind, F &&f) {
 
 typedef mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah> HalfCheetahEnv;
 typedef mjx::MjEnv<mjx::AntModel, mjx::kAnt> AntEnv;
+typedef mjx::MjEnv<mjx::HumanoidModel, mjx::kHumanoid> HumanoidEnv;
 bool is_mj(int kind) { return kind >= kClassicKinds; }
 template <class F>
 int dispatch_mj(int kind, F &&f) {
     switch (kind) {
     case MI_ENV_HALF_CHEETAH: return f(HalfCheetahEnv());
     case MI_ENV_ANT: return f(AntEnv());
+    case MI_ENV_HUMANOID: return f(HumanoidEnv());
     }
     return fail(MI_ERR_UNSUPPORTED, "this MuJoCo kind is not built into the HIP engine yet");
 }
@@ -772,7 +771,6 @@ int mi_device_count(void) {
 int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mi_config)) return fail(MI_ERR_INVALID_ARGUMENT, "bad mi_config");
     if (cfg->kind < 0 || cfg->kind >= MI_ENV_KIND_COUNT) return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
-    if (cfg->kind == MI_ENV_HUMANOID) return fail(MI_ERR_UNSUPPORTED, "Humanoid-v5 is not built into the HIP engine yet");
     if (cfg->num_envs < 1) return fail(MI_ERR_INVALID_ARGUMENT, "num_envs must be >= 1");
     if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2) return fail(MI_ERR_INVALID_ARGUMENT, "bad autoreset mode");
     if (cfg->max_episode_steps > (int)kElapsedMask) return fail(MI_ERR_INVALID_ARGUMENT, "max_episode_steps too large");
@@ -790,7 +788,10 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         dispatch_mj(cfg->kind, [&](auto env) -> int {
             using E = decltype(env);
             const int skip = P.p[3] != 0.0 ? E::SKIP : 0;
-            const int extra = (cfg->kind == MI_ENV_ANT && P.p[12] != 0.0) ? 6 * (E::NB - 1) : 0;
+            int extra = (cfg->kind == MI_ENV_ANT && P.p[12] != 0.0) ? 6 * (E::NB - 1) : 0;
+            if (cfg->kind == MI_ENV_HUMANOID)
+                extra = (P.p[12] != 0.0 ? 10 * (E::NB - 1) : 0) + (P.p[13] != 0.0 ? 6 * (E::NB - 1) : 0) + (P.p[14] != 0.0 ? E::NV - 6 : 0) +
+                        (P.p[15] != 0.0 ? 6 * (E::NB - 1) : 0);
             const mi_layout l = {E::NQ + E::NV - skip + extra, MI_F64, E::NU, MI_F32, E::S, E::INFO, {0, 0}};
             v->lay = l;
             return (int)MI_OK;

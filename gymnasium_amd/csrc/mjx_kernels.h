@@ -59,7 +59,16 @@ MJX_DEV T np_sum(const T *a) {
     return res;
 }
 
-enum MjKind { kHalfCheetah = 0, kAnt = 1 };
+enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2 };
+
+// quantities of the last forward pass that the observations read besides qpos / qvel (null pointer = zeros, which is
+// what mj_resetData leaves in cfrc_ext / qfrc_actuator)
+struct ObsExtras {
+    const double (*cfrc)[6];
+    const double (*cinert)[10];
+    const double (*cvel)[6];
+    const double *qfrc_actuator;
+};
 
 template <class M, int KIND>
 struct MjEnv {
@@ -68,34 +77,83 @@ struct MjEnv {
     static constexpr int S = NQ + 2 * NV + 2;  // state row: qpos, qvel, (warm-start slot, unused by the Newton solver), tracked xy
     static constexpr int INFO = KIND == kHalfCheetah ? 4 : 9;
     static constexpr int SKIP = KIND == kHalfCheetah ? 1 : 2;
+    static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (KIND == kHumanoid ? 22 * (NB - 1) + NV - 6 : 0);
 
     static MJX_DEV int obs_dim(const mi::EnvParams &P) {
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
         if (KIND == kAnt && P.p[12] != 0.0) n += 6 * (NB - 1);
+        if (KIND == kHumanoid)
+            n += (P.p[12] != 0.0 ? 10 * (NB - 1) : 0) + (P.p[13] != 0.0 ? 6 * (NB - 1) : 0) + (P.p[14] != 0.0 ? NV - 6 : 0) +
+                 (P.p[15] != 0.0 ? 6 * (NB - 1) : 0);
         return n;
     }
 
-    // observation of the CURRENT state row with the given external forces (zero right after a reset, mj_resetData)
-    static MJX_DEV void write_obs(const double *s, const double (*cfrc)[6], const mi::EnvParams &P, double *o) {
+    // ant_v5.py:393-404, half_cheetah_v5.py:248-257, humanoid_v5.py:430-466
+    static MJX_DEV void write_obs(const double *s, const ObsExtras &x, const mi::EnvParams &P, double *o) {
         int n = 0;
         for (int k = (P.p[3] != 0.0 ? SKIP : 0); k < NQ; k++) o[n++] = s[k];
         for (int k = 0; k < NV; k++) o[n++] = s[NQ + k];
         if (KIND == kAnt && P.p[12] != 0.0)
             for (int b = 1; b < NB; b++)
                 for (int k = 0; k < 6; k++) {
-                    const double f = cfrc ? cfrc[b][k] : 0.0;
-                    o[n++] = f < P.p[10] ? P.p[10] : (f > P.p[11] ? P.p[11] : f);
+                    const double f = x.cfrc ? x.cfrc[b][k] : 0.0;
+                    o[n++] = f < P.p[10] ? P.p[10] : (f > P.p[11] ? P.p[11] : f);  // np.clip(cfrc_ext, lo, hi)
                 }
+        if (KIND == kHumanoid) {
+            if (P.p[12] != 0.0)
+                for (int b = 1; b < NB; b++)
+                    for (int k = 0; k < 10; k++) o[n++] = x.cinert ? x.cinert[b][k] : 0.0;
+            if (P.p[13] != 0.0)
+                for (int b = 1; b < NB; b++)
+                    for (int k = 0; k < 6; k++) o[n++] = x.cvel ? x.cvel[b][k] : 0.0;
+            if (P.p[14] != 0.0)
+                for (int k = 6; k < NV; k++) o[n++] = x.qfrc_actuator ? x.qfrc_actuator[k] : 0.0;
+            if (P.p[15] != 0.0)
+                for (int b = 1; b < NB; b++)
+                    for (int k = 0; k < 6; k++) o[n++] = x.cfrc ? x.cfrc[b][k] : 0.0;
+        }
     }
 
-    // reset_model: qpos = init_qpos + U(-s, s, nq), qvel = s * standard_normal(nv); set_state; tracked position refreshed
-    static MJX_DEV void reset(mi::Pcg64 &rng, double *s, const mi::EnvParams &P) {
+    // mass_center (humanoid_v5.py:17-21): einsum("b,bj->j", body_mass, xipos) / body_mass.sum()
+    static MJX_DEV void mass_center_xy(const Data<M> &d, double *out) {
+        double nx = 0, ny = 0, mass[NB];
+        for (int b = 0; b < NB; b++) nx += M::body_mass[b] * d.xipos[b][0], ny += M::body_mass[b] * d.xipos[b][1], mass[b] = M::body_mass[b];
+        const double den = np_sum<double, NB>(mass);
+        out[0] = nx / den, out[1] = ny / den;
+    }
+
+    // reset_model + set_state (-> mj_forward); writes the reset observation when obs != nullptr
+    static MJX_DEV void reset(mi::Pcg64 &rng, double *s, const mi::EnvParams &P, double *obs) {
         const double scale = P.p[2];
         for (int k = 0; k < NQ; k++) s[k] = M::qpos0[k] + (-scale + (scale - (-scale)) * rng.next_double());
-        for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + scale * standard_normal(rng);
+        if (KIND == kHumanoid)  // humanoid_v5.py:526-528: uniform noise on the velocities as well
+            for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-scale + (scale - (-scale)) * rng.next_double());
+        else
+            for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + scale * standard_normal(rng);
         for (int k = 0; k < NV; k++) s[NQ + NV + k] = 0.0;
-        // mj_forward at the reset state: the tracked Cartesian position is the free joint's / slider's own coordinate
+        if (KIND == kHumanoid) {
+            // the observation shows cinert / cvel of the forward pass at the reset state, and the tracked point is the
+            // whole-body centre of mass
+            Data<M> d;
+            for (int k = 0; k < NQ; k++) d.qpos[k] = s[k];
+            for (int k = 0; k < NV; k++) d.qvel[k] = s[NQ + k];
+            kinematics<M>(d);
+            com_pos<M>(d);
+            double bias[NV];
+            com_vel_and_bias<M>(d, bias);
+            mass_center_xy(d, s + NQ + 2 * NV);
+            if (obs) {
+                const ObsExtras x = {nullptr, d.cinert, d.cvel, nullptr};
+                write_obs(s, x, P, obs);
+            }
+            return;
+        }
+        // free joint / slider: the tracked Cartesian position is the joint's own coordinate
         s[NQ + 2 * NV] = s[0], s[NQ + 2 * NV + 1] = KIND == kHalfCheetah ? 0.0 : s[1];
+        if (obs) {
+            const ObsExtras x = {nullptr, nullptr, nullptr, nullptr};
+            write_obs(s, x, P, obs);
+        }
     }
 
     static MJX_DEV void step(double *s, const float *action, const mi::EnvParams &P, double *obs, double &reward, bool &terminated,
@@ -111,8 +169,10 @@ struct MjEnv {
         double after[2];
         if (KIND == kHalfCheetah)
             after[0] = d.qpos[0], after[1] = 0.0;
-        else
+        else if (KIND == kAnt)
             after[0] = d.xpos[1][0], after[1] = d.xpos[1][1];
+        else
+            mass_center_xy(d, after);
         for (int k = 0; k < NQ; k++) s[k] = d.qpos[k];
         for (int k = 0; k < NV; k++) s[NQ + k] = d.qvel[k];
         s[NQ + 2 * NV] = after[0], s[NQ + 2 * NV + 1] = after[1];
@@ -125,28 +185,43 @@ struct MjEnv {
             const double forward_reward = P.p[0] * xv;
             reward = forward_reward - (double)ctrl_cost_f;
             terminated = false;
-            write_obs(s, nullptr, P, obs);
+            const ObsExtras x = {nullptr, nullptr, nullptr, nullptr};
+            write_obs(s, x, P, obs);
             if (info) info[0] = s[0], info[1] = xv, info[2] = forward_reward, info[3] = -(double)ctrl_cost_f;
             return;
         }
-        double cfrc[NB][6];
+        double cfrc[NB][6], c2[6 * NB];
         contact_forces<M>(d, cfrc);
-        bool finite = true;
-        for (int k = 0; k < NQ + NV; k++) finite &= isfinite(s[k]);
-        const bool healthy = finite && P.p[8] <= s[2] && s[2] <= P.p[9];
-        double c2[6 * NB];
-        for (int b = 0; b < NB; b++)
-            for (int k = 0; k < 6; k++) {
-                double f = cfrc[b][k];
-                f = f < P.p[10] ? P.p[10] : (f > P.p[11] ? P.p[11] : f);
-                c2[6 * b + k] = f * f;
-            }
-        const double contact_cost = P.p[5] * np_sum<double, 6 * NB>(c2), ctrl_cost = (double)ctrl_cost_f;
-        const double forward_reward = xv * P.p[0], healthy_reward = healthy ? P.p[6] : 0.0;
+        bool healthy;
+        double ctrl_cost, contact_cost;
+        if (KIND == kAnt) {
+            bool finite = true;
+            for (int k = 0; k < NQ + NV; k++) finite &= isfinite(s[k]);
+            healthy = finite && P.p[8] <= s[2] && s[2] <= P.p[9];
+            for (int b = 0; b < NB; b++)
+                for (int k = 0; k < 6; k++) {
+                    double f = cfrc[b][k];
+                    f = f < P.p[10] ? P.p[10] : (f > P.p[11] ? P.p[11] : f);
+                    c2[6 * b + k] = f * f;
+                }
+            contact_cost = P.p[5] * np_sum<double, 6 * NB>(c2), ctrl_cost = (double)ctrl_cost_f;
+        } else {
+            healthy = P.p[8] < s[2] && s[2] < P.p[9];
+            double sqd[NU];
+            for (int u = 0; u < NU; u++) sqd[u] = d.ctrl[u] * d.ctrl[u];  // np.square(self.data.ctrl): float64
+            ctrl_cost = P.p[1] * np_sum<double, NU>(sqd);
+            for (int b = 0; b < NB; b++)
+                for (int k = 0; k < 6; k++) c2[6 * b + k] = cfrc[b][k] * cfrc[b][k];
+            contact_cost = P.p[5] * np_sum<double, 6 * NB>(c2);
+            contact_cost = contact_cost < P.p[10] ? P.p[10] : (contact_cost > P.p[11] ? P.p[11] : contact_cost);
+        }
+        const double forward_reward = KIND == kAnt ? xv * P.p[0] : P.p[0] * xv, healthy_reward = healthy ? P.p[6] : 0.0;
         const double rewards = forward_reward + healthy_reward, costs = ctrl_cost + contact_cost;
         reward = rewards - costs;
         terminated = !healthy && P.p[7] != 0.0;
-        write_obs(s, cfrc, P, obs);
+        if (KIND == kHumanoid) com_pos<M>(d);  // crb() folded the per-body inertias into composites: restore them for the obs
+        const ObsExtras x = {cfrc, d.cinert, d.cvel, d.qfrc_actuator};
+        write_obs(s, x, P, obs);
         if (info) {
             info[0] = s[0], info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]), info[3] = xv, info[4] = yv;
             info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;

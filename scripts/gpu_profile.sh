@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 20 --warmup 3 --no-api --no-cpu-baseline $*"
+CMD="python $ROOT/bench.py --steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-3} --no-api --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -- $CMD > "$OUT/${TAG}_stats.log" 2>&1
 PMC=()
 for C in FETCH_SIZE WRITE_SIZE; do
