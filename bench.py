@@ -47,7 +47,7 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0):
     eng = env._engine
     eng.action_seed(_native.pcg_words(env.action_space.np_random))
     T = 4
-    obs = np.zeros((T, num_envs, eng.obs_dim), eng.obs_dtype)
+    obs = np.zeros((T, num_envs) if eng.obs_dtype is np.int64 else (T, num_envs, eng.obs_dim), eng.obs_dtype)
     rew, te, tr = np.zeros((T, num_envs)), np.zeros((T, num_envs), np.bool_), np.zeros((T, num_envs), np.bool_)
     acts = np.zeros((T, num_envs) if eng.act_dtype is np.int64 else (T, num_envs, eng.act_dim), dtype=eng.act_dtype)
     t0 = time.perf_counter()
@@ -104,9 +104,9 @@ def main():
     from gymnasium_amd import _native
 
     act_dtype = torch.int64 if env._discrete else torch.float32
-    obs_dtype = torch.float64 if eng.obs_dtype is np.float64 else torch.float32
+    obs_dtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
     acts = torch.empty((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=act_dtype, device=dev)
-    obs = torch.empty((inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
+    obs = torch.empty((inner, N) if eng.obs_dtype is np.int64 else (inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
     rew = torch.empty((inner, N), dtype=torch.float64, device=dev)
     te = torch.empty((inner, N), dtype=torch.bool, device=dev)
     tr = torch.empty((inner, N), dtype=torch.bool, device=dev)
@@ -149,7 +149,7 @@ def main():
         if args.env in ROLLOUT_BYTES:
             rollout_b, state_b = ROLLOUT_BYTES[args.env], STATE_BYTES[args.env]
         else:  # MuJoCo family: float32 action row + float64 obs row + reward + 2 flags per env-step; state row R+W per launch
-            rollout_b = 4 * eng.act_dim + 8 * eng.obs_dim + 8 + 2
+            rollout_b = (8 if env._discrete else 4 * eng.act_dim) + 8 * eng.obs_dim + 8 + 2
             state_b = 2 * (8 * eng.state_dim + 4 + 8 + 4)
         bytes_per_launch = (rollout_b * inner + state_b) * N
         achieved = bytes_per_launch / avg_kernel_s / 1e9
@@ -171,7 +171,7 @@ def main():
                        "env": args.env, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
                        "parallelism": f"env-sharded x{world} (no data-path collective)"},
             "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
-            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.env in ROLLOUT_BYTES else "mj_rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.env in ROLLOUT_BYTES else ("tab_rollout_kernel" if eng.obs_dtype is np.int64 else "mj_rollout_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3},
         }

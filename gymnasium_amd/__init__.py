@@ -22,16 +22,18 @@ def register_envs(override_stock_ids: bool = False) -> None:
     (envs/registration.py:564-638).  ``override_stock_ids=True`` additionally attaches the engine to the stock ids
     (``CartPole-v1`` ...), so that plain ``make_vec("CartPole-v1", n)`` picks it up (a spec with a
     ``vector_entry_point`` makes that the default mode, registration.py:887-891)."""
-    for env_id, (creator, max_steps, threshold) in ENV_TABLE.items():
+    for env_id, entry in ENV_TABLE.items():
+        creator, max_steps, threshold = entry[:3]
+        kw = dict(entry[3]) if len(entry) > 3 else {}
         name = f"{NAMESPACE}/{env_id}"
         if name not in registry:
-            register(id=name, vector_entry_point=creator, max_episode_steps=max_steps, reward_threshold=threshold)
+            register(id=name, vector_entry_point=creator, max_episode_steps=max_steps, reward_threshold=threshold, kwargs=kw)
         if override_stock_ids or not gym_api.HAVE_GYMNASIUM:
             if env_id in registry:
                 if override_stock_ids:
                     registry[env_id].vector_entry_point = creator
             else:
-                register(id=env_id, vector_entry_point=creator, max_episode_steps=max_steps, reward_threshold=threshold)
+                register(id=env_id, vector_entry_point=creator, max_episode_steps=max_steps, reward_threshold=threshold, kwargs=kw)
 
 
 register_envs()

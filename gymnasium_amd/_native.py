@@ -18,7 +18,7 @@ FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
 ABI_VERSION = 2
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
-             "half_cheetah": 5, "ant": 6, "humanoid": 7}
+             "half_cheetah": 5, "ant": 6, "humanoid": 7, "tabular": 8}
 AUTORESET = {"NextStep": 0, "SameStep": 1, "Disabled": 2}
 NP_DTYPES = {MI_F32: np.float32, MI_F64: np.float64, MI_I64: np.int64}
 
@@ -26,7 +26,7 @@ NP_DTYPES = {MI_F32: np.float32, MI_F64: np.float64, MI_I64: np.int64}
 SYMBOLS = [
     "abi_version", "last_error", "device_count", "create", "destroy", "get_layout", "set_stream", "synchronize",
     "seed", "seed_sequence", "reset", "step", "action_seed", "rollout", "get_stats", "reset_stats", "get_state",
-    "set_state", "get_rng",
+    "set_state", "get_rng", "tabular_load",
 ]
 
 
@@ -49,6 +49,12 @@ class MiStepIO(C.Structure):
 class MiRolloutIO(C.Structure):
     _fields_ = [("actions_in", C.c_void_p), ("actions_out", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p),
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
+
+
+class MiTabularTable(C.Structure):
+    _fields_ = [("num_states", C.c_int32), ("num_actions", C.c_int32), ("max_outcomes", C.c_int32), ("reserved", C.c_int32),
+                ("csprob", C.c_void_p), ("prob", C.c_void_p), ("next_state", C.c_void_p), ("reward", C.c_void_p),
+                ("terminated", C.c_void_p), ("count", C.c_void_p), ("isd_csprob", C.c_void_p)]
 
 
 class MiStats(C.Structure):
@@ -96,6 +102,7 @@ class NativeLib:
         self.get_state = f("get_state", [vp, vp, vp, vp], i32)
         self.set_state = f("set_state", [vp, vp, vp, vp], i32)
         self.get_rng = f("get_rng", [vp, vp], i32)
+        self.tabular_load = f("tabular_load", [vp, C.POINTER(MiTabularTable)], i32)
         if self.abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {self.abi_version()} != binding version {ABI_VERSION}")
 
@@ -249,6 +256,16 @@ class Engine:
         if flags is not None:
             flags = np.ascontiguousarray(flags, dtype=np.uint8)
         self.lib.check(self.lib.set_state(self.handle, _ptr(state), _ptr(elapsed), _ptr(flags)))
+
+    def load_table(self, csprob, prob, next_state, reward, terminated, count, isd_csprob):
+        """Hand a finite MDP's transition table to the engine (mi_tabular_load)."""
+        t = MiTabularTable()
+        t.num_states, t.num_actions, t.max_outcomes = csprob.shape
+        keep = [np.ascontiguousarray(csprob, np.float64), np.ascontiguousarray(prob, np.float64), np.ascontiguousarray(next_state, np.int32),
+                np.ascontiguousarray(reward, np.float64), np.ascontiguousarray(terminated, np.uint8), np.ascontiguousarray(count, np.int32),
+                np.ascontiguousarray(isd_csprob, np.float64)]
+        t.csprob, t.prob, t.next_state, t.reward, t.terminated, t.count, t.isd_csprob = [a.ctypes.data for a in keep]
+        self.lib.check(self.lib.tabular_load(self.handle, C.byref(t)))
 
     def get_rng(self) -> np.ndarray:
         words = np.empty((self.num_envs, 4), dtype=np.uint64)

@@ -37,6 +37,14 @@ constexpr int kBlock = 256;  // 4 wavefronts: one per SIMD of a CU
 constexpr int kErrInvalidAction = 1, kErrDisabledStepped = 2;
 constexpr uint32_t kFlagShift = 30, kElapsedMask = (1u << kFlagShift) - 1u;
 
+// Transition table of a tabular (ToyText) environment, device pointers (mi_tabular_load).
+struct TabTable {
+    int nS, nA, K;
+    const double *csprob, *prob, *reward, *isd;
+    const int32_t *next, *count;
+    const uint8_t *term;
+};
+
 // Device view of one vector environment (passed by value as a kernel argument).
 struct DevEnv {
     double *state;       // [S][N]   physics state, component-major
@@ -50,6 +58,7 @@ struct DevEnv {
     int N;
     int max_steps;
     EnvParams P;
+    TabTable tab;
 };
 
 struct LaneStats {
@@ -595,6 +604,167 @@ __global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtr
     block_accumulate(d, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ToyText: finite MDPs.  state row = {state index, probability of the last transition}; integer lookups only.
+//   step:  i = argmax(cumsum(p) > rng.random()) (toy_text/utils.py:4-8), then P[s][a][i]  (frozen_lake.py:324-335)
+//   reset: s = argmax(cumsum(initial_state_distrib) > rng.random())                        (frozen_lake.py:337-348)
+// ---------------------------------------------------------------------------------------------------------
+MI_DEV int tab_categorical(const double *csprob, int n, Pcg64 &rng) {
+    const double u = rng.next_double();
+    for (int k = 0; k < n; k++)
+        if (csprob[k] > u) return k;
+    return 0;  // np.argmax of an all-False array
+}
+struct TabLane {
+    double s, prob;
+    uint32_t elapsed, flags;
+    double ep_ret;
+    int32_t ep_len;
+};
+MI_DEV void tab_load(const DevEnv &d, int i, TabLane &L) {
+    L.s = d.state[i], L.prob = d.state[(size_t)d.N + i];
+    const uint32_t m = d.meta[i];
+    L.elapsed = m & kElapsedMask, L.flags = m >> kFlagShift;
+    L.ep_ret = d.ep_ret[i], L.ep_len = d.ep_len[i];
+}
+MI_DEV void tab_store(const DevEnv &d, int i, const TabLane &L) {
+    d.state[i] = L.s, d.state[(size_t)d.N + i] = L.prob;
+    d.meta[i] = (L.elapsed & kElapsedMask) | (L.flags << kFlagShift);
+    d.ep_ret[i] = L.ep_ret, d.ep_len[i] = L.ep_len;
+}
+MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L) {
+    Pcg64 rng = load_rng(d, i);
+    L.s = (double)tab_categorical(d.tab.isd, d.tab.nS, rng);
+    store_rng_state(d, i, rng);
+    L.prob = 1.0, L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+}
+template <int MODE>
+MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t &obs, int64_t &final_obs, bool &has_final, double &reward,
+                          bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st) {
+    te = tr = false, reward = 0.0, has_final = false;
+    if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
+        tab_autoreset(d, i, L);
+        st.reset_steps++;
+    } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
+        *d.error = kErrDisabledStepped;
+        obs = (int64_t)L.s, out_ret = 0.0, out_len = 0;
+        return;
+    } else {
+        if (a < 0 || a >= d.tab.nA) {
+            *d.error = kErrInvalidAction;
+            a = 0;
+        }
+        const size_t cell = (size_t)L.s * d.tab.nA + (size_t)a, row = cell * d.tab.K;
+        Pcg64 rng = load_rng(d, i);
+        const int k = tab_categorical(d.tab.csprob + row, d.tab.count[cell], rng);
+        store_rng_state(d, i, rng);
+        L.s = (double)d.tab.next[row + k], L.prob = d.tab.prob[row + k];
+        reward = d.tab.reward[row + k], te = d.tab.term[row + k] != 0;
+        L.elapsed += 1;
+        tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;
+        L.ep_ret += reward, L.ep_len += 1;
+        st.env_steps++;
+    }
+    const bool done = te || tr;
+    out_ret = done ? L.ep_ret : 0.0, out_len = done ? L.ep_len : 0;
+    if (done) st.episodes++, st.return_sum += L.ep_ret, st.length_sum += (uint64_t)L.ep_len;
+    if (MODE == MI_AUTORESET_SAME_STEP && done) {
+        final_obs = (int64_t)L.s, has_final = true;
+        tab_autoreset(d, i, L);
+    }
+    obs = (int64_t)L.s;
+    if (done && MODE != MI_AUTORESET_SAME_STEP)
+        L.flags |= kNeedsReset;
+    else
+        L.flags &= ~kNeedsReset;
+}
+
+struct TabStepPtrs {
+    const int64_t *actions;
+    int64_t *obs;
+    double *reward;
+    uint8_t *terminated, *truncated;
+    int64_t *final_obs;
+    double *ep_ret;
+    int32_t *ep_len;
+    double *info;
+};
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void tab_step_kernel(DevEnv d, TabStepPtrs io) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        TabLane L;
+        tab_load(d, i, L);
+        int64_t obs, fin = 0;
+        double reward, out_ret;
+        int32_t out_len;
+        bool te, tr, has_final;
+        tab_lane_step<MODE>(d, i, L, io.actions[i], obs, fin, has_final, reward, te, tr, out_ret, out_len, st);
+        tab_store(d, i, L);
+        if (io.obs) io.obs[i] = obs;
+        if (io.reward) io.reward[i] = reward;
+        if (io.terminated) io.terminated[i] = te;
+        if (io.truncated) io.truncated[i] = tr;
+        if (io.final_obs && has_final) io.final_obs[i] = fin;
+        if (io.ep_ret) io.ep_ret[i] = out_ret;
+        if (io.ep_len) io.ep_len[i] = out_len;
+        if (io.info) io.info[i] = L.prob;
+    }
+    block_accumulate(d, st);
+}
+__global__ __launch_bounds__(kBlock) void tab_reset_kernel(DevEnv d, const uint8_t *mask, int64_t *obs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.N || (mask && !mask[i])) return;
+    TabLane L;
+    tab_load(d, i, L);
+    L.flags &= ~kNeedsReset;
+    tab_autoreset(d, i, L);
+    tab_store(d, i, L);
+    if (obs) obs[i] = (int64_t)L.s;
+}
+template <int MODE, bool SAMPLE>
+__global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        TabLane L;
+        tab_load(d, i, L);
+        u128 astate = 0;
+        if (SAMPLE) {
+            astate = make_u128(as.state_hi, as.state_lo);
+            uint32_t delta = (uint32_t)i + 1u;
+            for (int j = 0; delta; j++, delta >>= 1)
+                if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
+        }
+        const size_t N = (size_t)d.N;
+        for (int t = 0; t < T; t++) {
+            int64_t a;
+            if (SAMPLE) {
+                const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate, x = hi ^ lo;
+                const unsigned rot = (unsigned)(hi >> 58);
+                const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+                a = (int64_t)((double)(out >> 11) * (1.0 / 9007199254740992.0) * (double)d.tab.nA);  // (random(N) * nvec).astype(int64)
+                astate = as.jump_n.mult * astate + as.jump_n.plus;
+                if (io.actions_out) static_cast<int64_t *>(io.actions_out)[t * N + i] = a;
+            } else {
+                a = static_cast<const int64_t *>(io.actions_in)[t * N + i];
+            }
+            int64_t obs, fin = 0;
+            double reward, out_ret;
+            int32_t out_len;
+            bool te, tr, has_final;
+            tab_lane_step<MODE>(d, i, L, a, obs, fin, has_final, reward, te, tr, out_ret, out_len, st);
+            if (io.obs) static_cast<int64_t *>(io.obs)[t * N + i] = obs;
+            if (io.reward) io.reward[t * N + i] = reward;
+            if (io.terminated) io.terminated[t * N + i] = te;
+            if (io.truncated) io.truncated[t * N + i] = tr;
+        }
+        tab_store(d, i, L);
+    }
+    block_accumulate(d, st);
+}
+
 __global__ void seed_words_kernel(DevEnv d, const uint64_t *words, const uint8_t *mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N || (mask && !mask[i])) return;
@@ -641,7 +811,7 @@ const mi_layout kLayouts[kClassicKinds] = {
     {MountainCar::OBS, MI_F32, 1, MI_I64, MountainCar::S, 0, {0, 0}},
     {MountainCarContinuous::OBS, MI_F32, 1, MI_F32, MountainCarContinuous::S, 0, {0, 0}},
 };
-const int kNumActions[MI_ENV_KIND_COUNT] = {2, 0, 3, 3, 0, 0, 0, 0};
+const int kNumActions[MI_ENV_KIND_COUNT] = {2, 0, 3, 3, 0, 0, 0, 0, 0};
 
 }  // namespace
 
@@ -666,6 +836,8 @@ struct mi_vecenv {
     size_t act_bytes, obs_bytes;
     double *d_info;
     size_t info_bytes;
+    void *tab_bufs[7];
+    bool tab_loaded;
 };
 
 namespace {
@@ -685,7 +857,8 @@ int dispatch_kind(int kind, F &&f) {
 typedef mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah> HalfCheetahEnv;
 typedef mjx::MjEnv<mjx::AntModel, mjx::kAnt> AntEnv;
 typedef mjx::MjEnv<mjx::HumanoidModel, mjx::kHumanoid> HumanoidEnv;
-bool is_mj(int kind) { return kind >= kClassicKinds; }
+bool is_mj(int kind) { return kind >= kClassicKinds && kind <= MI_ENV_HUMANOID; }
+bool is_tab(int kind) { return kind == MI_ENV_TABULAR; }
 template <class F>
 int dispatch_mj(int kind, F &&f) {
     switch (kind) {
@@ -796,6 +969,9 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
             v->lay = l;
             return (int)MI_OK;
         });
+    } else if (is_tab(cfg->kind)) {
+        const mi_layout l = {1, MI_I64, 1, MI_I64, 2, 1, {0, 0}};
+        v->lay = l;
     } else {
         v->lay = kLayouts[cfg->kind];
     }
@@ -825,7 +1001,7 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     HIP_TRY(hipMemsetAsync(d.blk_ret, 0, sizeof(double) * v->grid, v->stream));
     HIP_TRY(hipMemsetAsync(d.error, 0, sizeof(int), v->stream));
     v->act_bytes = N * (v->lay.act_dtype == MI_I64 ? 8 : 4) * v->lay.act_dim;
-    v->obs_bytes = N * (v->lay.obs_dtype == MI_F64 ? sizeof(double) : sizeof(float)) * v->lay.obs_dim;
+    v->obs_bytes = N * (v->lay.obs_dtype == MI_F32 ? sizeof(float) : sizeof(double)) * v->lay.obs_dim;
     v->info_bytes = N * sizeof(double) * (v->lay.info_dim > 0 ? v->lay.info_dim : 1);
     HIP_TRY(hipMalloc(&v->d_info, v->info_bytes));
     HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes));
@@ -852,6 +1028,8 @@ void mi_destroy(mi_vecenv *v) {
                     v->d_pow2, v->d_actions, v->d_obs, v->d_final, v->d_reward, v->d_epret, v->d_eplen, v->d_term,
                     v->d_trunc, v->d_mask, v->d_words, v->d_info};
     for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (void *p : v->tab_bufs)
         if (p) (void)hipFree(p);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
     delete v;
@@ -937,6 +1115,17 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
     }
     const int has_bounds = bounds != nullptr;
     const double b0 = has_bounds ? bounds[0] : 0.0, b1 = has_bounds ? bounds[1] : 0.0;
+    if (is_tab(v->cfg.kind)) {
+        if (!v->tab_loaded) return fail(MI_ERR_STATE, "tabular environment without a table: call mi_tabular_load first");
+        hipLaunchKernelGGL(tab_reset_kernel, dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, (int64_t *)dobs);
+        HIP_TRY(hipGetLastError());
+        v->was_reset = true;
+        if (loc == MI_HOST) {
+            if (obs) HIP_TRY(hipMemcpyAsync(obs, v->d_obs, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
+            HIP_TRY(hipStreamSynchronize(v->stream));
+        }
+        return MI_OK;
+    }
     int rc = is_mj(v->cfg.kind) ? dispatch_mj(v->cfg.kind, [&](auto env) -> int {
         using E = decltype(env);
         hipLaunchKernelGGL((mj_reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, (double *)dobs, v->lay.obs_dim);
@@ -966,7 +1155,7 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
     StepPtrs p;
     if (loc == MI_HOST) {
         // validate before anything is mutated (cartpole.py:165-167 asserts action_space.contains(action))
-        const int na = kNumActions[v->cfg.kind];
+        const int na = is_tab(v->cfg.kind) ? v->d.tab.nA : kNumActions[v->cfg.kind];
         if (na) {
             const int64_t *a = (const int64_t *)io->actions;
             for (size_t i = 0; i < N; i++)
@@ -985,7 +1174,18 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
     }
     double *dinfo = loc == MI_HOST ? (io->info ? v->d_info : nullptr) : io->info;
     int rc;
-    if (is_mj(v->cfg.kind)) {
+    if (is_tab(v->cfg.kind)) {
+        const TabStepPtrs tp = {(const int64_t *)p.actions, (int64_t *)p.obs, p.reward, p.terminated, p.truncated, (int64_t *)p.final_obs,
+                                p.ep_ret, p.ep_len, dinfo};
+        const dim3 g(v->grid), b(kBlock);
+        switch (v->cfg.autoreset_mode) {
+        case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_NEXT_STEP>), g, b, 0, v->stream, v->d, tp); break;
+        case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_SAME_STEP>), g, b, 0, v->stream, v->d, tp); break;
+        default: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_DISABLED>), g, b, 0, v->stream, v->d, tp); break;
+        }
+        HIP_TRY(hipGetLastError());
+        rc = MI_OK;
+    } else if (is_mj(v->cfg.kind)) {
         const MjStepPtrs mp = {(const float *)p.actions, (double *)p.obs, p.reward, p.terminated, p.truncated, (double *)p.final_obs,
                                p.ep_ret, p.ep_len, dinfo, v->lay.obs_dim};
         if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
@@ -1017,6 +1217,30 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
             HIP_TRY(hipMemcpyAsync(io->episode_length, v->d_eplen, sizeof(int32_t) * N, hipMemcpyDeviceToHost, v->stream));
         return check_device_error(v);  // synchronises
     }
+    return MI_OK;
+}
+
+int mi_tabular_load(mi_vecenv *v, const mi_tabular_table *t) {
+    if (!v || !t) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (!is_tab(v->cfg.kind)) return fail(MI_ERR_INVALID_ARGUMENT, "not a tabular environment");
+    if (t->num_states < 1 || t->num_actions < 1 || t->max_outcomes < 1) return fail(MI_ERR_INVALID_ARGUMENT, "empty table");
+    if (set_device(v)) return MI_ERR_HIP;
+    const size_t cells = (size_t)t->num_states * t->num_actions, n = cells * t->max_outcomes;
+    const void *src[7] = {t->csprob, t->prob, t->reward, t->isd_csprob, t->next_state, t->count, t->terminated};
+    const size_t bytes[7] = {n * 8, n * 8, n * 8, (size_t)t->num_states * 8, n * 4, cells * 4, n};
+    for (int k = 0; k < 7; k++) {
+        if (!src[k]) return fail(MI_ERR_INVALID_ARGUMENT, "null table array");
+        if (v->tab_bufs[k]) (void)hipFree(v->tab_bufs[k]);
+        HIP_TRY(hipMalloc(&v->tab_bufs[k], bytes[k]));
+        HIP_TRY(hipMemcpyAsync(v->tab_bufs[k], src[k], bytes[k], hipMemcpyHostToDevice, v->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    TabTable &tab = v->d.tab;
+    tab.nS = t->num_states, tab.nA = t->num_actions, tab.K = t->max_outcomes;
+    tab.csprob = (const double *)v->tab_bufs[0], tab.prob = (const double *)v->tab_bufs[1], tab.reward = (const double *)v->tab_bufs[2];
+    tab.isd = (const double *)v->tab_bufs[3], tab.next = (const int32_t *)v->tab_bufs[4], tab.count = (const int32_t *)v->tab_bufs[5];
+    tab.term = (const uint8_t *)v->tab_bufs[6];
+    v->tab_loaded = true;
     return MI_OK;
 }
 
@@ -1057,7 +1281,20 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
         as.pow2 = v->d_pow2, as.jump_n = v->jump_n;
     }
     int rc;
-    if (is_mj(v->cfg.kind)) {
+    if (is_tab(v->cfg.kind)) {
+        const dim3 g(v->grid), b(kBlock);
+        const bool next = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
+        if (next && sample)
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
+        else if (next)
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
+        else if (sample)
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
+        else
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
+        HIP_TRY(hipGetLastError());
+        rc = MI_OK;
+    } else if (is_mj(v->cfg.kind)) {
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int {
             using E = decltype(env);
             const dim3 g(v->grid), b(kBlock);

@@ -9,4 +9,7 @@ from .classic_control import ENV_TABLE as _CLASSIC
 from .mujoco.envs import AntVectorEnv, HalfCheetahVectorEnv, HumanoidVectorEnv  # noqa: F401
 from .mujoco.envs import ENV_TABLE as _MUJOCO
 
-ENV_TABLE = {**_CLASSIC, **_MUJOCO}
+from .toy_text import CliffWalkingVectorEnv, FrozenLakeVectorEnv, TaxiVectorEnv  # noqa: F401
+from .toy_text import ENV_TABLE as _TOY
+
+ENV_TABLE = {**_CLASSIC, **_MUJOCO, **_TOY}

@@ -41,6 +41,16 @@ class _MujocoVectorEnv(HipVectorEnv):
     def _parse_reset_options(self, options):
         return None  # MujocoEnv.reset ignores options (mujoco_env.py:172-187)
 
+    def _reset_infos(self, mask):
+        """_get_reset_info (half_cheetah_v5.py:277-280, ant_v5.py:423-428, humanoid_v5.py:534-541): positions only."""
+        sel = np.ones(self.num_envs, dtype=np.bool_) if mask is None else mask.view(np.bool_).copy()
+        qpos = self.get_state()[0]
+        infos = {"x_position": np.where(sel, qpos[:, 0], 0.0), "_x_position": sel}
+        if self.N_RESET_INFO_KEYS == 3:
+            infos.update({"y_position": np.where(sel, qpos[:, 1], 0.0), "_y_position": sel.copy(),
+                          "distance_from_origin": np.where(sel, np.sqrt(qpos[:, 0] ** 2 + qpos[:, 1] ** 2), 0.0), "_distance_from_origin": sel.copy()})
+        return infos
+
 
 class HalfCheetahVectorEnv(_MujocoVectorEnv):
     KIND = "half_cheetah"

@@ -1,0 +1,259 @@
+"""ToyText tabular environments (FrozenLake, CliffWalking, Taxi) as bit-exact integer kernels.
+
+Every env here is a finite MDP: the reference precomputes ``P[s][a] = [(prob, next_state, reward, terminated), ...]`` in its
+constructor and ``step`` is ``i = categorical_sample([t[0] for t in P[s][a]], np_random)`` -- ``np.argmax(np.cumsum(p) >
+np_random.random())`` (gymnasium/envs/toy_text/utils.py:4-8) -- followed by a table lookup; ``reset`` draws the start state the
+same way from ``initial_state_distrib``.  The classes below rebuild those tables from the env definitions (grid maps, wall
+strings, slip rules) and hand them to the engine (``mi_tabular_load``); the kernels then only need the per-env PCG64 stream
+and integer lookups, so trajectories equal the reference's bit for bit (tests/golden/toytext_*.npz are generated from it).
+
+  FrozenLakeVectorEnv    gymnasium/envs/toy_text/frozen_lake.py:226-360  (FrozenLake-v1, FrozenLake8x8-v1)
+  CliffWalkingVectorEnv  gymnasium/envs/toy_text/cliffwalking.py:103-207 (CliffWalking-v1, CliffWalkingSlippery-v1)
+  TaxiVectorEnv          gymnasium/envs/toy_text/taxi.py:163-472         (Taxi-v4, is_rainy=False, fickle_passenger=False)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..gym_api import error, spaces
+from ..vector.hip_vector_env import HipVectorEnv
+
+
+class TabularVectorEnv(HipVectorEnv):
+    KIND = "tabular"
+    INFO_KEYS = ("prob",)
+    N_RESET_INFO_KEYS = 1
+    RESET_PROB_IS_INT = True  # FrozenLake / CliffWalking reset() returns {"prob": 1} (an int); Taxi returns 1.0
+
+    def _build(self):
+        """Return (P, initial_state_distrib): P[s][a] = list of (prob, next_state, reward, terminated)."""
+        raise NotImplementedError
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, **kwargs):
+        P, isd = self._build()
+        self.P, self.initial_state_distrib = P, np.asarray(isd, dtype=np.float64)
+        self.nS, self.nA = len(P), len(P[0])
+        K = max(len(P[s][a]) for s in range(self.nS) for a in range(self.nA))
+        self._tab = dict(
+            csprob=np.ones((self.nS, self.nA, K), dtype=np.float64), prob=np.zeros((self.nS, self.nA, K), dtype=np.float64),
+            next_state=np.zeros((self.nS, self.nA, K), dtype=np.int32), reward=np.zeros((self.nS, self.nA, K), dtype=np.float64),
+            terminated=np.zeros((self.nS, self.nA, K), dtype=np.uint8), count=np.zeros((self.nS, self.nA), dtype=np.int32),
+            isd_csprob=np.cumsum(self.initial_state_distrib))
+        for s in range(self.nS):
+            for a in range(self.nA):
+                tr = P[s][a]
+                n = len(tr)
+                self._tab["count"][s, a] = n
+                self._tab["csprob"][s, a, :n] = np.cumsum(np.asarray([t[0] for t in tr]))  # exactly what categorical_sample forms
+                for k, (p, ns, r, te) in enumerate(tr):
+                    self._tab["prob"][s, a, k], self._tab["next_state"][s, a, k] = p, ns
+                    self._tab["reward"][s, a, k], self._tab["terminated"][s, a, k] = r, te
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
+        self._engine.load_table(**self._tab)
+
+    def _single_spaces(self):
+        return spaces.Discrete(self.nS), spaces.Discrete(self.nA)
+
+    def _engine_params(self):
+        return (float(self.nS), float(self.nA))
+
+    def _parse_reset_options(self, options):
+        return None
+
+    def _reset_infos(self, mask):
+        sel = np.ones(self.num_envs, dtype=np.bool_) if mask is None else mask.view(np.bool_).copy()
+        prob = np.where(sel, 1.0, 0.0)  # frozen_lake.py:348 / taxi.py:452: {"prob": 1}
+        return {"prob": prob.astype(np.int64) if self.RESET_PROB_IS_INT else prob, "_prob": sel}
+
+    def _build_infos(self):
+        # Reference quirk, mirrored: VectorEnv._add_info (vector_env.py:277-338) types a key's array after the FIRST sub-env
+        # that supplies it in a step.  When sub-env 0 is in its autoreset step its info is the reset info {"prob": 1} -- an
+        # int -- so the whole "prob" array becomes int64 and the other sub-envs' probabilities are truncated (1/3 -> 0).
+        env0_resetting = bool(self._was_done[0]) and self.autoreset_mode.value == "NextStep"
+        infos = super()._build_infos()
+        if self.RESET_PROB_IS_INT and env0_resetting:
+            infos["prob"] = infos["prob"].astype(np.int64)
+        return infos
+
+
+LEFT, DOWN, RIGHT, UP = 0, 1, 2, 3  # frozen_lake.py:15-18
+FROZEN_LAKE_MAPS = {  # frozen_lake.py:20-32
+    "4x4": ["SFFF", "FHFH", "FFFH", "HFFG"],
+    "8x8": ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"],
+}
+
+
+class FrozenLakeVectorEnv(TabularVectorEnv):
+    DEFAULT_MAX_EPISODE_STEPS = 100
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, desc=None, map_name: str = "4x4",
+                 is_slippery: bool = True, success_rate: float = 1.0 / 3.0, reward_schedule=(1, 0, 0), **kwargs):
+        if desc is None and map_name is None:
+            raise error.Error("random FrozenLake maps (map_name=None) are not supported by gymnasium_amd; pass desc=")
+        self.desc = [str(r) for r in (desc if desc is not None else FROZEN_LAKE_MAPS[map_name])]
+        self.is_slippery, self.success_rate, self.reward_schedule = bool(is_slippery), success_rate, tuple(reward_schedule)
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
+
+    def _build(self):
+        desc, nrow, ncol = self.desc, len(self.desc), len(self.desc[0])
+        fail_rate = (1.0 - self.success_rate) / 2.0
+        isd = np.array([[c == "S" for c in row] for row in desc]).astype("float64").ravel()
+        isd /= isd.sum()
+
+        def move(row, col, a):
+            if a == LEFT:
+                col = max(col - 1, 0)
+            elif a == DOWN:
+                row = min(row + 1, nrow - 1)
+            elif a == RIGHT:
+                col = min(col + 1, ncol - 1)
+            else:
+                row = max(row - 1, 0)
+            return row, col
+
+        def outcome(row, col, a):
+            r2, c2 = move(row, col, a)
+            letter = desc[r2][c2]
+            reward = self.reward_schedule["GHF".index(letter if letter in "GHF" else "F")]
+            return r2 * ncol + c2, reward, letter in "GH"
+
+        P = {}
+        for row in range(nrow):
+            for col in range(ncol):
+                s = row * ncol + col
+                P[s] = {}
+                for a in range(4):
+                    if desc[row][col] in "GH":
+                        P[s][a] = [(1.0, s, 0, True)]
+                    elif self.is_slippery:
+                        P[s][a] = [((self.success_rate if b == a else fail_rate), *outcome(row, col, b)) for b in ((a - 1) % 4, a, (a + 1) % 4)]
+                    else:
+                        P[s][a] = [(1.0, *outcome(row, col, a))]
+        return P, isd
+
+
+class CliffWalkingVectorEnv(TabularVectorEnv):
+    DEFAULT_MAX_EPISODE_STEPS = None
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, is_slippery: bool = False, **kwargs):
+        self.is_slippery = bool(is_slippery)
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
+
+    def _build(self):
+        nrow, ncol = 4, 12
+        start = 3 * ncol
+        deltas_of = {0: (-1, 0), 1: (0, 1), 2: (1, 0), 3: (0, -1)}  # UP, RIGHT, DOWN, LEFT (cliffwalking.py:13-18)
+        P = {}
+        for s in range(nrow * ncol):
+            row, col = divmod(s, ncol)
+            P[s] = {}
+            for a in range(4):
+                acts = [(a - 1) % 4, a, (a + 1) % 4] if self.is_slippery else [a]
+                out = []
+                for b in acts:
+                    r2 = max(min(row + deltas_of[b][0], nrow - 1), 0)
+                    c2 = max(min(col + deltas_of[b][1], ncol - 1), 0)
+                    if r2 == 3 and 1 <= c2 <= ncol - 2:  # the cliff
+                        out.append((1 / len(acts), start, -100, False))
+                    else:
+                        out.append((1 / len(acts), r2 * ncol + c2, -1, (r2, c2) == (nrow - 1, ncol - 1)))
+                P[s][a] = out
+        isd = np.zeros(nrow * ncol)
+        isd[start] = 1.0
+        return P, isd
+
+
+TAXI_MAP = ["+---------+", "|R: | : :G|", "| : | : : |", "| : : : : |", "| | : | : |", "|Y| : |B: |", "+---------+"]  # taxi.py:15-23
+TAXI_LOCS = [(0, 0), (0, 4), (4, 0), (4, 3)]
+
+
+class TaxiVectorEnv(TabularVectorEnv):
+    DEFAULT_MAX_EPISODE_STEPS = 200
+    RESET_PROB_IS_INT = False
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, is_rainy: bool = False,
+                 fickle_passenger: bool = False, rainy_probability: float = 0.8, fickle_probability: float = 0.3, **kwargs):
+        if is_rainy or fickle_passenger:
+            raise error.Error("gymnasium_amd Taxi implements the default dry, non-fickle dynamics only")
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
+        self._action_mask = np.stack([self.action_mask(s) for s in range(self.nS)])
+
+    @staticmethod
+    def encode(row, col, pass_loc, dest):
+        return ((row * 5 + col) * 5 + pass_loc) * 4 + dest
+
+    @staticmethod
+    def decode(i):
+        dest, i = i % 4, i // 4
+        pass_loc, i = i % 5, i // 5
+        col, row = i % 5, i // 5
+        return row, col, pass_loc, dest
+
+    def action_mask(self, state):  # taxi.py:397-417
+        mask = np.zeros(6, dtype=np.int8)
+        row, col, pass_loc, dest = self.decode(state)
+        mask[0] = row < 4
+        mask[1] = row > 0
+        mask[2] = col < 4 and TAXI_MAP[row + 1][2 * col + 2] == ":"
+        mask[3] = col > 0 and TAXI_MAP[row + 1][2 * col] == ":"
+        mask[4] = pass_loc < 4 and (row, col) == TAXI_LOCS[pass_loc]
+        mask[5] = pass_loc == 4 and (row, col) in TAXI_LOCS
+        return mask
+
+    def _build(self):
+        P, isd = {}, np.zeros(500)
+        for row in range(5):
+            for col in range(5):
+                for pass_idx in range(5):
+                    for dest in range(4):
+                        s = self.encode(row, col, pass_idx, dest)
+                        if pass_idx < 4 and pass_idx != dest:
+                            isd[s] += 1
+                        P[s] = {}
+                        for a in range(6):
+                            r2, c2, p2, reward, term = row, col, pass_idx, -1, False
+                            if a == 0:
+                                r2 = min(row + 1, 4)
+                            elif a == 1:
+                                r2 = max(row - 1, 0)
+                            elif a == 2 and TAXI_MAP[1 + row][2 * col + 2] == ":":
+                                c2 = min(col + 1, 4)
+                            elif a == 3 and TAXI_MAP[1 + row][2 * col] == ":":
+                                c2 = max(col - 1, 0)
+                            elif a == 4:  # pickup
+                                if pass_idx < 4 and (row, col) == TAXI_LOCS[pass_idx]:
+                                    p2 = 4
+                                else:
+                                    reward = -10
+                            elif a == 5:  # dropoff
+                                if (row, col) == TAXI_LOCS[dest] and pass_idx == 4:
+                                    p2, term, reward = dest, True, 20
+                                elif (row, col) in TAXI_LOCS and pass_idx == 4:
+                                    p2 = TAXI_LOCS.index((row, col))
+                                else:
+                                    reward = -10
+                            P[s][a] = [(1.0, self.encode(r2, c2, p2, dest), reward, term)]
+        isd /= isd.sum()
+        return P, isd
+
+    def _with_action_mask(self, infos):
+        obs = self._obs.cpu().numpy() if self.output == "torch" else self._obs
+        infos["action_mask"] = self._action_mask[np.asarray(obs).reshape(-1)]
+        infos["_action_mask"] = np.ones(self.num_envs, dtype=np.bool_)
+        return infos
+
+    def _build_infos(self):
+        return self._with_action_mask(TabularVectorEnv._build_infos(self))
+
+    def _reset_infos(self, mask):
+        return self._with_action_mask(super()._reset_infos(mask))
+
+
+# id -> (creator, max_episode_steps, reward_threshold, kwargs): gymnasium/envs/__init__.py:139-171
+ENV_TABLE = {
+    "FrozenLake-v1": (FrozenLakeVectorEnv, 100, 0.70, {"map_name": "4x4"}),
+    "FrozenLake8x8-v1": (FrozenLakeVectorEnv, 200, 0.85, {"map_name": "8x8"}),
+    "CliffWalking-v1": (CliffWalkingVectorEnv, None, None, {}),
+    "CliffWalkingSlippery-v1": (CliffWalkingVectorEnv, None, None, {"is_slippery": True}),
+    "Taxi-v4": (TaxiVectorEnv, 200, 8, {}),
+}

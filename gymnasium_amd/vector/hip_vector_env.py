@@ -127,22 +127,24 @@ class HipVectorEnv(VectorEnv):
             self._torch = torch
             dev = torch.device("cuda", self._device_index)
             self._tdev = dev
-            self._obs_tdtype = torch.float64 if eng.obs_dtype is np.float64 else torch.float32
-            self._obs = torch.zeros((N, eng.obs_dim), dtype=self._obs_tdtype, device=dev)
+            self._obs_tdtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
+            self._obs_shape = (N,) if eng.obs_dtype is np.int64 else (N, eng.obs_dim)  # Discrete states batch to MultiDiscrete: (N,)
+            self._obs = torch.zeros(self._obs_shape, dtype=self._obs_tdtype, device=dev)
             self._rew = torch.zeros((N,), dtype=torch.float64, device=dev)
             self._term = torch.zeros((N,), dtype=torch.bool, device=dev)
             self._trunc = torch.zeros((N,), dtype=torch.bool, device=dev)
-            self._final = torch.zeros((N, eng.obs_dim), dtype=self._obs_tdtype, device=dev) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
+            self._final = torch.zeros(self._obs_shape, dtype=self._obs_tdtype, device=dev) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
             self._info = torch.zeros((N, eng.info_dim), dtype=torch.float64, device=dev) if eng.info_dim else None
             self._ep_r = torch.zeros((N,), dtype=torch.float64, device=dev) if self.record_episode_statistics else None
             self._ep_l = torch.zeros((N,), dtype=torch.int32, device=dev) if self.record_episode_statistics else None
             self._loc = _native.MI_DEVICE
         else:
-            self._obs = np.zeros((N, eng.obs_dim), dtype=eng.obs_dtype)
+            self._obs_shape = (N,) if eng.obs_dtype is np.int64 else (N, eng.obs_dim)
+            self._obs = np.zeros(self._obs_shape, dtype=eng.obs_dtype)
             self._rew = np.zeros((N,), dtype=np.float64)
             self._term = np.zeros((N,), dtype=np.bool_)
             self._trunc = np.zeros((N,), dtype=np.bool_)
-            self._final = np.zeros((N, eng.obs_dim), dtype=eng.obs_dtype) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
+            self._final = np.zeros(self._obs_shape, dtype=eng.obs_dtype) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
             self._info = np.zeros((N, eng.info_dim), dtype=np.float64) if eng.info_dim else None
             self._ep_r = np.zeros((N,), dtype=np.float64) if self.record_episode_statistics else None
             self._ep_l = np.zeros((N,), dtype=np.int32) if self.record_episode_statistics else None
@@ -241,7 +243,11 @@ class HipVectorEnv(VectorEnv):
             else:
                 self._episode_start[mask.view(np.bool_)] = now
                 self._prev_dones[mask.view(np.bool_)] = False
-        return self._out(self._obs), {}
+        return self._out(self._obs), self._reset_infos(mask)
+
+    def _reset_infos(self, mask) -> dict:
+        """The scalar envs' reset info (``_get_reset_info`` / ``{"prob": 1}``) batched like VectorEnv._add_info does."""
+        return {}
 
     def _coerce_actions(self, actions):
         eng = self._engine
@@ -362,7 +368,7 @@ class HipVectorEnv(VectorEnv):
             eng.action_seed(_native.pcg_words(self.action_space.np_random))
             if return_actions:
                 a_out = t.empty(act_shape, dtype=act_dtype, device=dev)
-        obs = t.empty((T, N, eng.obs_dim), dtype=self._obs_tdtype, device=dev)
+        obs = t.empty((T,) + tuple(self._obs_shape), dtype=self._obs_tdtype, device=dev)
         rew = t.empty((T, N), dtype=t.float64, device=dev)
         term = t.empty((T, N), dtype=t.bool, device=dev)
         trunc = t.empty((T, N), dtype=t.bool, device=dev)

@@ -47,7 +47,10 @@ typedef enum mi_env_kind {
     MI_ENV_HALF_CHEETAH = 5,           /* envs/mujoco/half_cheetah_v5.py:153-281 + assets/half_cheetah.xml     */
     MI_ENV_ANT = 6,                    /* envs/mujoco/ant_v5.py:228-428 + assets/ant.xml                       */
     MI_ENV_HUMANOID = 7,               /* envs/mujoco/humanoid_v5.py:307-541 + assets/humanoid.xml             */
-    MI_ENV_KIND_COUNT = 8
+    /* ToyText: any finite MDP given as a transition table (mi_tabular_load); FrozenLake / CliffWalking / Taxi:
+     * envs/toy_text/frozen_lake.py:324-348, cliffwalking.py:195-215, taxi.py:419-472, utils.py:4-8               */
+    MI_ENV_TABULAR = 8,
+    MI_ENV_KIND_COUNT = 9
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */
@@ -77,6 +80,7 @@ typedef enum mi_dtype { MI_F32 = 0, MI_F64 = 1, MI_I64 = 2 } mi_dtype;
  *       [10],[11] ANT: contact_force_range / HUMANOID: contact_cost_range
  *       [12] ANT: include_cfrc_ext_in_observation / HUMANOID: include_cinert_in_observation
  *       [13],[14],[15] HUMANOID: include_cvel / include_qfrc_actuator / include_cfrc_ext _in_observation
+ *     TABULAR                  params[0] = number of states, params[1] = number of actions (table: mi_tabular_load)
  */
 typedef struct mi_config {
     int32_t struct_size;         /* = sizeof(mi_config) */
@@ -183,6 +187,24 @@ int mi_reset(mi_vecenv *env, const uint8_t *mask, const double *bounds, void *ob
 /* Replaces SyncVectorEnv.step (vector/sync_vector_env.py:266-337) with TimeLimit (wrappers/common.py:129-133)
  * and the scalar env's step() folded into one kernel launch. */
 int mi_step(mi_vecenv *env, const mi_step_io *io, int loc);
+
+/* Transition table of a MI_ENV_TABULAR environment (host pointers, copied to the device).  Replaces the `P` dict and
+ * `initial_state_distrib` the toy-text constructors build (frozen_lake.py:255-303, cliffwalking.py:118-135, taxi.py:281-334):
+ *   csprob[nS][nA][K]   np.cumsum of the outcome probabilities (what categorical_sample compares against, utils.py:4-8)
+ *   prob / next_state / reward / terminated [nS][nA][K]   the outcome tuples; count[nS][nA] outcomes are valid
+ *   isd_csprob[nS]      np.cumsum(initial_state_distrib)
+ * step: i = argmax(csprob[s][a] > rng.random()); reset: s = argmax(isd_csprob > rng.random()).  Observations are int64
+ * states; layout.info_dim = 1 (the "prob" entry of the info dict). */
+typedef struct mi_tabular_table {
+    int32_t num_states, num_actions, max_outcomes, reserved;
+    const double *csprob, *prob;
+    const int32_t *next_state;
+    const double *reward;
+    const uint8_t *terminated;
+    const int32_t *count;
+    const double *isd_csprob;
+} mi_tabular_table;
+int mi_tabular_load(mi_vecenv *env, const mi_tabular_table *table);
 
 /* Random policy on device: the action space's generator (spaces/space.py:112-122 Space.seed), given as the
  * PCG64 {state_hi,state_lo,inc_hi,inc_lo}.  rollout then reproduces

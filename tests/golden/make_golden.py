@@ -16,6 +16,8 @@ weak-scalar promotion) and records
   episode_stats.npz         wrappers.vector.RecordEpisodeStatistics r / l
   teacher_<env>.npz         teacher-forced single steps from random (state, action) pairs
   config1_cartpole.npz      BASELINE.json configs[0]: CartPole-v1, Sync, 4 envs, 1000 steps, seed 0
+  toytext_<env>.npz         FrozenLake / CliffWalking / Taxi: the reference's transition table P and initial distribution,
+                            plus a gym.make_vec(id, 8, "sync") trajectory with the info dict entries (prob, action_mask)
 
 Nothing here is read at run time by the product; tests compare the oracle (oracle/) and the HIP engine to it.
 """
@@ -283,7 +285,46 @@ def make_action_samples():
     save("action_samples.npz", **out)
 
 
+TOYTEXT = {"frozenlake": "FrozenLake-v1", "frozenlake8x8": "FrozenLake8x8-v1", "cliffwalking": "CliffWalking-v1",
+           "cliffwalking_slippery": "CliffWalkingSlippery-v1", "taxi": "Taxi-v4"}
+
+
+def make_toytext():
+    for key, env_id in TOYTEXT.items():
+        e = gym.make(env_id).unwrapped
+        nS, nA = e.observation_space.n, e.action_space.n
+        K = max(len(e.P[s][a]) for s in range(nS) for a in range(nA))
+        prob, nxt, rew, term = np.zeros((nS, nA, K)), np.zeros((nS, nA, K), np.int32), np.zeros((nS, nA, K)), np.zeros((nS, nA, K), np.uint8)
+        count = np.zeros((nS, nA), np.int32)
+        for s in range(nS):
+            for a in range(nA):
+                count[s, a] = len(e.P[s][a])
+                for k, (p, ns, r, t) in enumerate(e.P[s][a]):
+                    prob[s, a, k], nxt[s, a, k], rew[s, a, k], term[s, a, k] = p, ns, r, t
+        n, T = 8, 400
+        v = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync")
+        obs0, info0 = v.reset(seed=7)
+        v.action_space.seed(11)
+        A, O, R, TE, TR, PR, PM, AM = [], [], [], [], [], [], [], []
+        for _ in range(T):
+            a = v.action_space.sample()
+            o, r, te, tr, info = v.step(a)
+            A.append(a), O.append(o), R.append(r), TE.append(te), TR.append(tr)
+            PR.append(np.asarray(info["prob"], dtype=np.float64)), PM.append(info["_prob"])
+            if "action_mask" in info:
+                AM.append(np.stack([np.asarray(m) for m in info["action_mask"]]))
+        extra = {"action_mask": np.stack(AM), "action_mask0": np.stack([np.asarray(m) for m in info0["action_mask"]])} if AM else {}
+        save(f"toytext_{key}.npz", prob=prob, next_state=nxt, reward_table=rew, terminated_table=term, count=count,
+             isd=np.asarray(e.initial_state_distrib, dtype=np.float64), obs0=obs0, prob0=np.asarray(info0["prob"], dtype=np.float64),
+             actions=np.stack(A), obs=np.stack(O), reward=np.stack(R), term=np.stack(TE), trunc=np.stack(TR), prob_info=np.stack(PR),
+             prob_mask=np.stack(PM), rng_after=np.stack([pcg_words(x.unwrapped.np_random) for x in v.envs]), **extra)
+        v.close()
+
+
 if __name__ == "__main__":
+    if "--toytext-only" in sys.argv:
+        make_toytext()
+        sys.exit(0)
     print("reference gymnasium", gym.__version__, "numpy", np.__version__)
     make_rng()
     make_rollouts()
@@ -293,3 +334,4 @@ if __name__ == "__main__":
     make_episode_stats()
     make_teacher()
     make_action_samples()
+    make_toytext()

@@ -314,3 +314,35 @@ def check_rollout_fused(key, factory, n=64, T=40, **kw):
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
     assert np.array_equal(a.get_rng_state(), b.get_rng_state())
     a.close(), b.close()
+
+
+TOYTEXT_IDS = {"frozenlake": "FrozenLake-v1", "frozenlake8x8": "FrozenLake8x8-v1", "cliffwalking": "CliffWalking-v1",
+               "cliffwalking_slippery": "CliffWalkingSlippery-v1", "taxi": "Taxi-v4"}
+
+
+def check_toytext(key, factory):
+    """ToyText: transition tables equal the reference's P, and the gym.make_vec(id, 8, 'sync') trajectory (reset(seed=7),
+    action_space.seed(11), 400 random steps) is reproduced BIT-EXACTLY incl. info['prob'] / info['action_mask']."""
+    g = golden(f"toytext_{key}.npz")
+    n = g["obs0"].shape[0]
+    env = gymnasium_amd.make_vec(TOYTEXT_IDS[key], num_envs=n, _engine_factory=factory)
+    tab = env._tab
+    assert np.array_equal(tab["count"], g["count"]) and np.array_equal(tab["next_state"], g["next_state"])
+    assert np.array_equal(tab["prob"], g["prob"]) and np.array_equal(tab["reward"], g["reward_table"])
+    assert np.array_equal(tab["terminated"], g["terminated_table"]) and np.array_equal(env.initial_state_distrib, g["isd"])
+    obs, info = env.reset(seed=7)
+    assert obs.dtype == np.int64 and np.array_equal(obs, g["obs0"]) and np.array_equal(info["prob"], g["prob0"])
+    if "action_mask0" in g.files:
+        assert np.array_equal(info["action_mask"], g["action_mask0"])
+    env.action_space.seed(11)
+    for t in range(g["actions"].shape[0]):
+        a = env.action_space.sample()
+        assert np.array_equal(a, g["actions"][t])
+        o, r, te, tr, info = env.step(a)
+        assert np.array_equal(o, g["obs"][t]) and np.array_equal(r, g["reward"][t]), f"{key} t={t}"
+        assert np.array_equal(te, g["term"][t]) and np.array_equal(tr, g["trunc"][t]), f"{key} flags t={t}"
+        assert np.array_equal(info["prob"], g["prob_info"][t]) and np.array_equal(info["_prob"], g["prob_mask"][t])
+        if "action_mask" in g.files:
+            assert np.array_equal(info["action_mask"], g["action_mask"][t])
+    assert np.array_equal(env.get_rng_state(), g["rng_after"])
+    env.close()

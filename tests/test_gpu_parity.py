@@ -204,3 +204,32 @@ def test_full_size_spot_check_vs_oracle(oracle_factory):
         assert np.array_equal(teg[idx], tec) and np.array_equal(trg[idx], trc)
         np.testing.assert_allclose(og[idx], oc, rtol=1e-5, atol=1e-5)
     gpu.close(), cpu.close()
+
+
+# ---- ToyText: bit-exact integer kernels ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("key", list(ps.TOYTEXT_IDS))
+def test_toytext_bit_exact_vs_reference_golden(key):
+    ps.check_toytext(key, None)
+
+
+@pytest.mark.parametrize("key", ["frozenlake", "taxi", "cliffwalking_slippery"])
+def test_toytext_fused_rollout_and_full_size(key):
+    import torch
+
+    eid = ps.TOYTEXT_IDS[key]
+    a = gymnasium_amd.make_vec(eid, num_envs=65536, output="torch")
+    b = gymnasium_amd.make_vec(eid, num_envs=65536, output="torch")
+    a.reset(seed=1), b.reset(seed=1)
+    a.action_space.seed(2), b.action_space.seed(2)
+    out = a.rollout(24)
+    for t in range(24):
+        act = b.action_space.sample()
+        o, r, te, tr, _ = b.step(torch.from_numpy(act).cuda())
+        assert np.array_equal(out["actions"][t].cpu().numpy(), act)
+        assert torch.equal(out["obs"][t], o) and torch.equal(out["rewards"][t], r) and torch.equal(out["terminations"][t], te)
+        assert torch.equal(out["truncations"][t], tr)
+    assert np.array_equal(a.get_rng_state(), b.get_rng_state())
+    sa, sb = a.statistics(), b.statistics()
+    assert sa == sb and sa["env_steps"] + sa["reset_steps"] == 65536 * 24
+    a.close(), b.close()
