@@ -1,0 +1,1011 @@
+// mjx_coop.h -- cooperative articulated-body simulator for gfx950: G lanes of one wavefront advance ONE sub-environment.
+//
+// Why: the one-env-per-lane simulator (mjx_core.h) needs ~22 KB of private state per lane, which
+// lives in scratch: 1.2 MB of HBM traffic per Ant env-step, one wavefront per SIMD, 86 % of the cycles in s_waitcnt.
+// Here a group of G = 16 (HalfCheetah, Ant) or 32 (Humanoid) lanes shares one environment:
+//   * shared quantities (poses, motion subspaces, twists, contact frames, solver vectors) sit on a per-environment
+//     BLACKBOARD in LDS (struct Board),
+//   * every lane plays three roles -- body `lane + 1`, dof `lane`, contacts `lane + k G` -- and keeps the row of the mass
+//     matrix / Newton Hessian of its dof, the constants of its body and the state of its contacts in REGISTERS,
+//   * tree recursions run level by level (depth <= 6), matrix factorisations column by column with the pivot column
+//     exchanged through LDS, reductions as wavefront butterflies (__shfl_xor inside the group),
+//   * nothing is ever private-indexed dynamically, so nothing spills to scratch.
+// The same pipeline as mjx_core.h (which documents the formulation and stays as the one-lane cross-check): kinematics ->
+// com-based spatial quantities -> RNE bias -> CRB mass matrix -> Cholesky -> collision -> soft constraints (joint limits,
+// pyramidal / frictionless contacts) -> primal Newton with exact line search -> semi-implicit Euler (implicit joint damping)
+// or RK4.  Reference call sites replaced: gymnasium/envs/mujoco/mujoco_env.py:142 (mj_forward), :150 (mj_step(nstep)),
+// :155 (mj_rnePostConstraint).  Parity with `mujoco` itself: UNPINNED (see mjx_core.h).
+//
+// Synchronisation model: the G lanes of a group always sit in the same wavefront, so they run in lockstep; coop_sync() only
+// orders LDS traffic (a compiler + memory fence, no s_barrier).  Discipline (bulk-synchronous): between two coop_sync()
+// calls no LDS location is written by one lane and read or written by another.  Under MJX_HOST_EMU (tests/coop_emu, test
+// infrastructure only) the identical source runs on the CPU with one fiber per lane and coop_sync() = round-robin yield,
+// which is how the algorithm is validated against the C oracle without a GPU.
+#pragma once
+#include "mjx_core.h"
+
+namespace mjx {
+namespace coop {
+
+#if defined(MJX_HOST_EMU)
+void coop_sync();  // provided by the harness: yields to the next lane's fiber
+static inline unsigned lds_or(unsigned *p, unsigned v) {
+    const unsigned o = *p;
+    *p = o | v;
+    return o;
+}
+static inline double rsq(double x) { return 1.0 / sqrt(x); }
+static inline int popc(unsigned x) { return __builtin_popcount(x); }
+template <int G>
+static inline double group_sum(double v, double (*red)[32], int lane) {
+    for (int off = G / 2; off > 0; off >>= 1) {
+        red[0][lane] = v;
+        coop_sync();
+        v = v + red[0][lane ^ off];
+        coop_sync();
+    }
+    return v;
+}
+#else
+MJX_DEV void coop_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+MJX_DEV unsigned lds_or(unsigned *p, unsigned v) { return atomicOr(p, v); }
+// 1/sqrt(x): hardware estimate + two Newton-Raphson steps in FMA arithmetic (full double precision for the pivots)
+MJX_DEV double rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(y * 0.5, e, y);
+}
+MJX_DEV int popc(unsigned x) { return __popc(x); }
+template <int G>
+MJX_DEV double group_sum(double v, double (*)[32], int) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v = v + __shfl_xor(v, off, G);
+    return v;
+}
+#endif
+
+template <class M, int G_>
+struct Board {
+    static constexpr int G = G_, NQ = M::NQ, NV = M::NV, NB = M::NBODY, NU = M::NU, NTRI = M::NV * (M::NV + 1) / 2;
+    static constexpr int MAXCON = M::MAXCON, NSLOT = M::NSLOT, KC = (MAXCON + G - 1) / G, KS = (NSLOT + G - 1) / G;
+    static_assert(NB - 1 <= G && NV <= G && G <= 32, "one lane per body and per dof");
+    double qpos[NQ], qvel[NV], ctrl[NU];
+    double q0[NQ], dv[NV];                                    // RK4: base position, stage velocity
+    double xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3];
+    double com[3];
+    double cdof[NV][6];
+    double cvel[NB][6], cacc[NB][6], cfrc[NB][6];
+    double cinert[NB][10], cinertc[NB][10];
+    double buf[NV][6];
+    double tw[NB][6];                                         // per-body twist of a dof-space vector (J v without the frames)
+    double vx[NV], vdir[NV];                                  // Newton iterate and search direction
+    double col[2][NV];                                        // pivot column / substitution broadcast (double buffered)
+    double L[NTRI];                                           // packed lower Cholesky factor (column access in back substitution)
+    double con_r[MAXCON][3], con_frame[MAXCON][9], con_dist[MAXCON];
+    double con_g[MAXCON][3], con_W[MAXCON][5];                // per contact: sum_active D jar e, sum_active D e e^T
+    int con_pair[MAXCON];
+    double jc[2][3][NV];                                      // contact-frame Jacobian of the contact being assembled
+    double red[1][32];
+    unsigned cmask[KS], anyrow;
+    int ncon;
+};
+
+// Everything a lane keeps in registers across phases.
+template <class M, int G>
+struct Lane {
+    static constexpr int NV = M::NV, KC = Board<M, G>::KC;
+    // body role
+    double anchor[M::MAXJPB][3], axis[M::MAXJPB][3];
+    double cinert[10];
+    // dof role
+    double cdof[6], Mrow[NV], Hrow[NV], idiag;
+    double bias, qfrc_smooth, qfrc_actuator, qacc_smooth, qacc, qfrc_constraint;
+    bool lim_on[2];
+    double lim_D[2], lim_aref[2], lim_sign[2];
+    // contact role
+    bool c_on[KC];
+    int c_b1[KC], c_b2[KC], c_dim[KC];
+    double c_mu[KC], c_D[KC], c_kterm[KC], c_b[KC], c_jv[KC][3], c_jx[KC][3], c_jd[KC][3];
+};
+
+template <class M, int G>
+struct Sim {
+    typedef Board<M, G> B;
+    typedef Lane<M, G> R;
+    static constexpr int NQ = M::NQ, NV = M::NV, NB = M::NBODY, NU = M::NU, KC = B::KC, KS = B::KS, MAXCON = B::MAXCON;
+
+    // ---- one-time initialisation of the constant rows of the blackboard (world body) ----------------------------------
+    static MJX_DEV void init(B &bb, int lane) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) bb.xpos[0][k] = 0, bb.xipos[0][k] = 0;
+            bb.xquat[0][0] = 1, bb.xquat[0][1] = bb.xquat[0][2] = bb.xquat[0][3] = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) bb.xmat[0][k] = (k % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb.cvel[0][k] = 0, bb.cacc[0][k] = 0, bb.cfrc[0][k] = 0, bb.tw[0][k] = 0;
+            bb.cacc[0][3] = -M::gravity[0], bb.cacc[0][4] = -M::gravity[1], bb.cacc[0][5] = -M::gravity[2];
+#pragma unroll
+            for (int k = 0; k < 10; k++) bb.cinert[0][k] = 0, bb.cinertc[0][k] = 0;
+        }
+        coop_sync();
+    }
+
+    // ---- position stage ---------------------------------------------------------------------------------------------------
+    static MJX_DEV void kinematics(B &bb, R &r, int lane) {
+        const int b = lane + 1;
+        const bool isbody = b < NB;
+        const int bi = isbody ? b : 1;
+        const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+        for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
+            if (isbody && depth == lev) {
+                double pos[3], quat[4];
+                if (jn == 1 && M::jnt_type[ja] == FREE) {
+                    const int qa = M::jnt_qposadr[ja];
+                    pos[0] = bb.qpos[qa], pos[1] = bb.qpos[qa + 1], pos[2] = bb.qpos[qa + 2];
+                    quat[0] = bb.qpos[qa + 3], quat[1] = bb.qpos[qa + 4], quat[2] = bb.qpos[qa + 5], quat[3] = bb.qpos[qa + 6];
+                    quat_normalize(quat);
+                    r.anchor[0][0] = pos[0], r.anchor[0][1] = pos[1], r.anchor[0][2] = pos[2];
+                    r.axis[0][0] = 0, r.axis[0][1] = 0, r.axis[0][2] = 1;
+                } else {
+                    double t[3];
+                    rot_vec(t, bb.xmat[p], M::body_pos[bi]);
+                    pos[0] = bb.xpos[p][0] + t[0], pos[1] = bb.xpos[p][1] + t[1], pos[2] = bb.xpos[p][2] + t[2];
+                    quat_mul(quat, bb.xquat[p], M::body_quat[bi]);
+#pragma unroll
+                    for (int jj = 0; jj < M::MAXJPB; jj++) {
+                        if (jj < jn) {
+                            const int j = ja + jj;
+                            double Rm[9], ql[4];
+                            quat_to_mat(Rm, quat);
+                            rot_vec(t, Rm, M::jnt_pos[j]);
+                            r.anchor[jj][0] = pos[0] + t[0], r.anchor[jj][1] = pos[1] + t[1], r.anchor[jj][2] = pos[2] + t[2];
+                            rot_vec(r.axis[jj], Rm, M::jnt_axis[j]);
+                            const double q = bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]];
+                            if (M::jnt_type[j] == HINGE) {
+                                axis_angle_quat(ql, M::jnt_axis[j], q);
+                                quat_mul(quat, quat, ql);
+                                quat_to_mat(Rm, quat);
+                                rot_vec(t, Rm, M::jnt_pos[j]);
+                                pos[0] = r.anchor[jj][0] - t[0], pos[1] = r.anchor[jj][1] - t[1], pos[2] = r.anchor[jj][2] - t[2];
+                            } else {
+                                pos[0] += r.axis[jj][0] * q, pos[1] += r.axis[jj][1] * q, pos[2] += r.axis[jj][2] * q;
+                            }
+                        }
+                    }
+                }
+                quat_normalize(quat);
+                double xm[9], t[3];
+                quat_to_mat(xm, quat);
+                rot_vec(t, xm, M::body_ipos[bi]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) bb.xpos[b][k] = pos[k], bb.xipos[b][k] = pos[k] + t[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) bb.xquat[b][k] = quat[k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) bb.xmat[b][k] = xm[k];
+            }
+            coop_sync();
+        }
+    }
+
+    // subtree centre of mass of the tree (every lane computes it: same summation order as the one-lane code), the body's
+    // com-based inertia, the motion subspaces of the body's joints
+    static MJX_DEV void com_pos(B &bb, R &r, int lane) {
+        double mass = 0, c[3] = {0, 0, 0};
+#pragma unroll
+        for (int b = 1; b < NB; b++) {
+            mass += M::body_mass[b];
+            c[0] += M::body_mass[b] * bb.xipos[b][0], c[1] += M::body_mass[b] * bb.xipos[b][1], c[2] += M::body_mass[b] * bb.xipos[b][2];
+        }
+        const double com[3] = {c[0] / mass, c[1] / mass, c[2] / mass};
+        if (lane == 0) bb.com[0] = com[0], bb.com[1] = com[1], bb.com[2] = com[2];
+        const int b = lane + 1;
+        if (b < NB) {
+            const double *Rm = bb.xmat[b], *I = M::body_inertia[b];
+            const double off[3] = {bb.xipos[b][0] - com[0], bb.xipos[b][1] - com[1], bb.xipos[b][2] - com[2]};
+            double T[9], W[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) T[3 * i + j] = Rm[3 * i] * I[j] + Rm[3 * i + 1] * I[3 + j] + Rm[3 * i + 2] * I[6 + j];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) W[3 * i + j] = T[3 * i] * Rm[3 * j] + T[3 * i + 1] * Rm[3 * j + 1] + T[3 * i + 2] * Rm[3 * j + 2];
+            const double mm = M::body_mass[b], dd = dot3(off, off);
+            double *ci = r.cinert;
+            ci[0] = W[0] + mm * (dd - off[0] * off[0]), ci[1] = W[4] + mm * (dd - off[1] * off[1]), ci[2] = W[8] + mm * (dd - off[2] * off[2]);
+            ci[3] = W[1] - mm * off[0] * off[1], ci[4] = W[2] - mm * off[0] * off[2], ci[5] = W[5] - mm * off[1] * off[2];
+            ci[6] = mm * off[0], ci[7] = mm * off[1], ci[8] = mm * off[2], ci[9] = mm;
+#pragma unroll
+            for (int k = 0; k < 10; k++) bb.cinert[b][k] = ci[k];
+            const int ja = M::body_jntadr[b], jn = M::body_jntnum[b];
+#pragma unroll
+            for (int jj = 0; jj < M::MAXJPB; jj++) {
+                if (jj < jn) {
+                    const int j = ja + jj, a = M::jnt_dofadr[j];
+                    const double o[3] = {com[0] - r.anchor[jj][0], com[1] - r.anchor[jj][1], com[2] - r.anchor[jj][2]};
+                    if (M::jnt_type[j] == FREE) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+#pragma unroll
+                            for (int c6 = 0; c6 < 6; c6++) bb.cdof[a + k][c6] = 0;
+                            bb.cdof[a + k][3 + k] = 1.0;
+                            const double ax[3] = {Rm[k], Rm[3 + k], Rm[6 + k]};
+                            double cr[3];
+                            cross3(cr, ax, o);
+                            bb.cdof[a + 3 + k][0] = ax[0], bb.cdof[a + 3 + k][1] = ax[1], bb.cdof[a + 3 + k][2] = ax[2];
+                            bb.cdof[a + 3 + k][3] = cr[0], bb.cdof[a + 3 + k][4] = cr[1], bb.cdof[a + 3 + k][5] = cr[2];
+                        }
+                    } else if (M::jnt_type[j] == HINGE) {
+                        double cr[3];
+                        cross3(cr, r.axis[jj], o);
+                        bb.cdof[a][0] = r.axis[jj][0], bb.cdof[a][1] = r.axis[jj][1], bb.cdof[a][2] = r.axis[jj][2];
+                        bb.cdof[a][3] = cr[0], bb.cdof[a][4] = cr[1], bb.cdof[a][5] = cr[2];
+                    } else {
+                        bb.cdof[a][0] = bb.cdof[a][1] = bb.cdof[a][2] = 0;
+                        bb.cdof[a][3] = r.axis[jj][0], bb.cdof[a][4] = r.axis[jj][1], bb.cdof[a][5] = r.axis[jj][2];
+                    }
+                }
+            }
+        }
+        coop_sync();
+        if (lane < NV) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) r.cdof[k] = bb.cdof[lane][k];
+        }
+    }
+
+    // ---- velocity stage + RNE bias ----------------------------------------------------------------------------------------
+    static MJX_DEV void com_vel_and_bias(B &bb, R &r, int lane) {
+        const int b = lane + 1;
+        const bool isbody = b < NB;
+        const int bi = isbody ? b : 1;
+        const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+        for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
+            if (isbody && depth == lev) {
+                double v[6], a[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] = bb.cvel[p][k], a[k] = bb.cacc[p][k];
+#pragma unroll
+                for (int jj = 0; jj < M::MAXJPB; jj++) {
+                    if (jj < jn) {
+                        const int j = ja + jj, da = M::jnt_dofadr[j];
+                        if (M::jnt_type[j] == FREE) {
+#pragma unroll
+                            for (int k = 0; k < 3; k++)
+#pragma unroll
+                                for (int c = 0; c < 6; c++) v[c] += bb.cdof[da + k][c] * bb.qvel[da + k];
+                            double dd[3][6];
+#pragma unroll
+                            for (int k = 0; k < 3; k++) cross_motion(dd[k], v, bb.cdof[da + 3 + k]);
+#pragma unroll
+                            for (int k = 0; k < 3; k++)
+#pragma unroll
+                                for (int c = 0; c < 6; c++)
+                                    v[c] += bb.cdof[da + 3 + k][c] * bb.qvel[da + 3 + k], a[c] += dd[k][c] * bb.qvel[da + 3 + k];
+                        } else {
+                            double dd[6];
+                            cross_motion(dd, v, bb.cdof[da]);
+#pragma unroll
+                            for (int c = 0; c < 6; c++) v[c] += bb.cdof[da][c] * bb.qvel[da], a[c] += dd[c] * bb.qvel[da];
+                        }
+                    }
+                }
+                double Ia[6], Iv[6], x[6];
+                inert_mul(Ia, r.cinert, a), inert_mul(Iv, r.cinert, v), cross_force(x, v, Iv);
+#pragma unroll
+                for (int k = 0; k < 6; k++) bb.cvel[b][k] = v[k], bb.cacc[b][k] = a[k], bb.cfrc[b][k] = Ia[k] + x[k];
+            }
+            coop_sync();
+        }
+        // bias force of dof i: its motion subspace against the summed body forces of the subtree it moves
+        if (lane < NV) {
+            const unsigned desc = (unsigned)M::dof_descbodies[lane];
+            double f[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int d = NB - 1; d >= 1; d--) {
+                if ((desc >> d) & 1u) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) f[k] += bb.cfrc[d][k];
+                }
+            }
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) s += r.cdof[k] * f[k];
+            r.bias = s;
+        }
+    }
+
+    // ---- composite rigid body: full row `lane` of the mass matrix in registers -----------------------------------------------
+    static MJX_DEV void crb(B &bb, R &r, int lane) {
+        const int b = lane + 1;
+        if (b < NB) {
+            const unsigned desc = (unsigned)M::body_descmask[b];
+            double c[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) c[k] = 0;
+#pragma unroll
+            for (int d = NB - 1; d >= 1; d--) {
+                if ((desc >> d) & 1u) {
+#pragma unroll
+                    for (int k = 0; k < 10; k++) c[k] += bb.cinert[d][k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 10; k++) bb.cinertc[b][k] = c[k];
+        }
+        coop_sync();
+        double mybuf[6] = {0, 0, 0, 0, 0, 0};
+        if (lane < NV) {
+            inert_mul(mybuf, bb.cinertc[M::dof_bodyid[lane]], r.cdof);
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb.buf[lane][k] = mybuf[k];
+        }
+        coop_sync();
+        if (lane < NV) {
+            const unsigned anc = (unsigned)M::dof_ancmask[lane];
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                double s = 0;
+                if ((anc >> j) & 1u) {  // j is lane itself or one of its ancestors
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s += bb.cdof[j][k] * mybuf[k];
+                } else if (((unsigned)M::dof_ancmask[j] >> lane) & 1u) {  // lane is an ancestor of j
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s += r.cdof[k] * bb.buf[j][k];
+                }
+                r.Mrow[j] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+                if (j == lane) r.Mrow[j] += M::dof_armature[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; j++) r.Mrow[j] = 0;
+        }
+    }
+
+    // ---- dense Cholesky with one matrix row per lane ---------------------------------------------------------------------
+    // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.L
+    static MJX_DEV void chol_factor(B &bb, double *A, double &idiag, int lane) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            double (&col)[NV] = bb.col[k & 1];
+            if (lane >= k && lane < NV) col[lane] = A[k];
+            coop_sync();
+            if (lane >= k && lane < NV) {
+                double piv = col[k];
+                piv = piv < kMinVal ? kMinVal : piv;
+                const double inv = rsq(piv);
+                const double lik = A[k] * inv;
+                A[k] = lik;
+                if (lane == k) idiag = inv;
+                const double t = lik * inv;
+#pragma unroll
+                for (int j = k + 1; j < NV; j++)
+                    if (j <= lane) A[j] -= t * col[j];
+            }
+        }
+        if (lane < NV) {
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+                if (j <= lane) bb.L[tri(lane, 0) + j] = A[j];
+        }
+        coop_sync();
+    }
+    // solves L L^T x = rhs (rhs = this lane's component); returns this lane's component, the full solution is left in `out`
+    static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, double *out, int lane) {
+        double y = rhs;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            double (&col)[NV] = bb.col[k & 1];
+            if (lane == k) y = y * idiag, col[k] = y;
+            coop_sync();
+            if (lane > k && lane < NV) y -= Lrow[k] * col[k];
+        }
+#pragma unroll
+        for (int k = NV - 1; k >= 0; k--) {
+            double (&col)[NV] = bb.col[k & 1];
+            if (lane == k) y = y * idiag, col[k] = y, out[k] = y;
+            coop_sync();
+            if (lane < k) y -= bb.L[tri(k, 0) + lane] * col[k];
+        }
+        coop_sync();
+        return y;
+    }
+
+    // ---- collision: one candidate slot per lane and round, order-preserving compaction -------------------------------------------
+    static MJX_DEV void geom_pose(const B &bb, int g, double *pos, double *axis_z) {
+        const int b = M::geom_bodyid[g];
+        double t[3];
+        rot_vec(t, bb.xmat[b], M::geom_pos[g]);
+        pos[0] = bb.xpos[b][0] + t[0], pos[1] = bb.xpos[b][1] + t[1], pos[2] = bb.xpos[b][2] + t[2];
+        const double lz[3] = {M::geom_mat[g][2], M::geom_mat[g][5], M::geom_mat[g][8]};
+        rot_vec(axis_z, bb.xmat[b], lz);
+    }
+    struct Cand {
+        bool on;
+        double dist, pos[3], frame[9];
+    };
+    static MJX_DEV void finish(Cand &c, int pair, double dist, const double *pos, const double *n, const double *tangent, bool flip) {
+        c.on = dist < M::pair_margin[pair];
+        c.dist = dist;
+        const double sg = flip ? -1.0 : 1.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) c.pos[k] = pos[k], c.frame[k] = sg * n[k], c.frame[3 + k] = (tangent && !flip) ? tangent[k] : 0.0;
+        make_frame(c.frame);
+    }
+    static MJX_DEV void sphere_pair(Cand &c, int pair, const double *p1, double r1, const double *p2, double r2, bool flip) {
+        double n[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+        const double dist = sqrt(dot3(n, n));
+        if (dist < kMinVal)
+            n[0] = 1, n[1] = n[2] = 0;
+        else
+            n[0] /= dist, n[1] /= dist, n[2] /= dist;
+        double pos[3];
+        const double mid = r1 + 0.5 * (dist - r1 - r2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * mid;
+        finish(c, pair, dist - r1 - r2, pos, n, nullptr, flip);
+    }
+    static MJX_DEV void detect(const B &bb, int slot, Cand &c) {
+        const int p = M::slot_pair[slot], sub = M::slot_sub[slot];
+        int g1 = M::pair_geom1[p], g2 = M::pair_geom2[p];
+        bool flip = false;
+        if (M::geom_type[g1] > M::geom_type[g2]) {
+            const int t = g1;
+            g1 = g2, g2 = t, flip = true;
+        }
+        const int t1 = M::geom_type[g1], t2 = M::geom_type[g2];
+        double p1[3], z1[3], p2[3], z2[3];
+        geom_pose(bb, g1, p1, z1), geom_pose(bb, g2, p2, z2);
+        const double r1 = M::geom_size[g1][0], r2 = M::geom_size[g2][0], h1 = M::geom_size[g1][1], h2 = M::geom_size[g2][1];
+        c.on = false;
+        if (t1 == PLANE) {
+            if (t2 == SPHERE) {
+                double v[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, pos[3];
+                const double dist = dot3(v, z1) - r2;
+#pragma unroll
+                for (int k = 0; k < 3; k++) pos[k] = p2[k] - z1[k] * (r2 + 0.5 * dist);
+                finish(c, p, dist, pos, z1, nullptr, false);
+            } else {
+                const double s = sub == 0 ? 1.0 : -1.0;
+                double cc[3], v[3], pos[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) cc[k] = p2[k] + s * h2 * z2[k], v[k] = cc[k] - p1[k];
+                const double dist = dot3(v, z1) - r2;
+#pragma unroll
+                for (int k = 0; k < 3; k++) pos[k] = cc[k] - z1[k] * (r2 + 0.5 * dist);
+                finish(c, p, dist, pos, z1, z2, false);
+            }
+        } else if (t1 == SPHERE && t2 == SPHERE) {
+            sphere_pair(c, p, p1, r1, p2, r2, flip);
+        } else if (t1 == SPHERE && t2 == CAPSULE) {
+            double v[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+            double x = dot3(v, z2);
+            x = x > h2 ? h2 : (x < -h2 ? -h2 : x);
+            double cc[3] = {p2[0] + x * z2[0], p2[1] + x * z2[1], p2[2] + x * z2[2]};
+            sphere_pair(c, p, p1, r1, cc, r2, flip);
+        } else if (t1 == CAPSULE && t2 == CAPSULE) {
+            double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+            const double mb = -dot3(z1, z2), u = -dot3(z1, dif), v = dot3(z2, dif), det = 1.0 - mb * mb;
+            double x1, x2;
+            if (fabs(det) >= 1e-12) {
+                x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
+                if (x1 > h1)
+                    x1 = h1, x2 = v - mb * h1;
+                else if (x1 < -h1)
+                    x1 = -h1, x2 = v + mb * h1;
+                if (x2 > h2) {
+                    x2 = h2, x1 = u - mb * h2;
+                    x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1);
+                } else if (x2 < -h2) {
+                    x2 = -h2, x1 = u + mb * h2;
+                    x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1);
+                }
+            } else {
+                x2 = v;
+                x2 = x2 > h2 ? h2 : (x2 < -h2 ? -h2 : x2);
+                x1 = u - mb * x2;
+                x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1);
+            }
+            double c1[3], c2[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * z1[k], c2[k] = p2[k] + x2 * z2[k];
+            sphere_pair(c, p, c1, r1, c2, r2, flip);
+        }
+    }
+    static MJX_DEV void collision(B &bb, int lane) {
+        if (lane < KS) bb.cmask[lane] = 0;
+        if (lane == 0) bb.anyrow = 0;
+        coop_sync();
+        Cand cand[KS];
+#pragma unroll
+        for (int rd = 0; rd < KS; rd++) {
+            const int slot = rd * G + lane;
+            cand[rd].on = false;
+            if (slot < M::NSLOT) {
+                detect(bb, slot, cand[rd]);
+                if (cand[rd].on) lds_or(&bb.cmask[rd], 1u << lane);
+            }
+        }
+        coop_sync();
+        int base = 0;
+#pragma unroll
+        for (int rd = 0; rd < KS; rd++) {
+            const unsigned m = bb.cmask[rd];
+            if (cand[rd].on) {
+                const int idx = base + popc(m & ((1u << lane) - 1u));
+                if (idx < MAXCON) {
+                    bb.con_pair[idx] = M::slot_pair[rd * G + lane];
+                    bb.con_dist[idx] = cand[rd].dist;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) bb.con_r[idx][k] = cand[rd].pos[k] - bb.com[k];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) bb.con_frame[idx][k] = cand[rd].frame[k];
+                }
+            }
+            base += popc(m);
+        }
+        if (lane == 0) bb.ncon = base < MAXCON ? base : MAXCON;
+        coop_sync();
+    }
+
+    // velocity of the contact point of contact c under the twist field bb.tw, in the contact frame (body2 minus body1)
+    static MJX_DEV void contact_vel(const B &bb, int c, int b1, int b2, double *v) {
+        const double *rr = bb.con_r[c], *F = bb.con_frame[c];
+        double t1[3], t2[3];
+        cross3(t1, bb.tw[b1], rr), cross3(t2, bb.tw[b2], rr);
+        const double w[3] = {(bb.tw[b2][3] + t2[0]) - (bb.tw[b1][3] + t1[0]), (bb.tw[b2][4] + t2[1]) - (bb.tw[b1][4] + t1[1]),
+                             (bb.tw[b2][5] + t2[2]) - (bb.tw[b1][5] + t1[2])};
+        v[0] = dot3(F, w), v[1] = dot3(F + 3, w), v[2] = dot3(F + 6, w);
+    }
+    // bb.tw[b] = sum over the dofs on the path to body b of cdof_i vec_i
+    static MJX_DEV void twist(B &bb, const double *vec, int lane) {
+        const int b = lane + 1;
+        if (b < NB) {
+            const unsigned mask = (unsigned)M::body_dofmask[b];
+            double t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                if ((mask >> i) & 1u) {
+                    const double x = vec[i];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) t[k] += bb.cdof[i][k] * x;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb.tw[b][k] = t[k];
+        }
+        coop_sync();
+    }
+
+    // ---- constraint rows: joint limits (dof role) and contact parameters (contact role) -----------------------------------------
+    static MJX_DEV void make_constraint(B &bb, R &r, int lane) {
+        bool any = false;
+        r.lim_on[0] = r.lim_on[1] = false;
+        if (lane < NV) {
+            const int j = M::dof_jntid[lane];
+            if (M::jnt_limited[j] && (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)) {
+                const double value = bb.qpos[M::jnt_qposadr[j]];
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    const double side = sd == 0 ? -1.0 : 1.0;
+                    const double dist = side * (M::jnt_range[j][sd] - value);
+                    if (dist < M::jnt_margin[j]) {
+                        double k, b, imp, Rr;
+                        row_params<M>(M::jnt_solref[j], M::jnt_solimp[j], dist, M::jnt_margin[j], M::dof_invweight0[lane], k, b, imp, Rr);
+                        r.lim_on[sd] = true, r.lim_sign[sd] = -side, r.lim_D[sd] = 1.0 / Rr;
+                        r.lim_aref[sd] = -b * (-side * bb.qvel[lane]) - k * imp * (dist - M::jnt_margin[j]);
+                        any = true;
+                    }
+                }
+            }
+        }
+        const int ncon = bb.ncon;
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            const int c = kc * G + lane;
+            r.c_on[kc] = c < ncon;
+            r.c_b1[kc] = r.c_b2[kc] = 0, r.c_dim[kc] = 1, r.c_mu[kc] = 0, r.c_D[kc] = 0, r.c_kterm[kc] = 0, r.c_b[kc] = 0;
+            if (r.c_on[kc]) {
+                const int p = bb.con_pair[c];
+                const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+                const double tran = M::body_invweight0[b1][0] + M::body_invweight0[b2][0], mu = M::pair_friction[p];
+                const bool pyramid = M::pair_condim[p] > 1;
+                double k, b, imp, Rr;
+                row_params<M>(M::pair_solref[p], M::pair_solimp[p], bb.con_dist[c], M::pair_margin[p], pyramid ? tran + mu * mu * tran : tran, k, b,
+                              imp, Rr);
+                if (pyramid) {
+                    Rr = 2 * mu * mu * Rr;
+                    if (Rr < kMinVal) Rr = kMinVal;
+                }
+                r.c_b1[kc] = b1, r.c_b2[kc] = b2, r.c_dim[kc] = pyramid ? 3 : 1, r.c_mu[kc] = mu;
+                r.c_D[kc] = 1.0 / Rr, r.c_kterm[kc] = -k * imp * (bb.con_dist[c] - M::pair_margin[p]), r.c_b[kc] = b;
+                any = true;
+            }
+        }
+        if (any) lds_or(&bb.anyrow, 1u);
+        coop_sync();
+    }
+
+    // ---- primal Newton solver ---------------------------------------------------------------------------------------------
+    // residual of edge e of a contact: J_e x - aref_e, with J_e = J_n + sg J_t
+    static MJX_DEV void edge(const R &r, int kc, int e, const double *jq, double &val, double &sg, int &t) {
+        sg = (e & 1) ? -r.c_mu[kc] : r.c_mu[kc];
+        t = 1 + e / 2;
+        val = jq[0] + sg * jq[t];
+    }
+    static MJX_DEV double edge_aref(const R &r, int kc, double sg, int t) {
+        return -r.c_b[kc] * (r.c_jv[kc][0] + sg * r.c_jv[kc][t]) + r.c_kterm[kc];
+    }
+    // contact role: publishes g = sum_active D jar e and W = sum_active D e e^T of its contacts at the current iterate
+    static MJX_DEV void contact_state(B &bb, const R &r, int lane) {
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            if (r.c_on[kc]) {
+                const int c = kc * G + lane;
+                double g[3] = {0, 0, 0}, W[5] = {0, 0, 0, 0, 0};
+                const double D = r.c_D[kc];
+                if (r.c_dim[kc] == 1) {
+                    const double jar = r.c_jx[kc][0] - (-r.c_b[kc] * r.c_jv[kc][0] + r.c_kterm[kc]);
+                    if (jar < 0) g[0] = D * jar, W[0] = D;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        double v, sg;
+                        int t;
+                        edge(r, kc, e, r.c_jx[kc], v, sg, t);
+                        const double jar = v - edge_aref(r, kc, sg, t);
+                        if (jar < 0) {
+                            const double Dj = D * jar;
+                            g[0] += Dj, g[t] += Dj * sg;
+                            W[0] += D, W[t] += D * sg, W[2 + t] += D * sg * sg;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) bb.con_g[c][k] = g[k];
+#pragma unroll
+                for (int k = 0; k < 5; k++) bb.con_W[c][k] = W[k];
+            }
+        }
+        coop_sync();
+    }
+    // dof role: column `lane` of the contact-frame Jacobian of contact c
+    static MJX_DEV void jac_col(const B &bb, const R &r, int c, int lane, double *jcol) {
+        const int p = bb.con_pair[c];
+        const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+        const int in1 = ((unsigned)M::body_dofmask[b1] >> lane) & 1u, in2 = ((unsigned)M::body_dofmask[b2] >> lane) & 1u;
+        const double sg = (double)(in2 - in1);
+        double t[3];
+        cross3(t, r.cdof, bb.con_r[c]);
+        const double v[3] = {r.cdof[3] + t[0], r.cdof[4] + t[1], r.cdof[5] + t[2]};
+        const double *F = bb.con_frame[c];
+        jcol[0] = sg * dot3(F, v), jcol[1] = sg * dot3(F + 3, v), jcol[2] = sg * dot3(F + 6, v);
+    }
+    // gradient (and, if HESS, the Hessian row) of the cost at the current iterate; Mdx = this lane's (M (x - x_smooth))
+    template <bool HESS>
+    static MJX_DEV double assemble(B &bb, R &r, double Mdx, double xi, int lane) {
+        double grad = Mdx;
+        if (lane < NV) {
+            if (HESS) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j];
+            }
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                if (r.lim_on[sd]) {
+                    const double jar = r.lim_sign[sd] * xi - r.lim_aref[sd];
+                    if (jar < 0) {
+                        grad += r.lim_sign[sd] * r.lim_D[sd] * jar;
+                        if (HESS) {
+#pragma unroll
+                            for (int j = 0; j < NV; j++)
+                                if (j == lane) r.Hrow[j] += r.lim_D[sd];
+                        }
+                    }
+                }
+            }
+        }
+        const int ncon = bb.ncon;
+        for (int c = 0; c < ncon; c++) {
+            double jcol[3] = {0, 0, 0};
+            if (lane < NV) {
+                jac_col(bb, r, c, lane, jcol);
+                grad += jcol[0] * bb.con_g[c][0] + jcol[1] * bb.con_g[c][1] + jcol[2] * bb.con_g[c][2];
+            }
+            if (HESS) {
+                double (&J)[3][NV] = bb.jc[c & 1];
+                if (lane < NV) J[0][lane] = jcol[0], J[1][lane] = jcol[1], J[2][lane] = jcol[2];
+                coop_sync();
+                if (lane < NV) {
+                    const double *W = bb.con_W[c];
+                    const double t0 = W[0] * jcol[0] + W[1] * jcol[1] + W[2] * jcol[2], t1 = W[1] * jcol[0] + W[3] * jcol[1],
+                                 t2 = W[2] * jcol[0] + W[4] * jcol[2];
+#pragma unroll
+                    for (int j = 0; j < NV; j++)
+                        if (j <= lane) r.Hrow[j] += t0 * J[0][j] + t1 * J[1][j] + t2 * J[2][j];
+                }
+            }
+        }
+        return grad;
+    }
+
+    static MJX_DEV void solve_newton(B &bb, R &r, int lane) {
+        const bool isdof = lane < NV;
+        const int ncon = bb.ncon;
+        // contact-space velocity (for the reference acceleration) and the initial iterate x = qacc_smooth
+        // bb.tw currently holds nothing useful: cvel IS the twist field of qvel
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) r.c_jv[kc][k] = r.c_jx[kc][k] = r.c_jd[kc][k] = 0;
+        }
+        if (isdof) bb.vx[lane] = r.qacc_smooth;
+        coop_sync();
+        twist(bb, bb.qvel, lane);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++)
+            if (r.c_on[kc]) contact_vel(bb, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jv[kc]);
+        coop_sync();
+        twist(bb, bb.vx, lane);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++)
+            if (r.c_on[kc]) contact_vel(bb, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jx[kc]);
+        coop_sync();
+        double x = isdof ? r.qacc_smooth : 0.0, Mdx = 0.0;
+        const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
+        for (int it = 0; it < 50; it++) {
+            contact_state(bb, r, lane);
+            const double grad = assemble<true>(bb, r, Mdx, x, lane);
+            const double gn = group_sum<G>(isdof ? grad * grad : 0.0, bb.red, lane);
+            if (sqrt(gn) * scale < 1e-10) break;
+            chol_factor(bb, r.Hrow, r.idiag, lane);
+            const double dir = chol_solve(bb, r.Hrow, r.idiag, isdof ? -grad : 0.0, bb.vdir, lane);
+            // line search: phi'(alpha) = g0 + alpha h0 + sum_active D (jar + alpha jd) jd
+            double Md = 0;
+            if (isdof) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) Md += r.Mrow[j] * bb.vdir[j];
+            }
+            const double h0 = group_sum<G>(isdof ? dir * Md : 0.0, bb.red, lane);
+            const double g0 = group_sum<G>(isdof ? dir * Mdx : 0.0, bb.red, lane);
+            twist(bb, bb.vdir, lane);
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+                if (r.c_on[kc]) contact_vel(bb, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jd[kc]);
+            double alpha = 0, lo = 0, hi = INFINITY;
+            for (int ls = 0; ls < 40; ls++) {
+                double gl = 0, hl = 0;
+                if (isdof) {
+#pragma unroll
+                    for (int sd = 0; sd < 2; sd++) {
+                        if (r.lim_on[sd]) {
+                            const double jd = r.lim_sign[sd] * dir;
+                            const double v = (r.lim_sign[sd] * x - r.lim_aref[sd]) + alpha * jd;
+                            if (v < 0) gl += r.lim_D[sd] * v * jd, hl += r.lim_D[sd] * jd * jd;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++) {
+                    if (r.c_on[kc]) {
+                        const double D = r.c_D[kc];
+                        if (r.c_dim[kc] == 1) {
+                            const double jar = r.c_jx[kc][0] - (-r.c_b[kc] * r.c_jv[kc][0] + r.c_kterm[kc]), jd = r.c_jd[kc][0];
+                            const double v = jar + alpha * jd;
+                            if (v < 0) gl += D * v * jd, hl += D * jd * jd;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                double jx, jd, sg;
+                                int t;
+                                edge(r, kc, e, r.c_jx[kc], jx, sg, t);
+                                edge(r, kc, e, r.c_jd[kc], jd, sg, t);
+                                const double v = (jx - edge_aref(r, kc, sg, t)) + alpha * jd;
+                                if (v < 0) gl += D * v * jd, hl += D * jd * jd;
+                            }
+                        }
+                    }
+                }
+                const double g = (g0 + alpha * h0) + group_sum<G>(gl, bb.red, lane);
+                const double h = h0 + group_sum<G>(hl, bb.red, lane);
+                if (fabs(g) <= 1e-14 * (fabs(g0) + 1e-300)) break;
+                if (g < 0)
+                    lo = alpha;
+                else
+                    hi = alpha;
+                double next = alpha - g / h;
+                if (!(next > lo && next < hi)) next = hi < INFINITY ? 0.5 * (lo + hi) : 2 * alpha + 1.0;
+                if (next == alpha) break;
+                alpha = next;
+            }
+            if (!(alpha > 0)) break;
+            x += alpha * dir, Mdx += alpha * Md;
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) r.c_jx[kc][k] += alpha * r.c_jd[kc][k];
+            const double move = group_sum<G>(isdof ? fabs(alpha * dir) : 0.0, bb.red, lane);
+            if (move * scale < 1e-16) break;
+        }
+        // forces at the solution: J^T f = -(grad - M dx)
+        contact_state(bb, r, lane);
+        const double grad = assemble<false>(bb, r, Mdx, x, lane);
+        (void)ncon;
+        r.qacc = x, r.qfrc_constraint = Mdx - grad;
+        coop_sync();
+    }
+
+    // ---- forward dynamics -------------------------------------------------------------------------------------------------
+    // in: bb.qpos, bb.qvel, bb.ctrl.  out: r.qacc (+ r.qfrc_smooth, r.qfrc_constraint, r.Mrow) on the dof lanes, bb.con_g / frames
+    // of the active contacts, poses, cvel, cinert on the blackboard.
+    static MJX_DEV void forward(B &bb, R &r, int lane) {
+        kinematics(bb, r, lane);
+        com_pos(bb, r, lane);
+        collision(bb, lane);
+        com_vel_and_bias(bb, r, lane);
+        crb(bb, r, lane);
+        double Lrow[NV], idiag = 1.0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) Lrow[j] = r.Mrow[j];
+        chol_factor(bb, Lrow, idiag, lane);
+        make_constraint(bb, r, lane);
+        if (lane < NV) {
+            double act = 0.0;
+            const int u = M::dof_actuator[lane];
+            if (u >= 0) {
+                double c = bb.ctrl[u];
+                c = c < M::actuator_ctrlrange[u][0] ? M::actuator_ctrlrange[u][0] : (c > M::actuator_ctrlrange[u][1] ? M::actuator_ctrlrange[u][1] : c);
+                act = M::actuator_gear[u] * c;
+            }
+            r.qfrc_actuator = act;
+            double passive = -M::dof_damping[lane] * bb.qvel[lane];
+            const int j = M::dof_jntid[lane];
+            if (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)
+                passive -= M::jnt_stiffness[j] * (bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]]);
+            r.qfrc_smooth = passive - r.bias + act;
+        } else {
+            r.qfrc_smooth = 0, r.qfrc_actuator = 0;
+        }
+        r.qacc_smooth = chol_solve(bb, Lrow, idiag, r.qfrc_smooth, bb.vx, lane);
+        if (bb.anyrow == 0) {
+            r.qacc = r.qacc_smooth, r.qfrc_constraint = 0;
+            coop_sync();
+        } else {
+            solve_newton(bb, r, lane);
+        }
+    }
+
+    // joints of body `lane + 1`: position update of bb.qpos from the dof velocities in `vel` (mj_integratePos)
+    static MJX_DEV void integrate_pos(B &bb, const double *vel, double h, int lane) {
+        const int b = lane + 1;
+        if (b < NB) {
+            const int ja = M::body_jntadr[b], jn = M::body_jntnum[b];
+#pragma unroll
+            for (int jj = 0; jj < M::MAXJPB; jj++) {
+                if (jj < jn) {
+                    const int j = ja + jj, qa = M::jnt_qposadr[j], va = M::jnt_dofadr[j];
+                    if (M::jnt_type[j] == FREE) {
+                        bb.qpos[qa] += h * vel[va], bb.qpos[qa + 1] += h * vel[va + 1], bb.qpos[qa + 2] += h * vel[va + 2];
+                        double w[3] = {vel[va + 3], vel[va + 4], vel[va + 5]}, qr[4], q[4] = {bb.qpos[qa + 3], bb.qpos[qa + 4], bb.qpos[qa + 5], bb.qpos[qa + 6]};
+                        const double ang = h * normalize3(w);
+                        axis_angle_quat(qr, w, ang);
+                        quat_normalize(q);
+                        quat_mul(q, q, qr);
+                        bb.qpos[qa + 3] = q[0], bb.qpos[qa + 4] = q[1], bb.qpos[qa + 5] = q[2], bb.qpos[qa + 6] = q[3];
+                    } else {
+                        bb.qpos[qa] += h * vel[va];
+                    }
+                }
+            }
+        }
+        coop_sync();
+    }
+
+    // one mj_step
+    static MJX_DEV void step(B &bb, R &r, int lane) {
+        constexpr double h = M::TIMESTEP;
+        const bool isdof = lane < NV;
+        forward(bb, r, lane);
+        if (M::INTEGRATOR == 0) {
+            bool damped = false;
+#pragma unroll
+            for (int i = 0; i < NV; i++) damped |= M::dof_damping[i] > 0;
+            double qacc = r.qacc;
+            if (damped) {
+                double A[NV], idiag = 1.0;
+#pragma unroll
+                for (int j = 0; j < NV; j++) A[j] = r.Mrow[j] + ((j == lane) ? h * M::dof_damping[j] : 0.0);
+                chol_factor(bb, A, idiag, lane);
+                qacc = chol_solve(bb, A, idiag, isdof ? r.qfrc_smooth + r.qfrc_constraint : 0.0, bb.vdir, lane);
+            }
+            if (isdof) bb.qvel[lane] += h * qacc;
+            coop_sync();
+            integrate_pos(bb, bb.qvel, h, lane);
+        } else {
+            const double A[3] = {0.5, 0.5, 1.0}, Bw[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+            double v0 = 0, sumv = 0, suma = 0;
+            if (isdof) v0 = bb.qvel[lane], sumv = Bw[0] * v0, suma = Bw[0] * r.qacc;
+            for (int k = lane; k < NQ; k += G) bb.q0[k] = bb.qpos[k];
+            double fv = v0, fa = r.qacc;
+            coop_sync();
+            for (int i = 1; i < 4; i++) {
+                const double dv = A[i - 1] * fv, da = A[i - 1] * fa;
+                if (isdof) bb.dv[lane] = dv, bb.qvel[lane] = v0 + h * da;
+                for (int k = lane; k < NQ; k += G) bb.qpos[k] = bb.q0[k];
+                coop_sync();
+                integrate_pos(bb, bb.dv, h, lane);
+                forward(bb, r, lane);
+                if (isdof) fv = bb.qvel[lane], fa = r.qacc, sumv += Bw[i] * fv, suma += Bw[i] * fa;
+            }
+            if (isdof) bb.dv[lane] = sumv, bb.qvel[lane] = v0 + h * suma;
+            for (int k = lane; k < NQ; k += G) bb.qpos[k] = bb.q0[k];
+            coop_sync();
+            integrate_pos(bb, bb.dv, h, lane);
+        }
+    }
+
+    // mj_rnePostConstraint, the part the envs read: cfrc_ext of body `lane + 1` from the contact forces of the LAST forward pass
+    static MJX_DEV void contact_force_of_body(const B &bb, int lane, double *out) {
+        const int b = lane + 1;
+#pragma unroll
+        for (int k = 0; k < 6; k++) out[k] = 0;
+        const int ncon = bb.ncon;
+        for (int c = 0; c < ncon; c++) {
+            const int p = bb.con_pair[c];
+            const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+            if (b1 != b && b2 != b) continue;
+            const double *F = bb.con_frame[c], *g = bb.con_g[c], *rr = bb.con_r[c];
+            // contact-frame force = -g (force = -D jar summed over the active edges)
+            double Fw[3], tq[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) Fw[k] = -(F[k] * g[0] + F[3 + k] * g[1] + F[6 + k] * g[2]);
+            cross3(tq, rr, Fw);
+            const double sg = (b2 == b ? 1.0 : 0.0) - (b1 == b ? 1.0 : 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) out[k] += sg * tq[k], out[3 + k] += sg * Fw[k];
+        }
+    }
+
+    // What the per-env glue (mjx_kernels.h) reads from the last forward pass besides qpos / qvel, one row per environment:
+    //   [0..1] world position (x, y) of body 1, [2..3] sum_b mass_b xipos_b (x, y)  (humanoid_v5.py:17-21 mass_center numerator),
+    //   cfrc_ext[NB][6], cinert[NB][10], cvel[NB][6], qfrc_actuator[NV]
+    static constexpr int EX_XY = 0, EX_CFRC = 4, EX_CINERT = EX_CFRC + 6 * NB, EX_CVEL = EX_CINERT + 10 * NB, EX_QFA = EX_CVEL + 6 * NB,
+                         EX_TOTAL = EX_QFA + NV;
+    static MJX_DEV void write_extras(const B &bb, const R &r, int lane, double *ex) {
+        if (lane == 0) {
+            ex[EX_XY] = bb.xpos[1][0], ex[EX_XY + 1] = bb.xpos[1][1];
+            double nx = 0, ny = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) nx += M::body_mass[b] * bb.xipos[b][0], ny += M::body_mass[b] * bb.xipos[b][1];
+            ex[EX_XY + 2] = nx, ex[EX_XY + 3] = ny;
+#pragma unroll
+            for (int k = 0; k < 6; k++) ex[EX_CFRC + k] = 0, ex[EX_CVEL + k] = 0;
+#pragma unroll
+            for (int k = 0; k < 10; k++) ex[EX_CINERT + k] = 0;
+        }
+        const int b = lane + 1;
+        if (b < NB) {
+            double f[6];
+            contact_force_of_body(bb, lane, f);
+#pragma unroll
+            for (int k = 0; k < 6; k++) ex[EX_CFRC + 6 * b + k] = f[k], ex[EX_CVEL + 6 * b + k] = bb.cvel[b][k];
+#pragma unroll
+            for (int k = 0; k < 10; k++) ex[EX_CINERT + 10 * b + k] = r.cinert[k];
+        }
+        if (lane < NV) ex[EX_QFA + lane] = r.qfrc_actuator;
+    }
+};
+
+}  // namespace coop
+}  // namespace mjx

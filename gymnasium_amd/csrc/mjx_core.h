@@ -17,7 +17,12 @@
 //   * the mass matrix and the Newton Hessian are stored packed (lower triangle) and factorised as L L^T,
 //   * the primal Newton solver uses a bracketed 1-D Newton line search on the exact piecewise-quadratic cost.
 #pragma once
+// MJX_HOST_EMU: test-only host build of the same source (tests/coop_emu), never part of the product library.
+#if defined(MJX_HOST_EMU)
+#include <cmath>
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 
@@ -25,8 +30,13 @@
 
 namespace mjx {
 
+#if defined(MJX_HOST_EMU)
+#define MJX_DEV inline
+#define MJX_DEVN static
+#else
 #define MJX_DEV __device__ __forceinline__
 #define MJX_DEVN __device__ __noinline__
+#endif
 
 enum { FREE = 0, BALL = 1, SLIDE = 2, HINGE = 3 };
 enum { PLANE = 0, SPHERE = 2, CAPSULE = 3 };

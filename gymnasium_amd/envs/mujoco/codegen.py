@@ -64,7 +64,57 @@ def emit_model(m) -> str:
         ("actuator_ctrlrange", "double", m.actuator_ctrlrange, (nu, 2)),
     ]:
         s += _arr(name, ct, val, shape)
+    s += _emit_topology(m)
     s += "};\n"
+    return s
+
+
+def _emit_topology(m) -> str:
+    """Tables for the cooperative kernel (mjx_coop.h): tree depth, ancestor / descendant masks, static contact slots."""
+    nb, nv, nj, npair = m.nbody, m.nv, m.njnt, len(m.pair_geom1)
+    assert nv <= 32 and nb <= 32
+    depth = [0] * nb
+    for b in range(1, nb):
+        depth[b] = depth[m.body_parentid[b]] + 1
+    # dofs on the path root -> body (bodies without joints inherit their parent's chain)
+    body_dofmask = [0] * nb
+    for b in range(1, nb):
+        mask = body_dofmask[m.body_parentid[b]]
+        for k in range(m.body_dofnum[b]):
+            mask |= 1 << (m.body_dofadr[b] + k)
+        body_dofmask[b] = mask
+    body_descmask = [0] * nb
+    for b in range(nb - 1, 0, -1):
+        body_descmask[b] |= 1 << b
+        p = m.body_parentid[b]
+        if p > 0:
+            body_descmask[p] |= body_descmask[b]
+    dof_ancmask = [0] * nv
+    for i in range(nv):
+        j = i
+        while j >= 0:
+            dof_ancmask[i] |= 1 << j
+            j = m.dof_parentid[j]
+    dof_descbodies = [body_descmask[m.dof_bodyid[i]] for i in range(nv)]
+    dof_actuator = [-1] * nv
+    for u in range(m.nu):
+        assert dof_actuator[m.actuator_dofadr[u]] == -1, "one actuator per dof"
+        dof_actuator[m.actuator_dofadr[u]] = u
+    # static contact slots in the order the serial code emits contacts: pair order; plane-capsule pairs give two (+h, -h)
+    slot_pair, slot_sub = [], []
+    for p in range(npair):
+        g1, g2 = m.pair_geom1[p], m.pair_geom2[p]
+        t1, t2 = sorted((m.geom_type[g1], m.geom_type[g2]))
+        n = 2 if (t1 == compiler.PLANE and t2 == compiler.CAPSULE) else 1
+        for k in range(n):
+            slot_pair.append(p), slot_sub.append(k)
+    nslot = len(slot_pair)
+    s = (f"    static constexpr int MAXDEPTH = {max(depth)}, MAXJPB = {max(m.body_jntnum)}, NSLOT = {nslot}, "
+         f"MAXCON = {min(nslot, 40)};\n")
+    for name, val, n in [("body_depth", depth, nb), ("body_dofmask", body_dofmask, nb), ("body_descmask", body_descmask, nb),
+                         ("dof_ancmask", dof_ancmask, nv), ("dof_descbodies", dof_descbodies, nv), ("dof_actuator", dof_actuator, nv),
+                         ("slot_pair", slot_pair, nslot), ("slot_sub", slot_sub, nslot)]:
+        s += _arr(name, "int", val, (n,))
     return s
 
 

@@ -1,0 +1,129 @@
+// TEST INFRASTRUCTURE ONLY -- CPU emulation of the cooperative MuJoCo kernel (gymnasium_amd/csrc/mjx_coop.h).
+//
+// The device source is compiled for the host with MJX_HOST_EMU: every lane of a group becomes a fiber (ucontext), and
+// coop_sync() yields round-robin to the next lane, which is a barrier as long as all lanes execute the same sequence of
+// coop_sync() calls (they do: the kernel's control flow is group-uniform).  This lets tests/test_coop_emu.py compare the
+// cooperative algorithm with the C oracle (oracle/mujoco_core.c) without a GPU.  Nothing in the product links this file.
+#define MJX_HOST_EMU 1
+#include "../../gymnasium_amd/csrc/mjx_coop.h"
+
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+namespace {
+constexpr int kMaxLanes = 32;
+constexpr size_t kStack = 1 << 20;
+ucontext_t g_main, g_ctx[kMaxLanes];
+bool g_done[kMaxLanes];
+int g_cur = 0, g_n = 0;
+long g_syncs = 0;
+std::function<void(int)> g_body;
+
+void trampoline(int lane) {
+    g_body(lane);
+    g_done[lane] = true;
+    for (int k = 1; k <= g_n; k++) {
+        const int nxt = (lane + k) % g_n;
+        if (!g_done[nxt]) {
+            g_cur = nxt;
+            setcontext(&g_ctx[nxt]);
+        }
+    }
+    setcontext(&g_main);
+}
+
+void run_group(int n, std::function<void(int)> body) {
+    static std::vector<char> stacks;
+    stacks.resize(kStack * kMaxLanes);
+    g_body = std::move(body), g_n = n;
+    for (int l = 0; l < n; l++) {
+        g_done[l] = false;
+        getcontext(&g_ctx[l]);
+        g_ctx[l].uc_stack.ss_sp = stacks.data() + kStack * l, g_ctx[l].uc_stack.ss_size = kStack, g_ctx[l].uc_link = nullptr;
+        makecontext(&g_ctx[l], (void (*)())trampoline, 1, l);
+    }
+    g_cur = 0;
+    swapcontext(&g_main, &g_ctx[0]);
+}
+}  // namespace
+
+void mjx::coop::coop_sync() {
+    g_syncs++;
+    const int me = g_cur, nxt = (me + 1) % g_n;
+    g_cur = nxt;
+    swapcontext(&g_ctx[me], &g_ctx[nxt]);
+}
+
+namespace {
+using namespace mjx;
+
+template <class M, int G>
+int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsub, double *qpos_out, double *qvel_out, double *extras,
+             double *debug) {
+    typedef coop::Sim<M, G> S;
+    auto *bb = new typename S::B();
+    std::memset((void *)bb, 0, sizeof(*bb));
+    g_syncs = 0;
+    run_group(G, [&](int lane) {
+        typename S::R r;
+        std::memset((void *)&r, 0, sizeof(r));
+        S::init(*bb, lane);
+        for (int k = lane; k < M::NQ; k += G) bb->qpos[k] = qpos[k];
+        for (int k = lane; k < M::NV; k += G) bb->qvel[k] = qvel[k];
+        for (int k = lane; k < M::NU; k += G) bb->ctrl[k] = ctrl[k];
+        coop::coop_sync();
+        if (nsub == 0) {
+            S::forward(*bb, r, lane);
+        } else {
+            for (int s = 0; s < nsub; s++) S::step(*bb, r, lane);
+        }
+        coop::coop_sync();
+        S::write_extras(*bb, r, lane, extras);
+        if (debug && lane < M::NV) {  // qacc, qacc_smooth, bias, qfrc_constraint, then the mass-matrix rows
+            debug[lane] = r.qacc, debug[M::NV + lane] = r.qacc_smooth, debug[2 * M::NV + lane] = r.bias, debug[3 * M::NV + lane] = r.qfrc_constraint;
+            for (int j = 0; j < M::NV; j++) debug[4 * M::NV + lane * M::NV + j] = r.Mrow[j];
+        }
+        coop::coop_sync();
+    });
+    for (int k = 0; k < M::NQ; k++) qpos_out[k] = bb->qpos[k];
+    for (int k = 0; k < M::NV; k++) qvel_out[k] = bb->qvel[k];
+    const int ncon = bb->ncon;
+    delete bb;
+    return ncon;
+}
+}  // namespace
+
+extern "C" {
+// model: 0 half_cheetah, 1 ant, 2 humanoid.  nsub = 0: one forward pass only.  Returns the number of contacts of the last pass.
+__attribute__((visibility("default"))) int coop_emu_step(int model, const double *qpos, const double *qvel, const double *ctrl, int nsub,
+                                                          double *qpos_out, double *qvel_out, double *extras, double *debug) {
+    switch (model) {
+        case 0: return emu_step<HalfCheetahModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug);
+        case 1: return emu_step<AntModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug);
+        case 2: return emu_step<HumanoidModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug);
+    }
+    return -1;
+}
+__attribute__((visibility("default"))) int coop_emu_extras_dim(int model) {
+    switch (model) {
+        case 0: return coop::Sim<HalfCheetahModel, 16>::EX_TOTAL;
+        case 1: return coop::Sim<AntModel, 16>::EX_TOTAL;
+        case 2: return coop::Sim<HumanoidModel, 32>::EX_TOTAL;
+    }
+    return -1;
+}
+__attribute__((visibility("default"))) long coop_emu_board_bytes(int model) {
+    switch (model) {
+        case 0: return sizeof(coop::Board<HalfCheetahModel, 16>);
+        case 1: return sizeof(coop::Board<AntModel, 16>);
+        case 2: return sizeof(coop::Board<HumanoidModel, 32>);
+    }
+    return -1;
+}
+__attribute__((visibility("default"))) long coop_emu_last_syncs() { return g_syncs; }
+}

@@ -1,0 +1,103 @@
+"""CPU validation of the cooperative MuJoCo kernel (gymnasium_amd/csrc/mjx_coop.h).
+
+The device source is compiled for the host (tests/coop_emu/emu.cpp: one fiber per lane, coop_sync() = round-robin yield)
+and compared with the C oracle (oracle/mujoco_core.c) on the same states.  HIP-vs-oracle parity on the GPU is in
+tests/test_gpu_mujoco.py; this file pins the ALGORITHM (level-parallel tree passes, row-per-lane Cholesky, per-contact
+3x3 Hessian blocks, butterfly line search) without a GPU.  Physics parity with `mujoco` itself stays UNPINNED.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import mujoco as om
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "coop_emu")
+NAMES = ["half_cheetah", "ant", "humanoid"]
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so, src = os.path.join(EMU_DIR, "libcoop_emu.so"), os.path.join(EMU_DIR, "emu.cpp")
+        csrc = os.path.join(HERE, "..", "gymnasium_amd", "csrc")
+        deps = [src] + [os.path.join(csrc, f) for f in ("mjx_coop.h", "mjx_core.h", os.path.join("generated", "mjx_models.h"))]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            from gymnasium_amd.envs.mujoco import codegen
+
+            codegen.generate()
+            subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wno-unknown-pragmas",
+                            "-o", so, src], check=True, cwd=EMU_DIR)
+        _LIB = C.CDLL(so)
+        _LIB.coop_emu_step.restype = C.c_int
+        _LIB.coop_emu_board_bytes.restype = C.c_long
+    return _LIB
+
+
+def emu(model, m, qpos, qvel, ctrl, nsub):
+    qo, vo = np.zeros(m.nq), np.zeros(m.nv)
+    ex, dbg = np.zeros(lib().coop_emu_extras_dim(model)), np.zeros(4 * m.nv + m.nv * m.nv)
+    p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)
+    ncon = lib().coop_emu_step(model, p(qpos), p(qvel), p(ctrl), nsub, p(qo), p(vo), p(ex), p(dbg))
+    return qo, vo, ex, dbg, ncon
+
+
+@pytest.mark.parametrize("model", [0, 1, 2], ids=NAMES)
+def test_forward_matches_oracle(model):
+    om_ = om.OracleModel(NAMES[model])
+    m, d = om_.m, om_.make_data()
+    rng = np.random.default_rng(model)
+    nv = m.nv
+    for trial in range(6):
+        qpos = m.qpos0 + rng.uniform(-0.3, 0.3, m.nq)
+        qvel = rng.normal(size=nv)
+        if model > 0:
+            qpos[2] = m.qpos0[2] - (0.25 if trial % 2 else 0.0)  # push into the floor every other trial
+            qpos[3:7] /= np.linalg.norm(qpos[3:7])
+        ctrl = rng.uniform(-1, 1, m.nu)
+        d.reset(), d.set_state(qpos, qvel, ctrl), d.forward()
+        _, _, _, dbg, ncon = emu(model, m, qpos, qvel, ctrl, 0)
+        assert ncon == d.get("ncon")
+        scale = max(1.0, np.abs(d.get("qacc")).max())
+        np.testing.assert_allclose(dbg[4 * nv:].reshape(nv, nv), d.get("qM"), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(dbg[2 * nv:3 * nv], d.get("qfrc_bias"), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(dbg[nv:2 * nv], d.get("qacc_smooth"), rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(dbg[:nv], d.get("qacc"), rtol=0, atol=1e-11 * scale)
+        np.testing.assert_allclose(dbg[3 * nv:4 * nv], d.get("qfrc_constraint"), rtol=0, atol=1e-9 * scale)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2], ids=NAMES)
+def test_env_steps_match_oracle_with_contacts(model):
+    """frame_skip sub-steps (Euler with implicit damping / RK4) from states the oracle reached under a random policy."""
+    om_ = om.OracleModel(NAMES[model])
+    m, d = om_.m, om_.make_data()
+    nb, amp = m.nbody, (0.4 if model == 2 else 1.0)
+    seen_contacts = 0
+    for trial in range(2):
+        rng = np.random.default_rng(100 + trial)
+        qpos = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
+        if model > 0:
+            qpos[3:7] /= np.linalg.norm(qpos[3:7])
+        d.reset(), d.set_state(qpos, 0.1 * rng.normal(size=m.nv), np.zeros(m.nu))
+        for _ in range(120 if model == 2 else 60):
+            d.set_state(None, None, amp * rng.uniform(-1, 1, m.nu)), d.step(5)
+        q, v = d.get("qpos"), d.get("qvel")
+        for _ in range(4):
+            ctrl = amp * rng.uniform(-1, 1, m.nu)
+            d.set_state(q, v, ctrl), d.step(5), d.rne_post_constraint()
+            qo, vo, ex, _, ncon = emu(model, m, q, v, ctrl, 5)
+            assert ncon == d.get("ncon")
+            seen_contacts += ncon
+            np.testing.assert_allclose(qo, d.get("qpos"), rtol=0, atol=1e-11)
+            np.testing.assert_allclose(vo, d.get("qvel"), rtol=0, atol=1e-10)
+            cf = ex[4:4 + 6 * nb].reshape(nb, 6)
+            np.testing.assert_allclose(cf, d.get("cfrc_ext"), rtol=0, atol=1e-9 * max(1.0, np.abs(cf).max()))
+            np.testing.assert_allclose(ex[0:2], d.get("xpos")[1][:2], rtol=0, atol=1e-13)
+            np.testing.assert_allclose(ex[4 + 6 * nb:4 + 16 * nb].reshape(nb, 10), d.get("cinert"), rtol=0, atol=1e-12)
+            np.testing.assert_allclose(ex[4 + 16 * nb:4 + 22 * nb].reshape(nb, 6), d.get("cvel"), rtol=0, atol=1e-10)
+            q, v = d.get("qpos"), d.get("qvel")
+    assert seen_contacts > 0
