@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["engine.hip"]
-HEADERS = ["envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_kernels.h", "ziggurat_tables.h", os.path.join("generated", "mjx_models.h"),
+HEADERS = ["envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", "ziggurat_tables.h", os.path.join("generated", "mjx_models.h"),
            os.path.join("..", "..", "include", "mi355env.h")]
 OUT = os.path.join(HERE, "libmi355env.so")
 ARCH = "gfx950"

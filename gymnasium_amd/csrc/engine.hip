@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -28,6 +29,7 @@
 #include "envs_classic.h"
 #include "pcg64_dev.h"
 #include "mjx_kernels.h"
+#include "mjx_coop.h"
 
 using namespace mi;
 
@@ -456,6 +458,7 @@ struct MjStepPtrs {
     int32_t *ep_len;
     double *info;
     int obs_dim;
+    const double *extras;  // [N][EX_TOTAL] rows written by mj_physics_kernel, or nullptr (one-lane simulator inside the step kernel)
 };
 
 template <class E>
@@ -487,9 +490,12 @@ MI_DEV void mj_autoreset(const DevEnv &d, int i, MjLane<E> &L, double *obs) {
 }
 
 // one lockstep step of one MuJoCo sub-environment; obs / info rows are written straight to their destination
-template <class E, int MODE>
+// `extras` != nullptr: the physics of this step was already advanced by mj_physics_kernel (L.s holds the new qpos / qvel
+// and the old tracked point); nullptr: the one-lane simulator runs here.
+template <class E, int MODE, bool COOP = false>
 MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *action, double *obs, double *final_obs, double *info,
-                         double &reward, bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st) {
+                         double &reward, bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st,
+                         const double *extras = nullptr) {
     te = tr = false, reward = 0.0;
     if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
         mj_autoreset<E>(d, i, L, obs);
@@ -500,7 +506,19 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
         out_ret = 0.0, out_len = 0;
         return;
     } else {
-        E::step(L.s, action, d.P, obs, reward, te, info);
+        if (COOP) {
+            typedef mjx::coop::Sim<typename E::Model, E::COOP_G> S;
+            typename E::StepExtras x;
+            E::after_from_extras(L.s, extras, x.after);
+            x.cfrc = reinterpret_cast<const double (*)[6]>(extras + S::EX_CFRC);
+            x.cinert = reinterpret_cast<const double (*)[10]>(extras + S::EX_CINERT);
+            x.cvel = reinterpret_cast<const double (*)[6]>(extras + S::EX_CVEL);
+            x.qfrc_actuator = extras + S::EX_QFA;
+            const double before[2] = {L.s[E::NQ + 2 * E::NV], L.s[E::NQ + 2 * E::NV + 1]};
+            E::finish(L.s, before, x, action, d.P, obs, reward, te, info);
+        } else {
+            E::step(L.s, action, d.P, obs, reward, te, info);
+        }
         L.elapsed += 1;
         tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;
         L.ep_ret += reward, L.ep_len += 1;
@@ -520,7 +538,7 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
         L.flags &= ~kNeedsReset;
 }
 
-template <class E, int MODE>
+template <class E, int MODE, bool COOP>
 __global__ __launch_bounds__(kBlock) void mj_step_kernel(DevEnv d, MjStepPtrs io) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
@@ -530,9 +548,10 @@ __global__ __launch_bounds__(kBlock) void mj_step_kernel(DevEnv d, MjStepPtrs io
         double reward, out_ret;
         int32_t out_len;
         bool te, tr;
-        mj_lane_step<E, MODE>(d, i, L, io.actions + (size_t)i * E::NU, io.obs + (size_t)i * io.obs_dim,
+        mj_lane_step<E, MODE, COOP>(d, i, L, io.actions + (size_t)i * E::NU, io.obs + (size_t)i * io.obs_dim,
                               io.final_obs ? io.final_obs + (size_t)i * io.obs_dim : nullptr,
-                              io.info ? io.info + (size_t)i * E::INFO : nullptr, reward, te, tr, out_ret, out_len, st);
+                              io.info ? io.info + (size_t)i * E::INFO : nullptr, reward, te, tr, out_ret, out_len, st,
+                              COOP ? io.extras + (size_t)i * mjx::coop::Sim<typename E::Model, E::COOP_G>::EX_TOTAL : nullptr);
         mj_store<E>(d, i, L);
         if (io.reward) io.reward[i] = reward;
         if (io.terminated) io.terminated[i] = te;
@@ -602,6 +621,56 @@ __global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtr
         mj_store<E>(d, i, L);
     }
     block_accumulate(d, st);
+}
+
+// ---- cooperative physics (mjx_coop.h): G lanes per sub-environment, 64 / G sub-environments per wavefront --------------
+// Advances qpos / qvel of every sub-environment that takes a real step this call by frame_skip sub-steps, in place, and
+// leaves what the reward / observation code needs in `extras`.  Sub-environments in their NEXT_STEP autoreset step (or
+// finished ones under DISABLED) are skipped: the step kernel that follows resets them / reports the error.
+template <class E, int MODE>
+__global__ __launch_bounds__(64) void mj_physics_kernel(DevEnv d, const float *actions, double *extras) {
+    typedef typename E::Model M;
+    constexpr int G = E::COOP_G, EPW = 64 / G;
+    typedef mjx::coop::Sim<M, G> S;
+    __shared__ typename S::B boards[EPW];
+    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+    const int env = blockIdx.x * EPW + grp;
+    if (env >= d.N) return;
+    if (MODE != MI_AUTORESET_SAME_STEP && ((d.meta[env] >> kFlagShift) & kNeedsReset)) return;
+    typename S::B &bb = boards[grp];
+    typename S::R r;
+    S::init(bb, lane);
+    const size_t N = (size_t)d.N;
+    for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
+    for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
+    for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
+    mjx::coop::coop_sync();
+    const int frame_skip = (int)d.P.p[4];
+    for (int f = 0; f < frame_skip; f++) S::step(bb, r, lane);
+    mjx::coop::coop_sync();
+    for (int k = lane; k < M::NQ; k += G) d.state[(size_t)k * N + env] = bb.qpos[k];
+    for (int k = lane; k < M::NV; k += G) d.state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
+    S::write_extras(bb, r, lane, extras + (size_t)env * S::EX_TOTAL);
+}
+
+// Box.sample() of the batched action space for step t of a rollout: draw number (t N + i) NU + u of the stream
+template <class E>
+__global__ __launch_bounds__(kBlock) void mj_sample_kernel(DevEnv d, ActionStream as, int t, float *out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.N) return;
+    const u128 ainc = make_u128(as.inc_hi, as.inc_lo);
+    u128 astate = make_u128(as.state_hi, as.state_lo);
+    uint64_t delta = ((uint64_t)t * (uint64_t)d.N + (uint64_t)i) * E::NU + 1u;
+    for (int j = 0; delta; j++, delta >>= 1)
+        if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
+    for (int u = 0; u < E::NU; u++) {
+        const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate, x = hi ^ lo;
+        const unsigned rot = (unsigned)(hi >> 58);
+        const uint64_t o = (x >> rot) | (x << ((0u - rot) & 63u));
+        const double lo_b = (double)(float)E::Model::actuator_ctrlrange[u][0], hi_b = (double)(float)E::Model::actuator_ctrlrange[u][1];
+        out[(size_t)i * E::NU + u] = (float)(lo_b + (hi_b - lo_b) * ((double)(o >> 11) * (1.0 / 9007199254740992.0)));
+        astate = astate * pcg_mult() + ainc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -838,6 +907,12 @@ struct mi_vecenv {
     size_t info_bytes;
     void *tab_bufs[7];
     bool tab_loaded;
+    // MuJoCo family: cooperative physics kernel (default) or the one-lane simulator (MI355ENV_MJ_SERIAL=1, cross-check)
+    bool mj_coop;
+    int extras_dim;
+    double *d_extras;       // [N][EX_TOTAL]
+    float *d_act_scratch;   // [N][NU] actions of the current rollout step when the caller does not keep them
+    void *d_obs_scratch;    // [N][obs_dim] observations of the current rollout step when the caller does not keep them
 };
 
 namespace {
@@ -919,6 +994,67 @@ int launch_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, i
     return MI_OK;
 }
 
+// One vector step of a MuJoCo env: [cooperative physics ->] per-lane glue (autoreset state machine, reward, observation, stats)
+template <class E>
+int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
+    const dim3 g(v->grid), b(kBlock);
+    const int mode = v->cfg.autoreset_mode;
+    mp.extras = nullptr;
+    if (v->mj_coop) {
+        constexpr int EPW = 64 / E::COOP_G;
+        const dim3 pg((v->cfg.num_envs + EPW - 1) / EPW), pb(64);
+        switch (mode) {
+        case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((mj_physics_kernel<E, MI_AUTORESET_NEXT_STEP>), pg, pb, 0, v->stream, v->d, mp.actions, v->d_extras); break;
+        case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((mj_physics_kernel<E, MI_AUTORESET_SAME_STEP>), pg, pb, 0, v->stream, v->d, mp.actions, v->d_extras); break;
+        default: hipLaunchKernelGGL((mj_physics_kernel<E, MI_AUTORESET_DISABLED>), pg, pb, 0, v->stream, v->d, mp.actions, v->d_extras); break;
+        }
+        mp.extras = v->d_extras;
+    }
+    if (v->mj_coop) {
+        switch (mode) {
+        case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, mp); break;
+        case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, mp); break;
+        default: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_DISABLED, true>), g, b, 0, v->stream, v->d, mp); break;
+        }
+    } else {
+        switch (mode) {
+        case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, mp); break;
+        case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, mp); break;
+        default: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_DISABLED, false>), g, b, 0, v->stream, v->d, mp); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// T vector steps with the cooperative physics: per step [sample actions ->] physics -> glue, all on the env's stream
+template <class E>
+int launch_mj_rollout_coop(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample) {
+    const size_t N = (size_t)v->cfg.num_envs;
+    const dim3 g(v->grid), b(kBlock);
+    for (int t = 0; t < T; t++) {
+        const float *act;
+        if (sample) {
+            float *dst = p.actions_out ? static_cast<float *>(p.actions_out) + (size_t)t * N * E::NU : v->d_act_scratch;
+            hipLaunchKernelGGL((mj_sample_kernel<E>), g, b, 0, v->stream, v->d, as, t, dst);
+            act = dst;
+        } else {
+            act = static_cast<const float *>(p.actions_in) + (size_t)t * N * E::NU;
+        }
+        MjStepPtrs mp;
+        memset(&mp, 0, sizeof mp);
+        mp.actions = act;
+        mp.obs = p.obs ? static_cast<double *>(p.obs) + (size_t)t * N * v->lay.obs_dim : static_cast<double *>(v->d_obs_scratch);
+        mp.reward = p.reward ? p.reward + (size_t)t * N : nullptr;
+        mp.terminated = p.terminated ? p.terminated + (size_t)t * N : nullptr;
+        mp.truncated = p.truncated ? p.truncated + (size_t)t * N : nullptr;
+        mp.obs_dim = v->lay.obs_dim;
+        const int rc = launch_mj_step<E>(v, mp);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 int set_device(const mi_vecenv *v) {
     HIP_TRY(hipSetDevice(v->device));
     return MI_OK;
@@ -967,8 +1103,11 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
                         (P.p[15] != 0.0 ? 6 * (E::NB - 1) : 0);
             const mi_layout l = {E::NQ + E::NV - skip + extra, MI_F64, E::NU, MI_F32, E::S, E::INFO, {0, 0}};
             v->lay = l;
+            v->extras_dim = mjx::coop::Sim<typename E::Model, E::COOP_G>::EX_TOTAL;
             return (int)MI_OK;
         });
+        const char *serial = getenv("MI355ENV_MJ_SERIAL");
+        v->mj_coop = !(serial && serial[0] == '1');
     } else if (is_tab(cfg->kind)) {
         const mi_layout l = {1, MI_I64, 1, MI_I64, 2, 1, {0, 0}};
         v->lay = l;
@@ -1015,6 +1154,12 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     HIP_TRY(hipMalloc(&v->d_mask, N));
     HIP_TRY(hipMalloc(&v->d_words, sizeof(uint64_t) * 4 * N));
     HIP_TRY(hipMemsetAsync(v->d_obs, 0, v->obs_bytes, v->stream));
+    if (is_mj(cfg->kind)) {
+        HIP_TRY(hipMalloc(&v->d_extras, sizeof(double) * v->extras_dim * N));
+        HIP_TRY(hipMalloc(&v->d_act_scratch, v->act_bytes));
+        HIP_TRY(hipMalloc(&v->d_obs_scratch, v->obs_bytes));
+        HIP_TRY(hipMemsetAsync(v->d_extras, 0, sizeof(double) * v->extras_dim * N, v->stream));
+    }
     HIP_TRY(hipStreamSynchronize(v->stream));
     *out = v;
     return MI_OK;
@@ -1026,7 +1171,7 @@ void mi_destroy(mi_vecenv *v) {
     (void)hipStreamSynchronize(v->stream);
     void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d.error,
                     v->d_pow2, v->d_actions, v->d_obs, v->d_final, v->d_reward, v->d_epret, v->d_eplen, v->d_term,
-                    v->d_trunc, v->d_mask, v->d_words, v->d_info};
+                    v->d_trunc, v->d_mask, v->d_words, v->d_info, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : v->tab_bufs)
@@ -1187,19 +1332,9 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
         rc = MI_OK;
     } else if (is_mj(v->cfg.kind)) {
         const MjStepPtrs mp = {(const float *)p.actions, (double *)p.obs, p.reward, p.terminated, p.truncated, (double *)p.final_obs,
-                               p.ep_ret, p.ep_len, dinfo, v->lay.obs_dim};
+                               p.ep_ret, p.ep_len, dinfo, v->lay.obs_dim, nullptr};
         if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
-        rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int {
-            using E = decltype(env);
-            const dim3 g(v->grid), b(kBlock);
-            switch (v->cfg.autoreset_mode) {
-            case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_NEXT_STEP>), g, b, 0, v->stream, v->d, mp); break;
-            case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_SAME_STEP>), g, b, 0, v->stream, v->d, mp); break;
-            default: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_DISABLED>), g, b, 0, v->stream, v->d, mp); break;
-            }
-            HIP_TRY(hipGetLastError());
-            return (int)MI_OK;
-        });
+        rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int { return launch_mj_step<decltype(env)>(v, mp); });
     } else {
         rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
     }
@@ -1297,6 +1432,7 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
     } else if (is_mj(v->cfg.kind)) {
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int {
             using E = decltype(env);
+            if (v->mj_coop) return launch_mj_rollout_coop<E>(v, p, as, T, sample);
             const dim3 g(v->grid), b(kBlock);
             const bool next = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
             if (next && sample)

@@ -24,6 +24,10 @@
 #pragma once
 #include "mjx_core.h"
 
+#if !defined(MJX_HOST_EMU)
+#pragma clang fp contract(fast)
+#endif
+
 namespace mjx {
 namespace coop {
 
@@ -63,13 +67,18 @@ MJX_DEV double rsq(double x) {
 }
 MJX_DEV int popc(unsigned x) { return __popc(x); }
 template <int G>
-MJX_DEV double group_sum(double v, double (*)[32], int) {
+MJX_DEV double group_sum(double v, decltype(nullptr), int) {
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) v = v + __shfl_xor(v, off, G);
     return v;
 }
 #endif
 
+// Blackboard of one sub-environment (LDS).  Arrays whose lifetimes inside one forward pass do not overlap share storage:
+//   A: kinematics / collision (xquat, xmat)          | solver (packed Cholesky factor, exchange column, iterate, direction)
+//   B: RNE pass (cacc, cfrc)                         | CRB pass (per-body inertias of all bodies)
+//   C: CRB pass (composite inertias, I * cdof)       | solver (twists of the search direction, contact Jacobian exchange, forces)
+// Phase order in forward(): kinematics -> com_pos -> collision -> com_vel_and_bias -> crb -> constraint rows -> solver.
 template <class M, int G_>
 struct Board {
     static constexpr int G = G_, NQ = M::NQ, NV = M::NV, NB = M::NBODY, NU = M::NU, NTRI = M::NV * (M::NV + 1) / 2;
@@ -77,21 +86,42 @@ struct Board {
     static_assert(NB - 1 <= G && NV <= G && G <= 32, "one lane per body and per dof");
     double qpos[NQ], qvel[NV], ctrl[NU];
     double q0[NQ], dv[NV];                                    // RK4: base position, stage velocity
-    double xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3];
+    double xpos[NB][3], xipos[NB][3];
     double com[3];
     double cdof[NV][6];
-    double cvel[NB][6], cacc[NB][6], cfrc[NB][6];
-    double cinert[NB][10], cinertc[NB][10];
-    double buf[NV][6];
-    double tw[NB][6];                                         // per-body twist of a dof-space vector (J v without the frames)
-    double vx[NV], vdir[NV];                                  // Newton iterate and search direction
-    double col[2][NV];                                        // pivot column / substitution broadcast (double buffered)
-    double L[NTRI];                                           // packed lower Cholesky factor (column access in back substitution)
+    double cvel[NB][6];
     double con_r[MAXCON][3], con_frame[MAXCON][9], con_dist[MAXCON];
-    double con_g[MAXCON][3], con_W[MAXCON][5];                // per contact: sum_active D jar e, sum_active D e e^T
-    int con_pair[MAXCON];
-    double jc[2][3][NV];                                      // contact-frame Jacobian of the contact being assembled
+    union {
+        struct {
+            double xquat[NB][4], xmat[NB][9];
+        } kin;
+        struct {
+            double L[NTRI];                                   // packed lower Cholesky factor (column access in back substitution)
+            double col[2][NV];                                // pivot column / substitution broadcast (double buffered)
+            double vdir[NV];                                  // solution of the last solve (qacc_smooth, then the search directions)
+        } sol;
+    } A;
+    union {
+        struct {
+            double cacc[NB][6], cfrc[NB][6];
+        } rne;
+        double cinert[NB][10];
+    } Bu;
+    union {
+        struct {
+            double cinertc[NB][10], buf[NV][6];
+        } crb;
+        struct {
+            double tw[NB][6];                                 // per-body twist of a dof-space vector (J v without the frames)
+            double jc[2][3][NV];                              // contact-frame Jacobian of the contact being assembled
+            double gw[2][8];                                  // its owner's sum_active D jar e (3) and sum_active D e e^T (5)
+            double con_F[MAXCON][3];                          // world-frame contact forces of the last forward pass
+        } sol;
+    } C;
+#if defined(MJX_HOST_EMU)
     double red[1][32];
+#endif
+    int con_pair[MAXCON];
     unsigned cmask[KS], anyrow;
     int ncon;
 };
@@ -102,16 +132,16 @@ struct Lane {
     static constexpr int NV = M::NV, KC = Board<M, G>::KC;
     // body role
     double anchor[M::MAXJPB][3], axis[M::MAXJPB][3];
-    double cinert[10];
+    double xmat[9], cinert[10];
     // dof role
     double cdof[6], Mrow[NV], Hrow[NV], idiag;
-    double bias, qfrc_smooth, qfrc_actuator, qacc_smooth, qacc, qfrc_constraint;
+    double bias, qfrc_smooth, qfrc_actuator, qacc_smooth, qacc, qacc_int, qfrc_constraint;
     bool lim_on[2];
     double lim_D[2], lim_aref[2], lim_sign[2];
     // contact role
     bool c_on[KC];
     int c_b1[KC], c_b2[KC], c_dim[KC];
-    double c_mu[KC], c_D[KC], c_kterm[KC], c_b[KC], c_jv[KC][3], c_jx[KC][3], c_jd[KC][3];
+    double c_mu[KC], c_D[KC], c_kterm[KC], c_b[KC], c_jv[KC][3], c_jx[KC][3], c_jd[KC][3], c_gw[KC][8];
 };
 
 template <class M, int G>
@@ -119,20 +149,19 @@ struct Sim {
     typedef Board<M, G> B;
     typedef Lane<M, G> R;
     static constexpr int NQ = M::NQ, NV = M::NV, NB = M::NBODY, NU = M::NU, KC = B::KC, KS = B::KS, MAXCON = B::MAXCON;
+#if defined(MJX_HOST_EMU)
+#define MJX_RED(bb) (bb).red
+#else
+#define MJX_RED(bb) nullptr
+#endif
 
     // ---- one-time initialisation of the constant rows of the blackboard (world body) ----------------------------------
     static MJX_DEV void init(B &bb, int lane) {
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 3; k++) bb.xpos[0][k] = 0, bb.xipos[0][k] = 0;
-            bb.xquat[0][0] = 1, bb.xquat[0][1] = bb.xquat[0][2] = bb.xquat[0][3] = 0;
 #pragma unroll
-            for (int k = 0; k < 9; k++) bb.xmat[0][k] = (k % 4 == 0) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) bb.cvel[0][k] = 0, bb.cacc[0][k] = 0, bb.cfrc[0][k] = 0, bb.tw[0][k] = 0;
-            bb.cacc[0][3] = -M::gravity[0], bb.cacc[0][4] = -M::gravity[1], bb.cacc[0][5] = -M::gravity[2];
-#pragma unroll
-            for (int k = 0; k < 10; k++) bb.cinert[0][k] = 0, bb.cinertc[0][k] = 0;
+            for (int k = 0; k < 6; k++) bb.cvel[0][k] = 0;
         }
         coop_sync();
     }
@@ -143,6 +172,7 @@ struct Sim {
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
         const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+#pragma unroll 1
         for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
             if (isbody && depth == lev) {
                 double pos[3], quat[4];
@@ -155,9 +185,16 @@ struct Sim {
                     r.axis[0][0] = 0, r.axis[0][1] = 0, r.axis[0][2] = 1;
                 } else {
                     double t[3];
-                    rot_vec(t, bb.xmat[p], M::body_pos[bi]);
-                    pos[0] = bb.xpos[p][0] + t[0], pos[1] = bb.xpos[p][1] + t[1], pos[2] = bb.xpos[p][2] + t[2];
-                    quat_mul(quat, bb.xquat[p], M::body_quat[bi]);
+                    if (p == 0) {  // the world frame is the identity (its rows of the blackboard are not kept)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) pos[k] = M::body_pos[bi][k];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) quat[k] = M::body_quat[bi][k];
+                    } else {
+                        rot_vec(t, bb.A.kin.xmat[p], M::body_pos[bi]);
+                        pos[0] = bb.xpos[p][0] + t[0], pos[1] = bb.xpos[p][1] + t[1], pos[2] = bb.xpos[p][2] + t[2];
+                        quat_mul(quat, bb.A.kin.xquat[p], M::body_quat[bi]);
+                    }
 #pragma unroll
                     for (int jj = 0; jj < M::MAXJPB; jj++) {
                         if (jj < jn) {
@@ -181,15 +218,15 @@ struct Sim {
                     }
                 }
                 quat_normalize(quat);
-                double xm[9], t[3];
-                quat_to_mat(xm, quat);
-                rot_vec(t, xm, M::body_ipos[bi]);
+                double t[3];
+                quat_to_mat(r.xmat, quat);
+                rot_vec(t, r.xmat, M::body_ipos[bi]);
 #pragma unroll
                 for (int k = 0; k < 3; k++) bb.xpos[b][k] = pos[k], bb.xipos[b][k] = pos[k] + t[k];
 #pragma unroll
-                for (int k = 0; k < 4; k++) bb.xquat[b][k] = quat[k];
+                for (int k = 0; k < 4; k++) bb.A.kin.xquat[b][k] = quat[k];
 #pragma unroll
-                for (int k = 0; k < 9; k++) bb.xmat[b][k] = xm[k];
+                for (int k = 0; k < 9; k++) bb.A.kin.xmat[b][k] = r.xmat[k];
             }
             coop_sync();
         }
@@ -208,7 +245,7 @@ struct Sim {
         if (lane == 0) bb.com[0] = com[0], bb.com[1] = com[1], bb.com[2] = com[2];
         const int b = lane + 1;
         if (b < NB) {
-            const double *Rm = bb.xmat[b], *I = M::body_inertia[b];
+            const double *Rm = r.xmat, *I = M::body_inertia[b];
             const double off[3] = {bb.xipos[b][0] - com[0], bb.xipos[b][1] - com[1], bb.xipos[b][2] - com[2]};
             double T[9], W[9];
 #pragma unroll
@@ -224,8 +261,6 @@ struct Sim {
             ci[0] = W[0] + mm * (dd - off[0] * off[0]), ci[1] = W[4] + mm * (dd - off[1] * off[1]), ci[2] = W[8] + mm * (dd - off[2] * off[2]);
             ci[3] = W[1] - mm * off[0] * off[1], ci[4] = W[2] - mm * off[0] * off[2], ci[5] = W[5] - mm * off[1] * off[2];
             ci[6] = mm * off[0], ci[7] = mm * off[1], ci[8] = mm * off[2], ci[9] = mm;
-#pragma unroll
-            for (int k = 0; k < 10; k++) bb.cinert[b][k] = ci[k];
             const int ja = M::body_jntadr[b], jn = M::body_jntnum[b];
 #pragma unroll
             for (int jj = 0; jj < M::MAXJPB; jj++) {
@@ -269,11 +304,18 @@ struct Sim {
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
         const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+#pragma unroll 1
         for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
             if (isbody && depth == lev) {
                 double v[6], a[6];
+                if (p == 0) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) v[k] = bb.cvel[p][k], a[k] = bb.cacc[p][k];
+                    for (int k = 0; k < 6; k++) v[k] = 0, a[k] = 0;
+                    a[3] = -M::gravity[0], a[4] = -M::gravity[1], a[5] = -M::gravity[2];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v[k] = bb.cvel[p][k], a[k] = bb.Bu.rne.cacc[p][k];
+                }
 #pragma unroll
                 for (int jj = 0; jj < M::MAXJPB; jj++) {
                     if (jj < jn) {
@@ -302,7 +344,7 @@ struct Sim {
                 double Ia[6], Iv[6], x[6];
                 inert_mul(Ia, r.cinert, a), inert_mul(Iv, r.cinert, v), cross_force(x, v, Iv);
 #pragma unroll
-                for (int k = 0; k < 6; k++) bb.cvel[b][k] = v[k], bb.cacc[b][k] = a[k], bb.cfrc[b][k] = Ia[k] + x[k];
+                for (int k = 0; k < 6; k++) bb.cvel[b][k] = v[k], bb.Bu.rne.cacc[b][k] = a[k], bb.Bu.rne.cfrc[b][k] = Ia[k] + x[k];
             }
             coop_sync();
         }
@@ -312,21 +354,26 @@ struct Sim {
             double f[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int d = NB - 1; d >= 1; d--) {
-                if ((desc >> d) & 1u) {
+                const double w = ((desc >> d) & 1u) ? 1.0 : 0.0;  // predicated, not branched
 #pragma unroll
-                    for (int k = 0; k < 6; k++) f[k] += bb.cfrc[d][k];
-                }
+                for (int k = 0; k < 6; k++) f[k] += w * bb.Bu.rne.cfrc[d][k];
             }
             double s = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) s += r.cdof[k] * f[k];
             r.bias = s;
         }
+        coop_sync();  // cfrc is dead from here on: crb() reuses its storage
     }
 
     // ---- composite rigid body: full row `lane` of the mass matrix in registers -----------------------------------------------
     static MJX_DEV void crb(B &bb, R &r, int lane) {
         const int b = lane + 1;
+        if (b < NB) {
+#pragma unroll
+            for (int k = 0; k < 10; k++) bb.Bu.cinert[b][k] = r.cinert[k];
+        }
+        coop_sync();
         if (b < NB) {
             const unsigned desc = (unsigned)M::body_descmask[b];
             double c[10];
@@ -334,20 +381,19 @@ struct Sim {
             for (int k = 0; k < 10; k++) c[k] = 0;
 #pragma unroll
             for (int d = NB - 1; d >= 1; d--) {
-                if ((desc >> d) & 1u) {
+                const double w = ((desc >> d) & 1u) ? 1.0 : 0.0;
 #pragma unroll
-                    for (int k = 0; k < 10; k++) c[k] += bb.cinert[d][k];
-                }
+                for (int k = 0; k < 10; k++) c[k] += w * bb.Bu.cinert[d][k];
             }
 #pragma unroll
-            for (int k = 0; k < 10; k++) bb.cinertc[b][k] = c[k];
+            for (int k = 0; k < 10; k++) bb.C.crb.cinertc[b][k] = c[k];
         }
         coop_sync();
         double mybuf[6] = {0, 0, 0, 0, 0, 0};
         if (lane < NV) {
-            inert_mul(mybuf, bb.cinertc[M::dof_bodyid[lane]], r.cdof);
+            inert_mul(mybuf, bb.C.crb.cinertc[M::dof_bodyid[lane]], r.cdof);
 #pragma unroll
-            for (int k = 0; k < 6; k++) bb.buf[lane][k] = mybuf[k];
+            for (int k = 0; k < 6; k++) bb.C.crb.buf[lane][k] = mybuf[k];
         }
         coop_sync();
         if (lane < NV) {
@@ -360,7 +406,7 @@ struct Sim {
                     for (int k = 0; k < 6; k++) s += bb.cdof[j][k] * mybuf[k];
                 } else if (((unsigned)M::dof_ancmask[j] >> lane) & 1u) {  // lane is an ancestor of j
 #pragma unroll
-                    for (int k = 0; k < 6; k++) s += r.cdof[k] * bb.buf[j][k];
+                    for (int k = 0; k < 6; k++) s += r.cdof[k] * bb.C.crb.buf[j][k];
                 }
                 r.Mrow[j] = s;
             }
@@ -371,14 +417,15 @@ struct Sim {
 #pragma unroll
             for (int j = 0; j < NV; j++) r.Mrow[j] = 0;
         }
+        coop_sync();  // buf is dead from here on: the solver reuses its storage
     }
 
     // ---- dense Cholesky with one matrix row per lane ---------------------------------------------------------------------
-    // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.L
+    // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.A.sol.L
     static MJX_DEV void chol_factor(B &bb, double *A, double &idiag, int lane) {
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            double (&col)[NV] = bb.col[k & 1];
+            double (&col)[NV] = bb.A.sol.col[k & 1];
             if (lane >= k && lane < NV) col[lane] = A[k];
             coop_sync();
             if (lane >= k && lane < NV) {
@@ -390,33 +437,32 @@ struct Sim {
                 if (lane == k) idiag = inv;
                 const double t = lik * inv;
 #pragma unroll
-                for (int j = k + 1; j < NV; j++)
-                    if (j <= lane) A[j] -= t * col[j];
+                for (int j = k + 1; j < NV; j++) A[j] -= (j <= lane ? t : 0.0) * col[j];  // entries j > lane are never used
             }
         }
         if (lane < NV) {
 #pragma unroll
             for (int j = 0; j < NV; j++)
-                if (j <= lane) bb.L[tri(lane, 0) + j] = A[j];
+                if (j <= lane) bb.A.sol.L[tri(lane, 0) + j] = A[j];
         }
         coop_sync();
     }
-    // solves L L^T x = rhs (rhs = this lane's component); returns this lane's component, the full solution is left in `out`
-    static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, double *out, int lane) {
+    // solves L L^T x = rhs (rhs = this lane's component); returns this lane's component, the full solution is left in vdir
+    static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
         double y = rhs;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            double (&col)[NV] = bb.col[k & 1];
+            double (&col)[NV] = bb.A.sol.col[k & 1];
             if (lane == k) y = y * idiag, col[k] = y;
             coop_sync();
-            if (lane > k && lane < NV) y -= Lrow[k] * col[k];
+            y -= ((lane > k && lane < NV) ? Lrow[k] : 0.0) * col[k];
         }
 #pragma unroll
         for (int k = NV - 1; k >= 0; k--) {
-            double (&col)[NV] = bb.col[k & 1];
-            if (lane == k) y = y * idiag, col[k] = y, out[k] = y;
+            double (&col)[NV] = bb.A.sol.col[k & 1];
+            if (lane == k) y = y * idiag, col[k] = y, bb.A.sol.vdir[k] = y;
             coop_sync();
-            if (lane < k) y -= bb.L[tri(k, 0) + lane] * col[k];
+            y -= (lane < k ? bb.A.sol.L[tri(k, 0) + (lane < k ? lane : 0)] : 0.0) * col[k];
         }
         coop_sync();
         return y;
@@ -425,11 +471,16 @@ struct Sim {
     // ---- collision: one candidate slot per lane and round, order-preserving compaction -------------------------------------------
     static MJX_DEV void geom_pose(const B &bb, int g, double *pos, double *axis_z) {
         const int b = M::geom_bodyid[g];
-        double t[3];
-        rot_vec(t, bb.xmat[b], M::geom_pos[g]);
-        pos[0] = bb.xpos[b][0] + t[0], pos[1] = bb.xpos[b][1] + t[1], pos[2] = bb.xpos[b][2] + t[2];
         const double lz[3] = {M::geom_mat[g][2], M::geom_mat[g][5], M::geom_mat[g][8]};
-        rot_vec(axis_z, bb.xmat[b], lz);
+        if (b == 0) {  // the world frame is the identity (its rows of the blackboard are not kept)
+#pragma unroll
+            for (int k = 0; k < 3; k++) pos[k] = M::geom_pos[g][k], axis_z[k] = lz[k];
+            return;
+        }
+        double t[3];
+        rot_vec(t, bb.A.kin.xmat[b], M::geom_pos[g]);
+        pos[0] = bb.xpos[b][0] + t[0], pos[1] = bb.xpos[b][1] + t[1], pos[2] = bb.xpos[b][2] + t[2];
+        rot_vec(axis_z, bb.A.kin.xmat[b], lz);
     }
     struct Cand {
         bool on;
@@ -456,6 +507,15 @@ struct Sim {
         for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * mid;
         finish(c, pair, dist - r1 - r2, pos, n, nullptr, flip);
     }
+    // which (type1 <= type2) geometry combinations occur among the model's candidate pairs: the others compile to nothing
+    static constexpr bool has_pairs(int ta, int tb) {
+        for (int p = 0; p < M::NPAIR; p++) {
+            const int t1 = M::geom_type[M::pair_geom1[p]], t2 = M::geom_type[M::pair_geom2[p]];
+            const int lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+            if (lo == ta && hi == tb) return true;
+        }
+        return false;
+    }
     static MJX_DEV void detect(const B &bb, int slot, Cand &c) {
         const int p = M::slot_pair[slot], sub = M::slot_sub[slot];
         int g1 = M::pair_geom1[p], g2 = M::pair_geom2[p];
@@ -470,13 +530,13 @@ struct Sim {
         const double r1 = M::geom_size[g1][0], r2 = M::geom_size[g2][0], h1 = M::geom_size[g1][1], h2 = M::geom_size[g2][1];
         c.on = false;
         if (t1 == PLANE) {
-            if (t2 == SPHERE) {
+            if (has_pairs(PLANE, SPHERE) && (t2 == SPHERE || !has_pairs(PLANE, CAPSULE))) {
                 double v[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, pos[3];
                 const double dist = dot3(v, z1) - r2;
 #pragma unroll
                 for (int k = 0; k < 3; k++) pos[k] = p2[k] - z1[k] * (r2 + 0.5 * dist);
                 finish(c, p, dist, pos, z1, nullptr, false);
-            } else {
+            } else if (has_pairs(PLANE, CAPSULE)) {
                 const double s = sub == 0 ? 1.0 : -1.0;
                 double cc[3], v[3], pos[3];
 #pragma unroll
@@ -486,15 +546,15 @@ struct Sim {
                 for (int k = 0; k < 3; k++) pos[k] = cc[k] - z1[k] * (r2 + 0.5 * dist);
                 finish(c, p, dist, pos, z1, z2, false);
             }
-        } else if (t1 == SPHERE && t2 == SPHERE) {
+        } else if (has_pairs(SPHERE, SPHERE) && t1 == SPHERE && t2 == SPHERE) {
             sphere_pair(c, p, p1, r1, p2, r2, flip);
-        } else if (t1 == SPHERE && t2 == CAPSULE) {
+        } else if (has_pairs(SPHERE, CAPSULE) && t1 == SPHERE && t2 == CAPSULE) {
             double v[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
             double x = dot3(v, z2);
             x = x > h2 ? h2 : (x < -h2 ? -h2 : x);
             double cc[3] = {p2[0] + x * z2[0], p2[1] + x * z2[1], p2[2] + x * z2[2]};
             sphere_pair(c, p, p1, r1, cc, r2, flip);
-        } else if (t1 == CAPSULE && t2 == CAPSULE) {
+        } else if (has_pairs(CAPSULE, CAPSULE) && t1 == CAPSULE && t2 == CAPSULE) {
             double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
             const double mb = -dot3(z1, z2), u = -dot3(z1, dif), v = dot3(z2, dif), det = 1.0 - mb * mb;
             double x1, x2;
@@ -523,34 +583,38 @@ struct Sim {
             sphere_pair(c, p, c1, r1, c2, r2, flip);
         }
     }
+    // pass 1: every lane tests its candidate slots and publishes a bit per hit; pass 2: the hits are recomputed and written at
+    // their rank (slot order = the order in which the serial code emits contacts), truncated at MAXCON
     static MJX_DEV void collision(B &bb, int lane) {
         if (lane < KS) bb.cmask[lane] = 0;
         if (lane == 0) bb.anyrow = 0;
         coop_sync();
-        Cand cand[KS];
-#pragma unroll
+        unsigned mine = 0;
+#pragma unroll 1
         for (int rd = 0; rd < KS; rd++) {
             const int slot = rd * G + lane;
-            cand[rd].on = false;
             if (slot < M::NSLOT) {
-                detect(bb, slot, cand[rd]);
-                if (cand[rd].on) lds_or(&bb.cmask[rd], 1u << lane);
+                Cand c;
+                detect(bb, slot, c);
+                if (c.on) lds_or(&bb.cmask[rd], 1u << lane), mine |= 1u << rd;
             }
         }
         coop_sync();
         int base = 0;
-#pragma unroll
+#pragma unroll 1
         for (int rd = 0; rd < KS; rd++) {
             const unsigned m = bb.cmask[rd];
-            if (cand[rd].on) {
+            if ((mine >> rd) & 1u) {
                 const int idx = base + popc(m & ((1u << lane) - 1u));
                 if (idx < MAXCON) {
+                    Cand c;
+                    detect(bb, rd * G + lane, c);
                     bb.con_pair[idx] = M::slot_pair[rd * G + lane];
-                    bb.con_dist[idx] = cand[rd].dist;
+                    bb.con_dist[idx] = c.dist;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) bb.con_r[idx][k] = cand[rd].pos[k] - bb.com[k];
+                    for (int k = 0; k < 3; k++) bb.con_r[idx][k] = c.pos[k] - bb.com[k];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) bb.con_frame[idx][k] = cand[rd].frame[k];
+                    for (int k = 0; k < 9; k++) bb.con_frame[idx][k] = c.frame[k];
                 }
             }
             base += popc(m);
@@ -559,16 +623,22 @@ struct Sim {
         coop_sync();
     }
 
-    // velocity of the contact point of contact c under the twist field bb.tw, in the contact frame (body2 minus body1)
-    static MJX_DEV void contact_vel(const B &bb, int c, int b1, int b2, double *v) {
+    // velocity of the contact point of contact c under a per-body twist field ([ang; lin] about the tree com), in the contact
+    // frame (body2 minus body1); the world body (index 0) does not move
+    static MJX_DEV void contact_vel(const B &bb, const double (*field)[6], int c, int b1, int b2, double *v) {
         const double *rr = bb.con_r[c], *F = bb.con_frame[c];
-        double t1[3], t2[3];
-        cross3(t1, bb.tw[b1], rr), cross3(t2, bb.tw[b2], rr);
-        const double w[3] = {(bb.tw[b2][3] + t2[0]) - (bb.tw[b1][3] + t1[0]), (bb.tw[b2][4] + t2[1]) - (bb.tw[b1][4] + t1[1]),
-                             (bb.tw[b2][5] + t2[2]) - (bb.tw[b1][5] + t1[2])};
+        double w[3] = {0, 0, 0}, t[3];
+        if (b2 > 0) {
+            cross3(t, field[b2], rr);
+            w[0] += field[b2][3] + t[0], w[1] += field[b2][4] + t[1], w[2] += field[b2][5] + t[2];
+        }
+        if (b1 > 0) {
+            cross3(t, field[b1], rr);
+            w[0] -= field[b1][3] + t[0], w[1] -= field[b1][4] + t[1], w[2] -= field[b1][5] + t[2];
+        }
         v[0] = dot3(F, w), v[1] = dot3(F + 3, w), v[2] = dot3(F + 6, w);
     }
-    // bb.tw[b] = sum over the dofs on the path to body b of cdof_i vec_i
+    // bb.C.sol.tw[b] = sum over the dofs on the path to body b of cdof_i vec_i
     static MJX_DEV void twist(B &bb, const double *vec, int lane) {
         const int b = lane + 1;
         if (b < NB) {
@@ -576,14 +646,12 @@ struct Sim {
             double t[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < NV; i++) {
-                if ((mask >> i) & 1u) {
-                    const double x = vec[i];
+                const double x = ((mask >> i) & 1u) ? vec[i] : 0.0;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) t[k] += bb.cdof[i][k] * x;
-                }
+                for (int k = 0; k < 6; k++) t[k] += bb.cdof[i][k] * x;
             }
 #pragma unroll
-            for (int k = 0; k < 6; k++) bb.tw[b][k] = t[k];
+            for (int k = 0; k < 6; k++) bb.C.sol.tw[b][k] = t[k];
         }
         coop_sync();
     }
@@ -616,6 +684,10 @@ struct Sim {
             const int c = kc * G + lane;
             r.c_on[kc] = c < ncon;
             r.c_b1[kc] = r.c_b2[kc] = 0, r.c_dim[kc] = 1, r.c_mu[kc] = 0, r.c_D[kc] = 0, r.c_kterm[kc] = 0, r.c_b[kc] = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) r.c_jv[kc][k] = r.c_jx[kc][k] = r.c_jd[kc][k] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) r.c_gw[kc][k] = 0;
             if (r.c_on[kc]) {
                 const int p = bb.con_pair[c];
                 const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
@@ -630,6 +702,7 @@ struct Sim {
                 }
                 r.c_b1[kc] = b1, r.c_b2[kc] = b2, r.c_dim[kc] = pyramid ? 3 : 1, r.c_mu[kc] = mu;
                 r.c_D[kc] = 1.0 / Rr, r.c_kterm[kc] = -k * imp * (bb.con_dist[c] - M::pair_margin[p]), r.c_b[kc] = b;
+                contact_vel(bb, bb.cvel, c, b1, b2, r.c_jv[kc]);  // cvel IS the twist field of qvel
                 any = true;
             }
         }
@@ -638,7 +711,8 @@ struct Sim {
     }
 
     // ---- primal Newton solver ---------------------------------------------------------------------------------------------
-    // residual of edge e of a contact: J_e x - aref_e, with J_e = J_n + sg J_t
+    // cost(x) = 1/2 (x - x_s)' M (x - x_s) + sum_rows 1/2 D min(0, J x - aref)^2
+    // residual of edge e of a pyramidal contact: J_e x - aref_e, with J_e = J_n + sg J_t
     static MJX_DEV void edge(const R &r, int kc, int e, const double *jq, double &val, double &sg, int &t) {
         sg = (e & 1) ? -r.c_mu[kc] : r.c_mu[kc];
         t = 1 + e / 2;
@@ -647,12 +721,12 @@ struct Sim {
     static MJX_DEV double edge_aref(const R &r, int kc, double sg, int t) {
         return -r.c_b[kc] * (r.c_jv[kc][0] + sg * r.c_jv[kc][t]) + r.c_kterm[kc];
     }
-    // contact role: publishes g = sum_active D jar e and W = sum_active D e e^T of its contacts at the current iterate
-    static MJX_DEV void contact_state(B &bb, const R &r, int lane) {
+    // contact role: g = sum_active D jar e (gw[0..2]) and W = sum_active D e e^T (gw[3..7] = W00 W01 W02 W11 W22) of this
+    // lane's contacts at the current iterate (registers only)
+    static MJX_DEV void contact_state(R &r) {
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
             if (r.c_on[kc]) {
-                const int c = kc * G + lane;
                 double g[3] = {0, 0, 0}, W[5] = {0, 0, 0, 0, 0};
                 const double D = r.c_D[kc];
                 if (r.c_dim[kc] == 1) {
@@ -673,12 +747,11 @@ struct Sim {
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 3; k++) bb.con_g[c][k] = g[k];
+                for (int k = 0; k < 3; k++) r.c_gw[kc][k] = g[k];
 #pragma unroll
-                for (int k = 0; k < 5; k++) bb.con_W[c][k] = W[k];
+                for (int k = 0; k < 5; k++) r.c_gw[kc][3 + k] = W[k];
             }
         }
-        coop_sync();
     }
     // dof role: column `lane` of the contact-frame Jacobian of contact c
     static MJX_DEV void jac_col(const B &bb, const R &r, int c, int lane, double *jcol) {
@@ -692,12 +765,12 @@ struct Sim {
         const double *F = bb.con_frame[c];
         jcol[0] = sg * dot3(F, v), jcol[1] = sg * dot3(F + 3, v), jcol[2] = sg * dot3(F + 6, v);
     }
-    // gradient (and, if HESS, the Hessian row) of the cost at the current iterate; Mdx = this lane's (M (x - x_smooth))
-    template <bool HESS>
-    static MJX_DEV double assemble(B &bb, R &r, double Mdx, double xi, int lane) {
+    // gradient (and, if hess, the lower Hessian row in r.Hrow) of the cost at the iterate x; Mdx = this lane's (M (x - x_smooth)).
+    // One exchange per contact: its owner publishes (g, W), every dof lane its Jacobian column.
+    static MJX_DEV double assemble(B &bb, R &r, double Mdx, double xi, bool hess, int lane) {
         double grad = Mdx;
         if (lane < NV) {
-            if (HESS) {
+            if (hess) {
 #pragma unroll
                 for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j];
             }
@@ -707,7 +780,7 @@ struct Sim {
                     const double jar = r.lim_sign[sd] * xi - r.lim_aref[sd];
                     if (jar < 0) {
                         grad += r.lim_sign[sd] * r.lim_D[sd] * jar;
-                        if (HESS) {
+                        if (hess) {
 #pragma unroll
                             for (int j = 0; j < NV; j++)
                                 if (j == lane) r.Hrow[j] += r.lim_D[sd];
@@ -717,73 +790,163 @@ struct Sim {
             }
         }
         const int ncon = bb.ncon;
+#pragma unroll 1
         for (int c = 0; c < ncon; c++) {
             double jcol[3] = {0, 0, 0};
+            double (&J)[3][NV] = bb.C.sol.jc[c & 1];
+            double (&gw)[8] = bb.C.sol.gw[c & 1];
             if (lane < NV) {
                 jac_col(bb, r, c, lane, jcol);
-                grad += jcol[0] * bb.con_g[c][0] + jcol[1] * bb.con_g[c][1] + jcol[2] * bb.con_g[c][2];
+                J[0][lane] = jcol[0], J[1][lane] = jcol[1], J[2][lane] = jcol[2];
             }
-            if (HESS) {
-                double (&J)[3][NV] = bb.jc[c & 1];
-                if (lane < NV) J[0][lane] = jcol[0], J[1][lane] = jcol[1], J[2][lane] = jcol[2];
-                coop_sync();
-                if (lane < NV) {
-                    const double *W = bb.con_W[c];
-                    const double t0 = W[0] * jcol[0] + W[1] * jcol[1] + W[2] * jcol[2], t1 = W[1] * jcol[0] + W[3] * jcol[1],
-                                 t2 = W[2] * jcol[0] + W[4] * jcol[2];
+            if (lane == (c & (G - 1))) {
+                const int kc = c / G;
 #pragma unroll
-                    for (int j = 0; j < NV; j++)
-                        if (j <= lane) r.Hrow[j] += t0 * J[0][j] + t1 * J[1][j] + t2 * J[2][j];
+                for (int k = 0; k < 8; k++) {
+                    double v = r.c_gw[0][k];
+#pragma unroll
+                    for (int q = 1; q < KC; q++) v = (kc == q) ? r.c_gw[q][k] : v;
+                    gw[k] = v;
+                }
+            }
+            coop_sync();
+            if (lane < NV) {
+                grad += jcol[0] * gw[0] + jcol[1] * gw[1] + jcol[2] * gw[2];
+                if (hess) {
+                    const double t0 = gw[3] * jcol[0] + gw[4] * jcol[1] + gw[5] * jcol[2], t1 = gw[4] * jcol[0] + gw[6] * jcol[1],
+                                 t2 = gw[5] * jcol[0] + gw[7] * jcol[2];
+#pragma unroll
+                    for (int j = 0; j < NV; j++) r.Hrow[j] += t0 * J[0][j] + t1 * J[1][j] + t2 * J[2][j];  // entries j > lane are never used
                 }
             }
         }
         return grad;
     }
-
-    static MJX_DEV void solve_newton(B &bb, R &r, int lane) {
-        const bool isdof = lane < NV;
-        const int ncon = bb.ncon;
-        // contact-space velocity (for the reference acceleration) and the initial iterate x = qacc_smooth
-        // bb.tw currently holds nothing useful: cvel IS the twist field of qvel
+    // contact role: world-frame force of this lane's contacts from the current (g, W) registers (force = -sum_active D jar e)
+    static MJX_DEV void publish_forces(B &bb, const R &r, int lane) {
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
+            if (r.c_on[kc]) {
+                const int c = kc * G + lane;
+                const double *F = bb.con_frame[c], *g = r.c_gw[kc];
 #pragma unroll
-            for (int k = 0; k < 3; k++) r.c_jv[kc][k] = r.c_jx[kc][k] = r.c_jd[kc][k] = 0;
+                for (int k = 0; k < 3; k++) bb.C.sol.con_F[c][k] = -(F[k] * g[0] + F[3 + k] * g[1] + F[6 + k] * g[2]);
+            }
         }
-        if (isdof) bb.vx[lane] = r.qacc_smooth;
-        coop_sync();
-        twist(bb, bb.qvel, lane);
-#pragma unroll
-        for (int kc = 0; kc < KC; kc++)
-            if (r.c_on[kc]) contact_vel(bb, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jv[kc]);
-        coop_sync();
-        twist(bb, bb.vx, lane);
-#pragma unroll
-        for (int kc = 0; kc < KC; kc++)
-            if (r.c_on[kc]) contact_vel(bb, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jx[kc]);
-        coop_sync();
-        double x = isdof ? r.qacc_smooth : 0.0, Mdx = 0.0;
+    }
+
+    // ---- forward dynamics -------------------------------------------------------------------------------------------------
+    // in: bb.qpos, bb.qvel, bb.ctrl.  out (dof lanes): r.qacc, r.qacc_int (the acceleration the Euler integrator uses: implicit
+    // in the joint damping), r.qfrc_actuator; on the blackboard: poses, cvel, contact frames and world-frame contact forces.
+    // All linear solves (M for the unconstrained acceleration, the Newton Hessians, M + h B for the damped Euler update) go
+    // through ONE factor/solve site driven by a small state machine, which keeps the kernel inside the instruction cache.
+    enum { ST_SMOOTH = 0, ST_NEWTON = 1, ST_DAMPED = 2, ST_DONE = 3 };
+    static constexpr bool damped_euler() {
+        bool d = false;
+        for (int i = 0; i < NV; i++) d = d || M::dof_damping[i] > 0;
+        return d && M::INTEGRATOR == 0;
+    }
+    static MJX_DEV void forward(B &bb, R &r, int lane) {
+        const bool isdof = lane < NV;
+        kinematics(bb, r, lane);
+        com_pos(bb, r, lane);
+        collision(bb, lane);
+        com_vel_and_bias(bb, r, lane);
+        crb(bb, r, lane);
+        make_constraint(bb, r, lane);
+        if (isdof) {
+            double act = 0.0;
+            const int u = M::dof_actuator[lane];
+            if (u >= 0) {
+                double c = bb.ctrl[u];
+                c = c < M::actuator_ctrlrange[u][0] ? M::actuator_ctrlrange[u][0] : (c > M::actuator_ctrlrange[u][1] ? M::actuator_ctrlrange[u][1] : c);
+                act = M::actuator_gear[u] * c;
+            }
+            r.qfrc_actuator = act;
+            double passive = -M::dof_damping[lane] * bb.qvel[lane];
+            const int j = M::dof_jntid[lane];
+            if (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)
+                passive -= M::jnt_stiffness[j] * (bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]]);
+            r.qfrc_smooth = passive - r.bias + act;
+        } else {
+            r.qfrc_smooth = 0, r.qfrc_actuator = 0;
+        }
+        const bool anyrow = bb.anyrow != 0;
         const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
-        for (int it = 0; it < 50; it++) {
-            contact_state(bb, r, lane);
-            const double grad = assemble<true>(bb, r, Mdx, x, lane);
-            const double gn = group_sum<G>(isdof ? grad * grad : 0.0, bb.red, lane);
-            if (sqrt(gn) * scale < 1e-10) break;
+        constexpr double h = M::TIMESTEP;
+        int st = ST_SMOOTH, it = 0;
+        bool final_pass = false;
+        double x = 0, Mdx = 0, grad = 0;
+        r.qacc = 0, r.qacc_int = 0, r.qfrc_constraint = 0, r.qacc_smooth = 0;
+#pragma unroll 1
+        for (;;) {
+            double rhs = 0;
+            bool solve = true;
+            if (st == ST_SMOOTH) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j];
+                rhs = r.qfrc_smooth;
+            } else if (st == ST_NEWTON) {
+                contact_state(r);
+                grad = assemble(bb, r, Mdx, x, !final_pass, lane);
+                bool finished = final_pass;
+                if (!finished) {
+                    const double gn = group_sum<G>(isdof ? grad * grad : 0.0, MJX_RED(bb), lane);
+                    finished = sqrt(gn) * scale < 1e-10;
+                }
+                if (finished) {
+                    r.qacc = x, r.qfrc_constraint = Mdx - grad;  // J^T f = -(grad - M dx)
+                    publish_forces(bb, r, lane);
+                    st = damped_euler() ? ST_DAMPED : ST_DONE;
+                    solve = false;
+                }
+                rhs = isdof ? -grad : 0.0;
+            } else if (st == ST_DAMPED) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j] + ((j == lane) ? h * M::dof_damping[j] : 0.0);
+                rhs = isdof ? r.qfrc_smooth + r.qfrc_constraint : 0.0;
+            } else {
+                break;
+            }
+            if (!solve) continue;
             chol_factor(bb, r.Hrow, r.idiag, lane);
-            const double dir = chol_solve(bb, r.Hrow, r.idiag, isdof ? -grad : 0.0, bb.vdir, lane);
-            // line search: phi'(alpha) = g0 + alpha h0 + sum_active D (jar + alpha jd) jd
+            const double sol = chol_solve(bb, r.Hrow, r.idiag, rhs, lane);
+            if (st == ST_DAMPED) {
+                r.qacc_int = sol;
+                st = ST_DONE;
+                continue;
+            }
+            if (st == ST_SMOOTH && !anyrow) {
+                r.qacc_smooth = sol, r.qacc = sol, r.qfrc_constraint = 0;
+                st = damped_euler() ? ST_DAMPED : ST_DONE;
+                continue;
+            }
+            // contact-space image of the solution vector (the unconstrained acceleration, or a Newton direction)
+            twist(bb, bb.A.sol.vdir, lane);
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+                if (r.c_on[kc]) contact_vel(bb, bb.C.sol.tw, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jd[kc]);
+            if (st == ST_SMOOTH) {  // the iterate starts at the unconstrained acceleration: x = 0 + 1 * sol
+                r.qacc_smooth = sol, x = sol, Mdx = 0;
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) r.c_jx[kc][k] = r.c_jd[kc][k];
+                st = ST_NEWTON;
+                coop_sync();
+                continue;
+            }
+            // line search along dir = sol: phi'(alpha) = g0 + alpha h0 + sum_active D (jar + alpha jd) jd
+            const double dir = sol;
             double Md = 0;
             if (isdof) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) Md += r.Mrow[j] * bb.vdir[j];
+                for (int j = 0; j < NV; j++) Md += r.Mrow[j] * bb.A.sol.vdir[j];
             }
-            const double h0 = group_sum<G>(isdof ? dir * Md : 0.0, bb.red, lane);
-            const double g0 = group_sum<G>(isdof ? dir * Mdx : 0.0, bb.red, lane);
-            twist(bb, bb.vdir, lane);
-#pragma unroll
-            for (int kc = 0; kc < KC; kc++)
-                if (r.c_on[kc]) contact_vel(bb, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jd[kc]);
+            const double h0 = group_sum<G>(isdof ? dir * Md : 0.0, MJX_RED(bb), lane);
+            const double g0 = group_sum<G>(isdof ? dir * Mdx : 0.0, MJX_RED(bb), lane);
             double alpha = 0, lo = 0, hi = INFINITY;
+#pragma unroll 1
             for (int ls = 0; ls < 40; ls++) {
                 double gl = 0, hl = 0;
                 if (isdof) {
@@ -817,73 +980,37 @@ struct Sim {
                         }
                     }
                 }
-                const double g = (g0 + alpha * h0) + group_sum<G>(gl, bb.red, lane);
-                const double h = h0 + group_sum<G>(hl, bb.red, lane);
+                const double g = (g0 + alpha * h0) + group_sum<G>(gl, MJX_RED(bb), lane);
+                const double hh = h0 + group_sum<G>(hl, MJX_RED(bb), lane);
                 if (fabs(g) <= 1e-14 * (fabs(g0) + 1e-300)) break;
                 if (g < 0)
                     lo = alpha;
                 else
                     hi = alpha;
-                double next = alpha - g / h;
+                double next = alpha - g / hh;
                 if (!(next > lo && next < hi)) next = hi < INFINITY ? 0.5 * (lo + hi) : 2 * alpha + 1.0;
                 if (next == alpha) break;
                 alpha = next;
             }
-            if (!(alpha > 0)) break;
+            if (!(alpha > 0)) {  // no descent possible: the iterate (and the gradient just assembled) is final
+                r.qacc = x, r.qfrc_constraint = Mdx - grad;
+                publish_forces(bb, r, lane);
+                st = damped_euler() ? ST_DAMPED : ST_DONE;
+                coop_sync();
+                continue;
+            }
             x += alpha * dir, Mdx += alpha * Md;
 #pragma unroll
             for (int kc = 0; kc < KC; kc++)
 #pragma unroll
                 for (int k = 0; k < 3; k++) r.c_jx[kc][k] += alpha * r.c_jd[kc][k];
-            const double move = group_sum<G>(isdof ? fabs(alpha * dir) : 0.0, bb.red, lane);
-            if (move * scale < 1e-16) break;
-        }
-        // forces at the solution: J^T f = -(grad - M dx)
-        contact_state(bb, r, lane);
-        const double grad = assemble<false>(bb, r, Mdx, x, lane);
-        (void)ncon;
-        r.qacc = x, r.qfrc_constraint = Mdx - grad;
-        coop_sync();
-    }
-
-    // ---- forward dynamics -------------------------------------------------------------------------------------------------
-    // in: bb.qpos, bb.qvel, bb.ctrl.  out: r.qacc (+ r.qfrc_smooth, r.qfrc_constraint, r.Mrow) on the dof lanes, bb.con_g / frames
-    // of the active contacts, poses, cvel, cinert on the blackboard.
-    static MJX_DEV void forward(B &bb, R &r, int lane) {
-        kinematics(bb, r, lane);
-        com_pos(bb, r, lane);
-        collision(bb, lane);
-        com_vel_and_bias(bb, r, lane);
-        crb(bb, r, lane);
-        double Lrow[NV], idiag = 1.0;
-#pragma unroll
-        for (int j = 0; j < NV; j++) Lrow[j] = r.Mrow[j];
-        chol_factor(bb, Lrow, idiag, lane);
-        make_constraint(bb, r, lane);
-        if (lane < NV) {
-            double act = 0.0;
-            const int u = M::dof_actuator[lane];
-            if (u >= 0) {
-                double c = bb.ctrl[u];
-                c = c < M::actuator_ctrlrange[u][0] ? M::actuator_ctrlrange[u][0] : (c > M::actuator_ctrlrange[u][1] ? M::actuator_ctrlrange[u][1] : c);
-                act = M::actuator_gear[u] * c;
-            }
-            r.qfrc_actuator = act;
-            double passive = -M::dof_damping[lane] * bb.qvel[lane];
-            const int j = M::dof_jntid[lane];
-            if (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)
-                passive -= M::jnt_stiffness[j] * (bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]]);
-            r.qfrc_smooth = passive - r.bias + act;
-        } else {
-            r.qfrc_smooth = 0, r.qfrc_actuator = 0;
-        }
-        r.qacc_smooth = chol_solve(bb, Lrow, idiag, r.qfrc_smooth, bb.vx, lane);
-        if (bb.anyrow == 0) {
-            r.qacc = r.qacc_smooth, r.qfrc_constraint = 0;
+            it++;
+            const double move = group_sum<G>(isdof ? fabs(alpha * dir) : 0.0, MJX_RED(bb), lane);
+            if (move * scale < 1e-16 || it >= 50) final_pass = true;  // one more assembly for the forces at the final iterate
             coop_sync();
-        } else {
-            solve_newton(bb, r, lane);
         }
+        if (!damped_euler()) r.qacc_int = r.qacc;
+        coop_sync();
     }
 
     // joints of body `lane + 1`: position update of bb.qpos from the dof velocities in `vel` (mj_integratePos)
@@ -912,46 +1039,39 @@ struct Sim {
         coop_sync();
     }
 
-    // one mj_step
+    // one mj_step: semi-implicit Euler (one forward pass) or RK4 (four), through a single forward() call site
     static MJX_DEV void step(B &bb, R &r, int lane) {
         constexpr double h = M::TIMESTEP;
+        constexpr int NSTAGE = M::INTEGRATOR == 0 ? 1 : 4;
         const bool isdof = lane < NV;
-        forward(bb, r, lane);
-        if (M::INTEGRATOR == 0) {
-            bool damped = false;
-#pragma unroll
-            for (int i = 0; i < NV; i++) damped |= M::dof_damping[i] > 0;
-            double qacc = r.qacc;
-            if (damped) {
-                double A[NV], idiag = 1.0;
-#pragma unroll
-                for (int j = 0; j < NV; j++) A[j] = r.Mrow[j] + ((j == lane) ? h * M::dof_damping[j] : 0.0);
-                chol_factor(bb, A, idiag, lane);
-                qacc = chol_solve(bb, A, idiag, isdof ? r.qfrc_smooth + r.qfrc_constraint : 0.0, bb.vdir, lane);
-            }
-            if (isdof) bb.qvel[lane] += h * qacc;
-            coop_sync();
-            integrate_pos(bb, bb.qvel, h, lane);
-        } else {
-            const double A[3] = {0.5, 0.5, 1.0}, Bw[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
-            double v0 = 0, sumv = 0, suma = 0;
-            if (isdof) v0 = bb.qvel[lane], sumv = Bw[0] * v0, suma = Bw[0] * r.qacc;
-            for (int k = lane; k < NQ; k += G) bb.q0[k] = bb.qpos[k];
-            double fv = v0, fa = r.qacc;
-            coop_sync();
-            for (int i = 1; i < 4; i++) {
-                const double dv = A[i - 1] * fv, da = A[i - 1] * fa;
+        const double A[4] = {0.0, 0.5, 0.5, 1.0}, Bw[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+        double v0 = 0, sumv = 0, suma = 0;
+#pragma unroll 1
+        for (int i = 0; i < NSTAGE; i++) {
+            forward(bb, r, lane);
+            if (M::INTEGRATOR == 0) {
+                if (isdof) bb.qvel[lane] += h * r.qacc_int;
+                coop_sync();
+                integrate_pos(bb, bb.qvel, h, lane);
+            } else {
+                if (i == 0) {
+                    if (isdof) v0 = bb.qvel[lane];
+                    for (int k = lane; k < NQ; k += G) bb.q0[k] = bb.qpos[k];
+                }
+                const double fv = isdof ? bb.qvel[lane] : 0.0, fa = r.qacc;
+                if (i == 0)
+                    sumv = Bw[0] * fv, suma = Bw[0] * fa;
+                else
+                    sumv += Bw[i] * fv, suma += Bw[i] * fa;
+                const bool last = i == NSTAGE - 1;
+                const double dv = last ? sumv : A[i + 1 < 4 ? i + 1 : 3] * fv, da = last ? suma : A[i + 1 < 4 ? i + 1 : 3] * fa;
+                coop_sync();  // every lane has read the stage's qpos / qvel
                 if (isdof) bb.dv[lane] = dv, bb.qvel[lane] = v0 + h * da;
-                for (int k = lane; k < NQ; k += G) bb.qpos[k] = bb.q0[k];
+                if (i > 0)
+                    for (int k = lane; k < NQ; k += G) bb.qpos[k] = bb.q0[k];
                 coop_sync();
                 integrate_pos(bb, bb.dv, h, lane);
-                forward(bb, r, lane);
-                if (isdof) fv = bb.qvel[lane], fa = r.qacc, sumv += Bw[i] * fv, suma += Bw[i] * fa;
             }
-            if (isdof) bb.dv[lane] = sumv, bb.qvel[lane] = v0 + h * suma;
-            for (int k = lane; k < NQ; k += G) bb.qpos[k] = bb.q0[k];
-            coop_sync();
-            integrate_pos(bb, bb.dv, h, lane);
         }
     }
 
@@ -961,15 +1081,13 @@ struct Sim {
 #pragma unroll
         for (int k = 0; k < 6; k++) out[k] = 0;
         const int ncon = bb.ncon;
+#pragma unroll 1
         for (int c = 0; c < ncon; c++) {
             const int p = bb.con_pair[c];
             const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
             if (b1 != b && b2 != b) continue;
-            const double *F = bb.con_frame[c], *g = bb.con_g[c], *rr = bb.con_r[c];
-            // contact-frame force = -g (force = -D jar summed over the active edges)
-            double Fw[3], tq[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) Fw[k] = -(F[k] * g[0] + F[3 + k] * g[1] + F[6 + k] * g[2]);
+            const double *Fw = bb.C.sol.con_F[c], *rr = bb.con_r[c];
+            double tq[3];
             cross3(tq, rr, Fw);
             const double sg = (b2 == b ? 1.0 : 0.0) - (b1 == b ? 1.0 : 0.0);
 #pragma unroll
@@ -1005,7 +1123,12 @@ struct Sim {
         }
         if (lane < NV) ex[EX_QFA + lane] = r.qfrc_actuator;
     }
+#undef MJX_RED
 };
 
 }  // namespace coop
 }  // namespace mjx
+
+#if !defined(MJX_HOST_EMU)
+#pragma clang fp contract(off)
+#endif

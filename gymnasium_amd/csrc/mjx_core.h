@@ -28,6 +28,12 @@
 
 #include "generated/mjx_models.h"
 
+// The physics may fuse a*b+c (it is compared with the oracle at 1e-8 .. 1e-10, not bit for bit); the NumPy-exact env glue in
+// mjx_kernels.h and the classic-control envs stay unfused: contraction is switched back off at the end of this header.
+#if !defined(MJX_HOST_EMU)
+#pragma clang fp contract(fast)
+#endif
+
 namespace mjx {
 
 #if defined(MJX_HOST_EMU)
@@ -497,6 +503,9 @@ MJX_DEV void collision(Data<M> &d) {
 }
 
 // ---- constraints --------------------------------------------------------------------------------------------------
+// POW2: every solimp of the model has power == 2 (the MuJoCo default), so pow() -- ~1000 instructions per inlined call -- is
+// not even compiled in
+template <bool POW2 = false>
 MJX_DEV double impedance(const double *solimp, double pos, double margin) {
     double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
     dmin = dmin < kMinImp ? kMinImp : (dmin > kMaxImp ? kMaxImp : dmin);
@@ -512,11 +521,21 @@ MJX_DEV double impedance(const double *solimp, double pos, double margin) {
         y = 0;
     else if (power == 1)
         y = x;
+    else if (POW2 || power == 2)  // x^2 / mid and 1 - (1 - x)^2 / (1 - mid) without pow()
+        y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
     else if (x <= mid)
         y = pow(x, power) / pow(mid, power - 1);
     else
         y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
     return dmin + y * (dmax - dmin);
+}
+template <class M>
+constexpr bool all_power_two() {
+    for (int j = 0; j < M::NJNT; j++)
+        if (M::jnt_solimp[j][4] != 2.0) return false;
+    for (int p = 0; p < M::NPAIR; p++)
+        if (M::pair_solimp[p][4] != 2.0) return false;
+    return true;
 }
 // stiffness k, damping b, impedance and regulariser R of one row
 template <class M>
@@ -527,7 +546,7 @@ MJX_DEV void row_params(const double *solref, const double *solimp, double pos, 
     const double dmax = solimp[1] < kMinImp ? kMinImp : (solimp[1] > kMaxImp ? kMaxImp : solimp[1]);
     if (timeconst < 2 * M::TIMESTEP) timeconst = 2 * M::TIMESTEP;
     k = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), b = 2.0 / (dmax * timeconst);
-    imp = impedance(solimp, pos, margin);
+    imp = impedance<all_power_two<M>()>(solimp, pos, margin);
     R = (1 - imp) * diag_approx / imp;
     if (R < kMinVal) R = kMinVal;
 }
@@ -896,3 +915,7 @@ MJX_DEV void contact_forces(const Data<M> &d, double cfrc_ext[M::NBODY][6]) {
 }
 
 }  // namespace mjx
+
+#if !defined(MJX_HOST_EMU)
+#pragma clang fp contract(off)
+#endif

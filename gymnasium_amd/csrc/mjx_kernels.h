@@ -76,6 +76,7 @@ struct MjEnv {
     static constexpr int NQ = M::NQ, NV = M::NV, NU = M::NU, NB = M::NBODY;
     static constexpr int S = NQ + 2 * NV + 2;  // state row: qpos, qvel, (warm-start slot, unused by the Newton solver), tracked xy
     static constexpr int INFO = KIND == kHalfCheetah ? 4 : 9;
+    static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
     static constexpr int SKIP = KIND == kHalfCheetah ? 1 : 2;
     static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (KIND == kHumanoid ? 22 * (NB - 1) + NV - 6 : 0);
 
@@ -156,6 +157,16 @@ struct MjEnv {
         }
     }
 
+    // What the reward / observation code reads from the last forward pass of the physics (mj_rnePostConstraint included).
+    struct StepExtras {
+        double after[2];                 // tracked Cartesian point (x, y) after the step
+        const double (*cfrc)[6];         // cfrc_ext[NB][6]
+        const double (*cinert)[10];      // cinert[NB][10] (per body, not composite)
+        const double (*cvel)[6];         // cvel[NB][6]
+        const double *qfrc_actuator;     // [NV]
+    };
+
+    // One env.step() with the one-lane simulator (mjx_core.h): physics, then finish().
     static MJX_DEV void step(double *s, const float *action, const mi::EnvParams &P, double *obs, double &reward, bool &terminated,
                              double *info) {
         Data<M> d;
@@ -166,15 +177,42 @@ struct MjEnv {
         const int frame_skip = (int)P.p[4];
         for (int f = 0; f < frame_skip; f++) mjx::step<M>(d);
         // Cartesian quantities of the LAST forward pass (they lag qpos by one sub-step, as in the reference)
-        double after[2];
+        StepExtras x;
         if (KIND == kHalfCheetah)
-            after[0] = d.qpos[0], after[1] = 0.0;
+            x.after[0] = d.qpos[0], x.after[1] = 0.0;
         else if (KIND == kAnt)
-            after[0] = d.xpos[1][0], after[1] = d.xpos[1][1];
+            x.after[0] = d.xpos[1][0], x.after[1] = d.xpos[1][1];
         else
-            mass_center_xy(d, after);
+            mass_center_xy(d, x.after);
         for (int k = 0; k < NQ; k++) s[k] = d.qpos[k];
         for (int k = 0; k < NV; k++) s[NQ + k] = d.qvel[k];
+        double cfrc[NB][6];
+        if (KIND != kHalfCheetah) contact_forces<M>(d, cfrc);
+        if (KIND == kHumanoid) com_pos<M>(d);  // crb() folded the per-body inertias into composites: restore them for the obs
+        x.cfrc = cfrc, x.cinert = d.cinert, x.cvel = d.cvel, x.qfrc_actuator = d.qfrc_actuator;
+        finish(s, before, x, action, P, obs, reward, terminated, info);
+    }
+
+    // The tracked point from the cooperative kernel's extras row (coop::Sim::write_extras): body-1 position for Ant, the
+    // mass-weighted sum of xipos over np.sum(body_mass) for Humanoid (humanoid_v5.py:17-21), the root slider for HalfCheetah.
+    static MJX_DEV void after_from_extras(const double *s, const double *ex, double *after) {
+        if (KIND == kHalfCheetah) {
+            after[0] = s[0], after[1] = 0.0;
+        } else if (KIND == kAnt) {
+            after[0] = ex[0], after[1] = ex[1];
+        } else {
+            double mass[NB];
+            for (int b = 0; b < NB; b++) mass[b] = M::body_mass[b];
+            const double den = np_sum<double, NB>(mass);
+            after[0] = ex[2] / den, after[1] = ex[3] / den;
+        }
+    }
+
+    // Everything of env.step() after do_simulation: s holds the NEW qpos / qvel, `before` the tracked point before the step.
+    static MJX_DEV void finish(double *s, const double *before, const StepExtras &x, const float *action, const mi::EnvParams &P, double *obs,
+                               double &reward, bool &terminated, double *info) {
+        const int frame_skip = (int)P.p[4];
+        const double *after = x.after;
         s[NQ + 2 * NV] = after[0], s[NQ + 2 * NV + 1] = after[1];
         const double dt = M::TIMESTEP * frame_skip;
         const double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
@@ -185,13 +223,13 @@ struct MjEnv {
             const double forward_reward = P.p[0] * xv;
             reward = forward_reward - (double)ctrl_cost_f;
             terminated = false;
-            const ObsExtras x = {nullptr, nullptr, nullptr, nullptr};
-            write_obs(s, x, P, obs);
+            const ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
+            write_obs(s, ox, P, obs);
             if (info) info[0] = s[0], info[1] = xv, info[2] = forward_reward, info[3] = -(double)ctrl_cost_f;
             return;
         }
-        double cfrc[NB][6], c2[6 * NB];
-        contact_forces<M>(d, cfrc);
+        const double (*cfrc)[6] = x.cfrc;
+        double c2[6 * NB];
         bool healthy;
         double ctrl_cost, contact_cost;
         if (KIND == kAnt) {
@@ -208,7 +246,7 @@ struct MjEnv {
         } else {
             healthy = P.p[8] < s[2] && s[2] < P.p[9];
             double sqd[NU];
-            for (int u = 0; u < NU; u++) sqd[u] = d.ctrl[u] * d.ctrl[u];  // np.square(self.data.ctrl): float64
+            for (int u = 0; u < NU; u++) sqd[u] = (double)action[u] * (double)action[u];  // np.square(self.data.ctrl): float64
             ctrl_cost = P.p[1] * np_sum<double, NU>(sqd);
             for (int b = 0; b < NB; b++)
                 for (int k = 0; k < 6; k++) c2[6 * b + k] = cfrc[b][k] * cfrc[b][k];
@@ -219,9 +257,8 @@ struct MjEnv {
         const double rewards = forward_reward + healthy_reward, costs = ctrl_cost + contact_cost;
         reward = rewards - costs;
         terminated = !healthy && P.p[7] != 0.0;
-        if (KIND == kHumanoid) com_pos<M>(d);  // crb() folded the per-body inertias into composites: restore them for the obs
-        const ObsExtras x = {cfrc, d.cinert, d.cvel, d.qfrc_actuator};
-        write_obs(s, x, P, obs);
+        const ObsExtras ox = {cfrc, x.cinert, x.cvel, x.qfrc_actuator};
+        write_obs(s, ox, P, obs);
         if (info) {
             info[0] = s[0], info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]), info[3] = xv, info[4] = yv;
             info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
