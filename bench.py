@@ -31,6 +31,9 @@ sys.path.insert(0, ROOT)
 ROLLOUT_BYTES = {"CartPole-v1": 34, "Pendulum-v1": 26, "Acrobot-v1": 42, "MountainCar-v0": 26, "MountainCarContinuous-v0": 22}
 STATE_BYTES = {"CartPole-v1": 96, "Pendulum-v1": 64, "Acrobot-v1": 96, "MountainCar-v0": 64, "MountainCarContinuous-v0": 64}
 STEP_BYTES = {"CartPole-v1": 108, "Pendulum-v1": 68, "Acrobot-v1": 116, "MountainCar-v0": 68, "MountainCarContinuous-v0": 64}
+# MuJoCo family: which kernel dominates a rollout launch (Ant / Humanoid: `inner` x [mj_sample_kernel, mj_physics_kernel, mj_step_kernel];
+# the cooperative physics kernel is > 99 % of the time -- profiles/r01_k_ant_coop.txt)
+MJ_KERNEL = {"Ant-v5": "mj_physics_kernel", "Humanoid-v5": "mj_physics_kernel", "HalfCheetah-v5": "mj_rollout_kernel"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -171,7 +174,7 @@ def main():
                        "env": args.env, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
                        "parallelism": f"env-sharded x{world} (no data-path collective)"},
             "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
-            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.env in ROLLOUT_BYTES else ("tab_rollout_kernel" if eng.obs_dtype is np.int64 else "mj_rollout_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.env in ROLLOUT_BYTES else ("tab_rollout_kernel" if eng.obs_dtype is np.int64 else MJ_KERNEL.get(args.env, "mj_rollout_kernel")), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3},
         }

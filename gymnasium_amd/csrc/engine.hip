@@ -1106,8 +1106,13 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
             v->extras_dim = mjx::coop::Sim<typename E::Model, E::COOP_G>::EX_TOTAL;
             return (int)MI_OK;
         });
-        const char *serial = getenv("MI355ENV_MJ_SERIAL");
-        v->mj_coop = !(serial && serial[0] == '1');
+        // Which physics kernel: the cooperative one (mjx_coop.h) wins where the robot fills its 16 / 32 lanes (Ant 2.4M vs 1.4M
+        // env-steps/s, Humanoid 0.76M vs 0.23M); HalfCheetah (9 dofs, 7 bodies, one forward pass per sub-step) is faster on the
+        // one-lane kernel (16.4M vs 12.9M).  MI355ENV_MJ_SERIAL=1 / MI355ENV_MJ_COOP=1 force either one (cross-check tests).
+        const char *serial = getenv("MI355ENV_MJ_SERIAL"), *coop = getenv("MI355ENV_MJ_COOP");
+        v->mj_coop = cfg->kind != MI_ENV_HALF_CHEETAH;
+        if (serial && serial[0] == '1') v->mj_coop = false;
+        if (coop && coop[0] == '1') v->mj_coop = true;
     } else if (is_tab(cfg->kind)) {
         const mi_layout l = {1, MI_I64, 1, MI_I64, 2, 1, {0, 0}};
         v->lay = l;

@@ -33,6 +33,7 @@ namespace coop {
 
 #if defined(MJX_HOST_EMU)
 void coop_sync();  // provided by the harness: yields to the next lane's fiber
+extern long g_stat[8];  // harness counters: [0] forwards, [1] forwards with constraint rows, [2] Newton iterations, [3] line-search iterations
 static inline unsigned lds_or(unsigned *p, unsigned v) {
     const unsigned o = *p;
     *p = o | v;
@@ -872,6 +873,9 @@ struct Sim {
             r.qfrc_smooth = 0, r.qfrc_actuator = 0;
         }
         const bool anyrow = bb.anyrow != 0;
+#if defined(MJX_HOST_EMU)
+        if (lane == 0) g_stat[0]++, g_stat[1] += anyrow;
+#endif
         const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
         constexpr double h = M::TIMESTEP;
         int st = ST_SMOOTH, it = 0;
@@ -946,8 +950,14 @@ struct Sim {
             const double h0 = group_sum<G>(isdof ? dir * Md : 0.0, MJX_RED(bb), lane);
             const double g0 = group_sum<G>(isdof ? dir * Mdx : 0.0, MJX_RED(bb), lane);
             double alpha = 0, lo = 0, hi = INFINITY;
+#if defined(MJX_HOST_EMU)
+            if (lane == 0) g_stat[2]++;
+#endif
 #pragma unroll 1
             for (int ls = 0; ls < 40; ls++) {
+#if defined(MJX_HOST_EMU)
+                if (lane == 0) g_stat[3]++;
+#endif
                 double gl = 0, hl = 0;
                 if (isdof) {
 #pragma unroll

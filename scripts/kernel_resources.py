@@ -39,9 +39,11 @@ def main():
         if not m:
             continue
         k, v = m.groups()
-        if k == "name" and "name" in cur and "vgpr_count" in cur:
-            rows.append(cur), (cur := {})
-        if k == "name" and v.startswith("_Z") is False and "name" in cur:
+        if k == "group_segment_fixed_size":  # first of these keys in a kernel's (alphabetically sorted) metadata block
+            if "vgpr_count" in cur:
+                rows.append(cur)
+            cur = {}
+        if k == "name" and "name" in cur:  # argument names inside .args
             continue
         cur[k] = v
     if "vgpr_count" in cur:

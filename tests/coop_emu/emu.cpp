@@ -52,6 +52,7 @@ void run_group(int n, std::function<void(int)> body) {
 }
 }  // namespace
 
+long mjx::coop::g_stat[8] = {0};
 void mjx::coop::coop_sync() {
     g_syncs++;
     const int me = g_cur, nxt = (me + 1) % g_n;
@@ -126,4 +127,9 @@ __attribute__((visibility("default"))) long coop_emu_board_bytes(int model) {
     return -1;
 }
 __attribute__((visibility("default"))) long coop_emu_last_syncs() { return g_syncs; }
+__attribute__((visibility("default"))) void coop_emu_stats(long *out, int reset) {
+    for (int k = 0; k < 8; k++) out[k] = mjx::coop::g_stat[k];
+    if (reset)
+        for (int k = 0; k < 8; k++) mjx::coop::g_stat[k] = 0;
+}
 }

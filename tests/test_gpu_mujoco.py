@@ -120,7 +120,9 @@ def test_cooperative_kernel_equals_one_lane_simulator(name, monkeypatch):
     monkeypatch.setenv("MI355ENV_MJ_SERIAL", "1")
     ser = gymnasium_amd.make_vec(IDS[name], num_envs=n)
     monkeypatch.delenv("MI355ENV_MJ_SERIAL")
+    monkeypatch.setenv("MI355ENV_MJ_COOP", "1")
     coop = gymnasium_amd.make_vec(IDS[name], num_envs=n)
+    monkeypatch.delenv("MI355ENV_MJ_COOP")
     o1, _ = ser.reset(seed=21)
     o2, _ = coop.reset(seed=21)
     assert np.array_equal(o1, o2)
