@@ -15,7 +15,7 @@ MI_OK = 0
 MI_HOST, MI_DEVICE = 0, 1
 MI_F32, MI_F64, MI_I64 = 0, 1, 2
 FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
              "half_cheetah": 5, "ant": 6, "humanoid": 7, "tabular": 8}
@@ -28,6 +28,11 @@ SYMBOLS = [
     "seed", "seed_sequence", "reset", "step", "action_seed", "rollout", "get_stats", "reset_stats", "get_state",
     "set_state", "get_rng", "tabular_load",
 ]
+
+
+# The device-side vector wrappers (include/mi355env.h, gymnasium_amd/csrc/wrappers.hip); their checker is NumPy code
+# (oracle/wrappers.py), so they are not part of the orc_-prefixed checker ABI.
+WRAPPER_SYMBOLS = ["rms_create", "rms_destroy", "rms_get", "rms_set", "normalize_observation", "normalize_reward", "clip_reward"]
 
 
 class MiConfig(C.Structure):
@@ -105,6 +110,15 @@ class NativeLib:
         self.tabular_load = f("tabular_load", [vp, C.POINTER(MiTabularTable)], i32)
         if self.abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {self.abi_version()} != binding version {ABI_VERSION}")
+        if prefix == "mi_":
+            dbl = C.c_double
+            self.rms_create = f("rms_create", [i32, i32, i32, dbl, C.POINTER(vp)], i32)
+            self.rms_destroy = f("rms_destroy", [vp], None)
+            self.rms_get = f("rms_get", [vp, vp, vp, vp, vp], i32)
+            self.rms_set = f("rms_set", [vp, vp, vp, vp, vp], i32)
+            self.normalize_observation = f("normalize_observation", [vp, vp, vp, i32, i32, dbl, i32, vp], i32)
+            self.normalize_reward = f("normalize_reward", [vp, vp, vp, vp, vp, vp, vp, i32, dbl, dbl, i32, i32, vp], i32)
+            self.clip_reward = f("clip_reward", [i32, vp, vp, i32, vp, vp, vp], i32)
 
     def _fn(self, name, argtypes, restype):
         fn = getattr(self.dll, self.prefix + name)

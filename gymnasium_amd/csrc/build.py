@@ -10,12 +10,14 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["engine.hip"]
-HEADERS = ["envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", "ziggurat_tables.h", os.path.join("generated", "mjx_models.h"),
-           os.path.join("..", "..", "include", "mi355env.h")]
+SOURCES = {  # translation unit -> the headers it depends on
+    "engine.hip": ["envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", "ziggurat_tables.h",
+                   os.path.join("generated", "mjx_models.h"), os.path.join("..", "..", "include", "mi355env.h")],
+    "wrappers.hip": [os.path.join("..", "..", "include", "mi355env.h")],
+}
 OUT = os.path.join(HERE, "libmi355env.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
 
 
 def generate_models() -> None:
@@ -28,22 +30,32 @@ def generate_models() -> None:
     codegen.generate()
 
 
-def needs_build() -> bool:
-    if not os.path.exists(OUT):
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS + ["build.py"])
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every stale translation unit to an object file (hipcc, gfx950 only) and link libmi355env.so."""
     generate_models()
-    if not force and not needs_build():
-        return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=HERE)
+    objs, relink = [], force or not os.path.exists(OUT)
+    for src, headers in SOURCES.items():
+        obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src, "build.py"] + headers):
+            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", "-o", obj, os.path.join(HERE, src)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=HERE)
+            relink = True
+    if relink or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=HERE)
     return OUT
 
 

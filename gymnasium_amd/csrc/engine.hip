@@ -863,6 +863,16 @@ int fail(int code, const char *fmt, const char *detail = "") {
     return code;
 }
 
+}  // namespace
+// shared with the other translation units of the library (hidden visibility): sets mi_last_error(), returns `code`
+namespace mi_internal {
+int set_error(int code, const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+}  // namespace mi_internal
+namespace {
+
 #define HIP_TRY(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \

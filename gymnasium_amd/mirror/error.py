@@ -39,3 +39,7 @@ class InvalidAction(Error):
 
 class ClosedEnvironmentError(Error):
     """Use after ``close``."""
+
+
+class InvalidBound(Error):
+    """Raised when the clipping an array with invalid upper and/or lower bound (gymnasium/error.py:62-63)."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355ENV_ABI_VERSION 2
+#define MI355ENV_ABI_VERSION 3
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -227,6 +227,43 @@ int mi_get_state(mi_vecenv *env, double *state, int32_t *elapsed_steps, uint8_t 
 int mi_set_state(mi_vecenv *env, const double *state, const int32_t *elapsed_steps, const uint8_t *flags);
 /* Per-env PCG64 words, same layout as mi_seed (host pointer). */
 int mi_get_rng(mi_vecenv *env, uint64_t *pcg);
+
+/*
+ * Stateful vector wrappers as device epilogues of the step path.  All array arguments are DEVICE
+ * pointers; work is enqueued on `hip_stream` (NULL = the legacy default stream); nothing synchronises except mi_rms_get/set.
+ *
+ * mi_running_stats replaces gymnasium/wrappers/utils.py:33-71 RunningMeanStd (mean[dim], var[dim], count; __init__: mean 0,
+ * var 1, count = epsilon).  `dtype` is the dtype NumPy holds mean / var in there: MI_F32 for float32 observations
+ * (NormalizeObservation builds RunningMeanStd(dtype=float32)), MI_F64 for float64 observations and for the scalar return
+ * statistics of NormalizeReward.  mi_rms_get / mi_rms_set move the statistics to / from the host as float64 (checkpointing,
+ * `wrapper.obs_rms.mean` ...).
+ */
+typedef struct mi_running_stats mi_running_stats;
+int mi_rms_create(int device, int dim, int dtype, double epsilon, mi_running_stats **out);
+void mi_rms_destroy(mi_running_stats *stats);
+int mi_rms_get(mi_running_stats *stats, void *hip_stream, double *mean, double *var, double *count);       /* host pointers, synchronises */
+int mi_rms_set(mi_running_stats *stats, void *hip_stream, const double *mean, const double *var, const double *count);
+/*
+ * NormalizeObservation.observations (gymnasium/wrappers/vector/stateful_observation.py:144-160):
+ *   if update: obs_rms.update(obs)  [np.mean / np.var over axis 0, then update_mean_var_count_from_moments]
+ *   out = ((obs - mean) / sqrt(var + epsilon)).astype(float32)
+ * obs: [num_rows][dim] of obs_dtype (MI_F32 / MI_F64), out: [num_rows][dim] float32.
+ */
+int mi_normalize_observation(mi_running_stats *stats, void *hip_stream, const void *obs, int obs_dtype, int num_rows, double epsilon,
+                             int update, void *out);
+/*
+ * NormalizeReward.step after the wrapped step (gymnasium/wrappers/vector/stateful_reward.py:150-176):
+ *   active = all (same_step) | ~prev_done;  accumulated[active] = accumulated[active] * gamma * (1 - terminated) + reward
+ *   if update and any(active): return_rms.update(accumulated[active]);  prev_done = terminated | truncated
+ *   same_step: accumulated[prev_done] = 0;   out = reward / sqrt(return_rms.var + epsilon)
+ * accumulated: [num_envs] float32 (zeroed by the caller on reset()), prev_done: [num_envs] uint8, return_rms: dim 1, MI_F64.
+ */
+int mi_normalize_reward(mi_running_stats *return_rms, void *hip_stream, float *accumulated, uint8_t *prev_done, const double *reward,
+                        const uint8_t *terminated, const uint8_t *truncated, int num_envs, double gamma, double epsilon, int same_step,
+                        int update, double *out);
+/* ClipReward (gymnasium/wrappers/vector/vectorize_reward.py:115-151 -> np.clip(reward, min, max)); NULL bound = None. */
+int mi_clip_reward(int device, void *hip_stream, const double *reward, int num_envs, const double *min_reward, const double *max_reward,
+                   double *out);
 
 #ifdef __cplusplus
 }

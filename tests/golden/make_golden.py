@@ -16,6 +16,7 @@ weak-scalar promotion) and records
   episode_stats.npz         wrappers.vector.RecordEpisodeStatistics r / l
   teacher_<env>.npz         teacher-forced single steps from random (state, action) pairs
   config1_cartpole.npz      BASELINE.json configs[0]: CartPole-v1, Sync, 4 envs, 1000 steps, seed 0
+  wrappers_*.npz            NormalizeObservation / NormalizeReward / ClipReward (wrappers/vector) inputs and outputs
   toytext_<env>.npz         FrozenLake / CliffWalking / Taxi: the reference's transition table P and initial distribution,
                             plus a gym.make_vec(id, 8, "sync") trajectory with the info dict entries (prob, action_mask)
 
@@ -321,9 +322,64 @@ def make_toytext():
         v.close()
 
 
+def make_wrappers():
+    """The reference's stateful vector wrappers on its own SyncVectorEnv: raw batches (inputs) and wrapped outputs.
+
+    wrappers_normobs_<env>.npz   NormalizeObservation (stateful_observation.py) incl. frozen statistics for the last steps
+    wrappers_normrew_<env>.npz   NormalizeReward (stateful_reward.py), NEXT_STEP and SAME_STEP
+    wrappers_clip.npz            ClipReward
+    """
+    from gymnasium.wrappers.vector import ClipReward, NormalizeObservation, NormalizeReward
+
+    for key, env_id, T in (("cartpole", "CartPole-v1", 120), ("pendulum", "Pendulum-v1", 120)):
+        raw = gym.make_vec(env_id, num_envs=16, vectorization_mode="sync")
+        w = NormalizeObservation(gym.make_vec(env_id, num_envs=16, vectorization_mode="sync"))
+        o_raw, _ = raw.reset(seed=3)
+        o_w, _ = w.reset(seed=3)
+        raw.action_space.seed(5)
+        RAW, OUT_, FROZEN = [o_raw], [o_w], []
+        for t in range(T):
+            if t == T - 20:
+                w.update_running_mean = False
+            a = raw.action_space.sample()
+            RAW.append(raw.step(a)[0]), OUT_.append(w.step(a)[0]), FROZEN.append(not w.update_running_mean)
+        save(f"wrappers_normobs_{key}.npz", raw=np.stack(RAW), out=np.stack(OUT_), frozen=np.array(FROZEN), mean=w.obs_rms.mean, var=w.obs_rms.var,
+             count=np.float64(w.obs_rms.count))
+        raw.close(), w.close()
+    for key, env_id, T, mode in (("cartpole", "CartPole-v1", 200, AutoresetMode.NEXT_STEP), ("cartpole_same", "CartPole-v1", 200, AutoresetMode.SAME_STEP),
+                                 ("mountaincar_continuous", "MountainCarContinuous-v0", 150, AutoresetMode.NEXT_STEP)):
+        kw = dict(vector_kwargs={"autoreset_mode": mode})
+        raw = gym.make_vec(env_id, num_envs=16, vectorization_mode="sync", **kw)
+        w = NormalizeReward(gym.make_vec(env_id, num_envs=16, vectorization_mode="sync", **kw), gamma=0.97)
+        raw.reset(seed=9), w.reset(seed=9)
+        raw.action_space.seed(1)
+        R, TE, TR, OUT_ = [], [], [], []
+        for t in range(T):
+            a = raw.action_space.sample()
+            _, r, te, tr, _ = raw.step(a)
+            R.append(np.asarray(r, dtype=np.float64)), TE.append(te), TR.append(tr), OUT_.append(w.step(a)[1])
+        save(f"wrappers_normrew_{key}.npz", reward=np.stack(R), term=np.stack(TE), trunc=np.stack(TR), out=np.stack(OUT_),
+             same_step=np.bool_(mode == AutoresetMode.SAME_STEP), gamma=np.float64(0.97), var=np.float64(w.return_rms.var),
+             mean=np.float64(w.return_rms.mean), count=np.float64(w.return_rms.count), acc=w.accumulated_reward)
+        raw.close(), w.close()
+    raw = gym.make_vec("MountainCarContinuous-v0", num_envs=8, vectorization_mode="sync")
+    w = ClipReward(gym.make_vec("MountainCarContinuous-v0", num_envs=8, vectorization_mode="sync"), -0.05, -0.01)
+    raw.reset(seed=2), w.reset(seed=2)
+    raw.action_space.seed(2)
+    R, OUT_ = [], []
+    for t in range(30):
+        a = raw.action_space.sample()
+        R.append(np.asarray(raw.step(a)[1], dtype=np.float64)), OUT_.append(w.step(a)[1])
+    save("wrappers_clip.npz", reward=np.stack(R), out=np.stack(OUT_), lo=np.float64(-0.05), hi=np.float64(-0.01))
+    raw.close(), w.close()
+
+
 if __name__ == "__main__":
     if "--toytext-only" in sys.argv:
         make_toytext()
+        sys.exit(0)
+    if "--wrappers-only" in sys.argv:
+        make_wrappers()
         sys.exit(0)
     print("reference gymnasium", gym.__version__, "numpy", np.__version__)
     make_rng()
@@ -335,3 +391,4 @@ if __name__ == "__main__":
     make_teacher()
     make_action_samples()
     make_toytext()
+    make_wrappers()

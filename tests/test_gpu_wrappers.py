@@ -1,0 +1,131 @@
+"""-m gpu: the device-side vector wrappers (gymnasium_amd/csrc/wrappers.hip through the C ABI and gymnasium_amd.wrappers) against
+the reference-pinned NumPy oracle (oracle/wrappers.py) and the reference's own recorded outputs (tests/golden/wrappers_*.npz).
+
+Tolerance, stated: the running statistics are float32 in the reference (NormalizeObservation) or float64 fed with float32 batch
+moments (NormalizeReward); the reference's batch mean / variance are float32 sums with their own rounding error, the kernels
+sum in float64 and round once.  So statistics agree to a few float32 ulps per update (rtol 2e-5 after ~100 updates) and the
+normalised outputs to rtol 1e-4 / atol 2e-5; everything that is not a batch moment (discounted return accumulation, clip,
+done masks) is bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import gymnasium_amd
+from gymnasium_amd import wrappers as gw
+from oracle import wrappers as ow
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class _Replay:
+    """A stand-in vector env that replays recorded batches (so the wrappers see exactly the reference's inputs)."""
+
+    def __init__(self, obs=None, reward=None, term=None, trunc=None, same_step=False, tensor=False):
+        from gymnasium_amd.gym_api import AutoresetMode, spaces
+
+        self.obs, self.reward, self.term, self.trunc, self.t, self.tensor = obs, reward, term, trunc, 0, tensor
+        self.num_envs = (obs if obs is not None else reward).shape[1]
+        self.metadata = {"autoreset_mode": AutoresetMode.SAME_STEP if same_step else AutoresetMode.NEXT_STEP}
+        shape = obs.shape[2:] if obs is not None else (1,)
+        self.single_observation_space = spaces.Box(low=-np.inf, high=np.inf, shape=shape, dtype=obs.dtype if obs is not None else np.float32)
+        self._device_index = 0
+        self.unwrapped = self
+
+    def _w(self, a):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda() if self.tensor else a
+
+    def reset(self, *, seed=None, options=None):
+        self.t = 0
+        return (self._w(self.obs[0]) if self.obs is not None else None), {}
+
+    def step(self, actions):
+        t = self.t
+        self.t += 1
+        n = self.num_envs
+        o = self._w(self.obs[t + 1]) if self.obs is not None else None
+        r = self._w(self.reward[t]) if self.reward is not None else self._w(np.zeros(n))
+        te = self._w(self.term[t]) if self.term is not None else self._w(np.zeros(n, bool))
+        tr = self._w(self.trunc[t]) if self.trunc is not None else self._w(np.zeros(n, bool))
+        return o, r, te, tr, {}
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("key", ["cartpole", "pendulum"])
+@pytest.mark.parametrize("tensor", [False, True])
+def test_normalize_observation_vs_reference_recording(key, tensor):
+    g = np.load(os.path.join(GOLD, f"wrappers_normobs_{key}.npz"))
+    w = gw.NormalizeObservation(_Replay(obs=g["raw"], tensor=tensor))
+    o, _ = w.reset()
+    outs = [o]
+    for t in range(g["raw"].shape[0] - 1):
+        if g["frozen"][t]:
+            w.update_running_mean = False
+        outs.append(w.step(None)[0])
+    outs = [x.cpu().numpy() if tensor else x for x in outs]
+    assert outs[0].dtype == np.float32
+    for t, x in enumerate(outs):
+        np.testing.assert_allclose(x, g["out"][t], rtol=1e-4, atol=2e-5, err_msg=f"t={t}")
+    np.testing.assert_allclose(w.obs_rms.mean, g["mean"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(w.obs_rms.var, g["var"], rtol=2e-5, atol=1e-7)
+    assert w.obs_rms.count == float(g["count"])
+
+
+@pytest.mark.parametrize("key", ["cartpole", "cartpole_same", "mountaincar_continuous"])
+def test_normalize_reward_vs_reference_recording(key):
+    g = np.load(os.path.join(GOLD, f"wrappers_normrew_{key}.npz"))
+    w = gw.NormalizeReward(_Replay(reward=g["reward"], term=g["term"], trunc=g["trunc"], same_step=bool(g["same_step"])), gamma=float(g["gamma"]))
+    w.reset()
+    for t in range(g["reward"].shape[0]):
+        np.testing.assert_allclose(w.step(None)[1], g["out"][t], rtol=2e-5, atol=1e-9, err_msg=f"t={t}")
+    assert np.array_equal(w.accumulated_reward, g["acc"]), "the discounted return accumulation is bit-exact"
+    np.testing.assert_allclose(w.return_rms.var, g["var"], rtol=2e-5)
+    np.testing.assert_allclose(w.return_rms.mean, g["mean"], rtol=2e-5, atol=1e-7)
+    assert w.return_rms.count == float(g["count"])
+
+
+def test_clip_reward_bit_exact():
+    g = np.load(os.path.join(GOLD, "wrappers_clip.npz"))
+    w = gw.ClipReward(_Replay(reward=g["reward"]), float(g["lo"]), float(g["hi"]))
+    for t in range(g["reward"].shape[0]):
+        assert np.array_equal(w.step(None)[1], g["out"][t])
+    with pytest.raises(Exception):
+        gw.ClipReward(_Replay(reward=g["reward"]))
+
+
+def test_full_size_wrapped_rollout_properties():
+    """BASELINE configs[1] size: CartPole-v1 x 65536 with device tensors through NormalizeObservation + NormalizeReward:
+    the outputs never leave HBM, the statistics equal the float64 moments of everything seen, the normalised batch is centred."""
+    import torch
+
+    N, T = 65536, 40
+    env = gymnasium_amd.make_vec("CartPole-v1", num_envs=N, output="torch")
+    w = gw.NormalizeReward(gw.NormalizeObservation(env), gamma=0.99)
+    raw = gymnasium_amd.make_vec("CartPole-v1", num_envs=N, output="torch")
+    o, _ = w.reset(seed=0)
+    ro, _ = raw.reset(seed=0)
+    assert isinstance(o, torch.Tensor) and o.is_cuda and o.dtype == torch.float32
+    seen = [ro.double()]
+    env.action_space.seed(0)
+    chk = ow.NormalizeReward(N, gamma=0.99)
+    chk.reset()
+    for t in range(T):
+        a = torch.from_numpy(env.action_space.sample()).cuda()
+        o, r, te, tr, _ = w.step(a)
+        ro, rr, rte, rtr, _ = raw.step(a)
+        seen.append(ro.double())
+        exp_r = chk.step(rr.cpu().numpy(), rte.cpu().numpy(), rtr.cpu().numpy())
+        np.testing.assert_allclose(r.cpu().numpy(), exp_r, rtol=1e-4)
+    allobs = torch.cat(seen)
+    np.testing.assert_allclose(w.env.obs_rms.mean, allobs.mean(0).cpu().numpy(), rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(w.env.obs_rms.var, allobs.var(0, unbiased=False).cpu().numpy(), rtol=1e-3, atol=1e-5)
+    assert abs(w.env.obs_rms.count - (N * (T + 1) + 1e-4)) < 1e-3
+    z = (o.double().mean(0)).abs().max().item()
+    assert z < 0.2, z
+    env.close(), raw.close()
