@@ -644,12 +644,14 @@ __global__ __launch_bounds__(64) void mj_physics_kernel(DevEnv d, const float *a
     for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
+    r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
     mjx::coop::coop_sync();
     const int frame_skip = (int)d.P.p[4];
     for (int f = 0; f < frame_skip; f++) S::step(bb, r, lane);
     mjx::coop::coop_sync();
     for (int k = lane; k < M::NQ; k += G) d.state[(size_t)k * N + env] = bb.qpos[k];
     for (int k = lane; k < M::NV; k += G) d.state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
+    if (lane < M::NV) d.state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
     S::write_extras(bb, r, lane, extras + (size_t)env * S::EX_TOTAL);
 }
 

@@ -137,6 +137,7 @@ struct Lane {
     // dof role
     double cdof[6], Mrow[NV], Hrow[NV], idiag;
     double bias, qfrc_smooth, qfrc_actuator, qacc_smooth, qacc, qacc_int, qfrc_constraint;
+    double warm;  // qacc of the previous forward pass (mj qacc_warmstart): where the next constrained solve starts
     bool lim_on[2];
     double lim_D[2], lim_aref[2], lim_sign[2];
     // contact role
@@ -882,6 +883,14 @@ struct Sim {
         bool final_pass = false;
         double x = 0, Mdx = 0, grad = 0;
         r.qacc = 0, r.qacc_int = 0, r.qfrc_constraint = 0, r.qacc_smooth = 0;
+        // With constraint rows present the unconstrained acceleration is never needed by itself: the gradient of the cost is
+        // M x - qfrc_smooth + J^T(...), so Newton starts straight from the warm start (the previous pass's qacc) and the separate
+        // factorisation of M is skipped -- one factor/solve less per forward pass (of 2.4), fewer iterations near the solution.
+        bool warm_start = anyrow;
+        if (warm_start) {
+            if (isdof) bb.A.sol.vdir[lane] = r.warm;
+            coop_sync();
+        }
 #pragma unroll 1
         for (;;) {
             double rhs = 0;
@@ -890,6 +899,7 @@ struct Sim {
 #pragma unroll
                 for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j];
                 rhs = r.qfrc_smooth;
+                solve = !warm_start;
             } else if (st == ST_NEWTON) {
                 contact_state(r);
                 grad = assemble(bb, r, Mdx, x, !final_pass, lane);
@@ -912,9 +922,12 @@ struct Sim {
             } else {
                 break;
             }
-            if (!solve) continue;
-            chol_factor(bb, r.Hrow, r.idiag, lane);
-            const double sol = chol_solve(bb, r.Hrow, r.idiag, rhs, lane);
+            if (!solve && !(st == ST_SMOOTH && warm_start)) continue;
+            double sol = r.warm;
+            if (solve) {
+                chol_factor(bb, r.Hrow, r.idiag, lane);
+                sol = chol_solve(bb, r.Hrow, r.idiag, rhs, lane);
+            }
             if (st == ST_DAMPED) {
                 r.qacc_int = sol;
                 st = ST_DONE;
@@ -930,8 +943,17 @@ struct Sim {
 #pragma unroll
             for (int kc = 0; kc < KC; kc++)
                 if (r.c_on[kc]) contact_vel(bb, bb.C.sol.tw, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jd[kc]);
-            if (st == ST_SMOOTH) {  // the iterate starts at the unconstrained acceleration: x = 0 + 1 * sol
+            if (st == ST_SMOOTH) {  // the iterate starts at sol (the unconstrained acceleration, or the warm start): x = 0 + 1 * sol
                 r.qacc_smooth = sol, x = sol, Mdx = 0;
+                if (warm_start) {  // M (x - x_smooth) = M x - qfrc_smooth
+                    double Mx = 0;
+                    if (isdof) {
+#pragma unroll
+                        for (int j = 0; j < NV; j++) Mx += r.Mrow[j] * bb.A.sol.vdir[j];
+                    }
+                    Mdx = isdof ? Mx - r.qfrc_smooth : 0.0;
+                    warm_start = false;
+                }
 #pragma unroll
                 for (int kc = 0; kc < KC; kc++)
 #pragma unroll
@@ -1020,6 +1042,7 @@ struct Sim {
             coop_sync();
         }
         if (!damped_euler()) r.qacc_int = r.qacc;
+        r.warm = r.qacc;
         coop_sync();
     }
 

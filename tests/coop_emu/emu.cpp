@@ -65,7 +65,7 @@ using namespace mjx;
 
 template <class M, int G>
 int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsub, double *qpos_out, double *qvel_out, double *extras,
-             double *debug) {
+             double *debug, double *warm) {
     typedef coop::Sim<M, G> S;
     auto *bb = new typename S::B();
     std::memset((void *)bb, 0, sizeof(*bb));
@@ -73,6 +73,7 @@ int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsu
     run_group(G, [&](int lane) {
         typename S::R r;
         std::memset((void *)&r, 0, sizeof(r));
+        if (warm && lane < M::NV) r.warm = warm[lane];
         S::init(*bb, lane);
         for (int k = lane; k < M::NQ; k += G) bb->qpos[k] = qpos[k];
         for (int k = lane; k < M::NV; k += G) bb->qvel[k] = qvel[k];
@@ -85,6 +86,7 @@ int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsu
         }
         coop::coop_sync();
         S::write_extras(*bb, r, lane, extras);
+        if (warm && lane < M::NV) warm[lane] = r.warm;
         if (debug && lane < M::NV) {  // qacc, qacc_smooth, bias, qfrc_constraint, then the mass-matrix rows
             debug[lane] = r.qacc, debug[M::NV + lane] = r.qacc_smooth, debug[2 * M::NV + lane] = r.bias, debug[3 * M::NV + lane] = r.qfrc_constraint;
             for (int j = 0; j < M::NV; j++) debug[4 * M::NV + lane * M::NV + j] = r.Mrow[j];
@@ -102,11 +104,11 @@ int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsu
 extern "C" {
 // model: 0 half_cheetah, 1 ant, 2 humanoid.  nsub = 0: one forward pass only.  Returns the number of contacts of the last pass.
 __attribute__((visibility("default"))) int coop_emu_step(int model, const double *qpos, const double *qvel, const double *ctrl, int nsub,
-                                                          double *qpos_out, double *qvel_out, double *extras, double *debug) {
-    switch (model) {
-        case 0: return emu_step<HalfCheetahModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug);
-        case 1: return emu_step<AntModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug);
-        case 2: return emu_step<HumanoidModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug);
+                                                          double *qpos_out, double *qvel_out, double *extras, double *debug, double *warm) {
+    switch (model) {  // warm: in/out qacc_warmstart[nv] (NULL = start from zero)
+        case 0: return emu_step<HalfCheetahModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
+        case 1: return emu_step<AntModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
+        case 2: return emu_step<HumanoidModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
     }
     return -1;
 }
