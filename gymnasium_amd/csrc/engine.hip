@@ -514,6 +514,7 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
             x.cinert = reinterpret_cast<const double (*)[10]>(extras + S::EX_CINERT);
             x.cvel = reinterpret_cast<const double (*)[6]>(extras + S::EX_CVEL);
             x.qfrc_actuator = extras + S::EX_QFA;
+            x.qfrc_constraint = nullptr;
             const double before[2] = {L.s[E::NQ + 2 * E::NV], L.s[E::NQ + 2 * E::NV + 1]};
             E::finish(L.s, before, x, action, d.P, obs, reward, te, info);
         } else {
@@ -944,7 +945,11 @@ int dispatch_kind(int kind, F &&f) {
 typedef mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah> HalfCheetahEnv;
 typedef mjx::MjEnv<mjx::AntModel, mjx::kAnt> AntEnv;
 typedef mjx::MjEnv<mjx::HumanoidModel, mjx::kHumanoid> HumanoidEnv;
-bool is_mj(int kind) { return kind >= kClassicKinds && kind <= MI_ENV_HUMANOID; }
+typedef mjx::MjEnv<mjx::HopperModel, mjx::kHopper> HopperEnv;
+typedef mjx::MjEnv<mjx::Walker2dModel, mjx::kWalker2d> Walker2dEnv;
+typedef mjx::MjEnv<mjx::InvertedPendulumModel, mjx::kInvertedPendulum> InvertedPendulumEnv;
+typedef mjx::MjEnv<mjx::InvertedDoublePendulumModel, mjx::kInvertedDoublePendulum> InvertedDoublePendulumEnv;
+bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM); }
 bool is_tab(int kind) { return kind == MI_ENV_TABULAR; }
 template <class F>
 int dispatch_mj(int kind, F &&f) {
@@ -952,6 +957,10 @@ int dispatch_mj(int kind, F &&f) {
     case MI_ENV_HALF_CHEETAH: return f(HalfCheetahEnv());
     case MI_ENV_ANT: return f(AntEnv());
     case MI_ENV_HUMANOID: return f(HumanoidEnv());
+    case MI_ENV_HOPPER: return f(HopperEnv());
+    case MI_ENV_WALKER2D: return f(Walker2dEnv());
+    case MI_ENV_INVERTED_PENDULUM: return f(InvertedPendulumEnv());
+    case MI_ENV_INVERTED_DOUBLE_PENDULUM: return f(InvertedDoublePendulumEnv());
     }
     return fail(MI_ERR_UNSUPPORTED, "this MuJoCo kind is not built into the HIP engine yet");
 }
@@ -1012,6 +1021,15 @@ int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
     const dim3 g(v->grid), b(kBlock);
     const int mode = v->cfg.autoreset_mode;
     mp.extras = nullptr;
+    if constexpr (!E::HAS_COOP) {
+        switch (mode) {
+        case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, mp); break;
+        case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, mp); break;
+        default: hipLaunchKernelGGL((mj_step_kernel<E, MI_AUTORESET_DISABLED, false>), g, b, 0, v->stream, v->d, mp); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    } else {
     if (v->mj_coop) {
         constexpr int EPW = 64 / E::COOP_G;
         const dim3 pg((v->cfg.num_envs + EPW - 1) / EPW), pb(64);
@@ -1037,6 +1055,7 @@ int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;
+    }
 }
 
 // T vector steps with the cooperative physics: per step [sample actions ->] physics -> glue, all on the env's stream
@@ -1108,12 +1127,7 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         for (int k = 0; k < 16; k++) P.p[k] = cfg->params[k];
         dispatch_mj(cfg->kind, [&](auto env) -> int {
             using E = decltype(env);
-            const int skip = P.p[3] != 0.0 ? E::SKIP : 0;
-            int extra = (cfg->kind == MI_ENV_ANT && P.p[12] != 0.0) ? 6 * (E::NB - 1) : 0;
-            if (cfg->kind == MI_ENV_HUMANOID)
-                extra = (P.p[12] != 0.0 ? 10 * (E::NB - 1) : 0) + (P.p[13] != 0.0 ? 6 * (E::NB - 1) : 0) + (P.p[14] != 0.0 ? E::NV - 6 : 0) +
-                        (P.p[15] != 0.0 ? 6 * (E::NB - 1) : 0);
-            const mi_layout l = {E::NQ + E::NV - skip + extra, MI_F64, E::NU, MI_F32, E::S, E::INFO, {0, 0}};
+            const mi_layout l = {E::obs_dim_host(P), MI_F64, E::NU, MI_F32, E::S, E::INFO, {0, 0}};
             v->lay = l;
             v->extras_dim = mjx::coop::Sim<typename E::Model, E::COOP_G>::EX_TOTAL;
             return (int)MI_OK;
@@ -1122,9 +1136,10 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         // env-steps/s, Humanoid 0.76M vs 0.23M); HalfCheetah (9 dofs, 7 bodies, one forward pass per sub-step) is faster on the
         // one-lane kernel (16.4M vs 12.9M).  MI355ENV_MJ_SERIAL=1 / MI355ENV_MJ_COOP=1 force either one (cross-check tests).
         const char *serial = getenv("MI355ENV_MJ_SERIAL"), *coop = getenv("MI355ENV_MJ_COOP");
-        v->mj_coop = cfg->kind != MI_ENV_HALF_CHEETAH;
+        v->mj_coop = cfg->kind == MI_ENV_ANT || cfg->kind == MI_ENV_HUMANOID;
         if (serial && serial[0] == '1') v->mj_coop = false;
         if (coop && coop[0] == '1') v->mj_coop = true;
+        if (cfg->kind >= MI_ENV_HOPPER) v->mj_coop = false;  // the small robots are built for the one-lane kernel only
     } else if (is_tab(cfg->kind)) {
         const mi_layout l = {1, MI_I64, 1, MI_I64, 2, 1, {0, 0}};
         v->lay = l;

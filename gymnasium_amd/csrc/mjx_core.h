@@ -157,7 +157,7 @@ struct Limits {
             n += (M::geom_type[M::pair_geom1[p]] == PLANE && M::geom_type[M::pair_geom2[p]] == CAPSULE) ? 2 : 1;
         return n;
     }
-    static constexpr int MAXCON = max_contacts() < 40 ? max_contacts() : 40;
+    static constexpr int MAXCON = max_contacts() < 40 ? (max_contacts() > 0 ? max_contacts() : 1) : 40;  // >= 1: C++ has no empty arrays
 };
 
 template <class M>

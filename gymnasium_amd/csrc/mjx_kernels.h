@@ -4,6 +4,8 @@
 //   gymnasium/envs/mujoco/mujoco_env.py:132-155,172-187   set_state / do_simulation / reset
 //   gymnasium/envs/mujoco/half_cheetah_v5.py:220-281      step, _get_rew, _get_obs, reset_model
 //   gymnasium/envs/mujoco/ant_v5.py:327-428               contact_forces, is_healthy, step, _get_rew, _get_obs, reset_model
+//   gymnasium/envs/mujoco/hopper_v5.py:236-343, walker2d_v5.py:241-345            (planar walkers: same skeleton)
+//   gymnasium/envs/mujoco/inverted_pendulum_v5.py:160-196, inverted_double_pendulum_v5.py:186-246
 // and the vectoriser semantics shared with the classic-control kernels (TimeLimit, autoreset modes, episode statistics).
 // Physics: mjx_core.h.  NumPy arithmetic that the reference inherits (np.sum pairwise order, float32 promotion of the
 // control cost, Generator.uniform / standard_normal streams) is reproduced bit for bit.
@@ -59,7 +61,7 @@ MJX_DEV T np_sum(const T *a) {
     return res;
 }
 
-enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2 };
+enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6 };
 
 // quantities of the last forward pass that the observations read besides qpos / qvel (null pointer = zeros, which is
 // what mj_resetData leaves in cfrc_ext / qfrc_actuator)
@@ -68,6 +70,7 @@ struct ObsExtras {
     const double (*cinert)[10];
     const double (*cvel)[6];
     const double *qfrc_actuator;
+    const double *qfrc_constraint = nullptr;  // [NV], InvertedDoublePendulum's observation
 };
 
 template <class M, int KIND>
@@ -75,12 +78,28 @@ struct MjEnv {
     typedef M Model;
     static constexpr int NQ = M::NQ, NV = M::NV, NU = M::NU, NB = M::NBODY;
     static constexpr int S = NQ + 2 * NV + 2;  // state row: qpos, qvel, (warm-start slot, unused by the Newton solver), tracked xy
-    static constexpr int INFO = KIND == kHalfCheetah ? 4 : 9;
+    static constexpr bool PLANAR_WALKER = KIND == kHopper || KIND == kWalker2d;
+    static constexpr bool PENDULUM = KIND == kInvertedPendulum || KIND == kInvertedDoublePendulum;
+    static constexpr int INFO = KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : 9)));
+    static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || KIND == kHumanoid;  // small robots: one-lane kernel only
     static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
-    static constexpr int SKIP = KIND == kHalfCheetah ? 1 : 2;
-    static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (KIND == kHumanoid ? 22 * (NB - 1) + NV - 6 : 0);
+    static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : (PENDULUM ? 0 : 2);
+    static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (KIND == kHumanoid ? 22 * (NB - 1) + NV - 6 : 0) +
+                                   (KIND == kInvertedDoublePendulum ? NQ : 0);
 
+    static int obs_dim_host(const mi::EnvParams &P) {  // the same rule, host side (mi_create)
+        if (KIND == kInvertedPendulum) return NQ + NV;
+        if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
+        int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
+        if (KIND == kAnt && P.p[12] != 0.0) n += 6 * (NB - 1);
+        if (KIND == kHumanoid)
+            n += (P.p[12] != 0.0 ? 10 * (NB - 1) : 0) + (P.p[13] != 0.0 ? 6 * (NB - 1) : 0) + (P.p[14] != 0.0 ? NV - 6 : 0) +
+                 (P.p[15] != 0.0 ? 6 * (NB - 1) : 0);
+        return n;
+    }
     static MJX_DEV int obs_dim(const mi::EnvParams &P) {
+        if (KIND == kInvertedPendulum) return NQ + NV;
+        if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
         if (KIND == kAnt && P.p[12] != 0.0) n += 6 * (NB - 1);
         if (KIND == kHumanoid)
@@ -92,8 +111,21 @@ struct MjEnv {
     // ant_v5.py:393-404, half_cheetah_v5.py:248-257, humanoid_v5.py:430-466
     static MJX_DEV void write_obs(const double *s, const ObsExtras &x, const mi::EnvParams &P, double *o) {
         int n = 0;
-        for (int k = (P.p[3] != 0.0 ? SKIP : 0); k < NQ; k++) o[n++] = s[k];
-        for (int k = 0; k < NV; k++) o[n++] = s[NQ + k];
+        if (KIND == kInvertedDoublePendulum) {
+            // inverted_double_pendulum_v5.py:217-226: x, sin(angles), cos(angles), clip(qvel, -10, 10), clip(qfrc_constraint, -10, 10)[:1]
+            o[n++] = s[0];
+            for (int k = 1; k < NQ; k++) o[n++] = sin(s[k]);
+            for (int k = 1; k < NQ; k++) o[n++] = cos(s[k]);
+            for (int k = 0; k < NV; k++) o[n++] = s[NQ + k] < -10.0 ? -10.0 : (s[NQ + k] > 10.0 ? 10.0 : s[NQ + k]);
+            const double f = x.qfrc_constraint ? x.qfrc_constraint[0] : 0.0;
+            o[n++] = f < -10.0 ? -10.0 : (f > 10.0 ? 10.0 : f);
+            return;
+        }
+        for (int k = ((P.p[3] != 0.0 && !PENDULUM) ? SKIP : 0); k < NQ; k++) o[n++] = s[k];
+        for (int k = 0; k < NV; k++) {
+            const double v = s[NQ + k];
+            o[n++] = PLANAR_WALKER ? (v < -10.0 ? -10.0 : (v > 10.0 ? 10.0 : v)) : v;  // np.clip(qvel, -10, 10): hopper_v5.py:262
+        }
         if (KIND == kAnt && P.p[12] != 0.0)
             for (int b = 1; b < NB; b++)
                 for (int k = 0; k < 6; k++) {
@@ -127,7 +159,7 @@ struct MjEnv {
     static MJX_DEV void reset(mi::Pcg64 &rng, double *s, const mi::EnvParams &P, double *obs) {
         const double scale = P.p[2];
         for (int k = 0; k < NQ; k++) s[k] = M::qpos0[k] + (-scale + (scale - (-scale)) * rng.next_double());
-        if (KIND == kHumanoid)  // humanoid_v5.py:526-528: uniform noise on the velocities as well
+        if (KIND == kHumanoid || PLANAR_WALKER || KIND == kInvertedPendulum)  // humanoid_v5.py:526-528, hopper_v5.py:318-331: uniform noise on the velocities as well
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-scale + (scale - (-scale)) * rng.next_double());
         else
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + scale * standard_normal(rng);
@@ -150,7 +182,7 @@ struct MjEnv {
             return;
         }
         // free joint / slider: the tracked Cartesian position is the joint's own coordinate
-        s[NQ + 2 * NV] = s[0], s[NQ + 2 * NV + 1] = KIND == kHalfCheetah ? 0.0 : s[1];
+        s[NQ + 2 * NV] = s[0], s[NQ + 2 * NV + 1] = (KIND == kHalfCheetah || PLANAR_WALKER || PENDULUM) ? 0.0 : s[1];
         if (obs) {
             const ObsExtras x = {nullptr, nullptr, nullptr, nullptr};
             write_obs(s, x, P, obs);
@@ -164,6 +196,7 @@ struct MjEnv {
         const double (*cinert)[10];      // cinert[NB][10] (per body, not composite)
         const double (*cvel)[6];         // cvel[NB][6]
         const double *qfrc_actuator;     // [NV]
+        const double *qfrc_constraint;   // [NV]
     };
 
     // One env.step() with the one-lane simulator (mjx_core.h): physics, then finish().
@@ -178,7 +211,12 @@ struct MjEnv {
         for (int f = 0; f < frame_skip; f++) mjx::step<M>(d);
         // Cartesian quantities of the LAST forward pass (they lag qpos by one sub-step, as in the reference)
         StepExtras x;
-        if (KIND == kHalfCheetah)
+        if (KIND == kInvertedDoublePendulum) {  // the tip site of the LAST forward pass: x and z (the reference's `x, _, y = site_xpos[0]`)
+            const int sb = M::site_bodyid[0];
+            double t[3];
+            rot_vec(t, d.xmat[sb], M::site_pos[0]);
+            x.after[0] = d.xpos[sb][0] + t[0], x.after[1] = d.xpos[sb][2] + t[2];
+        } else if (KIND == kHalfCheetah || PLANAR_WALKER || KIND == kInvertedPendulum)
             x.after[0] = d.qpos[0], x.after[1] = 0.0;
         else if (KIND == kAnt)
             x.after[0] = d.xpos[1][0], x.after[1] = d.xpos[1][1];
@@ -187,9 +225,9 @@ struct MjEnv {
         for (int k = 0; k < NQ; k++) s[k] = d.qpos[k];
         for (int k = 0; k < NV; k++) s[NQ + k] = d.qvel[k];
         double cfrc[NB][6];
-        if (KIND != kHalfCheetah) contact_forces<M>(d, cfrc);
+        if (KIND == kAnt || KIND == kHumanoid) contact_forces<M>(d, cfrc);
         if (KIND == kHumanoid) com_pos<M>(d);  // crb() folded the per-body inertias into composites: restore them for the obs
-        x.cfrc = cfrc, x.cinert = d.cinert, x.cvel = d.cvel, x.qfrc_actuator = d.qfrc_actuator;
+        x.cfrc = cfrc, x.cinert = d.cinert, x.cvel = d.cvel, x.qfrc_actuator = d.qfrc_actuator, x.qfrc_constraint = d.qfrc_constraint;
         finish(s, before, x, action, P, obs, reward, terminated, info);
     }
 
@@ -219,6 +257,49 @@ struct MjEnv {
         float sq[NU];
         for (int u = 0; u < NU; u++) sq[u] = action[u] * action[u];
         const float ctrl_cost_f = (float)P.p[1] * np_sum<float, NU>(sq);  // weight * np.sum(np.square(float32 action)): float32
+        if (KIND == kInvertedPendulum) {
+            // inverted_pendulum_v5.py:160-176: terminated = not isfinite(obs).all() or |angle| > 0.2; reward = int(not terminated)
+            bool finite = true;
+            for (int k = 0; k < NQ + NV; k++) finite &= isfinite(s[k]);
+            terminated = !finite || fabs(s[1]) > 0.2;
+            reward = terminated ? 0.0 : 1.0;
+            const ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
+            write_obs(s, ox, P, obs);
+            if (info) info[0] = reward;
+            return;
+        }
+        if (KIND == kInvertedDoublePendulum) {
+            // inverted_double_pendulum_v5.py:186-215: tip site (x, y = height), penalties on the distance from upright and the joint speeds
+            const double tx = after[0], ty = after[1];
+            terminated = ty <= 1.0;
+            const double v1 = s[NQ + 1], v2 = s[NQ + 2];
+            const double dist_penalty = 0.01 * (tx * tx) + (ty - 2) * (ty - 2);
+            const double vel_penalty = 1e-3 * (v1 * v1) + 5e-3 * (v2 * v2);
+            const double alive_bonus = P.p[6] * (terminated ? 0.0 : 1.0);
+            reward = alive_bonus - dist_penalty - vel_penalty;
+            ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
+            ox.qfrc_constraint = x.qfrc_constraint;
+            write_obs(s, ox, P, obs);
+            if (info) info[0] = alive_bonus, info[1] = -dist_penalty, info[2] = -vel_penalty;
+            return;
+        }
+        if (PLANAR_WALKER) {
+            // hopper_v5.py:240-257,266-309 / walker2d_v5.py:245-259,268-311
+            const double forward_reward = P.p[0] * xv;
+            const double z = s[1], angle = s[2];
+            bool healthy = P.p[8] < z && z < P.p[9] && P.p[10] < angle && angle < P.p[11];
+            if (KIND == kHopper)  // healthy_state_range on state_vector()[2:]
+                for (int k = 2; k < NQ + NV; k++) healthy = healthy && P.p[12] < s[k] && s[k] < P.p[13];
+            const double healthy_reward = healthy ? P.p[6] : 0.0;
+            reward = (forward_reward + healthy_reward) - (double)ctrl_cost_f;
+            terminated = !healthy && P.p[7] != 0.0;
+            const ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
+            write_obs(s, ox, P, obs);
+            if (info)
+                info[0] = s[0], info[1] = s[1] - M::qpos0[1], info[2] = xv, info[3] = forward_reward, info[4] = -(double)ctrl_cost_f,
+                info[5] = healthy_reward;
+            return;
+        }
         if (KIND == kHalfCheetah) {
             const double forward_reward = P.p[0] * xv;
             reward = forward_reward - (double)ctrl_cost_f;
@@ -266,7 +347,12 @@ struct MjEnv {
     }
     static MJX_DEV void reset_info(const double *s, double *info) {
         for (int k = 0; k < INFO; k++) info[k] = 0.0;
+        if (PENDULUM) return;  // _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
         info[0] = s[0];
+        if (PLANAR_WALKER) {
+            info[1] = s[1] - M::qpos0[1];  // z_distance_from_origin (hopper_v5.py:338-342)
+            return;
+        }
         if (KIND != kHalfCheetah) info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]);
     }
 };

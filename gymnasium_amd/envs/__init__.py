@@ -6,7 +6,15 @@ from .classic_control import (  # noqa: F401
     PendulumVectorEnv,
 )
 from .classic_control import ENV_TABLE as _CLASSIC
-from .mujoco.envs import AntVectorEnv, HalfCheetahVectorEnv, HumanoidVectorEnv  # noqa: F401
+from .mujoco.envs import (  # noqa: F401
+    AntVectorEnv,
+    HalfCheetahVectorEnv,
+    HopperVectorEnv,
+    HumanoidVectorEnv,
+    InvertedDoublePendulumVectorEnv,
+    InvertedPendulumVectorEnv,
+    Walker2dVectorEnv,
+)
 from .mujoco.envs import ENV_TABLE as _MUJOCO
 
 from .toy_text import CliffWalkingVectorEnv, FrozenLakeVectorEnv, TaxiVectorEnv  # noqa: F401

@@ -13,11 +13,15 @@ import numpy as np
 from . import compiler
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc", "generated", "mjx_models.h")
-STRUCT = {"half_cheetah": "HalfCheetahModel", "ant": "AntModel", "humanoid": "HumanoidModel"}
+STRUCT = {"half_cheetah": "HalfCheetahModel", "ant": "AntModel", "humanoid": "HumanoidModel", "hopper": "HopperModel", "walker2d": "Walker2dModel",
+          "inverted_pendulum": "InvertedPendulumModel", "inverted_double_pendulum": "InvertedDoublePendulumModel"}
 
 
 def _arr(name, ctype, values, shape):
     v = np.asarray(values).reshape(-1)
+    if shape[0] == 0:  # C++ has no zero-length arrays: one zero row, the count constant (NPAIR, NSLOT) says it is unused
+        shape = (1,) + tuple(shape[1:])
+        v = np.zeros(int(np.prod(shape)))
     dims = "".join(f"[{d}]" for d in shape)
     if ctype == "double":
         body = ", ".join(float(x).hex() if np.isfinite(x) else ("INFINITY" if x > 0 else "-INFINITY") for x in v)
@@ -58,13 +62,17 @@ def emit_model(m) -> str:
         ("geom_type", "int", m.geom_type, (ng,)), ("geom_bodyid", "int", m.geom_bodyid, (ng,)), ("geom_size", "double", m.geom_size, (ng, 3)),
         ("geom_pos", "double", m.geom_pos, (ng, 3)), ("geom_mat", "double", m.geom_mat, (ng, 9)),
         ("pair_geom1", "int", m.pair_geom1, (npair,)), ("pair_geom2", "int", m.pair_geom2, (npair,)), ("pair_condim", "int", m.pair_condim, (npair,)),
-        ("pair_friction", "double", m.pair_friction[:, 0], (npair,)), ("pair_margin", "double", m.pair_margin, (npair,)),
+        ("pair_friction", "double", m.pair_friction[:, 0] if npair else np.zeros(0), (npair,)), ("pair_margin", "double", m.pair_margin, (npair,)),
         ("pair_solref", "double", m.pair_solref, (npair, 2)), ("pair_solimp", "double", m.pair_solimp, (npair, 5)),
         ("actuator_dofadr", "int", m.actuator_dofadr, (nu,)), ("actuator_gear", "double", m.actuator_gear, (nu,)),
         ("actuator_ctrlrange", "double", m.actuator_ctrlrange, (nu, 2)),
     ]:
         s += _arr(name, ct, val, shape)
     s += _emit_topology(m)
+    sites = getattr(m, "sites", [])
+    s += f"    static constexpr int NSITE = {len(sites)};\n"
+    s += _arr("site_bodyid", "int", [b for b, _ in sites], (len(sites),))
+    s += _arr("site_pos", "double", [p for _, p in sites], (len(sites), 3))
     s += "};\n"
     return s
 
@@ -122,7 +130,7 @@ def generate(path: str = OUT) -> str:
     text = ("// mjx_models.h -- GENERATED by gymnasium_amd/envs/mujoco/codegen.py from gymnasium_amd/envs/mujoco/models.py (a transcription of\n"
             "// the reference's MJCF assets, gymnasium/envs/mujoco/assets/{half_cheetah,ant,humanoid}.xml).  Do not edit.\n"
             "#pragma once\n#include <math.h>\nnamespace mjx {\n")
-    for name in ("half_cheetah", "ant", "humanoid"):
+    for name in STRUCT:
         text += emit_model(compiler.compile_model(name))
     text += "}  // namespace mjx\n"
     os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -133,13 +133,16 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
 
     # ---- geoms: world plane first (geom 0), then the bodies' geoms in order --------------------------------------
     geoms = []
-    fl = dict(gdef, **desc["floor"])
+    # a model without a ground plane still gets geom 0 (the engine's tables are never empty), with collisions switched off
+    fl = dict(gdef, **(desc["floor"] if desc["floor"] is not None else dict(contype=0, conaffinity=0)))
     geoms.append(dict(name="floor", type=PLANE, body=0, size=(0, 0, 0), pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), mass=0.0,
                       inertia=np.zeros(3), **{k: fl[k] for k in ("contype", "conaffinity", "condim", "friction", "margin", "gap", "solref", "solimp", "solmix")}))
     for bi in range(1, nbody):
         for g in bodies[bi]["geoms"]:
             p = dict(gdef)
             p.update({k: v for k, v in g.items() if k in GEOM_DEFAULTS})
+            if len(p["friction"]) < 3:  # friction="0.9": only the sliding coefficient is overridden (XML attribute completion)
+                p["friction"] = tuple(p["friction"]) + tuple(gdef["friction"][len(p["friction"]):])
             size = g["size"]
             radius = float(size[0] if isinstance(size, (tuple, list)) else size)
             if g["type"] == "capsule":
@@ -149,10 +152,15 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
                     quat = z_to_quat(a - b)  # MuJoCo: vec = from - to
                 else:
                     half = float(size[1])
-                    pos = np.array(g["pos"], dtype=np.float64)
+                    pos = np.array(g["pos"] if g["pos"] is not None else (0, 0, 0), dtype=np.float64)
                     aa = g["axisangle"]
-                    ang = math.radians(aa[3]) if deg else aa[3]
-                    quat = axisangle_to_quat(aa[:3], ang) if aa is not None else np.array([1.0, 0, 0, 0])
+                    if g.get("quat") is not None:
+                        quat = np.array(g["quat"], dtype=np.float64)
+                        quat /= np.linalg.norm(quat)
+                    elif aa is not None:
+                        quat = axisangle_to_quat(aa[:3], math.radians(aa[3]) if deg else aa[3])
+                    else:
+                        quat = np.array([1.0, 0, 0, 0])
                 height = 2 * half
                 vol = math.pi * radius * radius * height + 4.0 / 3.0 * math.pi * radius ** 3
                 mass = p["density"] * vol
@@ -245,8 +253,9 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
                 parent_dof = len(D["bodyid"]) - 1
             if jt == FREE:
                 qpos0.extend(list(m.body_pos[bi]) + list(m.body_quat[bi]))
-            else:
-                qpos0.append(0.0)
+            else:  # `ref`: the joint coordinate of the configuration the XML draws (degrees for hinges under angle="degree")
+                ref = float(p_["ref"])
+                qpos0.append(math.radians(ref) if (deg and jt == HINGE) else ref)
             m.body_jntnum[bi] += 1
             m.body_dofnum[bi] += ndof
         if b["joints"]:
@@ -265,11 +274,14 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
     m.qpos0 = np.array(qpos0)
     m.qpos_spring = m.qpos0.copy()
 
+    # ---- sites: (body index, position in the body frame) ------------------------------------------------------------
+    m.sites = [(m.body_names.index(b), tuple(float(x) for x in pos)) for _, b, pos in desc.get("sites", [])]
     # ---- actuators (motors on joints) ---------------------------------------------------------------------------
     m.nu = len(desc["actuators"])
-    m.actuator_dofadr = np.array([m.jnt_dofadr[J["name"].index(jn)] for jn, _ in desc["actuators"]], dtype=np.int32)
-    m.actuator_gear = np.array([g for _, g in desc["actuators"]], dtype=np.float64)
-    m.actuator_ctrlrange = np.tile(np.array(desc["ctrlrange"], dtype=np.float64), (m.nu, 1))
+    m.actuator_dofadr = np.array([m.jnt_dofadr[J["name"].index(a[0])] for a in desc["actuators"]], dtype=np.int32)
+    m.actuator_gear = np.array([a[1] for a in desc["actuators"]], dtype=np.float64)
+    # (joint, gear) uses the model-wide ctrlrange, (joint, gear, (lo, hi)) its own
+    m.actuator_ctrlrange = np.array([a[2] if len(a) > 2 else desc["ctrlrange"] for a in desc["actuators"]], dtype=np.float64).reshape(m.nu, 2)
 
     # ---- contact candidates -------------------------------------------------------------------------------------
     P = dict(g1=[], g2=[], condim=[], friction=[], margin=[], solref=[], solimp=[])

@@ -148,9 +148,125 @@ class HumanoidVectorEnv(_MujocoVectorEnv):
         return self._params
 
 
-# id -> (creator, max_episode_steps, reward_threshold): gymnasium/envs/__init__.py:283-288, 353-358, 370-374
+class _PlanarWalkerVectorEnv(_MujocoVectorEnv):
+    """Hopper-v5 / Walker2d-v5: obs = qpos[1:] + clip(qvel, -10, 10); reward = forward + healthy - ctrl (hopper_v5.py:236-343)."""
+
+    DEFAULT_MAX_EPISODE_STEPS = 1000
+    CTRL_LOW, CTRL_HIGH = -1.0, 1.0
+    INFO_KEYS = ("x_position", "z_distance_from_origin", "x_velocity", "reward_forward", "reward_ctrl", "reward_survive")
+    N_RESET_INFO_KEYS = 2
+
+    def _init_walker(self, num_envs, max_episode_steps, xml_file, frame_skip, forward_reward_weight, ctrl_cost_weight, healthy_reward,
+                     terminate_when_unhealthy, healthy_state_range, healthy_z_range, healthy_angle_range, reset_noise_scale, exclude, kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._exclude = bool(exclude)
+        self._params = (forward_reward_weight, ctrl_cost_weight, reset_noise_scale, float(self._exclude), float(frame_skip), 0.0, healthy_reward,
+                        float(bool(terminate_when_unhealthy)), healthy_z_range[0], healthy_z_range[1], healthy_angle_range[0],
+                        healthy_angle_range[1], healthy_state_range[0], healthy_state_range[1])
+        self.observation_structure = {"skipped_qpos": 1 * self._exclude, "qpos": self.NQ - 1 * self._exclude, "qvel": self.NV}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return self.NQ + self.NV - self._exclude
+
+    def _engine_params(self):
+        return self._params
+
+    def _reset_infos(self, mask):
+        sel = np.ones(self.num_envs, dtype=np.bool_) if mask is None else mask.view(np.bool_).copy()
+        qpos = self.get_state()[0]
+        return {"x_position": np.where(sel, qpos[:, 0], 0.0), "_x_position": sel,
+                "z_distance_from_origin": np.where(sel, qpos[:, 1] - self.INIT_Z, 0.0), "_z_distance_from_origin": sel.copy()}
+
+
+class HopperVectorEnv(_PlanarWalkerVectorEnv):
+    KIND = "hopper"
+    STOCK_XML = "hopper.xml"
+    NQ, NV, NU, NBODY = 6, 6, 3, 5
+    INIT_Z = 1.25
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "hopper.xml", frame_skip: int = 4,
+                 forward_reward_weight: float = 1.0, ctrl_cost_weight: float = 1e-3, healthy_reward: float = 1.0,
+                 terminate_when_unhealthy: bool = True, healthy_state_range=(-100.0, 100.0), healthy_z_range=(0.7, float("inf")),
+                 healthy_angle_range=(-0.2, 0.2), reset_noise_scale: float = 5e-3, exclude_current_positions_from_observation: bool = True, **kwargs):
+        self._init_walker(num_envs, max_episode_steps, xml_file, frame_skip, forward_reward_weight, ctrl_cost_weight, healthy_reward,
+                          terminate_when_unhealthy, healthy_state_range, healthy_z_range, healthy_angle_range, reset_noise_scale,
+                          exclude_current_positions_from_observation, kwargs)
+
+
+class Walker2dVectorEnv(_PlanarWalkerVectorEnv):
+    KIND = "walker2d"
+    STOCK_XML = "walker2d_v5.xml"
+    NQ, NV, NU, NBODY = 9, 9, 6, 8
+    INIT_Z = 1.25
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "walker2d_v5.xml", frame_skip: int = 4,
+                 forward_reward_weight: float = 1.0, ctrl_cost_weight: float = 1e-3, healthy_reward: float = 1.0,
+                 terminate_when_unhealthy: bool = True, healthy_z_range=(0.8, 2.0), healthy_angle_range=(-1.0, 1.0),
+                 reset_noise_scale: float = 5e-3, exclude_current_positions_from_observation: bool = True, **kwargs):
+        self._init_walker(num_envs, max_episode_steps, xml_file, frame_skip, forward_reward_weight, ctrl_cost_weight, healthy_reward,
+                          terminate_when_unhealthy, (-np.inf, np.inf), healthy_z_range, healthy_angle_range, reset_noise_scale,
+                          exclude_current_positions_from_observation, kwargs)
+
+
+class _PendulumVectorEnv(_MujocoVectorEnv):
+    DEFAULT_MAX_EPISODE_STEPS = 1000
+    N_RESET_INFO_KEYS = 0
+
+    def _engine_params(self):
+        return self._params
+
+    def _reset_infos(self, mask):
+        return {}  # _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
+
+
+class InvertedPendulumVectorEnv(_PendulumVectorEnv):
+    """inverted_pendulum_v5.py:100-199: obs = qpos + qvel (float64[4]), action float32[1] in [-3, 3]."""
+
+    KIND = "inverted_pendulum"
+    STOCK_XML = "inverted_pendulum.xml"
+    NQ, NV, NU, NBODY = 2, 2, 1, 3
+    CTRL_LOW, CTRL_HIGH = -3.0, 3.0
+    INFO_KEYS = ("reward_survive",)
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "inverted_pendulum.xml", frame_skip: int = 2,
+                 reset_noise_scale: float = 0.01, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._params = (0.0, 0.0, reset_noise_scale, 0.0, float(frame_skip))
+        self.observation_structure = {"qpos": self.NQ, "qvel": self.NV}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return self.NQ + self.NV
+
+
+class InvertedDoublePendulumVectorEnv(_PendulumVectorEnv):
+    """inverted_double_pendulum_v5.py:125-246: obs float64[9], action float32[1] in [-1, 1]."""
+
+    KIND = "inverted_double_pendulum"
+    STOCK_XML = "inverted_double_pendulum.xml"
+    NQ, NV, NU, NBODY = 3, 3, 1, 4
+    CTRL_LOW, CTRL_HIGH = -1.0, 1.0
+    INFO_KEYS = ("reward_survive", "distance_penalty", "velocity_penalty")
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "inverted_double_pendulum.xml", frame_skip: int = 5,
+                 healthy_reward: float = 10.0, reset_noise_scale: float = 0.1, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._params = (0.0, 0.0, reset_noise_scale, 0.0, float(frame_skip), 0.0, healthy_reward)
+        self.observation_structure = {"qpos": 1, "sinqpos": 2, "cosqpos": 2, "qvel": self.NV, "qfrc_constraint": 1}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return 1 + 2 * (self.NQ - 1) + self.NV + 1
+
+
+# id -> (creator, max_episode_steps, reward_threshold): gymnasium/envs/__init__.py:246-374
 ENV_TABLE = {
     "HalfCheetah-v5": (HalfCheetahVectorEnv, 1000, 4800.0),
     "Ant-v5": (AntVectorEnv, 1000, 6000.0),
     "Humanoid-v5": (HumanoidVectorEnv, 1000, None),
+    "Hopper-v5": (HopperVectorEnv, 1000, 3800.0),
+    "Walker2d-v5": (Walker2dVectorEnv, 1000, None),
+    "InvertedPendulum-v5": (InvertedPendulumVectorEnv, 1000, 950.0),
+    "InvertedDoublePendulum-v5": (InvertedDoublePendulumVectorEnv, 1000, 9100.0),
 }

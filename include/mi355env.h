@@ -50,7 +50,12 @@ typedef enum mi_env_kind {
     /* ToyText: any finite MDP given as a transition table (mi_tabular_load); FrozenLake / CliffWalking / Taxi:
      * envs/toy_text/frozen_lake.py:324-348, cliffwalking.py:195-215, taxi.py:419-472, utils.py:4-8               */
     MI_ENV_TABULAR = 8,
-    MI_ENV_KIND_COUNT = 9
+    /* more of the MuJoCo family: same physics core, their own reward / observation glue */
+    MI_ENV_HOPPER = 9,                     /* envs/mujoco/hopper_v5.py:146-343 + assets/hopper.xml                        */
+    MI_ENV_WALKER2D = 10,                  /* envs/mujoco/walker2d_v5.py:151-345 + assets/walker2d_v5.xml                 */
+    MI_ENV_INVERTED_PENDULUM = 11,         /* envs/mujoco/inverted_pendulum_v5.py:100-199 + assets/inverted_pendulum.xml  */
+    MI_ENV_INVERTED_DOUBLE_PENDULUM = 12,  /* envs/mujoco/inverted_double_pendulum_v5.py:125-246 + its asset              */
+    MI_ENV_KIND_COUNT = 13
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */
@@ -78,6 +83,9 @@ typedef enum mi_dtype { MI_F32 = 0, MI_F64 = 1, MI_I64 = 2 } mi_dtype;
  *       [3] exclude_current_positions_from_observation (0/1)  [4] frame_skip
  *       [5] contact_cost_weight  [6] healthy_reward  [7] terminate_when_unhealthy (0/1)  [8],[9] healthy_z_range
  *       [10],[11] ANT: contact_force_range / HUMANOID: contact_cost_range
+ *     HOPPER / WALKER2D (hopper_v5.py:146-160, walker2d_v5.py:172-185): slots 0-4 and 6-9 as above,
+ *       [10],[11] healthy_angle_range  [12],[13] HOPPER: healthy_state_range
+ *     INVERTED_PENDULUM / INVERTED_DOUBLE_PENDULUM: [2] reset_noise_scale [4] frame_skip [6] healthy_reward (double pendulum)
  *       [12] ANT: include_cfrc_ext_in_observation / HUMANOID: include_cinert_in_observation
  *       [13],[14],[15] HUMANOID: include_cvel / include_qfrc_actuator / include_cfrc_ext _in_observation
  *     TABULAR                  params[0] = number of states, params[1] = number of actions (table: mi_tabular_load)

@@ -87,24 +87,35 @@ static float pairwise_f32(const float *a, int n) {
 float orc_np_sum_f32(const float *a, int n) { return pairwise_f32(a, n); }
 
 /* ---- model registry (filled by oracle/oracle.py at load time) -------------------------------------------------- */
-static mjo_model *g_models[3];
+static mjo_model *g_models[ORC_MJ_COUNT];
 __attribute__((visibility("default"))) int orc_mj_register_model(int which, const double *blob, int n) {
-    if (which < 0 || which > 2) return -1;
+    if (which < 0 || which >= ORC_MJ_COUNT) return -1;
     if (!g_models[which]) g_models[which] = (mjo_model *)malloc(sizeof(mjo_model));
     return mjo_model_from_blob(g_models[which], blob, n);
 }
-const mjo_model *orc_mj_model(int which) { return which >= 0 && which < 3 ? g_models[which] : 0; }
+const mjo_model *orc_mj_model(int which) { return which >= 0 && which < ORC_MJ_COUNT ? g_models[which] : 0; }
 
 /* ---- layout ----------------------------------------------------------------------------------------------------- */
+static int is_planar_walker(int which) { return which == ORC_MJ_HOPPER || which == ORC_MJ_WALKER2D; }
+static int is_pendulum(int which) { return which == ORC_MJ_INVERTED_PENDULUM || which == ORC_MJ_INVERTED_DOUBLE_PENDULUM; }
+
 int orc_mjenv_obs_dim(int which, const double *P) {
     const mjo_model *m = g_models[which];
     int excl = P[3] != 0.0;
+    if (which == ORC_MJ_INVERTED_PENDULUM) return m->nq + m->nv;
+    if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 1 + 2 * (m->nq - 1) + m->nv + 1;
+    if (is_planar_walker(which)) return m->nq - (excl ? 1 : 0) + m->nv;
     if (which == ORC_MJ_HALF_CHEETAH) return m->nq - (excl ? 1 : 0) + m->nv;
     if (which == ORC_MJ_ANT) return m->nq - (excl ? 2 : 0) + m->nv + (P[12] != 0.0 ? 6 * (m->nbody - 1) : 0);
     return m->nq - (excl ? 2 : 0) + m->nv + (P[12] != 0.0 ? 10 * (m->nbody - 1) : 0) + (P[13] != 0.0 ? 6 * (m->nbody - 1) : 0) +
            (P[14] != 0.0 ? m->nv - 6 : 0) + (P[15] != 0.0 ? 6 * (m->nbody - 1) : 0);
 }
-int orc_mjenv_info_dim(int which) { return which == ORC_MJ_HALF_CHEETAH ? 4 : 9; }
+int orc_mjenv_info_dim(int which) {
+    if (is_planar_walker(which)) return 6;
+    if (which == ORC_MJ_INVERTED_PENDULUM) return 1;
+    if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 3;
+    return which == ORC_MJ_HALF_CHEETAH ? 4 : 9;
+}
 int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
 
 /* ---- per-env glue ----------------------------------------------------------------------------------------------- */
@@ -126,7 +137,13 @@ static void mass_center_xy(const orc_mjenv *e, double out[2]) { /* humanoid_v5.p
 /* the position the env differentiates to get its velocity reward, read from the LAST forward pass (the reference reads
  * data.qpos / data.body().xpos / data.xipos after mj_step, and those Cartesian quantities lag qpos by one sub-step) */
 static void tracked_xy(const orc_mjenv *e, double out[2]) {
-    if (e->which == ORC_MJ_HALF_CHEETAH)
+    if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* data.site_xpos[0]: x and height of the tip (inverted_double_pendulum_v5.py:189) */
+        const double tip[3] = {0, 0, 0.6}; /* <site name="tip" pos="0 0 .6"/> on pole2 = the last body */
+        const int b = e->m->nbody - 1;
+        const double *R = e->d.xmat[b];
+        out[0] = e->d.xpos[b][0] + R[0] * tip[0] + R[1] * tip[1] + R[2] * tip[2];
+        out[1] = e->d.xpos[b][2] + R[6] * tip[0] + R[7] * tip[1] + R[8] * tip[2];
+    } else if (e->which == ORC_MJ_HALF_CHEETAH || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM)
         out[0] = e->d.qpos[0], out[1] = 0;
     else if (e->which == ORC_MJ_ANT)
         out[0] = e->d.xpos[1][0], out[1] = e->d.xpos[1][1]; /* main_body = 1 (torso) */
@@ -137,9 +154,22 @@ static void tracked_xy(const orc_mjenv *e, double out[2]) {
 void orc_mjenv_obs(const orc_mjenv *e, const double *P, double *o) {
     const mjo_model *m = e->m;
     const mjo_data *d = &e->d;
-    int skip = P[3] != 0.0 ? (e->which == ORC_MJ_HALF_CHEETAH ? 1 : 2) : 0, n = 0;
+    int skip = P[3] != 0.0 ? ((e->which == ORC_MJ_HALF_CHEETAH || is_planar_walker(e->which)) ? 1 : 2) : 0, n = 0;
+    if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* inverted_double_pendulum_v5.py:217-226 */
+        o[n++] = d->qpos[0];
+        for (int k = 1; k < m->nq; k++) o[n++] = sin(d->qpos[k]);
+        for (int k = 1; k < m->nq; k++) o[n++] = cos(d->qpos[k]);
+        for (int k = 0; k < m->nv; k++) o[n++] = d->qvel[k] < -10.0 ? -10.0 : (d->qvel[k] > 10.0 ? 10.0 : d->qvel[k]);
+        const double f = d->qfrc_constraint[0];
+        o[n++] = f < -10.0 ? -10.0 : (f > 10.0 ? 10.0 : f);
+        return;
+    }
+    if (is_pendulum(e->which)) skip = 0;
     for (int k = skip; k < m->nq; k++) o[n++] = d->qpos[k];
-    for (int k = 0; k < m->nv; k++) o[n++] = d->qvel[k];
+    for (int k = 0; k < m->nv; k++) {
+        const double v = d->qvel[k];
+        o[n++] = is_planar_walker(e->which) ? (v < -10.0 ? -10.0 : (v > 10.0 ? 10.0 : v)) : v; /* np.clip(qvel, -10, 10) hopper_v5.py:262 */
+    }
     if (e->which == ORC_MJ_ANT && P[12] != 0.0) {
         for (int b = 1; b < m->nbody; b++)
             for (int k = 0; k < 6; k++) {
@@ -167,7 +197,7 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
     mjo_reset_data(m, &e->d); /* mj_resetData */
     /* qpos = init_qpos + uniform(-s, s, nq): Generator.uniform = low + (high - low) * next_double */
     for (int k = 0; k < m->nq; k++) qpos[k] = m->qpos0[k] + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
-    if (e->which == ORC_MJ_HUMANOID) /* humanoid_v5.py:526-528: uniform noise on the velocities too */
+    if (e->which == ORC_MJ_HUMANOID || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM) /* humanoid_v5.py:526-528, hopper_v5.py:318-331, inverted_pendulum_v5.py:178-190: uniform noise on the velocities too */
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
     else /* init_qvel + scale * standard_normal(nv) */
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + scale * orc_standard_normal(rng);
@@ -193,6 +223,41 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     const double dt = m->timestep * frame_skip;
     const double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
     const double forward_reward = e->which == ORC_MJ_ANT ? xv * P[0] : P[0] * xv;
+    if (e->which == ORC_MJ_INVERTED_PENDULUM) { /* inverted_pendulum_v5.py:160-176 */
+        int finite = 1;
+        for (int k = 0; k < m->nq; k++) finite &= isfinite(d->qpos[k]) != 0;
+        for (int k = 0; k < m->nv; k++) finite &= isfinite(d->qvel[k]) != 0;
+        *terminated = !finite || fabs(d->qpos[1]) > 0.2;
+        *reward = *terminated ? 0.0 : 1.0;
+        info[0] = *reward;
+        return;
+    }
+    if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* inverted_double_pendulum_v5.py:186-215 */
+        const double x = after[0], y = after[1], v1 = d->qvel[1], v2 = d->qvel[2];
+        *terminated = y <= 1.0;
+        const double dist_penalty = 0.01 * (x * x) + (y - 2) * (y - 2), vel_penalty = 1e-3 * (v1 * v1) + 5e-3 * (v2 * v2);
+        const double alive_bonus = P[6] * (*terminated ? 0.0 : 1.0);
+        *reward = alive_bonus - dist_penalty - vel_penalty;
+        info[0] = alive_bonus, info[1] = -dist_penalty, info[2] = -vel_penalty;
+        return;
+    }
+    if (is_planar_walker(e->which)) { /* hopper_v5.py:240-309, walker2d_v5.py:245-311 */
+        float sq[MJO_MAXU];
+        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
+        const float ctrl_cost = (float)P[1] * orc_np_sum_f32(sq, nu);
+        const double z = d->qpos[1], angle = d->qpos[2];
+        int healthy = P[8] < z && z < P[9] && P[10] < angle && angle < P[11];
+        if (e->which == ORC_MJ_HOPPER) { /* healthy_state_range on state_vector()[2:] */
+            for (int k = 2; k < m->nq; k++) healthy = healthy && P[12] < d->qpos[k] && d->qpos[k] < P[13];
+            for (int k = 0; k < m->nv; k++) healthy = healthy && P[12] < d->qvel[k] && d->qvel[k] < P[13];
+        }
+        const double healthy_reward = healthy ? P[6] : 0.0;
+        *reward = (forward_reward + healthy_reward) - (double)ctrl_cost;
+        *terminated = !healthy && P[7] != 0.0;
+        info[0] = d->qpos[0], info[1] = d->qpos[1] - m->qpos0[1], info[2] = xv, info[3] = forward_reward, info[4] = -(double)ctrl_cost,
+        info[5] = healthy_reward;
+        return;
+    }
     if (e->which == ORC_MJ_HALF_CHEETAH) {
         /* control_cost: weight * np.sum(np.square(action)) with a float32 action -> float32 (NEP 50) */
         float sq[MJO_MAXU];
@@ -237,6 +302,16 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     *terminated = !healthy && P[7] != 0.0;
     info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = sqrt(d->qpos[0] * d->qpos[0] + d->qpos[1] * d->qpos[1]);
     info[3] = xv, info[4] = yv, info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
+}
+
+/* _get_reset_info of the scalar env: positions only */
+void orc_mjenv_reset_info(const orc_mjenv *e, double *row) {
+    if (is_pendulum(e->which)) return; /* {} (inverted_pendulum_v5.py:198-199) */
+    row[0] = e->d.qpos[0];
+    if (is_planar_walker(e->which))
+        row[1] = e->d.qpos[1] - e->m->qpos0[1]; /* z_distance_from_origin, hopper_v5.py:338-342 */
+    else if (e->which != ORC_MJ_HALF_CHEETAH)
+        row[1] = e->d.qpos[1], row[2] = sqrt(row[0] * row[0] + row[1] * row[1]);
 }
 
 /* checkpoint row: qpos, qvel, qacc_warmstart, tracked xy of the last forward pass */

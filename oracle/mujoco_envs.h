@@ -4,7 +4,8 @@
 #include "mujoco_core.h"
 #include "pcg64.h"
 
-enum { ORC_MJ_HALF_CHEETAH = 0, ORC_MJ_ANT = 1, ORC_MJ_HUMANOID = 2 };
+enum { ORC_MJ_HALF_CHEETAH = 0, ORC_MJ_ANT = 1, ORC_MJ_HUMANOID = 2, ORC_MJ_HOPPER = 3, ORC_MJ_WALKER2D = 4, ORC_MJ_INVERTED_PENDULUM = 5,
+       ORC_MJ_INVERTED_DOUBLE_PENDULUM = 6, ORC_MJ_COUNT = 7 };
 
 typedef struct orc_mjenv {
     int which;
@@ -25,6 +26,7 @@ orc_mjenv *orc_mjenv_create(int which);
 void orc_mjenv_obs(const orc_mjenv *e, const double *params, double *obs);
 void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *params);
 void orc_mjenv_step(orc_mjenv *e, const float *action, const double *params, double *reward, int *terminated, double *info);
+void orc_mjenv_reset_info(const orc_mjenv *e, double *row);
 void orc_mjenv_get_state(const orc_mjenv *e, double *s);
 void orc_mjenv_set_state(orc_mjenv *e, const double *s);
 #endif

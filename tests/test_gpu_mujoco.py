@@ -14,16 +14,22 @@ import gymnasium_amd
 
 pytestmark = pytest.mark.gpu
 IDS = {"half_cheetah": "HalfCheetah-v5", "ant": "Ant-v5", "humanoid": "Humanoid-v5"}
+# more robots on the same physics core (one-lane kernel), their own glue
+MORE = {"hopper": "Hopper-v5", "walker2d": "Walker2d-v5", "inverted_pendulum": "InvertedPendulum-v5",
+        "inverted_double_pendulum": "InvertedDoublePendulum-v5"}
+ALL = {**IDS, **MORE}
+NSTATE = {"half_cheetah": 17, "ant": 27, "humanoid": 45, "hopper": 11, "walker2d": 17, "inverted_pendulum": 4, "inverted_double_pendulum": 0}
+FIRST_INFO = {"inverted_pendulum": ("reward_survive",), "inverted_double_pendulum": ("reward_survive", "distance_penalty", "velocity_penalty")}
 
 
-@pytest.mark.parametrize("name", list(IDS))
+@pytest.mark.parametrize("name", list(ALL))
 def test_reset_bit_exact_and_windowed_parity(name, oracle_factory):
     n, window, T = (256, 10, 60) if name != "humanoid" else (128, 5, 40)
-    gpu = gymnasium_amd.make_vec(IDS[name], num_envs=n)
-    cpu = gymnasium_amd.make_vec(IDS[name], num_envs=n, _engine_factory=oracle_factory)
+    gpu = gymnasium_amd.make_vec(ALL[name], num_envs=n)
+    cpu = gymnasium_amd.make_vec(ALL[name], num_envs=n, _engine_factory=oracle_factory)
     og, _ = gpu.reset(seed=11)
     oc, _ = cpu.reset(seed=11)
-    nstate = {"half_cheetah": 17, "ant": 27, "humanoid": 45}[name]  # qpos / qvel part: pure NumPy-stream arithmetic
+    nstate = NSTATE[name]  # qpos / qvel part: pure NumPy-stream arithmetic (the double pendulum shows sin / cos of it: tolerance)
     assert og.dtype == np.float64 and np.array_equal(og[:, :nstate], oc[:, :nstate]), "reset state must be bit-exact"
     # the humanoid's reset observation also shows cinert / cvel of the forward pass at the reset state (computed quantities)
     np.testing.assert_allclose(og[:, nstate:], oc[:, nstate:], rtol=1e-9, atol=1e-9)
@@ -38,7 +44,7 @@ def test_reset_bit_exact_and_windowed_parity(name, oracle_factory):
         worst, worst_r = max(worst, float(np.abs(og - oc).max())), max(worst_r, float(np.abs(rg - rc).max()))
         np.testing.assert_allclose(og, oc, rtol=1e-5, atol=1e-5, err_msg=f"{name} obs t={t}")
         np.testing.assert_allclose(rg, rc, rtol=1e-5, atol=1e-5, err_msg=f"{name} reward t={t}")
-        for k in ("x_position", "x_velocity", "reward_forward", "reward_ctrl"):
+        for k in FIRST_INFO.get(name, ("x_position", "x_velocity", "reward_forward", "reward_ctrl")):
             np.testing.assert_allclose(ig[k], ic[k], rtol=1e-5, atol=1e-5, err_msg=k)
             assert np.array_equal(ig["_" + k], ic["_" + k])
         if (t + 1) % window == 0:
@@ -73,13 +79,13 @@ def test_free_running_divergence_report(name, oracle_factory):
     gpu.close(), cpu.close()
 
 
-@pytest.mark.parametrize("name", list(IDS))
+@pytest.mark.parametrize("name", list(ALL))
 def test_fused_rollout_equals_stepping(name):
     import torch
 
     n, T = (128, 12) if name != "humanoid" else (64, 6)
-    a = gymnasium_amd.make_vec(IDS[name], num_envs=n, output="torch")
-    b = gymnasium_amd.make_vec(IDS[name], num_envs=n, output="torch")
+    a = gymnasium_amd.make_vec(ALL[name], num_envs=n, output="torch")
+    b = gymnasium_amd.make_vec(ALL[name], num_envs=n, output="torch")
     a.reset(seed=3), b.reset(seed=3)
     a.action_space.seed(7), b.action_space.seed(7)
     out = a.rollout(T)

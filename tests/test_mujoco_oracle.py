@@ -266,3 +266,66 @@ def test_humanoid_pgs50_residual_vs_converged_newton():
     rel = np.abs(an - ap).max() / np.abs(an).max()
     print(f"PGS/50 vs converged Newton: max relative qacc difference {rel:.2e}, PGS sweeps {dp.get('solver_iter')}")
     assert rel < 5e-2
+
+
+# ---- Hopper / Walker2d / InvertedPendulum / InvertedDoublePendulum on the same pipeline ----------------------
+MORE_SPECS = {  # nq, nv, nu, nbody, njnt (test_mujoco_v5.py:526-580), obs, frame_skip * timestep, reset-noise scale, uniform velocity noise?
+    "hopper": ("Hopper-v5", 6, 6, 3, 5, 6, 11, 0.008, 5e-3, True), "walker2d": ("Walker2d-v5", 9, 9, 6, 8, 9, 17, 0.008, 5e-3, True),
+    "inverted_pendulum": ("InvertedPendulum-v5", 2, 2, 1, 3, 2, 4, 0.04, 0.01, True),
+    "inverted_double_pendulum": ("InvertedDoublePendulum-v5", 3, 3, 1, 4, 3, 9, 0.05, 0.1, False)}
+
+
+@pytest.mark.parametrize("name", list(MORE_SPECS))
+def test_more_robots_model_counts_reset_streams_and_rewards(name, oracle_factory):
+    env_id, nq, nv, nu, nbody, njnt, obs_dim, dt, scale, uniform_vel = MORE_SPECS[name]
+    m = cp.compile_model(name)
+    assert (m.nq, m.nv, m.nu, m.nbody, m.njnt) == (nq, nv, nu, nbody, njnt)
+    if name in ("hopper", "walker2d"):  # rootz has ref="1.25" (hopper.xml:19): init_qpos[1] = 1.25, the rest 0
+        assert m.qpos0[1] == 1.25 and not np.delete(m.qpos0, 1).any()
+    if name == "inverted_double_pendulum":  # test_mujoco_v5.py:489-498: the tip site starts 1.2 above the rail
+        d = omj.OracleModel(name).make_data()
+        d.reset(), d.forward()
+        assert abs(d.get("xpos")[-1][2] + 0.6 - 1.2) < 1e-15
+    pend = name.startswith("inverted")
+    kw = {} if pend else dict(exclude_current_positions_from_observation=False)
+    env = gymnasium_amd.make_vec(env_id, num_envs=3, _engine_factory=oracle_factory, **kw)
+    assert env.single_observation_space.shape == ((obs_dim + (0 if pend else 1)),) and env.single_action_space.shape == (nu,)
+    obs, _ = env.reset(seed=100)
+    if name != "inverted_double_pendulum":  # (its observation is sin / cos of the state)
+        for i in range(3):
+            g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(100 + i)))
+            qpos = m.qpos0 + g.uniform(low=-scale, high=scale, size=m.nq)
+            qvel = g.uniform(low=-scale, high=scale, size=m.nv) if uniform_vel else scale * g.standard_normal(m.nv)
+            assert np.array_equal(obs[i, :m.nq], qpos) and np.array_equal(obs[i, m.nq:m.nq + m.nv], qvel)
+            assert np.array_equal(env.get_rng_state()[i], gymnasium_amd._native.pcg_words(g))
+    env.close()
+    a = gymnasium_amd.make_vec(env_id, num_envs=4, _engine_factory=oracle_factory)
+    b = gymnasium_amd.make_vec(env_id, num_envs=4, _engine_factory=oracle_factory)
+    assert a.single_observation_space.shape == (obs_dim,) and a.single_observation_space.dtype == np.float64
+    oa, _ = a.reset(seed=9)
+    ob, _ = b.reset(seed=9)
+    assert np.array_equal(oa, ob)
+    a.action_space.seed(1)
+    prev_done, prev_x, terms = np.zeros(4, dtype=bool), None, 0
+    for t in range(120):
+        act = a.action_space.sample()
+        oa, ra, tea, tra, ia = a.step(act)
+        ob, rb, teb, _, _ = b.step(act)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(tea, teb) and np.isfinite(oa).all()
+        live = ~prev_done
+        if name in ("hopper", "walker2d"):
+            total = ia["reward_forward"] + ia["reward_ctrl"] + ia["reward_survive"]
+            if prev_x is not None:  # info velocity = finite difference of info positions (test_mujoco_v5.py:116-152)
+                np.testing.assert_allclose(ia["x_velocity"][live & ~was_reset], ((ia["x_position"] - prev_x) / dt)[live & ~was_reset], rtol=1e-9, atol=1e-9)
+            prev_x, was_reset = ia["x_position"].copy(), prev_done.copy()
+        elif name == "inverted_pendulum":
+            total = ia["reward_survive"]
+            assert np.array_equal(tea[live], np.abs(oa[live, 1]) > 0.2)
+        else:
+            total = ia["reward_survive"] + ia["distance_penalty"] + ia["velocity_penalty"]
+        np.testing.assert_allclose(ra[live], total[live], rtol=1e-12, atol=1e-12)
+        assert (ra[prev_done] == 0).all() and not tea[prev_done].any()
+        terms += int(tea.sum())
+        prev_done = tea | tra
+    assert terms > 0, "a random policy ends episodes of these robots within 120 steps"
+    a.close(), b.close()
