@@ -17,7 +17,7 @@ from .mujoco.envs import (  # noqa: F401
 )
 from .mujoco.envs import ENV_TABLE as _MUJOCO
 
-from .toy_text import CliffWalkingVectorEnv, FrozenLakeVectorEnv, TaxiVectorEnv  # noqa: F401
+from .toy_text import BlackjackVectorEnv, CliffWalkingVectorEnv, FrozenLakeVectorEnv, TaxiVectorEnv  # noqa: F401
 from .toy_text import ENV_TABLE as _TOY
 
 ENV_TABLE = {**_CLASSIC, **_MUJOCO, **_TOY}

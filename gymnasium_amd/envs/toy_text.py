@@ -10,6 +10,7 @@ and integer lookups, so trajectories equal the reference's bit for bit (tests/go
   FrozenLakeVectorEnv    gymnasium/envs/toy_text/frozen_lake.py:226-360  (FrozenLake-v1, FrozenLake8x8-v1)
   CliffWalkingVectorEnv  gymnasium/envs/toy_text/cliffwalking.py:103-207 (CliffWalking-v1, CliffWalkingSlippery-v1)
   TaxiVectorEnv          gymnasium/envs/toy_text/taxi.py:163-472         (Taxi-v4, is_rainy=False, fickle_passenger=False)
+  BlackjackVectorEnv     gymnasium/envs/toy_text/blackjack.py:56-232     (Blackjack-v1; integer card game, not a table)
 """
 from __future__ import annotations
 
@@ -250,7 +251,43 @@ class TaxiVectorEnv(TabularVectorEnv):
 
 
 # id -> (creator, max_episode_steps, reward_threshold, kwargs): gymnasium/envs/__init__.py:139-171
+class BlackjackVectorEnv(HipVectorEnv):
+    """Blackjack-v1 (gymnasium/envs/toy_text/blackjack.py:56-232): not a table lookup -- cards are drawn with
+    ``np_random.choice(deck)`` (Lemire-bounded 32-bit halves of the PCG64 stream), the dealer plays out on `stick` -- but every
+    quantity is an integer, so the kernel is bit-exact.  Observations are the reference's Tuple(Discrete(32), Discrete(11),
+    Discrete(2)) batched by SyncVectorEnv: a tuple of three int64 arrays (player sum, dealer's showing card, usable ace)."""
+
+    KIND = "blackjack"
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, natural: bool = False, sab: bool = False, **kwargs):
+        self.natural, self.sab = bool(natural), bool(sab)
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
+
+    def _single_spaces(self):
+        return spaces.Tuple((spaces.Discrete(32), spaces.Discrete(11), spaces.Discrete(2))), spaces.Discrete(2)
+
+    def _engine_params(self):
+        return (float(self.natural), float(self.sab))
+
+    def _parse_reset_options(self, options):
+        return None
+
+    def _tuple(self, obs):  # (N, 3) -> the batched Tuple observation (vector/utils/space_utils.py concatenate for Tuple spaces)
+        return (obs[:, 0], obs[:, 1], obs[:, 2])
+
+    def reset(self, *, seed=None, options=None):
+        obs, info = super().reset(seed=seed, options=options)
+        return self._tuple(obs), info
+
+    def step(self, actions):
+        obs, r, te, tr, info = super().step(actions)
+        if "final_obs" in info:
+            info["final_obs"] = np.array([None if f is None else tuple(int(x) for x in f) for f in info["final_obs"]], dtype=object)
+        return self._tuple(obs), r, te, tr, info
+
+
 ENV_TABLE = {
+    "Blackjack-v1": (BlackjackVectorEnv, None, None, {"sab": True, "natural": False}),   # envs/__init__.py:134-138
     "FrozenLake-v1": (FrozenLakeVectorEnv, 100, 0.70, {"map_name": "4x4"}),
     "FrozenLake8x8-v1": (FrozenLakeVectorEnv, 200, 0.85, {"map_name": "8x8"}),
     "CliffWalking-v1": (CliffWalkingVectorEnv, None, None, {}),

@@ -215,8 +215,52 @@ class MultiDiscrete(Space):
                 and np.all(self.nvec == other.nvec) and np.all(self.start == other.start))
 
 
+class Tuple(Space):
+    """A product of spaces (spaces/tuple.py:17-150): samples are tuples, one element per sub-space."""
+
+    def __init__(self, spaces, seed=None):
+        self.spaces = tuple(spaces)
+        for sp in self.spaces:
+            assert isinstance(sp, Space), f"{sp} does not inherit from `gymnasium.Space`. Actual Type: {type(sp)}"
+        super().__init__(None, None, None)
+        if seed is not None:
+            self.seed(seed)
+
+    def seed(self, seed=None):
+        """spaces/tuple.py:58-97: None -> every sub-space seeds itself; int -> sub-seeds drawn from one generator."""
+        if seed is None:
+            return tuple(sp.seed(None) for sp in self.spaces)
+        if isinstance(seed, (int, np.integer)):
+            super().seed(int(seed))
+            subseeds = self.np_random.integers(np.iinfo(np.int32).max, size=len(self.spaces))
+            return tuple(sp.seed(int(ss)) for sp, ss in zip(self.spaces, subseeds))
+        return tuple(sp.seed(ss) for sp, ss in zip(self.spaces, seed))
+
+    def sample(self, mask=None, probability=None):
+        return tuple(sp.sample() for sp in self.spaces)
+
+    def contains(self, x) -> bool:
+        if isinstance(x, (list, np.ndarray)):
+            x = tuple(x)
+        return isinstance(x, tuple) and len(x) == len(self.spaces) and all(sp.contains(p) for sp, p in zip(self.spaces, x))
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __getitem__(self, i):
+        return self.spaces[i]
+
+    def __repr__(self):
+        return "Tuple(" + ", ".join(str(sp) for sp in self.spaces) + ")"
+
+    def __eq__(self, other):
+        return isinstance(other, Tuple) and self.spaces == other.spaces
+
+
 def batch_space(space, n=1):
-    """n independent copies of ``space`` as one batched space (space_utils.py:51-100; Box and Discrete only)."""
+    """n independent copies of ``space`` as one batched space (space_utils.py:51-100; Box, Discrete and Tuple only)."""
+    if isinstance(space, Tuple):
+        return Tuple(tuple(batch_space(sp, n) for sp in space.spaces), seed=deepcopy(space._np_random))
     if isinstance(space, Box):
         repeats = tuple([n] + [1] * space.low.ndim)
         return Box(low=np.tile(space.low, repeats), high=np.tile(space.high, repeats), dtype=space.dtype,

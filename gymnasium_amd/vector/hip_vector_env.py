@@ -128,7 +128,7 @@ class HipVectorEnv(VectorEnv):
             dev = torch.device("cuda", self._device_index)
             self._tdev = dev
             self._obs_tdtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
-            self._obs_shape = (N,) if eng.obs_dtype is np.int64 else (N, eng.obs_dim)  # Discrete states batch to MultiDiscrete: (N,)
+            self._obs_shape = (N,) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (N, eng.obs_dim)  # Discrete states batch to MultiDiscrete: (N,)
             self._obs = torch.zeros(self._obs_shape, dtype=self._obs_tdtype, device=dev)
             self._rew = torch.zeros((N,), dtype=torch.float64, device=dev)
             self._term = torch.zeros((N,), dtype=torch.bool, device=dev)
@@ -139,7 +139,7 @@ class HipVectorEnv(VectorEnv):
             self._ep_l = torch.zeros((N,), dtype=torch.int32, device=dev) if self.record_episode_statistics else None
             self._loc = _native.MI_DEVICE
         else:
-            self._obs_shape = (N,) if eng.obs_dtype is np.int64 else (N, eng.obs_dim)
+            self._obs_shape = (N,) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (N, eng.obs_dim)
             self._obs = np.zeros(self._obs_shape, dtype=eng.obs_dtype)
             self._rew = np.zeros((N,), dtype=np.float64)
             self._term = np.zeros((N,), dtype=np.bool_)

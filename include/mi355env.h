@@ -55,7 +55,10 @@ typedef enum mi_env_kind {
     MI_ENV_WALKER2D = 10,                  /* envs/mujoco/walker2d_v5.py:151-345 + assets/walker2d_v5.xml                 */
     MI_ENV_INVERTED_PENDULUM = 11,         /* envs/mujoco/inverted_pendulum_v5.py:100-199 + assets/inverted_pendulum.xml  */
     MI_ENV_INVERTED_DOUBLE_PENDULUM = 12,  /* envs/mujoco/inverted_double_pendulum_v5.py:125-246 + its asset              */
-    MI_ENV_KIND_COUNT = 13
+    /* ToyText Blackjack-v1: envs/toy_text/blackjack.py:17-232 (Generator.choice card draws, dealer play-out, natural / sab rules);
+     * observation row = int64[3] (player sum, dealer's showing card, usable ace); params[0] = natural, params[1] = sab */
+    MI_ENV_BLACKJACK = 13,
+    MI_ENV_KIND_COUNT = 14
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */

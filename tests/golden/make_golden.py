@@ -322,6 +322,24 @@ def make_toytext():
         v.close()
 
 
+def make_blackjack():
+    """Blackjack-v1 (toy_text/blackjack.py): gym.make_vec(id, 8, "sync") trajectories for the registered rules (sab) and for
+    natural=True; observations are the batched Tuple (three int64 arrays), stored as (T, 3, N)."""
+    for key, kw in (("sab", {}), ("natural", {"natural": True, "sab": False})):
+        v = gym.make_vec("Blackjack-v1", num_envs=8, vectorization_mode="sync", **kw)
+        o0, _ = v.reset(seed=21)
+        v.action_space.seed(4)
+        A, O, R, TE, TR = [], [], [], [], []
+        for _ in range(400):
+            a = v.action_space.sample()
+            o, r, te, tr, _ = v.step(a)
+            A.append(a), O.append(np.stack(o)), R.append(np.asarray(r, dtype=np.float64)), TE.append(te), TR.append(tr)
+        save(f"toytext_blackjack_{key}.npz", obs0=np.stack(o0), actions=np.stack(A), obs=np.stack(O), reward=np.stack(R), term=np.stack(TE),
+             trunc=np.stack(TR), rng_after=np.stack([pcg_words(x.unwrapped.np_random) for x in v.envs]),
+             natural=np.bool_(kw.get("natural", False)), sab=np.bool_(kw.get("sab", True)))
+        v.close()
+
+
 def make_wrappers():
     """The reference's stateful vector wrappers on its own SyncVectorEnv: raw batches (inputs) and wrapped outputs.
 
@@ -378,6 +396,9 @@ if __name__ == "__main__":
     if "--toytext-only" in sys.argv:
         make_toytext()
         sys.exit(0)
+    if "--blackjack-only" in sys.argv:
+        make_blackjack()
+        sys.exit(0)
     if "--wrappers-only" in sys.argv:
         make_wrappers()
         sys.exit(0)
@@ -392,3 +413,4 @@ if __name__ == "__main__":
     make_action_samples()
     make_toytext()
     make_wrappers()
+    make_blackjack()

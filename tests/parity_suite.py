@@ -346,3 +346,25 @@ def check_toytext(key, factory):
             assert np.array_equal(info["action_mask"], g["action_mask"][t])
     assert np.array_equal(env.get_rng_state(), g["rng_after"])
     env.close()
+
+
+
+def check_blackjack(key, factory):
+    """Blackjack-v1 against the reference recording (tests/golden/toytext_blackjack_<key>.npz): every observation, reward, flag
+    and the final generator states, bit for bit (integer card game: Generator.choice draws, dealer play-out, natural / sab rules)."""
+    import pytest
+
+    g = golden(f"toytext_blackjack_{key}.npz")
+    env = gymnasium_amd.make_vec("Blackjack-v1", num_envs=8, natural=bool(g["natural"]), sab=bool(g["sab"]), _engine_factory=factory)
+    obs, info = env.reset(seed=21)
+    assert isinstance(obs, tuple) and len(obs) == 3 and all(o.dtype == np.int64 for o in obs) and info == {}
+    assert np.array_equal(np.stack(obs), g["obs0"])
+    for t in range(g["actions"].shape[0]):
+        obs, r, te, tr, info = env.step(g["actions"][t])
+        assert np.array_equal(np.stack(obs), g["obs"][t]), t
+        assert np.array_equal(r, g["reward"][t]) and r.dtype == np.float64, t
+        assert np.array_equal(te, g["term"][t]) and np.array_equal(tr, g["trunc"][t]), t
+    assert np.array_equal(env.get_rng_state(), g["rng_after"])
+    with pytest.raises(AssertionError):
+        env.step(np.full(8, 2))
+    env.close()
