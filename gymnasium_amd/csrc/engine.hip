@@ -704,11 +704,92 @@ MI_DEV void tab_store(const DevEnv &d, int i, const TabLane &L) {
     d.meta[i] = (L.elapsed & kElapsedMask) | (L.flags << kFlagShift);
     d.ep_ret[i] = L.ep_ret, d.ep_len[i] = L.ep_len;
 }
+// ---- Blackjack-v1 (gymnasium/envs/toy_text/blackjack.py:17-232) rides on the tabular kernels (d.tab.nS < 0) --------------
+// state word  = player raw sum | has-ace << 6 | two-cards << 7 | dealer card 0 << 8 | dealer card 1 << 12
+// second word = the generator's buffered 32-bit half (1 << 32 | value; 0 = empty): draw_card is np_random.choice(deck) =
+// Lemire's bounded uint32 on next_uint32, and PCG64's next_uint32 hands out the low, then the high half of one 64-bit output.
+MI_DEV bool is_blackjack(const DevEnv &d) { return d.tab.nS < 0; }
+MI_DEV uint32_t bj_next32(Pcg64 &rng, double &aux_slot) {
+    const uint64_t aux = (uint64_t)aux_slot;
+    if (aux >> 32) {
+        aux_slot = 0.0;
+        return (uint32_t)aux;
+    }
+    const uint64_t x = rng.next64();
+    aux_slot = (double)((1ull << 32) | (x >> 32));
+    return (uint32_t)x;
+}
+MI_DEV uint32_t bj_bounded(Pcg64 &rng, double &aux, uint32_t n) {
+    uint64_t m = (uint64_t)bj_next32(rng, aux) * n;
+    uint32_t left = (uint32_t)m;
+    if (left < n) {
+        const uint32_t thr = (uint32_t)((0x100000000ull - n) % n);
+        while (left < thr) m = (uint64_t)bj_next32(rng, aux) * n, left = (uint32_t)m;
+    }
+    return (uint32_t)(m >> 32);
+}
+MI_DEV int bj_card(Pcg64 &rng, double &aux) {  // deck = [1..10, 10, 10, 10]
+    const uint32_t k = bj_bounded(rng, aux, 13);
+    return k < 9 ? (int)k + 1 : 10;
+}
+MI_DEV int bj_sum_hand(int raw, int ace) { return (ace && raw + 10 <= 21) ? raw + 10 : raw; }
+MI_DEV void bj_obs(double s, int64_t *o) {  // _get_obs: (player sum with a usable ace as 11, dealer's first card, usable ace)
+    const int64_t p = (int64_t)s;
+    const int psum = (int)(p & 63), pace = (int)((p >> 6) & 1);
+    o[0] = bj_sum_hand(psum, pace), o[1] = (p >> 8) & 15, o[2] = pace && psum + 10 <= 21;
+}
+MI_DEV void bj_reset(Pcg64 &rng, double &s, double &aux) {  // blackjack.py:181-202 incl. the render-only suit / face draws
+    const int d0 = bj_card(rng, aux), d1 = bj_card(rng, aux), p0 = bj_card(rng, aux), p1 = bj_card(rng, aux);
+    (void)bj_bounded(rng, aux, 4);
+    if (d0 == 10) (void)bj_bounded(rng, aux, 3);
+    s = (double)((p0 + p1) | ((int)(p0 == 1 || p1 == 1) << 6) | (1 << 7) | (d0 << 8) | (d1 << 12));
+}
+MI_DEV void bj_step(Pcg64 &rng, double &s, double &aux, int64_t action, bool natural, bool sab, double &reward, bool &te) {  // :143-174
+    const int64_t p = (int64_t)s;
+    int psum = (int)(p & 63), pace = (int)((p >> 6) & 1), ptwo = (int)((p >> 7) & 1);
+    const int d0 = (int)((p >> 8) & 15), d1 = (int)((p >> 12) & 15);
+    if (action) {  // hit
+        const int c = bj_card(rng, aux);
+        psum += c, pace |= c == 1, ptwo = 0;
+        te = bj_sum_hand(psum, pace) > 21;
+        reward = te ? -1.0 : 0.0;
+    } else {  // stick: the dealer draws to 17, then the hands are scored
+        int dsum = d0 + d1, dace = d0 == 1 || d1 == 1, dtwo = 1;
+        while (bj_sum_hand(dsum, dace) < 17) {
+            const int c = bj_card(rng, aux);
+            dsum += c, dace |= c == 1, dtwo = 0;
+        }
+        const int ph = bj_sum_hand(psum, pace), dh = bj_sum_hand(dsum, dace);
+        const int ps = ph > 21 ? 0 : ph, ds = dh > 21 ? 0 : dh;
+        te = true;
+        reward = (double)(ps > ds) - (double)(ps < ds);
+        const bool pnat = ptwo && pace && psum == 11, dnat = dtwo && dace && dsum == 11;  // sorted(hand) == [1, 10]
+        if (sab && pnat && !dnat)
+            reward = 1.0;
+        else if (!sab && natural && pnat && reward == 1.0)
+            reward = 1.5;
+    }
+    s = (double)(psum | (pace << 6) | (ptwo << 7) | (d0 << 8) | (d1 << 12));
+}
+
 MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L) {
     Pcg64 rng = load_rng(d, i);
+    if (is_blackjack(d)) {
+        bj_reset(rng, L.s, L.prob);
+        store_rng_state(d, i, rng);
+        L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+        return;
+    }
     L.s = (double)tab_categorical(d.tab.isd, d.tab.nS, rng);
     store_rng_state(d, i, rng);
     L.prob = 1.0, L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+}
+// observation row of a tabular lane: the state index, or Blackjack's three integers
+MI_DEV void tab_write_obs(const DevEnv &d, double s, int64_t *base, size_t row) {
+    if (is_blackjack(d))
+        bj_obs(s, base + 3 * row);
+    else
+        base[row] = (int64_t)s;
 }
 template <int MODE>
 MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t &obs, int64_t &final_obs, bool &has_final, double &reward,
@@ -726,12 +807,17 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
             *d.error = kErrInvalidAction;
             a = 0;
         }
-        const size_t cell = (size_t)L.s * d.tab.nA + (size_t)a, row = cell * d.tab.K;
         Pcg64 rng = load_rng(d, i);
-        const int k = tab_categorical(d.tab.csprob + row, d.tab.count[cell], rng);
-        store_rng_state(d, i, rng);
-        L.s = (double)d.tab.next[row + k], L.prob = d.tab.prob[row + k];
-        reward = d.tab.reward[row + k], te = d.tab.term[row + k] != 0;
+        if (is_blackjack(d)) {
+            bj_step(rng, L.s, L.prob, a, d.P.p[0] != 0.0, d.P.p[1] != 0.0, reward, te);
+            store_rng_state(d, i, rng);
+        } else {
+            const size_t cell = (size_t)L.s * d.tab.nA + (size_t)a, row = cell * d.tab.K;
+            const int k = tab_categorical(d.tab.csprob + row, d.tab.count[cell], rng);
+            store_rng_state(d, i, rng);
+            L.s = (double)d.tab.next[row + k], L.prob = d.tab.prob[row + k];
+            reward = d.tab.reward[row + k], te = d.tab.term[row + k] != 0;
+        }
         L.elapsed += 1;
         tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;
         L.ep_ret += reward, L.ep_len += 1;
@@ -774,14 +860,14 @@ __global__ __launch_bounds__(kBlock) void tab_step_kernel(DevEnv d, TabStepPtrs 
         bool te, tr, has_final;
         tab_lane_step<MODE>(d, i, L, io.actions[i], obs, fin, has_final, reward, te, tr, out_ret, out_len, st);
         tab_store(d, i, L);
-        if (io.obs) io.obs[i] = obs;
+        if (io.obs) tab_write_obs(d, (double)obs, io.obs, (size_t)i);
         if (io.reward) io.reward[i] = reward;
         if (io.terminated) io.terminated[i] = te;
         if (io.truncated) io.truncated[i] = tr;
-        if (io.final_obs && has_final) io.final_obs[i] = fin;
+        if (io.final_obs && has_final) tab_write_obs(d, (double)fin, io.final_obs, (size_t)i);
         if (io.ep_ret) io.ep_ret[i] = out_ret;
         if (io.ep_len) io.ep_len[i] = out_len;
-        if (io.info) io.info[i] = L.prob;
+        if (io.info && !is_blackjack(d)) io.info[i] = L.prob;
     }
     block_accumulate(d, st);
 }
@@ -793,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void tab_reset_kernel(DevEnv d, const uint8
     L.flags &= ~kNeedsReset;
     tab_autoreset(d, i, L);
     tab_store(d, i, L);
-    if (obs) obs[i] = (int64_t)L.s;
+    if (obs) tab_write_obs(d, L.s, obs, (size_t)i);
 }
 template <int MODE, bool SAMPLE>
 __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
@@ -827,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
             int32_t out_len;
             bool te, tr, has_final;
             tab_lane_step<MODE>(d, i, L, a, obs, fin, has_final, reward, te, tr, out_ret, out_len, st);
-            if (io.obs) static_cast<int64_t *>(io.obs)[t * N + i] = obs;
+            if (io.obs) tab_write_obs(d, (double)obs, static_cast<int64_t *>(io.obs), t * N + i);
             if (io.reward) io.reward[t * N + i] = reward;
             if (io.terminated) io.terminated[t * N + i] = te;
             if (io.truncated) io.truncated[t * N + i] = tr;
@@ -842,6 +928,7 @@ __global__ void seed_words_kernel(DevEnv d, const uint64_t *words, const uint8_t
     if (i >= d.N || (mask && !mask[i])) return;
 #pragma unroll
     for (int k = 0; k < 4; k++) d.rng[(size_t)k * d.N + i] = words[(size_t)4 * i + k];
+    if (d.tab.nS < 0) d.state[(size_t)d.N + i] = 0.0;  // Blackjack: a fresh Generator has no buffered 32-bit half
 }
 
 __global__ void seed_sequence_kernel(DevEnv d, uint64_t first_seed, const uint8_t *mask) {
@@ -853,6 +940,7 @@ __global__ void seed_sequence_kernel(DevEnv d, uint64_t first_seed, const uint8_
     r.srandom(w);
     d.rng[i] = (uint64_t)(r.state >> 64), d.rng[(size_t)d.N + i] = (uint64_t)r.state;
     d.rng[(size_t)2 * d.N + i] = (uint64_t)(r.inc >> 64), d.rng[(size_t)3 * d.N + i] = (uint64_t)r.inc;
+    if (d.tab.nS < 0) d.state[(size_t)d.N + i] = 0.0;  // Blackjack: a fresh Generator has no buffered 32-bit half
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -950,7 +1038,7 @@ typedef mjx::MjEnv<mjx::Walker2dModel, mjx::kWalker2d> Walker2dEnv;
 typedef mjx::MjEnv<mjx::InvertedPendulumModel, mjx::kInvertedPendulum> InvertedPendulumEnv;
 typedef mjx::MjEnv<mjx::InvertedDoublePendulumModel, mjx::kInvertedDoublePendulum> InvertedDoublePendulumEnv;
 bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM); }
-bool is_tab(int kind) { return kind == MI_ENV_TABULAR; }
+bool is_tab(int kind) { return kind == MI_ENV_TABULAR || kind == MI_ENV_BLACKJACK; }  // Blackjack rides on the tabular kernels
 template <class F>
 int dispatch_mj(int kind, F &&f) {
     switch (kind) {
@@ -1140,6 +1228,11 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         if (serial && serial[0] == '1') v->mj_coop = false;
         if (coop && coop[0] == '1') v->mj_coop = true;
         if (cfg->kind >= MI_ENV_HOPPER) v->mj_coop = false;  // the small robots are built for the one-lane kernel only
+    } else if (cfg->kind == MI_ENV_BLACKJACK) {
+        const mi_layout l = {3, MI_I64, 1, MI_I64, 2, 0, {0, 0}};
+        v->lay = l;
+        v->d.tab.nS = -1, v->d.tab.nA = 2, v->d.tab.K = 0;  // the marker the kernels branch on (is_blackjack)
+        v->tab_loaded = true;
     } else if (is_tab(cfg->kind)) {
         const mi_layout l = {1, MI_I64, 1, MI_I64, 2, 1, {0, 0}};
         v->lay = l;
@@ -1389,7 +1482,7 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
 
 int mi_tabular_load(mi_vecenv *v, const mi_tabular_table *t) {
     if (!v || !t) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
-    if (!is_tab(v->cfg.kind)) return fail(MI_ERR_INVALID_ARGUMENT, "not a tabular environment");
+    if (v->cfg.kind != MI_ENV_TABULAR) return fail(MI_ERR_INVALID_ARGUMENT, "not a tabular environment");
     if (t->num_states < 1 || t->num_actions < 1 || t->max_outcomes < 1) return fail(MI_ERR_INVALID_ARGUMENT, "empty table");
     if (set_device(v)) return MI_ERR_HIP;
     const size_t cells = (size_t)t->num_states * t->num_actions, n = cells * t->max_outcomes;
