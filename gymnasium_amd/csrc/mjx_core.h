@@ -177,6 +177,7 @@ struct Data {
     double cinert[NB][10], cdof[NV][6], cvel[NB][6];
     double qM[NTRI], qL[NTRI];
     double qfrc_smooth[NV], qfrc_actuator[NV], qacc_smooth[NV], qacc[NV], qfrc_constraint[NV];
+    double qacc_warm[NV];  // qacc of the previous forward pass (mj qacc_warmstart): where a constrained solve starts
     int ncon, nlimit;
     Contact<M> con[MAXCON];
     // joint-limit rows
@@ -713,13 +714,13 @@ MJX_DEV int solve_newton(Data<M> &d) {
     }();
     double x[NV], grad[NV], dir[NV], H[Data<M>::NTRI], HL[Data<M>::NTRI], dx[NV], Mdx[NV];
 #pragma unroll
-    for (int i = 0; i < NV; i++) x[i] = d.qacc_smooth[i];
+    for (int i = 0; i < NV; i++) x[i] = d.qacc_warm[i];  // warm start; M (x - x_smooth) = M x - qfrc_smooth needs no x_smooth
     const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
     int it = 0;
     for (; it < 50; it++) {
+        sym_mul<NV>(d.qM, x, dx);
 #pragma unroll
-        for (int i = 0; i < NV; i++) dx[i] = x[i] - d.qacc_smooth[i];
-        sym_mul<NV>(d.qM, dx, Mdx);
+        for (int i = 0; i < NV; i++) Mdx[i] = dx[i] - d.qfrc_smooth[i];
 #pragma unroll
         for (int i = 0; i < NV; i++) grad[i] = Mdx[i];
         for (int k = 0; k < Data<M>::NTRI; k++) H[k] = d.qM[k];
@@ -812,7 +813,6 @@ MJX_DEVN void forward(Data<M> &d) {
     double bias[NV];
     com_vel_and_bias<M>(d, bias);  // uses the per-body cinert; crb() then turns cinert into composite inertias
     crb<M>(d);
-    chol_factor<NV>(d.qM, d.qL);
     collision<M>(d);
     make_constraint<M>(d);
 #pragma unroll
@@ -832,13 +832,16 @@ MJX_DEVN void forward(Data<M> &d) {
         d.qfrc_smooth[i] = passive - bias[i] + d.qfrc_actuator[i];
         d.qacc_smooth[i] = d.qfrc_smooth[i];
     }
-    chol_solve<NV>(d.qL, d.qacc_smooth);
-    if (d.nlimit + d.ncon == 0) {
+    if (d.nlimit + d.ncon == 0) {  // unconstrained: one factorisation of M
+        chol_factor<NV>(d.qM, d.qL);
+        chol_solve<NV>(d.qL, d.qacc_smooth);
 #pragma unroll
         for (int i = 0; i < NV; i++) d.qacc[i] = d.qacc_smooth[i], d.qfrc_constraint[i] = 0;
-    } else {
+    } else {  // constrained: Newton from the warm start, M is never factorised by itself (see mjx_coop.h forward())
         solve_newton<M>(d);
     }
+#pragma unroll
+    for (int i = 0; i < NV; i++) d.qacc_warm[i] = d.qacc[i];
 }
 
 template <class M>

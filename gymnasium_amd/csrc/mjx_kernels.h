@@ -206,9 +206,11 @@ struct MjEnv {
         for (int k = 0; k < NQ; k++) d.qpos[k] = s[k];
         for (int k = 0; k < NV; k++) d.qvel[k] = s[NQ + k];
         for (int u = 0; u < NU; u++) d.ctrl[u] = (double)action[u];
+        for (int k = 0; k < NV; k++) d.qacc_warm[k] = s[NQ + NV + k];  // the qacc_warmstart slot of the state row
         const double before[2] = {s[NQ + 2 * NV], s[NQ + 2 * NV + 1]};
         const int frame_skip = (int)P.p[4];
         for (int f = 0; f < frame_skip; f++) mjx::step<M>(d);
+        for (int k = 0; k < NV; k++) s[NQ + NV + k] = d.qacc_warm[k];
         // Cartesian quantities of the LAST forward pass (they lag qpos by one sub-step, as in the reference)
         StepExtras x;
         if (KIND == kInvertedDoublePendulum) {  // the tip site of the LAST forward pass: x and z (the reference's `x, _, y = site_xpos[0]`)
