@@ -23,6 +23,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libmi355env.so (built artefacts are not tracked): build it once so that the CPU-side ABI
+    tests can load it.  Only when it is MISSING -- never a rebuild on the GPU box, where the prebuilt library travels."""
+    so = os.path.join(ROOT, "gymnasium_amd", "csrc", "libmi355env.so")
+    if not os.path.exists(so) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        from gymnasium_amd.csrc import build
+
+        build.build(verbose=False)
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
