@@ -489,7 +489,7 @@ struct Sim {
         double dist, pos[3], frame[9];
     };
     static MJX_DEV void finish(Cand &c, int pair, double dist, const double *pos, const double *n, const double *tangent, bool flip) {
-        c.on = dist < M::pair_margin[pair];
+        c.on = dist < M::pair_margin[uniform_pairs() ? 0 : pair];
         c.dist = dist;
         const double sg = flip ? -1.0 : 1.0;
 #pragma unroll
@@ -659,6 +659,34 @@ struct Sim {
     }
 
     // ---- constraint rows: joint limits (dof role) and contact parameters (contact role) -----------------------------------------
+    // Robots usually give every limited joint (and every contact pair) the same solref / solimp / margin (the MJCF defaults): then
+    // the parameters are compile-time constants instead of per-lane table loads, and the stiffness / damping divisions fold away.
+    static constexpr int first_limited_joint() {
+        for (int j = 0; j < M::NJNT; j++)
+            if (M::jnt_limited[j] && (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)) return j;
+        return 0;
+    }
+    static constexpr bool uniform_limits() {
+        const int f = first_limited_joint();
+        for (int j = 0; j < M::NJNT; j++) {
+            if (!(M::jnt_limited[j] && (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE))) continue;
+            if (M::jnt_margin[j] != M::jnt_margin[f] || M::jnt_solref[j][0] != M::jnt_solref[f][0] || M::jnt_solref[j][1] != M::jnt_solref[f][1])
+                return false;
+            for (int k = 0; k < 5; k++)
+                if (M::jnt_solimp[j][k] != M::jnt_solimp[f][k]) return false;
+        }
+        return true;
+    }
+    static constexpr bool uniform_pairs() {
+        for (int p = 1; p < M::NPAIR; p++) {
+            if (M::pair_margin[p] != M::pair_margin[0] || M::pair_friction[p] != M::pair_friction[0] || M::pair_condim[p] != M::pair_condim[0] ||
+                M::pair_solref[p][0] != M::pair_solref[0][0] || M::pair_solref[p][1] != M::pair_solref[0][1])
+                return false;
+            for (int k = 0; k < 5; k++)
+                if (M::pair_solimp[p][k] != M::pair_solimp[0][k]) return false;
+        }
+        return M::NPAIR > 0;
+    }
     static MJX_DEV void make_constraint(B &bb, R &r, int lane) {
         bool any = false;
         r.lim_on[0] = r.lim_on[1] = false;
@@ -670,11 +698,14 @@ struct Sim {
                 for (int sd = 0; sd < 2; sd++) {
                     const double side = sd == 0 ? -1.0 : 1.0;
                     const double dist = side * (M::jnt_range[j][sd] - value);
-                    if (dist < M::jnt_margin[j]) {
+                    constexpr int JF = first_limited_joint();
+                    const int jp = uniform_limits() ? JF : j;  // constant index -> the table reads below fold into immediates
+                    const double margin = M::jnt_margin[jp];
+                    if (dist < margin) {
                         double k, b, imp, Rr;
-                        row_params<M>(M::jnt_solref[j], M::jnt_solimp[j], dist, M::jnt_margin[j], M::dof_invweight0[lane], k, b, imp, Rr);
+                        row_params<M>(M::jnt_solref[jp], M::jnt_solimp[jp], dist, margin, M::dof_invweight0[lane], k, b, imp, Rr);
                         r.lim_on[sd] = true, r.lim_sign[sd] = -side, r.lim_D[sd] = 1.0 / Rr;
-                        r.lim_aref[sd] = -b * (-side * bb.qvel[lane]) - k * imp * (dist - M::jnt_margin[j]);
+                        r.lim_aref[sd] = -b * (-side * bb.qvel[lane]) - k * imp * (dist - margin);
                         any = true;
                     }
                 }
@@ -692,18 +723,19 @@ struct Sim {
             for (int k = 0; k < 8; k++) r.c_gw[kc][k] = 0;
             if (r.c_on[kc]) {
                 const int p = bb.con_pair[c];
+                const int pp = uniform_pairs() ? 0 : p;  // constant index -> immediates
                 const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
-                const double tran = M::body_invweight0[b1][0] + M::body_invweight0[b2][0], mu = M::pair_friction[p];
-                const bool pyramid = M::pair_condim[p] > 1;
+                const double tran = M::body_invweight0[b1][0] + M::body_invweight0[b2][0], mu = M::pair_friction[pp];
+                const bool pyramid = M::pair_condim[pp] > 1;
                 double k, b, imp, Rr;
-                row_params<M>(M::pair_solref[p], M::pair_solimp[p], bb.con_dist[c], M::pair_margin[p], pyramid ? tran + mu * mu * tran : tran, k, b,
+                row_params<M>(M::pair_solref[pp], M::pair_solimp[pp], bb.con_dist[c], M::pair_margin[pp], pyramid ? tran + mu * mu * tran : tran, k, b,
                               imp, Rr);
                 if (pyramid) {
                     Rr = 2 * mu * mu * Rr;
                     if (Rr < kMinVal) Rr = kMinVal;
                 }
                 r.c_b1[kc] = b1, r.c_b2[kc] = b2, r.c_dim[kc] = pyramid ? 3 : 1, r.c_mu[kc] = mu;
-                r.c_D[kc] = 1.0 / Rr, r.c_kterm[kc] = -k * imp * (bb.con_dist[c] - M::pair_margin[p]), r.c_b[kc] = b;
+                r.c_D[kc] = 1.0 / Rr, r.c_kterm[kc] = -k * imp * (bb.con_dist[c] - M::pair_margin[pp]), r.c_b[kc] = b;
                 contact_vel(bb, bb.cvel, c, b1, b2, r.c_jv[kc]);  // cvel IS the twist field of qvel
                 any = true;
             }
@@ -1077,7 +1109,7 @@ struct Sim {
         constexpr double h = M::TIMESTEP;
         constexpr int NSTAGE = M::INTEGRATOR == 0 ? 1 : 4;
         const bool isdof = lane < NV;
-        const double A[4] = {0.0, 0.5, 0.5, 1.0}, Bw[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+        // RK4 tableau as selects on the stage index: sub-diagonal (0.5, 0.5, 1) and weights (1/6, 1/3, 1/3, 1/6)
         double v0 = 0, sumv = 0, suma = 0;
 #pragma unroll 1
         for (int i = 0; i < NSTAGE; i++) {
@@ -1092,12 +1124,13 @@ struct Sim {
                     for (int k = lane; k < NQ; k += G) bb.q0[k] = bb.qpos[k];
                 }
                 const double fv = isdof ? bb.qvel[lane] : 0.0, fa = r.qacc;
+                const double bw = (i == 0 || i == 3) ? 1.0 / 6 : 1.0 / 3, anext = i == 2 ? 1.0 : 0.5;
                 if (i == 0)
-                    sumv = Bw[0] * fv, suma = Bw[0] * fa;
+                    sumv = bw * fv, suma = bw * fa;
                 else
-                    sumv += Bw[i] * fv, suma += Bw[i] * fa;
+                    sumv += bw * fv, suma += bw * fa;
                 const bool last = i == NSTAGE - 1;
-                const double dv = last ? sumv : A[i + 1 < 4 ? i + 1 : 3] * fv, da = last ? suma : A[i + 1 < 4 ? i + 1 : 3] * fa;
+                const double dv = last ? sumv : anext * fv, da = last ? suma : anext * fa;
                 coop_sync();  // every lane has read the stage's qpos / qvel
                 if (isdof) bb.dv[lane] = dv, bb.qvel[lane] = v0 + h * da;
                 if (i > 0)
