@@ -1037,7 +1037,8 @@ typedef mjx::MjEnv<mjx::HopperModel, mjx::kHopper> HopperEnv;
 typedef mjx::MjEnv<mjx::Walker2dModel, mjx::kWalker2d> Walker2dEnv;
 typedef mjx::MjEnv<mjx::InvertedPendulumModel, mjx::kInvertedPendulum> InvertedPendulumEnv;
 typedef mjx::MjEnv<mjx::InvertedDoublePendulumModel, mjx::kInvertedDoublePendulum> InvertedDoublePendulumEnv;
-bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM); }
+typedef mjx::MjEnv<mjx::ReacherModel, mjx::kReacher> ReacherEnv;
+bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER; }
 bool is_tab(int kind) { return kind == MI_ENV_TABULAR || kind == MI_ENV_BLACKJACK; }  // Blackjack rides on the tabular kernels
 template <class F>
 int dispatch_mj(int kind, F &&f) {
@@ -1049,6 +1050,7 @@ int dispatch_mj(int kind, F &&f) {
     case MI_ENV_WALKER2D: return f(Walker2dEnv());
     case MI_ENV_INVERTED_PENDULUM: return f(InvertedPendulumEnv());
     case MI_ENV_INVERTED_DOUBLE_PENDULUM: return f(InvertedDoublePendulumEnv());
+    case MI_ENV_REACHER: return f(ReacherEnv());
     }
     return fail(MI_ERR_UNSUPPORTED, "this MuJoCo kind is not built into the HIP engine yet");
 }

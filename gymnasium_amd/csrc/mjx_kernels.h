@@ -5,7 +5,7 @@
 //   gymnasium/envs/mujoco/half_cheetah_v5.py:220-281      step, _get_rew, _get_obs, reset_model
 //   gymnasium/envs/mujoco/ant_v5.py:327-428               contact_forces, is_healthy, step, _get_rew, _get_obs, reset_model
 //   gymnasium/envs/mujoco/hopper_v5.py:236-343, walker2d_v5.py:241-345            (planar walkers: same skeleton)
-//   gymnasium/envs/mujoco/inverted_pendulum_v5.py:160-196, inverted_double_pendulum_v5.py:186-246
+//   gymnasium/envs/mujoco/inverted_pendulum_v5.py:160-196, inverted_double_pendulum_v5.py:186-246, reacher_v5.py:188-245
 // and the vectoriser semantics shared with the classic-control kernels (TimeLimit, autoreset modes, episode statistics).
 // Physics: mjx_core.h.  NumPy arithmetic that the reference inherits (np.sum pairwise order, float32 promotion of the
 // control cost, Generator.uniform / standard_normal streams) is reproduced bit for bit.
@@ -61,7 +61,7 @@ MJX_DEV T np_sum(const T *a) {
     return res;
 }
 
-enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6 };
+enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7 };
 
 // quantities of the last forward pass that the observations read besides qpos / qvel (null pointer = zeros, which is
 // what mj_resetData leaves in cfrc_ext / qfrc_actuator)
@@ -71,6 +71,7 @@ struct ObsExtras {
     const double (*cvel)[6];
     const double *qfrc_actuator;
     const double *qfrc_constraint = nullptr;  // [NV], InvertedDoublePendulum's observation
+    const double *vec = nullptr;              // [3] fingertip - target, Reacher's observation
 };
 
 template <class M, int KIND>
@@ -80,14 +81,16 @@ struct MjEnv {
     static constexpr int S = NQ + 2 * NV + 2;  // state row: qpos, qvel, (warm-start slot, unused by the Newton solver), tracked xy
     static constexpr bool PLANAR_WALKER = KIND == kHopper || KIND == kWalker2d;
     static constexpr bool PENDULUM = KIND == kInvertedPendulum || KIND == kInvertedDoublePendulum;
-    static constexpr int INFO = KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : 9)));
+    static constexpr int INFO =
+        KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : 9))));
     static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || KIND == kHumanoid;  // small robots: one-lane kernel only
     static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
-    static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : (PENDULUM ? 0 : 2);
+    static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : ((PENDULUM || KIND == kReacher) ? 0 : 2);
     static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (KIND == kHumanoid ? 22 * (NB - 1) + NV - 6 : 0) +
-                                   (KIND == kInvertedDoublePendulum ? NQ : 0);
+                                   (KIND == kInvertedDoublePendulum ? NQ : 0) + (KIND == kReacher ? 2 : 0);
 
     static int obs_dim_host(const mi::EnvParams &P) {  // the same rule, host side (mi_create)
+        if (KIND == kReacher) return 10;
         if (KIND == kInvertedPendulum) return NQ + NV;
         if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
@@ -98,6 +101,7 @@ struct MjEnv {
         return n;
     }
     static MJX_DEV int obs_dim(const mi::EnvParams &P) {
+        if (KIND == kReacher) return 10;
         if (KIND == kInvertedPendulum) return NQ + NV;
         if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
@@ -111,6 +115,12 @@ struct MjEnv {
     // ant_v5.py:393-404, half_cheetah_v5.py:248-257, humanoid_v5.py:430-466
     static MJX_DEV void write_obs(const double *s, const ObsExtras &x, const mi::EnvParams &P, double *o) {
         int n = 0;
+        if (KIND == kReacher) {
+            // reacher_v5.py:232-245: cos(theta), sin(theta), target qpos, arm qvel, (fingertip - target)[:2]
+            o[0] = cos(s[0]), o[1] = cos(s[1]), o[2] = sin(s[0]), o[3] = sin(s[1]), o[4] = s[2], o[5] = s[3], o[6] = s[NQ], o[7] = s[NQ + 1];
+            o[8] = x.vec ? x.vec[0] : 0.0, o[9] = x.vec ? x.vec[1] : 0.0;
+            return;
+        }
         if (KIND == kInvertedDoublePendulum) {
             // inverted_double_pendulum_v5.py:217-226: x, sin(angles), cos(angles), clip(qvel, -10, 10), clip(qfrc_constraint, -10, 10)[:1]
             o[n++] = s[0];
@@ -157,6 +167,29 @@ struct MjEnv {
 
     // reset_model + set_state (-> mj_forward); writes the reset observation when obs != nullptr
     static MJX_DEV void reset(mi::Pcg64 &rng, double *s, const mi::EnvParams &P, double *obs) {
+        if (KIND == kReacher) {
+            // reacher_v5.py:209-226: arm + target noise, the goal re-drawn until it lies inside the 0.2 disc, small arm velocities
+            for (int k = 0; k < NQ; k++) s[k] = (-0.1 + (0.1 - (-0.1)) * rng.next_double()) + M::qpos0[k];
+            for (;;) {
+                const double g0 = -0.2 + (0.2 - (-0.2)) * rng.next_double(), g1 = -0.2 + (0.2 - (-0.2)) * rng.next_double();
+                s[2] = g0, s[3] = g1;
+                if (sqrt(g0 * g0 + g1 * g1) < 0.2) break;
+            }
+            for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * rng.next_double());
+            s[NQ + 2] = 0.0, s[NQ + 3] = 0.0;
+            for (int k = 0; k < NV; k++) s[NQ + NV + k] = 0.0;
+            s[NQ + 2 * NV] = 0.0, s[NQ + 2 * NV + 1] = 0.0;
+            if (obs) {  // the observation shows fingertip - target of the forward pass at the reset state
+                Data<M> d;
+                for (int k = 0; k < NQ; k++) d.qpos[k] = s[k];
+                kinematics<M>(d);
+                const double vec[3] = {d.xpos[3][0] - d.xpos[4][0], d.xpos[3][1] - d.xpos[4][1], d.xpos[3][2] - d.xpos[4][2]};
+                ObsExtras x = {nullptr, nullptr, nullptr, nullptr};
+                x.vec = vec;
+                write_obs(s, x, P, obs);
+            }
+            return;
+        }
         const double scale = P.p[2];
         for (int k = 0; k < NQ; k++) s[k] = M::qpos0[k] + (-scale + (scale - (-scale)) * rng.next_double());
         if (KIND == kHumanoid || PLANAR_WALKER || KIND == kInvertedPendulum)  // humanoid_v5.py:526-528, hopper_v5.py:318-331: uniform noise on the velocities as well
@@ -197,6 +230,7 @@ struct MjEnv {
         const double (*cvel)[6];         // cvel[NB][6]
         const double *qfrc_actuator;     // [NV]
         const double *qfrc_constraint;   // [NV]
+        double vec[3];                   // Reacher: fingertip - target (body frames 3 and 4) of the last forward pass
     };
 
     // One env.step() with the one-lane simulator (mjx_core.h): physics, then finish().
@@ -213,7 +247,10 @@ struct MjEnv {
         for (int k = 0; k < NV; k++) s[NQ + NV + k] = d.qacc_warm[k];
         // Cartesian quantities of the LAST forward pass (they lag qpos by one sub-step, as in the reference)
         StepExtras x;
-        if (KIND == kInvertedDoublePendulum) {  // the tip site of the LAST forward pass: x and z (the reference's `x, _, y = site_xpos[0]`)
+        if (KIND == kReacher) {
+            x.after[0] = x.after[1] = 0.0;
+            for (int k = 0; k < 3; k++) x.vec[k] = d.xpos[3][k] - d.xpos[4][k];
+        } else if (KIND == kInvertedDoublePendulum) {  // the tip site of the LAST forward pass: x and z (the reference's `x, _, y = site_xpos[0]`)
             const int sb = M::site_bodyid[0];
             double t[3];
             rot_vec(t, d.xmat[sb], M::site_pos[0]);
@@ -259,6 +296,18 @@ struct MjEnv {
         float sq[NU];
         for (int u = 0; u < NU; u++) sq[u] = action[u] * action[u];
         const float ctrl_cost_f = (float)P.p[1] * np_sum<float, NU>(sq);  // weight * np.sum(np.square(float32 action)): float32
+        if (KIND == kReacher) {
+            // reacher_v5.py:188-207: reward = -|fingertip - target| w_dist - sum(a^2) w_ctrl (the control term in float32); never terminates
+            const double reward_dist = -sqrt(x.vec[0] * x.vec[0] + x.vec[1] * x.vec[1] + x.vec[2] * x.vec[2]) * P.p[0];
+            const float reward_ctrl = -np_sum<float, NU>(sq) * (float)P.p[1];
+            reward = reward_dist + (double)reward_ctrl;
+            terminated = false;
+            ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
+            ox.vec = x.vec;
+            write_obs(s, ox, P, obs);
+            if (info) info[0] = reward_dist, info[1] = (double)reward_ctrl;
+            return;
+        }
         if (KIND == kInvertedPendulum) {
             // inverted_pendulum_v5.py:160-176: terminated = not isfinite(obs).all() or |angle| > 0.2; reward = int(not terminated)
             bool finite = true;
@@ -349,7 +398,7 @@ struct MjEnv {
     }
     static MJX_DEV void reset_info(const double *s, double *info) {
         for (int k = 0; k < INFO; k++) info[k] = 0.0;
-        if (PENDULUM) return;  // _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
+        if (PENDULUM || KIND == kReacher) return;  // _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
         info[0] = s[0];
         if (PLANAR_WALKER) {
             info[1] = s[1] - M::qpos0[1];  // z_distance_from_origin (hopper_v5.py:338-342)

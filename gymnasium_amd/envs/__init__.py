@@ -13,6 +13,7 @@ from .mujoco.envs import (  # noqa: F401
     HumanoidVectorEnv,
     InvertedDoublePendulumVectorEnv,
     InvertedPendulumVectorEnv,
+    ReacherVectorEnv,
     Walker2dVectorEnv,
 )
 from .mujoco.envs import ENV_TABLE as _MUJOCO

@@ -260,6 +260,28 @@ class InvertedDoublePendulumVectorEnv(_PendulumVectorEnv):
         return 1 + 2 * (self.NQ - 1) + self.NV + 1
 
 
+class ReacherVectorEnv(_PendulumVectorEnv):
+    """reacher_v5.py:127-245: obs float64[10] (cos / sin of the arm angles, target, arm velocities, fingertip - target), action
+    float32[2] in [-1, 1]; never terminates (TimeLimit 50)."""
+
+    KIND = "reacher"
+    DEFAULT_MAX_EPISODE_STEPS = 50
+    STOCK_XML = "reacher.xml"
+    NQ, NV, NU, NBODY = 4, 4, 2, 5
+    CTRL_LOW, CTRL_HIGH = -1.0, 1.0
+    INFO_KEYS = ("reward_dist", "reward_ctrl")
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "reacher.xml", frame_skip: int = 2,
+                 reward_dist_weight: float = 1, reward_control_weight: float = 1, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._params = (reward_dist_weight, reward_control_weight, 0.0, 0.0, float(frame_skip))
+        self.observation_structure = {"cos": 2, "sin": 2, "target": 2, "qvel": 2, "fingertip_dist": 2}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return 10
+
+
 # id -> (creator, max_episode_steps, reward_threshold): gymnasium/envs/__init__.py:246-374
 ENV_TABLE = {
     "HalfCheetah-v5": (HalfCheetahVectorEnv, 1000, 4800.0),
@@ -269,4 +291,5 @@ ENV_TABLE = {
     "Walker2d-v5": (Walker2dVectorEnv, 1000, None),
     "InvertedPendulum-v5": (InvertedPendulumVectorEnv, 1000, 950.0),
     "InvertedDoublePendulum-v5": (InvertedDoublePendulumVectorEnv, 1000, 9100.0),
+    "Reacher-v5": (ReacherVectorEnv, 50, -3.75),
 }

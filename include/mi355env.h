@@ -58,7 +58,9 @@ typedef enum mi_env_kind {
     /* ToyText Blackjack-v1: envs/toy_text/blackjack.py:17-232 (Generator.choice card draws, dealer play-out, natural / sab rules);
      * observation row = int64[3] (player sum, dealer's showing card, usable ace); params[0] = natural, params[1] = sab */
     MI_ENV_BLACKJACK = 13,
-    MI_ENV_KIND_COUNT = 14
+    MI_ENV_REACHER = 14,                   /* envs/mujoco/reacher_v5.py:127-245 + assets/reacher.xml; params[0] = reward_dist_weight,
+                                            * [1] = reward_control_weight, [4] = frame_skip                                  */
+    MI_ENV_KIND_COUNT = 15
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */

@@ -104,6 +104,7 @@ int orc_mjenv_obs_dim(int which, const double *P) {
     int excl = P[3] != 0.0;
     if (which == ORC_MJ_INVERTED_PENDULUM) return m->nq + m->nv;
     if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 1 + 2 * (m->nq - 1) + m->nv + 1;
+    if (which == ORC_MJ_REACHER) return 10;
     if (is_planar_walker(which)) return m->nq - (excl ? 1 : 0) + m->nv;
     if (which == ORC_MJ_HALF_CHEETAH) return m->nq - (excl ? 1 : 0) + m->nv;
     if (which == ORC_MJ_ANT) return m->nq - (excl ? 2 : 0) + m->nv + (P[12] != 0.0 ? 6 * (m->nbody - 1) : 0);
@@ -114,6 +115,7 @@ int orc_mjenv_info_dim(int which) {
     if (is_planar_walker(which)) return 6;
     if (which == ORC_MJ_INVERTED_PENDULUM) return 1;
     if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 3;
+    if (which == ORC_MJ_REACHER) return 2;
     return which == ORC_MJ_HALF_CHEETAH ? 4 : 9;
 }
 int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
@@ -137,7 +139,9 @@ static void mass_center_xy(const orc_mjenv *e, double out[2]) { /* humanoid_v5.p
 /* the position the env differentiates to get its velocity reward, read from the LAST forward pass (the reference reads
  * data.qpos / data.body().xpos / data.xipos after mj_step, and those Cartesian quantities lag qpos by one sub-step) */
 static void tracked_xy(const orc_mjenv *e, double out[2]) {
-    if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* data.site_xpos[0]: x and height of the tip (inverted_double_pendulum_v5.py:189) */
+    if (e->which == ORC_MJ_REACHER) {
+        out[0] = out[1] = 0;
+    } else if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* data.site_xpos[0]: x and height of the tip (inverted_double_pendulum_v5.py:189) */
         const double tip[3] = {0, 0, 0.6}; /* <site name="tip" pos="0 0 .6"/> on pole2 = the last body */
         const int b = e->m->nbody - 1;
         const double *R = e->d.xmat[b];
@@ -155,6 +159,12 @@ void orc_mjenv_obs(const orc_mjenv *e, const double *P, double *o) {
     const mjo_model *m = e->m;
     const mjo_data *d = &e->d;
     int skip = P[3] != 0.0 ? ((e->which == ORC_MJ_HALF_CHEETAH || is_planar_walker(e->which)) ? 1 : 2) : 0, n = 0;
+    if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:232-245; get_body_com = data.body(name).xpos: fingertip = body 3, target = body 4 */
+        o[0] = cos(d->qpos[0]), o[1] = cos(d->qpos[1]), o[2] = sin(d->qpos[0]), o[3] = sin(d->qpos[1]);
+        o[4] = d->qpos[2], o[5] = d->qpos[3], o[6] = d->qvel[0], o[7] = d->qvel[1];
+        o[8] = d->xpos[3][0] - d->xpos[4][0], o[9] = d->xpos[3][1] - d->xpos[4][1];
+        return;
+    }
     if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* inverted_double_pendulum_v5.py:217-226 */
         o[n++] = d->qpos[0];
         for (int k = 1; k < m->nq; k++) o[n++] = sin(d->qpos[k]);
@@ -195,6 +205,20 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
     const mjo_model *m = e->m;
     double scale = P[2], qpos[MJO_MAXQ], qvel[MJO_MAXV];
     mjo_reset_data(m, &e->d); /* mj_resetData */
+    if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:209-226 */
+        for (int k = 0; k < m->nq; k++) qpos[k] = (-0.1 + (0.1 - (-0.1)) * orc_pcg64_double(rng)) + m->qpos0[k];
+        for (;;) { /* the goal is re-drawn until it lies inside the 0.2 disc (np.linalg.norm of 2 elements = sqrt(g0 g0 + g1 g1)) */
+            const double g0 = -0.2 + (0.2 - (-0.2)) * orc_pcg64_double(rng), g1 = -0.2 + (0.2 - (-0.2)) * orc_pcg64_double(rng);
+            qpos[2] = g0, qpos[3] = g1;
+            if (sqrt(g0 * g0 + g1 * g1) < 0.2) break;
+        }
+        for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * orc_pcg64_double(rng));
+        qvel[2] = 0.0, qvel[3] = 0.0;
+        memcpy(e->d.qpos, qpos, sizeof(double) * m->nq), memcpy(e->d.qvel, qvel, sizeof(double) * m->nv);
+        mjo_forward(m, &e->d);
+        e->has_override = 0;
+        return;
+    }
     /* qpos = init_qpos + uniform(-s, s, nq): Generator.uniform = low + (high - low) * next_double */
     for (int k = 0; k < m->nq; k++) qpos[k] = m->qpos0[k] + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
     if (e->which == ORC_MJ_HUMANOID || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM) /* humanoid_v5.py:526-528, hopper_v5.py:318-331, inverted_pendulum_v5.py:178-190: uniform noise on the velocities too */
@@ -223,6 +247,17 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     const double dt = m->timestep * frame_skip;
     const double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
     const double forward_reward = e->which == ORC_MJ_ANT ? xv * P[0] : P[0] * xv;
+    if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:188-207 */
+        const double v[3] = {d->xpos[3][0] - d->xpos[4][0], d->xpos[3][1] - d->xpos[4][1], d->xpos[3][2] - d->xpos[4][2]};
+        const double reward_dist = -sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * P[0];
+        float sq[MJO_MAXU];
+        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
+        const float reward_ctrl = -orc_np_sum_f32(sq, nu) * (float)P[1]; /* float32 array sum times a Python float: float32 */
+        *reward = reward_dist + (double)reward_ctrl;
+        *terminated = 0;
+        info[0] = reward_dist, info[1] = (double)reward_ctrl;
+        return;
+    }
     if (e->which == ORC_MJ_INVERTED_PENDULUM) { /* inverted_pendulum_v5.py:160-176 */
         int finite = 1;
         for (int k = 0; k < m->nq; k++) finite &= isfinite(d->qpos[k]) != 0;
@@ -306,7 +341,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
 
 /* _get_reset_info of the scalar env: positions only */
 void orc_mjenv_reset_info(const orc_mjenv *e, double *row) {
-    if (is_pendulum(e->which)) return; /* {} (inverted_pendulum_v5.py:198-199) */
+    if (is_pendulum(e->which) || e->which == ORC_MJ_REACHER) return; /* {} (inverted_pendulum_v5.py:198-199) */
     row[0] = e->d.qpos[0];
     if (is_planar_walker(e->which))
         row[1] = e->d.qpos[1] - e->m->qpos0[1]; /* z_distance_from_origin, hopper_v5.py:338-342 */

@@ -272,7 +272,8 @@ def test_humanoid_pgs50_residual_vs_converged_newton():
 MORE_SPECS = {  # nq, nv, nu, nbody, njnt (test_mujoco_v5.py:526-580), obs, frame_skip * timestep, reset-noise scale, uniform velocity noise?
     "hopper": ("Hopper-v5", 6, 6, 3, 5, 6, 11, 0.008, 5e-3, True), "walker2d": ("Walker2d-v5", 9, 9, 6, 8, 9, 17, 0.008, 5e-3, True),
     "inverted_pendulum": ("InvertedPendulum-v5", 2, 2, 1, 3, 2, 4, 0.04, 0.01, True),
-    "inverted_double_pendulum": ("InvertedDoublePendulum-v5", 3, 3, 1, 4, 3, 9, 0.05, 0.1, False)}
+    "inverted_double_pendulum": ("InvertedDoublePendulum-v5", 3, 3, 1, 4, 3, 9, 0.05, 0.1, False),
+    "reacher": ("Reacher-v5", 4, 4, 2, 5, 4, 10, 0.02, 0.1, True)}
 
 
 @pytest.mark.parametrize("name", list(MORE_SPECS))
@@ -286,12 +287,25 @@ def test_more_robots_model_counts_reset_streams_and_rewards(name, oracle_factory
         d = omj.OracleModel(name).make_data()
         d.reset(), d.forward()
         assert abs(d.get("xpos")[-1][2] + 0.6 - 1.2) < 1e-15
-    pend = name.startswith("inverted")
+    pend = name.startswith("inverted") or name == "reacher"
     kw = {} if pend else dict(exclude_current_positions_from_observation=False)
     env = gymnasium_amd.make_vec(env_id, num_envs=3, _engine_factory=oracle_factory, **kw)
     assert env.single_observation_space.shape == ((obs_dim + (0 if pend else 1)),) and env.single_action_space.shape == (nu,)
     obs, _ = env.reset(seed=100)
-    if name != "inverted_double_pendulum":  # (its observation is sin / cos of the state)
+    if name == "reacher":  # reacher_v5.py:209-226: its own reset sequence (goal rejection loop), observation = functions of the state
+        for i in range(3):
+            g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(100 + i)))
+            qpos = g.uniform(low=-0.1, high=0.1, size=4) + m.qpos0
+            while True:
+                goal = g.uniform(low=-0.2, high=0.2, size=2)
+                if np.linalg.norm(goal) < 0.2:
+                    break
+            qpos[-2:] = goal
+            qvel = g.uniform(low=-0.005, high=0.005, size=4)
+            assert np.array_equal(obs[i, 4:8], np.concatenate([qpos[2:], qvel[:2]]))
+            np.testing.assert_allclose(obs[i, :4], np.concatenate([np.cos(qpos[:2]), np.sin(qpos[:2])]), rtol=0, atol=1e-15)
+            assert np.array_equal(env.get_rng_state()[i], gymnasium_amd._native.pcg_words(g))
+    elif name != "inverted_double_pendulum":  # (its observation is sin / cos of the state)
         for i in range(3):
             g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(100 + i)))
             qpos = m.qpos0 + g.uniform(low=-scale, high=scale, size=m.nq)
@@ -321,11 +335,14 @@ def test_more_robots_model_counts_reset_streams_and_rewards(name, oracle_factory
         elif name == "inverted_pendulum":
             total = ia["reward_survive"]
             assert np.array_equal(tea[live], np.abs(oa[live, 1]) > 0.2)
+        elif name == "reacher":
+            total = ia["reward_dist"] + ia["reward_ctrl"]
+            np.testing.assert_allclose(ia["reward_dist"][live], -np.hypot(oa[live, 8], oa[live, 9]), rtol=1e-12)  # z offsets cancel
         else:
             total = ia["reward_survive"] + ia["distance_penalty"] + ia["velocity_penalty"]
         np.testing.assert_allclose(ra[live], total[live], rtol=1e-12, atol=1e-12)
         assert (ra[prev_done] == 0).all() and not tea[prev_done].any()
         terms += int(tea.sum())
         prev_done = tea | tra
-    assert terms > 0, "a random policy ends episodes of these robots within 120 steps"
+    assert terms > 0 or name == "reacher", "a random policy ends episodes of these robots within 120 steps (Reacher only truncates)"
     a.close(), b.close()
