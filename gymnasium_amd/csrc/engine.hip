@@ -1038,7 +1038,8 @@ typedef mjx::MjEnv<mjx::Walker2dModel, mjx::kWalker2d> Walker2dEnv;
 typedef mjx::MjEnv<mjx::InvertedPendulumModel, mjx::kInvertedPendulum> InvertedPendulumEnv;
 typedef mjx::MjEnv<mjx::InvertedDoublePendulumModel, mjx::kInvertedDoublePendulum> InvertedDoublePendulumEnv;
 typedef mjx::MjEnv<mjx::ReacherModel, mjx::kReacher> ReacherEnv;
-bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER; }
+typedef mjx::MjEnv<mjx::HumanoidStandupModel, mjx::kHumanoidStandup> HumanoidStandupEnv;
+bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER || kind == MI_ENV_HUMANOID_STANDUP; }
 bool is_tab(int kind) { return kind == MI_ENV_TABULAR || kind == MI_ENV_BLACKJACK; }  // Blackjack rides on the tabular kernels
 template <class F>
 int dispatch_mj(int kind, F &&f) {
@@ -1051,6 +1052,7 @@ int dispatch_mj(int kind, F &&f) {
     case MI_ENV_INVERTED_PENDULUM: return f(InvertedPendulumEnv());
     case MI_ENV_INVERTED_DOUBLE_PENDULUM: return f(InvertedDoublePendulumEnv());
     case MI_ENV_REACHER: return f(ReacherEnv());
+    case MI_ENV_HUMANOID_STANDUP: return f(HumanoidStandupEnv());
     }
     return fail(MI_ERR_UNSUPPORTED, "this MuJoCo kind is not built into the HIP engine yet");
 }
@@ -1226,10 +1228,10 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         // env-steps/s, Humanoid 0.76M vs 0.23M); HalfCheetah (9 dofs, 7 bodies, one forward pass per sub-step) is faster on the
         // one-lane kernel (16.4M vs 12.9M).  MI355ENV_MJ_SERIAL=1 / MI355ENV_MJ_COOP=1 force either one (cross-check tests).
         const char *serial = getenv("MI355ENV_MJ_SERIAL"), *coop = getenv("MI355ENV_MJ_COOP");
-        v->mj_coop = cfg->kind == MI_ENV_ANT || cfg->kind == MI_ENV_HUMANOID;
+        v->mj_coop = cfg->kind == MI_ENV_ANT || cfg->kind == MI_ENV_HUMANOID || cfg->kind == MI_ENV_HUMANOID_STANDUP;
         if (serial && serial[0] == '1') v->mj_coop = false;
         if (coop && coop[0] == '1') v->mj_coop = true;
-        if (cfg->kind >= MI_ENV_HOPPER) v->mj_coop = false;  // the small robots are built for the one-lane kernel only
+        if (cfg->kind >= MI_ENV_HOPPER && cfg->kind != MI_ENV_HUMANOID_STANDUP) v->mj_coop = false;  // the small robots: one-lane kernel only
     } else if (cfg->kind == MI_ENV_BLACKJACK) {
         const mi_layout l = {3, MI_I64, 1, MI_I64, 2, 0, {0, 0}};
         v->lay = l;

@@ -61,7 +61,7 @@ MJX_DEV T np_sum(const T *a) {
     return res;
 }
 
-enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7 };
+enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7, kHumanoidStandup = 8 };
 
 // quantities of the last forward pass that the observations read besides qpos / qvel (null pointer = zeros, which is
 // what mj_resetData leaves in cfrc_ext / qfrc_actuator)
@@ -80,13 +80,14 @@ struct MjEnv {
     static constexpr int NQ = M::NQ, NV = M::NV, NU = M::NU, NB = M::NBODY;
     static constexpr int S = NQ + 2 * NV + 2;  // state row: qpos, qvel, (warm-start slot, unused by the Newton solver), tracked xy
     static constexpr bool PLANAR_WALKER = KIND == kHopper || KIND == kWalker2d;
+    static constexpr bool HUMANOID_LIKE = KIND == kHumanoid || KIND == kHumanoidStandup;  // same model family, same observation
     static constexpr bool PENDULUM = KIND == kInvertedPendulum || KIND == kInvertedDoublePendulum;
     static constexpr int INFO =
-        KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : 9))));
-    static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || KIND == kHumanoid;  // small robots: one-lane kernel only
+        KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : (KIND == kHumanoidStandup ? 6 : 9)))));
+    static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || HUMANOID_LIKE;  // small robots: one-lane kernel only
     static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
     static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : ((PENDULUM || KIND == kReacher) ? 0 : 2);
-    static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (KIND == kHumanoid ? 22 * (NB - 1) + NV - 6 : 0) +
+    static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (HUMANOID_LIKE ? 22 * (NB - 1) + NV - 6 : 0) +
                                    (KIND == kInvertedDoublePendulum ? NQ : 0) + (KIND == kReacher ? 2 : 0);
 
     static int obs_dim_host(const mi::EnvParams &P) {  // the same rule, host side (mi_create)
@@ -95,7 +96,7 @@ struct MjEnv {
         if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
         if (KIND == kAnt && P.p[12] != 0.0) n += 6 * (NB - 1);
-        if (KIND == kHumanoid)
+        if (HUMANOID_LIKE)
             n += (P.p[12] != 0.0 ? 10 * (NB - 1) : 0) + (P.p[13] != 0.0 ? 6 * (NB - 1) : 0) + (P.p[14] != 0.0 ? NV - 6 : 0) +
                  (P.p[15] != 0.0 ? 6 * (NB - 1) : 0);
         return n;
@@ -106,7 +107,7 @@ struct MjEnv {
         if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
         if (KIND == kAnt && P.p[12] != 0.0) n += 6 * (NB - 1);
-        if (KIND == kHumanoid)
+        if (HUMANOID_LIKE)
             n += (P.p[12] != 0.0 ? 10 * (NB - 1) : 0) + (P.p[13] != 0.0 ? 6 * (NB - 1) : 0) + (P.p[14] != 0.0 ? NV - 6 : 0) +
                  (P.p[15] != 0.0 ? 6 * (NB - 1) : 0);
         return n;
@@ -142,7 +143,7 @@ struct MjEnv {
                     const double f = x.cfrc ? x.cfrc[b][k] : 0.0;
                     o[n++] = f < P.p[10] ? P.p[10] : (f > P.p[11] ? P.p[11] : f);  // np.clip(cfrc_ext, lo, hi)
                 }
-        if (KIND == kHumanoid) {
+        if (HUMANOID_LIKE) {
             if (P.p[12] != 0.0)
                 for (int b = 1; b < NB; b++)
                     for (int k = 0; k < 10; k++) o[n++] = x.cinert ? x.cinert[b][k] : 0.0;
@@ -192,12 +193,12 @@ struct MjEnv {
         }
         const double scale = P.p[2];
         for (int k = 0; k < NQ; k++) s[k] = M::qpos0[k] + (-scale + (scale - (-scale)) * rng.next_double());
-        if (KIND == kHumanoid || PLANAR_WALKER || KIND == kInvertedPendulum)  // humanoid_v5.py:526-528, hopper_v5.py:318-331: uniform noise on the velocities as well
+        if (HUMANOID_LIKE || PLANAR_WALKER || KIND == kInvertedPendulum)  // humanoid_v5.py:526-528, hopper_v5.py:318-331: uniform noise on the velocities as well
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-scale + (scale - (-scale)) * rng.next_double());
         else
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + scale * standard_normal(rng);
         for (int k = 0; k < NV; k++) s[NQ + NV + k] = 0.0;
-        if (KIND == kHumanoid) {
+        if (HUMANOID_LIKE) {
             // the observation shows cinert / cvel of the forward pass at the reset state, and the tracked point is the
             // whole-body centre of mass
             Data<M> d;
@@ -247,7 +248,9 @@ struct MjEnv {
         for (int k = 0; k < NV; k++) s[NQ + NV + k] = d.qacc_warm[k];
         // Cartesian quantities of the LAST forward pass (they lag qpos by one sub-step, as in the reference)
         StepExtras x;
-        if (KIND == kReacher) {
+        if (KIND == kHumanoidStandup) {
+            x.after[0] = x.after[1] = 0.0;
+        } else if (KIND == kReacher) {
             x.after[0] = x.after[1] = 0.0;
             for (int k = 0; k < 3; k++) x.vec[k] = d.xpos[3][k] - d.xpos[4][k];
         } else if (KIND == kInvertedDoublePendulum) {  // the tip site of the LAST forward pass: x and z (the reference's `x, _, y = site_xpos[0]`)
@@ -264,8 +267,8 @@ struct MjEnv {
         for (int k = 0; k < NQ; k++) s[k] = d.qpos[k];
         for (int k = 0; k < NV; k++) s[NQ + k] = d.qvel[k];
         double cfrc[NB][6];
-        if (KIND == kAnt || KIND == kHumanoid) contact_forces<M>(d, cfrc);
-        if (KIND == kHumanoid) com_pos<M>(d);  // crb() folded the per-body inertias into composites: restore them for the obs
+        if (KIND == kAnt || HUMANOID_LIKE) contact_forces<M>(d, cfrc);
+        if (HUMANOID_LIKE) com_pos<M>(d);  // crb() folded the per-body inertias into composites: restore them for the obs
         x.cfrc = cfrc, x.cinert = d.cinert, x.cvel = d.cvel, x.qfrc_actuator = d.qfrc_actuator, x.qfrc_constraint = d.qfrc_constraint;
         finish(s, before, x, action, P, obs, reward, terminated, info);
     }
@@ -273,7 +276,9 @@ struct MjEnv {
     // The tracked point from the cooperative kernel's extras row (coop::Sim::write_extras): body-1 position for Ant, the
     // mass-weighted sum of xipos over np.sum(body_mass) for Humanoid (humanoid_v5.py:17-21), the root slider for HalfCheetah.
     static MJX_DEV void after_from_extras(const double *s, const double *ex, double *after) {
-        if (KIND == kHalfCheetah) {
+        if (KIND == kHumanoidStandup) {
+            after[0] = after[1] = 0.0;
+        } else if (KIND == kHalfCheetah) {
             after[0] = s[0], after[1] = 0.0;
         } else if (KIND == kAnt) {
             after[0] = ex[0], after[1] = ex[1];
@@ -296,6 +301,25 @@ struct MjEnv {
         float sq[NU];
         for (int u = 0; u < NU; u++) sq[u] = action[u] * action[u];
         const float ctrl_cost_f = (float)P.p[1] * np_sum<float, NU>(sq);  // weight * np.sum(np.square(float32 action)): float32
+        if (KIND == kHumanoidStandup) {
+            // humanoidstandup_v5.py:423-462: reward = z / opt.timestep - w_ctrl sum(ctrl^2) - clip(w_impact sum(cfrc_ext^2)) + 1 (the
+            // `uph_cost_weight` argument is stored but never applied there); never terminates
+            const double uph_cost = (s[2] - 0) / M::TIMESTEP;
+            double sqd[NU], c2s[6 * NB];
+            for (int u = 0; u < NU; u++) sqd[u] = (double)action[u] * (double)action[u];
+            const double quad_ctrl_cost = P.p[1] * np_sum<double, NU>(sqd);
+            for (int b = 0; b < NB; b++)
+                for (int k = 0; k < 6; k++) c2s[6 * b + k] = x.cfrc[b][k] * x.cfrc[b][k];
+            double quad_impact_cost = P.p[5] * np_sum<double, 6 * NB>(c2s);
+            quad_impact_cost = quad_impact_cost < P.p[10] ? P.p[10] : (quad_impact_cost > P.p[11] ? P.p[11] : quad_impact_cost);
+            reward = uph_cost - quad_ctrl_cost - quad_impact_cost + 1;
+            terminated = false;
+            const ObsExtras ox = {x.cfrc, x.cinert, x.cvel, x.qfrc_actuator};
+            write_obs(s, ox, P, obs);
+            if (info)
+                info[0] = s[0], info[1] = s[1], info[2] = s[2] - M::qpos0[2], info[3] = uph_cost, info[4] = -quad_ctrl_cost, info[5] = -quad_impact_cost;
+            return;
+        }
         if (KIND == kReacher) {
             // reacher_v5.py:188-207: reward = -|fingertip - target| w_dist - sum(a^2) w_ctrl (the control term in float32); never terminates
             const double reward_dist = -sqrt(x.vec[0] * x.vec[0] + x.vec[1] * x.vec[1] + x.vec[2] * x.vec[2]) * P.p[0];
@@ -400,6 +424,10 @@ struct MjEnv {
         for (int k = 0; k < INFO; k++) info[k] = 0.0;
         if (PENDULUM || KIND == kReacher) return;  // _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
         info[0] = s[0];
+        if (KIND == kHumanoidStandup) {
+            info[1] = s[1], info[2] = s[2] - M::qpos0[2];  // humanoidstandup_v5.py:479-486
+            return;
+        }
         if (PLANAR_WALKER) {
             info[1] = s[1] - M::qpos0[1];  // z_distance_from_origin (hopper_v5.py:338-342)
             return;

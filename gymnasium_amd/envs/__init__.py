@@ -10,6 +10,7 @@ from .mujoco.envs import (  # noqa: F401
     AntVectorEnv,
     HalfCheetahVectorEnv,
     HopperVectorEnv,
+    HumanoidStandupVectorEnv,
     HumanoidVectorEnv,
     InvertedDoublePendulumVectorEnv,
     InvertedPendulumVectorEnv,

@@ -148,6 +148,39 @@ class HumanoidVectorEnv(_MujocoVectorEnv):
         return self._params
 
 
+class HumanoidStandupVectorEnv(HumanoidVectorEnv):
+    """humanoidstandup_v5.py:266-486: the humanoid lying on its back; same spaces and observation as Humanoid-v5, reward for height."""
+
+    KIND = "humanoid_standup"
+    STOCK_XML = "humanoidstandup.xml"
+    INFO_KEYS = ("x_position", "y_position", "z_distance_from_origin", "reward_linup", "reward_quadctrl", "reward_impact")
+    N_RESET_INFO_KEYS = 3
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "humanoidstandup.xml", frame_skip: int = 5,
+                 uph_cost_weight: float = 1, ctrl_cost_weight: float = 0.1, impact_cost_weight: float = 0.5e-6,
+                 impact_cost_range=(-np.inf, 10.0), reset_noise_scale: float = 1e-2, exclude_current_positions_from_observation: bool = True,
+                 include_cinert_in_observation: bool = True, include_cvel_in_observation: bool = True,
+                 include_qfrc_actuator_in_observation: bool = True, include_cfrc_ext_in_observation: bool = True, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._exclude = bool(exclude_current_positions_from_observation)
+        inc = [bool(include_cinert_in_observation), bool(include_cvel_in_observation), bool(include_qfrc_actuator_in_observation),
+               bool(include_cfrc_ext_in_observation)]
+        self._inc = inc
+        self._params = (uph_cost_weight, ctrl_cost_weight, reset_noise_scale, float(self._exclude), float(frame_skip), impact_cost_weight, 0.0, 0.0,
+                        0.0, 0.0, impact_cost_range[0], impact_cost_range[1], *[float(x) for x in inc])
+        nb1 = self.NBODY - 1
+        self.observation_structure = {"skipped_qpos": 2 * self._exclude, "qpos": self.NQ - 2 * self._exclude, "qvel": self.NV,
+                                      "cinert": 10 * nb1 * inc[0], "cvel": 6 * nb1 * inc[1], "qfrc_actuator": (self.NV - 6) * inc[2],
+                                      "cfrc_ext": 6 * nb1 * inc[3], "ten_length": 0, "ten_velocity": 0}
+        _MujocoVectorEnv.__init__(self, num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _reset_infos(self, mask):
+        sel = np.ones(self.num_envs, dtype=np.bool_) if mask is None else mask.view(np.bool_).copy()
+        qpos = self.get_state()[0]
+        return {"x_position": np.where(sel, qpos[:, 0], 0.0), "_x_position": sel, "y_position": np.where(sel, qpos[:, 1], 0.0), "_y_position": sel.copy(),
+                "z_distance_from_origin": np.where(sel, qpos[:, 2] - 0.105, 0.0), "_z_distance_from_origin": sel.copy()}
+
+
 class _PlanarWalkerVectorEnv(_MujocoVectorEnv):
     """Hopper-v5 / Walker2d-v5: obs = qpos[1:] + clip(qvel, -10, 10); reward = forward + healthy - ctrl (hopper_v5.py:236-343)."""
 
@@ -292,4 +325,5 @@ ENV_TABLE = {
     "InvertedPendulum-v5": (InvertedPendulumVectorEnv, 1000, 950.0),
     "InvertedDoublePendulum-v5": (InvertedDoublePendulumVectorEnv, 1000, 9100.0),
     "Reacher-v5": (ReacherVectorEnv, 50, -3.75),
+    "HumanoidStandup-v5": (HumanoidStandupVectorEnv, 1000, None),
 }

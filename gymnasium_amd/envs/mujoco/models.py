@@ -11,6 +11,7 @@ cited so the judge can diff the numbers):
   inverted_pendulum()         gymnasium/envs/mujoco/assets/inverted_pendulum.xml:1-26
   inverted_double_pendulum()  gymnasium/envs/mujoco/assets/inverted_double_pendulum.xml:18-49
   reacher()       gymnasium/envs/mujoco/assets/reacher.xml:1-40
+  humanoid(standup=True)      gymnasium/envs/mujoco/assets/humanoidstandup.xml:1-121
 
 Only what influences the physics is kept (no textures, lights, cameras, colours).  Angles are stored exactly as the XML
 writes them together with the file's ``compiler angle`` unit; `compiler.py` applies MuJoCo's defaults and derives
@@ -120,7 +121,10 @@ def ant():
     )
 
 
-def humanoid():
+def humanoid(standup: bool = False):
+    # standup=True: gymnasium/envs/mujoco/assets/humanoidstandup.xml -- the same tree lying on its back: torso at z = .105, the
+    # waist / pelvis / legs laid out along +x instead of -z (lines 27-61 of that file), left_hip_y range -120 20 (:56); everything else
+    # (joints, arms, defaults, actuators, tendons, options) is line-for-line humanoid.xml.
     # <compiler angle="degree" inertiafromgeom="true"/> :2
     # <default><joint armature="1" damping="1" limited="true"/>  :4   <geom conaffinity="1" condim="1" contype="1" margin="0.001"/> :5
     #          <motor ctrllimited="true" ctrlrange="-.4 .4"/> :6
@@ -135,15 +139,21 @@ def humanoid():
 
     def leg(side, y, hipx_axis, hipz_axis, thigh_to, shin_pos, hipy_armature, knee_stiffness):
         # right :42-54, left :55-67
-        return body(f"{side}_thigh", (0, y, -0.04),
+        hipy_range = (-120, 20) if (standup and side == "left") else (-110, 20)   # humanoidstandup.xml:56
+        if standup:  # the leg points along +x: thigh pos z 0, fromto / shin pos with x and z swapped, foot at (.35, 0, -.1)
+            thigh_pos, thigh_to_, shin_pos_ = (0, y, 0), (-thigh_to[2], thigh_to[1], 0), (-shin_pos[2], shin_pos[1], 0)
+            shin_to, foot_pos = (0, 0, 0, 0.3, 0, 0), (0.35, 0, -.1)
+        else:
+            thigh_pos, thigh_to_, shin_pos_, shin_to, foot_pos = (0, y, -0.04), thigh_to, shin_pos, (0, 0, 0, 0, 0, -.3), (0, 0, -0.45)
+        return body(f"{side}_thigh", thigh_pos,
                     joints=[hinge(f"{side}_hip_x", hipx_axis, (0, 0, 0), (-25, 5), 0.01, 5, 10),
                             hinge(f"{side}_hip_z", hipz_axis, (0, 0, 0), (-60, 35), 0.01, 5, 10),
-                            hinge(f"{side}_hip_y", (0, 1, 0), (0, 0, 0), (-110, 20), hipy_armature, 5, 20)],
-                    geoms=[capsule(f"{side}_thigh1", 0.06, fromto=(0, 0, 0) + thigh_to)],
-                    children=[body(f"{side}_shin", shin_pos,
+                            hinge(f"{side}_hip_y", (0, 1, 0), (0, 0, 0), hipy_range, hipy_armature, 5, 20)],
+                    geoms=[capsule(f"{side}_thigh1", 0.06, fromto=(0, 0, 0) + thigh_to_)],
+                    children=[body(f"{side}_shin", shin_pos_,
                                    joints=[hinge(f"{side}_knee", (0, -1, 0), (0, 0, .02), (-160, -2), 0.0060, None, knee_stiffness)],
-                                   geoms=[capsule(f"{side}_shin1", 0.049, fromto=(0, 0, 0, 0, 0, -.3))],
-                                   children=[body(f"{side}_foot", (0, 0, -0.45), geoms=[sphere(f"{side}_foot", 0.075, pos=(0, 0, 0.1))])])])
+                                   geoms=[capsule(f"{side}_shin1", 0.049, fromto=shin_to)],
+                                   children=[body(f"{side}_foot", foot_pos, geoms=[sphere(f"{side}_foot", 0.075, pos=(0, 0, 0.1))])])])
 
     def arm(side, y, s1_axis, s2_axis, rng, uarm_to, larm_pos, elbow_axis, larm_fromto, hand_pos):
         # right :69-79, left :80-89
@@ -155,18 +165,19 @@ def humanoid():
                                    joints=[hinge(f"{side}_elbow", elbow_axis, (0, 0, 0), (-90, 50), 0.0028, None, 0)],
                                    geoms=[capsule(f"{side}_larm", 0.031, fromto=larm_fromto), sphere(f"{side}_hand", 0.04, pos=hand_pos)])])
 
+    su = standup
     torso = body(
-        "torso", (0, 0, 1.4),
+        "torso", (0, 0, .105) if su else (0, 0, 1.4),
         joints=[joint("root", "free", armature=0, damping=0, limited=False, stiffness=0)],   # :29
         geoms=[capsule("torso1", 0.07, fromto=(0, -.07, 0, 0, .07, 0)),                       # :30
-               sphere("head", .09, pos=(0, 0, .19)),                                          # :31
-               capsule("uwaist", 0.06, fromto=(-.01, -.06, -.12, -.01, .06, -.12))],          # :32
+               sphere("head", .09, pos=(-.15, 0, 0) if su else (0, 0, .19)),                  # :31
+               capsule("uwaist", 0.06, fromto=(.11, -.06, 0, .11, .06, 0) if su else (-.01, -.06, -.12, -.01, .06, -.12))],   # :32
         children=[
-            body("lwaist", (-.01, 0, -0.260), quat=(1.000, 0, -0.002, 0),                     # :33
+            body("lwaist", (.21, 0, 0) if su else (-.01, 0, -0.260), quat=(1.000, 0, -0.002, 0),   # :33
                  geoms=[capsule("lwaist", 0.06, fromto=(0, -.06, 0, 0, .06, 0))],             # :34
                  joints=[hinge("abdomen_z", (0, 0, 1), (0, 0, 0.065), (-45, 45), 0.02, 5, 20),   # :35
                          hinge("abdomen_y", (0, 1, 0), (0, 0, 0.065), (-75, 30), 0.02, 5, 10)],  # :36
-                 children=[body("pelvis", (0, 0, -0.165), quat=(1.000, 0, -0.002, 0),          # :37
+                 children=[body("pelvis", (0.165, 0, 0) if su else (0, 0, -0.165), quat=(1.000, 0, -0.002, 0),          # :37
                                 joints=[hinge("abdomen_x", (1, 0, 0), (0, 0, 0.1), (-35, 35), 0.02, 5, 10)],   # :38
                                 geoms=[capsule("butt", 0.09, fromto=(-.02, -.07, 0, -.02, .07, 0))],           # :39
                                 children=[
@@ -179,7 +190,7 @@ def humanoid():
                 (0.01, -0.01, 0.01, .17, -.17, .17), (.18, -.18, .18)),
         ])
     return dict(
-        name="humanoid", angle="degree", settotalmass=None,
+        name="humanoid_standup" if standup else "humanoid", angle="degree", settotalmass=None,
         option=dict(timestep=0.003, gravity=(0, 0, -9.81), integrator="RK4", solver="PGS", iterations=50),
         joint_default=dict(armature=1, damping=1, limited=True),
         geom_default=dict(conaffinity=1, condim=1, contype=1, margin=0.001),
@@ -334,5 +345,5 @@ def reacher():
     )
 
 
-MODELS = {"reacher": reacher, "half_cheetah": half_cheetah, "ant": ant, "humanoid": humanoid, "hopper": hopper, "walker2d": walker2d,
+MODELS = {"humanoid_standup": lambda: humanoid(standup=True), "reacher": reacher, "half_cheetah": half_cheetah, "ant": ant, "humanoid": humanoid, "hopper": hopper, "walker2d": walker2d,
           "inverted_pendulum": inverted_pendulum, "inverted_double_pendulum": inverted_double_pendulum}

@@ -60,7 +60,9 @@ typedef enum mi_env_kind {
     MI_ENV_BLACKJACK = 13,
     MI_ENV_REACHER = 14,                   /* envs/mujoco/reacher_v5.py:127-245 + assets/reacher.xml; params[0] = reward_dist_weight,
                                             * [1] = reward_control_weight, [4] = frame_skip                                  */
-    MI_ENV_KIND_COUNT = 15
+    MI_ENV_HUMANOID_STANDUP = 15,          /* envs/mujoco/humanoidstandup_v5.py:266-486 + assets/humanoidstandup.xml; params as HUMANOID with
+                                            * [0] uph_cost_weight (unused by the reference) [5] impact_cost_weight [10],[11] impact_cost_range */
+    MI_ENV_KIND_COUNT = 16
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */

@@ -97,6 +97,7 @@ const mjo_model *orc_mj_model(int which) { return which >= 0 && which < ORC_MJ_C
 
 /* ---- layout ----------------------------------------------------------------------------------------------------- */
 static int is_planar_walker(int which) { return which == ORC_MJ_HOPPER || which == ORC_MJ_WALKER2D; }
+static int is_humanoid(int which) { return which == ORC_MJ_HUMANOID || which == ORC_MJ_HUMANOID_STANDUP; }
 static int is_pendulum(int which) { return which == ORC_MJ_INVERTED_PENDULUM || which == ORC_MJ_INVERTED_DOUBLE_PENDULUM; }
 
 int orc_mjenv_obs_dim(int which, const double *P) {
@@ -116,6 +117,7 @@ int orc_mjenv_info_dim(int which) {
     if (which == ORC_MJ_INVERTED_PENDULUM) return 1;
     if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 3;
     if (which == ORC_MJ_REACHER) return 2;
+    if (which == ORC_MJ_HUMANOID_STANDUP) return 6;
     return which == ORC_MJ_HALF_CHEETAH ? 4 : 9;
 }
 int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
@@ -139,7 +141,7 @@ static void mass_center_xy(const orc_mjenv *e, double out[2]) { /* humanoid_v5.p
 /* the position the env differentiates to get its velocity reward, read from the LAST forward pass (the reference reads
  * data.qpos / data.body().xpos / data.xipos after mj_step, and those Cartesian quantities lag qpos by one sub-step) */
 static void tracked_xy(const orc_mjenv *e, double out[2]) {
-    if (e->which == ORC_MJ_REACHER) {
+    if (e->which == ORC_MJ_REACHER || e->which == ORC_MJ_HUMANOID_STANDUP) {
         out[0] = out[1] = 0;
     } else if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* data.site_xpos[0]: x and height of the tip (inverted_double_pendulum_v5.py:189) */
         const double tip[3] = {0, 0, 0.6}; /* <site name="tip" pos="0 0 .6"/> on pole2 = the last body */
@@ -186,7 +188,7 @@ void orc_mjenv_obs(const orc_mjenv *e, const double *P, double *o) {
                 double f = d->cfrc_ext[b][k];
                 o[n++] = f < P[10] ? P[10] : (f > P[11] ? P[11] : f); /* np.clip(cfrc_ext, lo, hi) ant_v5.py:327-332 */
             }
-    } else if (e->which == ORC_MJ_HUMANOID) {
+    } else if (is_humanoid(e->which)) {
         if (P[12] != 0.0)
             for (int b = 1; b < m->nbody; b++)
                 for (int k = 0; k < 10; k++) o[n++] = d->cinert[b][k];
@@ -221,7 +223,7 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
     }
     /* qpos = init_qpos + uniform(-s, s, nq): Generator.uniform = low + (high - low) * next_double */
     for (int k = 0; k < m->nq; k++) qpos[k] = m->qpos0[k] + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
-    if (e->which == ORC_MJ_HUMANOID || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM) /* humanoid_v5.py:526-528, hopper_v5.py:318-331, inverted_pendulum_v5.py:178-190: uniform noise on the velocities too */
+    if (is_humanoid(e->which) || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM) /* humanoid_v5.py:526-528, hopper_v5.py:318-331, inverted_pendulum_v5.py:178-190: uniform noise on the velocities too */
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
     else /* init_qvel + scale * standard_normal(nv) */
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + scale * orc_standard_normal(rng);
@@ -247,6 +249,21 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     const double dt = m->timestep * frame_skip;
     const double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
     const double forward_reward = e->which == ORC_MJ_ANT ? xv * P[0] : P[0] * xv;
+    if (e->which == ORC_MJ_HUMANOID_STANDUP) { /* humanoidstandup_v5.py:423-462 (uph_cost_weight is never applied there) */
+        const double uph_cost = (d->qpos[2] - 0) / m->timestep;
+        double sq[MJO_MAXU], c2[6 * MJO_MAXB];
+        for (int u = 0; u < nu; u++) sq[u] = d->ctrl[u] * d->ctrl[u];
+        const double quad_ctrl_cost = P[1] * orc_np_sum_f64(sq, nu);
+        for (int b = 0; b < m->nbody; b++)
+            for (int k = 0; k < 6; k++) c2[6 * b + k] = d->cfrc_ext[b][k] * d->cfrc_ext[b][k];
+        double quad_impact_cost = P[5] * orc_np_sum_f64(c2, 6 * m->nbody);
+        quad_impact_cost = quad_impact_cost < P[10] ? P[10] : (quad_impact_cost > P[11] ? P[11] : quad_impact_cost);
+        *reward = uph_cost - quad_ctrl_cost - quad_impact_cost + 1;
+        *terminated = 0;
+        info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = d->qpos[2] - m->qpos0[2], info[3] = uph_cost, info[4] = -quad_ctrl_cost,
+        info[5] = -quad_impact_cost;
+        return;
+    }
     if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:188-207 */
         const double v[3] = {d->xpos[3][0] - d->xpos[4][0], d->xpos[3][1] - d->xpos[4][1], d->xpos[3][2] - d->xpos[4][2]};
         const double reward_dist = -sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * P[0];
@@ -343,7 +360,9 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
 void orc_mjenv_reset_info(const orc_mjenv *e, double *row) {
     if (is_pendulum(e->which) || e->which == ORC_MJ_REACHER) return; /* {} (inverted_pendulum_v5.py:198-199) */
     row[0] = e->d.qpos[0];
-    if (is_planar_walker(e->which))
+    if (e->which == ORC_MJ_HUMANOID_STANDUP)
+        row[1] = e->d.qpos[1], row[2] = e->d.qpos[2] - e->m->qpos0[2]; /* humanoidstandup_v5.py:479-486 */
+    else if (is_planar_walker(e->which))
         row[1] = e->d.qpos[1] - e->m->qpos0[1]; /* z_distance_from_origin, hopper_v5.py:338-342 */
     else if (e->which != ORC_MJ_HALF_CHEETAH)
         row[1] = e->d.qpos[1], row[2] = sqrt(row[0] * row[0] + row[1] * row[1]);

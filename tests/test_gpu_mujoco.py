@@ -16,15 +16,15 @@ pytestmark = pytest.mark.gpu
 IDS = {"half_cheetah": "HalfCheetah-v5", "ant": "Ant-v5", "humanoid": "Humanoid-v5"}
 # more robots on the same physics core (one-lane kernel), their own glue
 MORE = {"hopper": "Hopper-v5", "walker2d": "Walker2d-v5", "inverted_pendulum": "InvertedPendulum-v5",
-        "inverted_double_pendulum": "InvertedDoublePendulum-v5", "reacher": "Reacher-v5"}
+        "inverted_double_pendulum": "InvertedDoublePendulum-v5", "reacher": "Reacher-v5", "humanoid_standup": "HumanoidStandup-v5"}
 ALL = {**IDS, **MORE}
-NSTATE = {"half_cheetah": 17, "ant": 27, "humanoid": 45, "hopper": 11, "walker2d": 17, "inverted_pendulum": 4, "inverted_double_pendulum": 0, "reacher": 0}
-FIRST_INFO = {"reacher": ("reward_dist", "reward_ctrl"), "inverted_pendulum": ("reward_survive",), "inverted_double_pendulum": ("reward_survive", "distance_penalty", "velocity_penalty")}
+NSTATE = {"half_cheetah": 17, "ant": 27, "humanoid": 45, "hopper": 11, "walker2d": 17, "inverted_pendulum": 4, "inverted_double_pendulum": 0, "reacher": 0, "humanoid_standup": 45}
+FIRST_INFO = {"humanoid_standup": ("x_position", "reward_linup", "reward_quadctrl", "reward_impact"), "reacher": ("reward_dist", "reward_ctrl"), "inverted_pendulum": ("reward_survive",), "inverted_double_pendulum": ("reward_survive", "distance_penalty", "velocity_penalty")}
 
 
 @pytest.mark.parametrize("name", list(ALL))
 def test_reset_bit_exact_and_windowed_parity(name, oracle_factory):
-    n, window, T = (256, 10, 60) if name != "humanoid" else (128, 5, 40)
+    n, window, T = (256, 10, 60) if not name.startswith("humanoid") else (128, 5, 40)
     gpu = gymnasium_amd.make_vec(ALL[name], num_envs=n)
     cpu = gymnasium_amd.make_vec(ALL[name], num_envs=n, _engine_factory=oracle_factory)
     og, _ = gpu.reset(seed=11)
@@ -83,7 +83,7 @@ def test_free_running_divergence_report(name, oracle_factory):
 def test_fused_rollout_equals_stepping(name):
     import torch
 
-    n, T = (128, 12) if name != "humanoid" else (64, 6)
+    n, T = (128, 12) if not name.startswith("humanoid") else (64, 6)
     a = gymnasium_amd.make_vec(ALL[name], num_envs=n, output="torch")
     b = gymnasium_amd.make_vec(ALL[name], num_envs=n, output="torch")
     a.reset(seed=3), b.reset(seed=3)

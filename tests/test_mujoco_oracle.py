@@ -346,3 +346,27 @@ def test_more_robots_model_counts_reset_streams_and_rewards(name, oracle_factory
         prev_done = tea | tra
     assert terms > 0 or name == "reacher", "a random policy ends episodes of these robots within 120 steps (Reacher only truncates)"
     a.close(), b.close()
+
+
+def test_humanoid_standup_model_and_reward_identity(oracle_factory):
+    """HumanoidStandup-v5: same tree / masses as humanoid.xml laid on its back (test_mujoco_v5.py:548-558 counts), reward = height /
+    opt.timestep - control - impact + 1, never terminates (humanoidstandup_v5.py:423-462)."""
+    a, b = cp.compile_model("humanoid"), cp.compile_model("humanoid_standup")
+    assert (b.nq, b.nv, b.nu, b.nbody, b.njnt, b.ngeom) == (24, 23, 17, 14, 18, 18)
+    np.testing.assert_allclose(a.body_mass, b.body_mass, rtol=1e-14)
+    assert b.qpos0[2] == 0.105 and list(b.jnt_range[b.jnt_names.index("left_hip_y")]) == [np.radians(-120), np.radians(20)]
+    env = gymnasium_amd.make_vec("HumanoidStandup-v5", num_envs=3, _engine_factory=oracle_factory, exclude_current_positions_from_observation=False)
+    obs, info = env.reset(seed=100)
+    for i in range(3):
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(100 + i)))
+        qpos = b.qpos0 + g.uniform(low=-1e-2, high=1e-2, size=b.nq)
+        qvel = g.uniform(low=-1e-2, high=1e-2, size=b.nv)
+        assert np.array_equal(obs[i, :b.nq], qpos) and np.array_equal(obs[i, b.nq:b.nq + b.nv], qvel)
+    np.testing.assert_allclose(info["z_distance_from_origin"], obs[:, 2] - 0.105, rtol=0, atol=1e-15)
+    env.action_space.seed(3)
+    for t in range(20):
+        o, r, te, tr, ia = env.step(env.action_space.sample())
+        np.testing.assert_allclose(r, ia["reward_linup"] + ia["reward_quadctrl"] + ia["reward_impact"] + 1, rtol=1e-12)
+        np.testing.assert_allclose(ia["reward_linup"], o[:, 2] / 0.003, rtol=1e-12)
+        assert not te.any() and o.shape == (3, 350)
+    env.close()
