@@ -122,6 +122,11 @@ struct Board {
 #if defined(MJX_HOST_EMU)
     double red[1][32];
 #endif
+    // Mass matrix rows: in registers for 16-lane robots; for NV > 16 (Humanoid: 23 doubles per lane on top of the 23 of the
+    // Hessian row) they live here, stored column-wise (M is symmetric: lane i reads M[j][i] at [j][i], consecutive lanes ->
+    // consecutive addresses), which is what keeps that kernel from spilling.
+    static constexpr bool M_IN_LDS = NV > 16;
+    double Mt[M_IN_LDS ? NV : 1][M_IN_LDS ? NV : 1];
     int con_pair[MAXCON];
     unsigned cmask[KS], anyrow;
     int ncon;
@@ -135,7 +140,7 @@ struct Lane {
     double anchor[M::MAXJPB][3], axis[M::MAXJPB][3];
     double xmat[9], cinert[10];
     // dof role
-    double cdof[6], Mrow[NV], Hrow[NV], idiag;
+    double cdof[6], Mrow[Board<M, G>::M_IN_LDS ? 1 : NV], Hrow[NV], idiag;
     double bias, qfrc_smooth, qfrc_actuator, qacc_smooth, qacc, qacc_int, qfrc_constraint;
     double warm;  // qacc of the previous forward pass (mj qacc_warmstart): where the next constrained solve starts
     bool lim_on[2];
@@ -156,6 +161,16 @@ struct Sim {
 #else
 #define MJX_RED(bb) nullptr
 #endif
+
+    // entry j of this lane's mass-matrix row (registers or LDS, see Board::M_IN_LDS); j is always a compile-time constant
+    static MJX_DEV double mrow(const B &bb, const R &r, int lane, int j) { return B::M_IN_LDS ? bb.Mt[j][lane < NV ? lane : 0] : r.Mrow[B::M_IN_LDS ? 0 : j]; }
+    static MJX_DEV void set_mrow(B &bb, R &r, int lane, int j, double v) {
+        if (B::M_IN_LDS) {
+            if (lane < NV) bb.Mt[j][lane] = v;
+        } else {
+            r.Mrow[B::M_IN_LDS ? 0 : j] = v;
+        }
+    }
 
     // ---- one-time initialisation of the constant rows of the blackboard (world body) ----------------------------------
     static MJX_DEV void init(B &bb, int lane) {
@@ -410,14 +425,12 @@ struct Sim {
 #pragma unroll
                     for (int k = 0; k < 6; k++) s += r.cdof[k] * bb.C.crb.buf[j][k];
                 }
-                r.Mrow[j] = s;
+                if (j == lane) s += M::dof_armature[j];
+                set_mrow(bb, r, lane, j, s);
             }
+        } else if (!B::M_IN_LDS) {
 #pragma unroll
-            for (int j = 0; j < NV; j++)
-                if (j == lane) r.Mrow[j] += M::dof_armature[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < NV; j++) r.Mrow[j] = 0;
+            for (int j = 0; j < NV; j++) set_mrow(bb, r, lane, j, 0.0);
         }
         coop_sync();  // buf is dead from here on: the solver reuses its storage
     }
@@ -806,7 +819,7 @@ struct Sim {
         if (lane < NV) {
             if (hess) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j];
+                for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
             }
 #pragma unroll
             for (int sd = 0; sd < 2; sd++) {
@@ -929,7 +942,7 @@ struct Sim {
             bool solve = true;
             if (st == ST_SMOOTH) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j];
+                for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
                 rhs = r.qfrc_smooth;
                 solve = !warm_start;
             } else if (st == ST_NEWTON) {
@@ -949,7 +962,7 @@ struct Sim {
                 rhs = isdof ? -grad : 0.0;
             } else if (st == ST_DAMPED) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) r.Hrow[j] = r.Mrow[j] + ((j == lane) ? h * M::dof_damping[j] : 0.0);
+                for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j) + ((j == lane) ? h * M::dof_damping[j] : 0.0);
                 rhs = isdof ? r.qfrc_smooth + r.qfrc_constraint : 0.0;
             } else {
                 break;
@@ -981,7 +994,7 @@ struct Sim {
                     double Mx = 0;
                     if (isdof) {
 #pragma unroll
-                        for (int j = 0; j < NV; j++) Mx += r.Mrow[j] * bb.A.sol.vdir[j];
+                        for (int j = 0; j < NV; j++) Mx += mrow(bb, r, lane, j) * bb.A.sol.vdir[j];
                     }
                     Mdx = isdof ? Mx - r.qfrc_smooth : 0.0;
                     warm_start = false;
@@ -999,7 +1012,7 @@ struct Sim {
             double Md = 0;
             if (isdof) {
 #pragma unroll
-                for (int j = 0; j < NV; j++) Md += r.Mrow[j] * bb.A.sol.vdir[j];
+                for (int j = 0; j < NV; j++) Md += mrow(bb, r, lane, j) * bb.A.sol.vdir[j];
             }
             const double h0 = group_sum<G>(isdof ? dir * Md : 0.0, MJX_RED(bb), lane);
             const double g0 = group_sum<G>(isdof ? dir * Mdx : 0.0, MJX_RED(bb), lane);

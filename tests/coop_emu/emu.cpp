@@ -89,7 +89,7 @@ int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsu
         if (warm && lane < M::NV) warm[lane] = r.warm;
         if (debug && lane < M::NV) {  // qacc, qacc_smooth, bias, qfrc_constraint, then the mass-matrix rows
             debug[lane] = r.qacc, debug[M::NV + lane] = r.qacc_smooth, debug[2 * M::NV + lane] = r.bias, debug[3 * M::NV + lane] = r.qfrc_constraint;
-            for (int j = 0; j < M::NV; j++) debug[4 * M::NV + lane * M::NV + j] = r.Mrow[j];
+            for (int j = 0; j < M::NV; j++) debug[4 * M::NV + lane * M::NV + j] = S::mrow(*bb, r, lane, j);
         }
         coop::coop_sync();
     });
