@@ -67,19 +67,45 @@ MJX_DEV double rsq(double x) {
     return fma(y * 0.5, e, y);
 }
 MJX_DEV int popc(unsigned x) { return __popc(x); }
+// Data-parallel-primitive move of a double inside each row of 16 lanes (two 32-bit v_mov_b32_dpp: a VALU operand modifier, no LDS
+// round trip, no s_waitcnt).  CTRL: 0x120 + n = row_ror:n (rotate right by n lanes), 0x150 + k = row_newbcast:k (lane k to all).
+template <int CTRL>
+MJX_DEV double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// All-reduce over the G lanes of a group: rotations by 8, 4, 2, 1 inside the 16-lane DPP row (every lane ends with the same
+// bits: the partial sums of one level are identical on the lanes that get combined at the next, the same tree as the xor
+// butterfly of the host emulation); a 32-lane group first folds its two rows with one ds_bpermute.
 template <int G>
 MJX_DEV double group_sum(double v, decltype(nullptr), int) {
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) v = v + __shfl_xor(v, off, G);
+    if (G == 32) v = v + __shfl_xor(v, 16, 32);
+    v = v + dpp_mov<0x128>(v);
+    v = v + dpp_mov<0x124>(v);
+    v = v + dpp_mov<0x122>(v);
+    v = v + dpp_mov<0x121>(v);
     return v;
 }
 #endif
 
 // Blackboard of one sub-environment (LDS).  Arrays whose lifetimes inside one forward pass do not overlap share storage:
-//   A: kinematics / collision (xquat, xmat)          | solver (packed Cholesky factor, exchange column, iterate, direction)
+//   A: kinematics / collision (xquat, xmat)          | solver (packed Cholesky factor, search direction)
 //   B: RNE pass (cacc, cfrc)                         | CRB pass (per-body inertias of all bodies)
 //   C: CRB pass (composite inertias, I * cdof)       | solver (twists of the search direction, contact Jacobian exchange, forces)
 // Phase order in forward(): kinematics -> com_pos -> collision -> com_vel_and_bias -> crb -> constraint rows -> solver.
+// Phase timing (scripts/coop_phase_bench.hip only): MJX_PHASE(r, k) adds the shader cycles since the previous mark to slot k.
+#if defined(MJX_PHASE_TIMING) && !defined(MJX_HOST_EMU)
+#define MJX_PHASE(r, k)                                         \
+    do {                                                        \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        (r).tphase[k] += now_ - (r).tmark, (r).tmark = now_;    \
+    } while (0)
+#else
+#define MJX_PHASE(r, k) ((void)0)
+#endif
+
 template <class M, int G_>
 struct Board {
     static constexpr int G = G_, NQ = M::NQ, NV = M::NV, NB = M::NBODY, NU = M::NU, NTRI = M::NV * (M::NV + 1) / 2;
@@ -98,7 +124,7 @@ struct Board {
         } kin;
         struct {
             double L[NTRI];                                   // packed lower Cholesky factor (column access in back substitution)
-            double col[2][NV];                                // pivot column / substitution broadcast (double buffered)
+            double col[2][G_ == 16 ? 1 : NV];                 // pivot column / substitution exchange of the 32-lane variant (double buffered)
             double vdir[NV];                                  // solution of the last solve (qacc_smooth, then the search directions)
         } sol;
     } A;
@@ -142,6 +168,9 @@ struct Lane {
     // dof role
     double cdof[6], Mrow[Board<M, G>::M_IN_LDS ? 1 : NV], Hrow[NV], idiag;
     double bias, qfrc_smooth, qfrc_actuator, qacc_smooth, qacc, qacc_int, qfrc_constraint;
+#if defined(MJX_PHASE_TIMING) && !defined(MJX_HOST_EMU)
+    unsigned long long tphase[12], tmark;
+#endif
     double warm;  // qacc of the previous forward pass (mj qacc_warmstart): where the next constrained solve starts
     bool lim_on[2];
     double lim_D[2], lim_aref[2], lim_sign[2];
@@ -436,8 +465,85 @@ struct Sim {
     }
 
     // ---- dense Cholesky with one matrix row per lane ---------------------------------------------------------------------
+    // Lane-to-group broadcast of lane K's value: a DPP row_newbcast for 16-lane groups (two VALU moves, no LDS traffic, no wait),
+    // a ds_bpermute for 32-lane groups; the host emulation goes through the blackboard.
+    template <int K>
+    static MJX_DEV double bcast(double v, B &bb, int lane) {
+#if defined(MJX_HOST_EMU)
+        bb.red[0][lane] = v;
+        coop_sync();
+        const double out = bb.red[0][K];
+        coop_sync();
+        return out;
+#else
+        (void)bb, (void)lane;
+        if (G == 16) return dpp_mov<0x150 + (K & 15)>(v);
+        return __shfl(v, K, G);
+#endif
+    }
+    // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.A.sol.L.
+    // Right-looking, column by column: the pivot and the column below it come from the other lanes' registers by broadcast.
+    template <int K, int J>
+    static MJX_DEV void chol_update(B &bb, double *A, double ak, double t, int lane) {
+        const double cj = bcast<J>(ak, bb, lane);  // A'[J][K], held by lane J
+        A[J] -= (J <= lane ? t : 0.0) * cj;        // entries J > lane are never used
+        if constexpr (J + 1 < NV) chol_update<K, J + 1>(bb, A, ak, t, lane);
+    }
+    template <int K>
+    static MJX_DEV void chol_column(B &bb, double *A, double &idiag, int lane) {
+        const double ak = A[K];
+        double piv = bcast<K>(ak, bb, lane);
+        piv = piv < kMinVal ? kMinVal : piv;
+        const double inv = rsq(piv);
+        const double lik = ak * inv;
+        if (lane >= K) A[K] = lik;
+        if (lane == K) idiag = inv;
+        if constexpr (K + 1 < NV) {
+            chol_update<K, K + 1>(bb, A, ak, lik * inv, lane);
+#if !defined(MJX_HOST_EMU)
+            __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of later columns from being hoisted (register pressure)
+#endif
+            chol_column<K + 1>(bb, A, idiag, lane);
+        }
+    }
+    static MJX_DEV void chol_factor_bcast(B &bb, double *A, double &idiag, int lane) {
+        chol_column<0>(bb, A, idiag, lane);
+        if (lane < NV) {
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+                if (j <= lane) bb.A.sol.L[tri(lane, 0) + j] = A[j];
+        }
+        coop_sync();
+    }
+    // solves L L^T x = rhs (rhs = this lane's component); returns this lane's component, the full solution is left in vdir
+    template <int K>
+    static MJX_DEV void solve_forward(B &bb, const double *Lrow, double idiag, double &y, int lane) {
+        if (lane == K) y = y * idiag;
+        const double yk = bcast<K>(y, bb, lane);
+        y -= ((lane > K && lane < NV) ? Lrow[K] : 0.0) * yk;
+        if constexpr (K + 1 < NV) solve_forward<K + 1>(bb, Lrow, idiag, y, lane);
+    }
+    template <int K>
+    static MJX_DEV void solve_backward(B &bb, double idiag, double &y, int lane) {
+        const double lki = bb.A.sol.L[tri(K, 0) + (lane < K ? lane : 0)];  // L[K][lane]: column access through the packed copy
+        if (lane == K) y = y * idiag;
+        const double zk = bcast<K>(y, bb, lane);
+        y -= (lane < K ? lki : 0.0) * zk;
+        if constexpr (K > 0) solve_backward<K - 1>(bb, idiag, y, lane);
+    }
+    static MJX_DEV double chol_solve_bcast(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
+        double y = rhs;
+        solve_forward<0>(bb, Lrow, idiag, y, lane);
+        solve_backward<NV - 1>(bb, idiag, y, lane);
+        if (lane < NV) bb.A.sol.vdir[lane] = y;
+        coop_sync();
+        return y;
+    }
+
+    // 32-lane groups (two DPP rows): the pivot column is exchanged through LDS instead -- broadcasting by ds_bpermute keeps ~2 NV values
+    // in flight per column and made the Humanoid kernel spill (335 VGPRs against 71 this way).
     // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.A.sol.L
-    static MJX_DEV void chol_factor(B &bb, double *A, double &idiag, int lane) {
+    static MJX_DEV void chol_factor_lds(B &bb, double *A, double &idiag, int lane) {
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             double (&col)[NV] = bb.A.sol.col[k & 1];
@@ -463,7 +569,7 @@ struct Sim {
         coop_sync();
     }
     // solves L L^T x = rhs (rhs = this lane's component); returns this lane's component, the full solution is left in vdir
-    static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
+    static MJX_DEV double chol_solve_lds(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
         double y = rhs;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
@@ -481,6 +587,19 @@ struct Sim {
         }
         coop_sync();
         return y;
+    }
+
+    static MJX_DEV void chol_factor(B &bb, double *A, double &idiag, int lane) {
+        if constexpr (G == 16)
+            chol_factor_bcast(bb, A, idiag, lane);
+        else
+            chol_factor_lds(bb, A, idiag, lane);
+    }
+    static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
+        if constexpr (G == 16)
+            return chol_solve_bcast(bb, Lrow, idiag, rhs, lane);
+        else
+            return chol_solve_lds(bb, Lrow, idiag, rhs, lane);
     }
 
     // ---- collision: one candidate slot per lane and round, order-preserving compaction -------------------------------------------
@@ -895,12 +1014,19 @@ struct Sim {
     }
     static MJX_DEV void forward(B &bb, R &r, int lane) {
         const bool isdof = lane < NV;
+        MJX_PHASE(r, 0);
         kinematics(bb, r, lane);
+        MJX_PHASE(r, 1);
         com_pos(bb, r, lane);
+        MJX_PHASE(r, 2);
         collision(bb, lane);
+        MJX_PHASE(r, 3);
         com_vel_and_bias(bb, r, lane);
+        MJX_PHASE(r, 4);
         crb(bb, r, lane);
+        MJX_PHASE(r, 5);
         make_constraint(bb, r, lane);
+        MJX_PHASE(r, 6);
         if (isdof) {
             double act = 0.0;
             const int u = M::dof_actuator[lane];
@@ -946,8 +1072,10 @@ struct Sim {
                 rhs = r.qfrc_smooth;
                 solve = !warm_start;
             } else if (st == ST_NEWTON) {
+                MJX_PHASE(r, 11);
                 contact_state(r);
                 grad = assemble(bb, r, Mdx, x, !final_pass, lane);
+                MJX_PHASE(r, 7);
                 bool finished = final_pass;
                 if (!finished) {
                     const double gn = group_sum<G>(isdof ? grad * grad : 0.0, MJX_RED(bb), lane);
@@ -969,10 +1097,12 @@ struct Sim {
             }
             if (!solve && !(st == ST_SMOOTH && warm_start)) continue;
             double sol = r.warm;
+            MJX_PHASE(r, 11);
             if (solve) {
                 chol_factor(bb, r.Hrow, r.idiag, lane);
                 sol = chol_solve(bb, r.Hrow, r.idiag, rhs, lane);
             }
+            MJX_PHASE(r, 8);
             if (st == ST_DAMPED) {
                 r.qacc_int = sol;
                 st = ST_DONE;
@@ -988,6 +1118,7 @@ struct Sim {
 #pragma unroll
             for (int kc = 0; kc < KC; kc++)
                 if (r.c_on[kc]) contact_vel(bb, bb.C.sol.tw, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.c_jd[kc]);
+            MJX_PHASE(r, 9);
             if (st == ST_SMOOTH) {  // the iterate starts at sol (the unconstrained acceleration, or the warm start): x = 0 + 1 * sol
                 r.qacc_smooth = sol, x = sol, Mdx = 0;
                 if (warm_start) {  // M (x - x_smooth) = M x - qfrc_smooth
@@ -1069,6 +1200,7 @@ struct Sim {
                 if (next == alpha) break;
                 alpha = next;
             }
+            MJX_PHASE(r, 10);
             if (!(alpha > 0)) {  // no descent possible: the iterate (and the gradient just assembled) is final
                 r.qacc = x, r.qfrc_constraint = Mdx - grad;
                 publish_forces(bb, r, lane);
@@ -1089,6 +1221,7 @@ struct Sim {
         if (!damped_euler()) r.qacc_int = r.qacc;
         r.warm = r.qacc;
         coop_sync();
+        MJX_PHASE(r, 11);
     }
 
     // joints of body `lane + 1`: position update of bb.qpos from the dof velocities in `vel` (mj_integratePos)

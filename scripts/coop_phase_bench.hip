@@ -1,0 +1,92 @@
+// coop_phase_bench.hip -- standalone timing harness for the cooperative MuJoCo kernel (gymnasium_amd/csrc/mjx_coop.h).
+// Not part of the library: it compiles the same header with MJX_PHASE_TIMING, advances N robots from perturbed initial states
+// for a few env-steps (so that contacts and joint limits are active) and prints, per phase of forward(), the share of shader cycles
+// (s_memtime deltas summed over wavefronts).  Build + run (on the GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Igymnasium_amd/csrc scripts/coop_phase_bench.hip -o gpurun_out/coop_phase_bench
+//   gpurun_out/coop_phase_bench [ant|humanoid] [num_envs]
+#define MJX_PHASE_TIMING 1
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "mjx_coop.h"
+
+using namespace mjx;
+
+template <class M, int G>
+__global__ __launch_bounds__(64) void phys(double *state, const float *actions, int N, int nsub, unsigned long long *phase) {
+    typedef coop::Sim<M, G> S;
+    constexpr int EPW = 64 / G;
+    __shared__ typename S::B boards[EPW];
+    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+    const int env = blockIdx.x * EPW + grp;
+    if (env >= N) return;
+    typename S::B &bb = boards[grp];
+    typename S::R r;
+    for (int k = 0; k < 12; k++) r.tphase[k] = 0;
+    S::init(bb, lane);
+    for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = state[(size_t)k * N + env];
+    for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
+    for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
+    r.warm = lane < M::NV ? state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;
+    coop::coop_sync();
+    r.tmark = __builtin_readcyclecounter();
+    for (int s = 0; s < nsub; s++) S::step(bb, r, lane);
+    coop::coop_sync();
+    for (int k = lane; k < M::NQ; k += G) state[(size_t)k * N + env] = bb.qpos[k];
+    for (int k = lane; k < M::NV; k += G) state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
+    if (lane < M::NV) state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 12; k++) atomicAdd(&phase[k], r.tphase[k]);
+}
+
+template <class M, int G>
+int run(int N, int nsub, float amp) {
+    const int S = M::NQ + 2 * M::NV;
+    std::vector<double> st((size_t)S * N, 0.0);
+    std::vector<float> act((size_t)N * M::NU);
+    unsigned long long seed = 88172645463325252ull;
+    auto rnd = [&]() { seed ^= seed << 13, seed ^= seed >> 7, seed ^= seed << 17; return (double)(seed >> 11) / 9007199254740992.0; };
+    for (int i = 0; i < N; i++) {
+        for (int k = 0; k < M::NQ; k++) st[(size_t)k * N + i] = M::qpos0[k] + 0.1 * (2 * rnd() - 1) * (k >= 3 && k < 7 ? 0.1 : 1.0);
+        for (int k = 0; k < M::NV; k++) st[(size_t)(M::NQ + k) * N + i] = 0.1 * (2 * rnd() - 1);
+    }
+    double *d_st;
+    float *d_act;
+    unsigned long long *d_ph;
+    hipMalloc(&d_st, sizeof(double) * st.size()), hipMalloc(&d_act, sizeof(float) * act.size()), hipMalloc(&d_ph, 12 * 8);
+    hipMemcpy(d_st, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice);
+    const dim3 grid((N + 64 / G - 1) / (64 / G)), block(64);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    const int warm = 40, timed = 6;
+    float ms = 0;
+    for (int t = 0; t < warm + timed; t++) {
+        for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
+        hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
+        if (t == warm) hipMemset(d_ph, 0, 12 * 8), hipEventRecord(e0);
+        hipLaunchKernelGGL((phys<M, G>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph);
+    }
+    hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long ph[12];
+    hipMemcpy(ph, d_ph, sizeof ph, hipMemcpyDeviceToHost);
+    const char *names[12] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "make_constraint",
+                             "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other"};
+    double tot = 0;
+    for (int k = 0; k < 12; k++) tot += (double)ph[k];
+    printf("%d envs, %d sub-steps per launch: %.3f ms per launch (incl. host action upload), %.4g env-steps/s\n", N, nsub, ms / timed, N / (ms / timed * 1e-3));
+    const double waves = (double)((N + 64 / G - 1) / (64 / G)) * timed, forwards = waves * nsub * (M::INTEGRATOR ? 4 : 1);
+    for (int k = 0; k < 12; k++) printf("  %-26s %5.1f %%   %8.0f cycles per forward pass\n", names[k], 100.0 * ph[k] / tot, ph[k] / forwards);
+    printf("  total %.0f cycles per forward pass and wavefront (%d envs per wavefront)\n", tot / forwards, 64 / G);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    const char *which = argc > 1 ? argv[1] : "ant";
+    const int N = argc > 2 ? atoi(argv[2]) : 32768;
+    if (!strcmp(which, "humanoid")) return run<HumanoidModel, 32>(N, 5, 0.4f);
+    return run<AntModel, 16>(N, 5, 1.0f);
+}
