@@ -79,9 +79,20 @@ MJX_DEV double dpp_mov(double v) {
 // All-reduce over the G lanes of a group: rotations by 8, 4, 2, 1 inside the 16-lane DPP row (every lane ends with the same
 // bits: the partial sums of one level are identical on the lanes that get combined at the next, the same tree as the xor
 // butterfly of the host emulation); a 32-lane group first folds its two rows with one ds_bpermute.
+// v_permlane16_swap (new on gfx950) exchanges the odd 16-lane rows of one register with the even rows of another; fed the same
+// value twice it returns {even row's data in both rows, odd row's data in both rows}: the cross-row step of a 32-lane group.
+MJX_DEV void row_pair(double v, double &even_rows, double &odd_rows) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    even_rows = __hiloint2double((int)hi[0], (int)lo[0]), odd_rows = __hiloint2double((int)hi[1], (int)lo[1]);
+}
 template <int G>
 MJX_DEV double group_sum(double v, decltype(nullptr), int) {
-    if (G == 32) v = v + __shfl_xor(v, 16, 32);
+    if (G == 32) {
+        double a, b;
+        row_pair(v, a, b);
+        v = a + b;
+    }
     v = v + dpp_mov<0x128>(v);
     v = v + dpp_mov<0x124>(v);
     v = v + dpp_mov<0x122>(v);
@@ -478,7 +489,9 @@ struct Sim {
 #else
         (void)bb, (void)lane;
         if (G == 16) return dpp_mov<0x150 + (K & 15)>(v);
-        return __shfl(v, K, G);
+        double a, b;  // 32-lane group: pick the row that holds lane K, then broadcast inside the rows
+        row_pair(v, a, b);
+        return dpp_mov<0x150 + (K & 15)>(K < 16 ? a : b);
 #endif
     }
     // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.A.sol.L.
@@ -589,14 +602,17 @@ struct Sim {
         return y;
     }
 
+#ifndef MJX_CHOL_LDS_FOR_32
+#define MJX_CHOL_LDS_FOR_32 1  // measured: the broadcast variant makes the 23-row Humanoid kernel spill 350 VGPRs (71 this way)
+#endif
     static MJX_DEV void chol_factor(B &bb, double *A, double &idiag, int lane) {
-        if constexpr (G == 16)
+        if constexpr (G == 16 || !MJX_CHOL_LDS_FOR_32)
             chol_factor_bcast(bb, A, idiag, lane);
         else
             chol_factor_lds(bb, A, idiag, lane);
     }
     static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
-        if constexpr (G == 16)
+        if constexpr (G == 16 || !MJX_CHOL_LDS_FOR_32)
             return chol_solve_bcast(bb, Lrow, idiag, rhs, lane);
         else
             return chol_solve_lds(bb, Lrow, idiag, rhs, lane);
