@@ -1039,7 +1039,8 @@ typedef mjx::MjEnv<mjx::InvertedPendulumModel, mjx::kInvertedPendulum> InvertedP
 typedef mjx::MjEnv<mjx::InvertedDoublePendulumModel, mjx::kInvertedDoublePendulum> InvertedDoublePendulumEnv;
 typedef mjx::MjEnv<mjx::ReacherModel, mjx::kReacher> ReacherEnv;
 typedef mjx::MjEnv<mjx::HumanoidStandupModel, mjx::kHumanoidStandup> HumanoidStandupEnv;
-bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER || kind == MI_ENV_HUMANOID_STANDUP; }
+typedef mjx::MjEnv<mjx::SwimmerModel, mjx::kSwimmer> SwimmerEnv;
+bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER || kind == MI_ENV_HUMANOID_STANDUP || kind == MI_ENV_SWIMMER; }
 bool is_tab(int kind) { return kind == MI_ENV_TABULAR || kind == MI_ENV_BLACKJACK; }  // Blackjack rides on the tabular kernels
 template <class F>
 int dispatch_mj(int kind, F &&f) {
@@ -1053,6 +1054,7 @@ int dispatch_mj(int kind, F &&f) {
     case MI_ENV_INVERTED_DOUBLE_PENDULUM: return f(InvertedDoublePendulumEnv());
     case MI_ENV_REACHER: return f(ReacherEnv());
     case MI_ENV_HUMANOID_STANDUP: return f(HumanoidStandupEnv());
+    case MI_ENV_SWIMMER: return f(SwimmerEnv());
     }
     return fail(MI_ERR_UNSUPPORTED, "this MuJoCo kind is not built into the HIP engine yet");
 }

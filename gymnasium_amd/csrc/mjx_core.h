@@ -804,6 +804,57 @@ MJX_DEV int solve_newton(Data<M> &d) {
     return it;
 }
 
+// ---- fluid forces of the medium (option density / viscosity), MuJoCo's inertia-box model ---------------------------------
+// Every body is replaced by the box with its mass and principal moments (M::body_fluidbox, axes M::body_imat); in that frame,
+// at the body's centre of mass, the velocity (w, v) gives  viscous: t -= pi d^3 mu w, f -= 3 pi d mu v  (d = mean edge) and
+// drag: t_k -= rho b_k (b_i^4 + b_j^4) |w_k| w_k / 64, f_k -= rho b_i b_j |v_k| v_k / 2; the wrench is applied at the centre of
+// mass.  Same arithmetic as oracle/mujoco_core.c fluid().  Adds into qfrc[NV].
+template <class M>
+MJX_DEV void fluid(const Data<M> &d, double *qfrc) {
+    constexpr double PI = 3.14159265358979323846;
+#pragma unroll
+    for (int b = 1; b < M::NBODY; b++) {
+        if (M::body_mass[b] < 1e-15) continue;
+        double R[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                R[3 * i + j] = d.xmat[b][3 * i] * M::body_imat[b][j] + d.xmat[b][3 * i + 1] * M::body_imat[b][3 + j] + d.xmat[b][3 * i + 2] * M::body_imat[b][6 + j];
+        const double off[3] = {d.xipos[b][0] - d.com[0], d.xipos[b][1] - d.com[1], d.xipos[b][2] - d.com[2]};
+        const double *w = d.cvel[b], *vl = d.cvel[b] + 3;
+        const double vc[3] = {vl[0] + w[1] * off[2] - w[2] * off[1], vl[1] + w[2] * off[0] - w[0] * off[2], vl[2] + w[0] * off[1] - w[1] * off[0]};
+        double lw[3], lv[3], lt[3], lf[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lw[k] = R[k] * w[0] + R[3 + k] * w[1] + R[6 + k] * w[2];
+            lv[k] = R[k] * vc[0] + R[3 + k] * vc[1] + R[6 + k] * vc[2];
+            lt[k] = 0, lf[k] = 0;
+        }
+        const double bx0 = M::body_fluidbox[b][0], bx1 = M::body_fluidbox[b][1], bx2 = M::body_fluidbox[b][2];
+        if (M::VISCOSITY > 0) {
+            const double diam = (bx0 + bx1 + bx2) / 3.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) lt[k] += -PI * diam * diam * diam * M::VISCOSITY * lw[k], lf[k] += -3.0 * PI * diam * M::VISCOSITY * lv[k];
+        }
+        if (M::DENSITY > 0) {
+            lf[0] -= 0.5 * M::DENSITY * bx1 * bx2 * fabs(lv[0]) * lv[0];
+            lf[1] -= 0.5 * M::DENSITY * bx0 * bx2 * fabs(lv[1]) * lv[1];
+            lf[2] -= 0.5 * M::DENSITY * bx0 * bx1 * fabs(lv[2]) * lv[2];
+            lt[0] -= M::DENSITY * bx0 * (bx1 * bx1 * bx1 * bx1 + bx2 * bx2 * bx2 * bx2) * fabs(lw[0]) * lw[0] / 64.0;
+            lt[1] -= M::DENSITY * bx1 * (bx0 * bx0 * bx0 * bx0 + bx2 * bx2 * bx2 * bx2) * fabs(lw[1]) * lw[1] / 64.0;
+            lt[2] -= M::DENSITY * bx2 * (bx0 * bx0 * bx0 * bx0 + bx1 * bx1 * bx1 * bx1) * fabs(lw[2]) * lw[2] / 64.0;
+        }
+        double gt[3], gf[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            gt[k] = R[3 * k] * lt[0] + R[3 * k + 1] * lt[1] + R[3 * k + 2] * lt[2], gf[k] = R[3 * k] * lf[0] + R[3 * k + 1] * lf[1] + R[3 * k + 2] * lf[2];
+        const double tq[3] = {gt[0] + off[1] * gf[2] - off[2] * gf[1], gt[1] + off[2] * gf[0] - off[0] * gf[2], gt[2] + off[0] * gf[1] - off[1] * gf[0]};
+        for (int i = M::body_dofadr[b] + M::body_dofnum[b] - 1; i >= 0; i = M::dof_parentid[i])
+            qfrc[i] += d.cdof[i][0] * tq[0] + d.cdof[i][1] * tq[1] + d.cdof[i][2] * tq[2] + d.cdof[i][3] * gf[0] + d.cdof[i][4] * gf[1] + d.cdof[i][5] * gf[2];
+    }
+}
+
 // ---- forward dynamics -------------------------------------------------------------------------------------------------
 template <class M>
 MJX_DEVN void forward(Data<M> &d) {
@@ -823,9 +874,13 @@ MJX_DEVN void forward(Data<M> &d) {
         c = c < M::actuator_ctrlrange[u][0] ? M::actuator_ctrlrange[u][0] : (c > M::actuator_ctrlrange[u][1] ? M::actuator_ctrlrange[u][1] : c);
         d.qfrc_actuator[M::actuator_dofadr[u]] += M::actuator_gear[u] * c;
     }
+    double fl[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) fl[i] = 0;
+    if constexpr (M::DENSITY > 0 || M::VISCOSITY > 0) fluid<M>(d, fl);
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-        double passive = -M::dof_damping[i] * d.qvel[i];
+        double passive = fl[i] - M::dof_damping[i] * d.qvel[i];
         const int j = M::dof_jntid[i];
         if (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)
             passive -= M::jnt_stiffness[j] * (d.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]]);

@@ -61,7 +61,7 @@ MJX_DEV T np_sum(const T *a) {
     return res;
 }
 
-enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7, kHumanoidStandup = 8 };
+enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7, kHumanoidStandup = 8, kSwimmer = 9 };
 
 // quantities of the last forward pass that the observations read besides qpos / qvel (null pointer = zeros, which is
 // what mj_resetData leaves in cfrc_ext / qfrc_actuator)
@@ -83,7 +83,7 @@ struct MjEnv {
     static constexpr bool HUMANOID_LIKE = KIND == kHumanoid || KIND == kHumanoidStandup;  // same model family, same observation
     static constexpr bool PENDULUM = KIND == kInvertedPendulum || KIND == kInvertedDoublePendulum;
     static constexpr int INFO =
-        KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : (KIND == kHumanoidStandup ? 6 : 9)))));
+        KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : (KIND == kHumanoidStandup ? 6 : (KIND == kSwimmer ? 7 : 9))))));
     static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || HUMANOID_LIKE;  // small robots: one-lane kernel only
     static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
     static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : ((PENDULUM || KIND == kReacher) ? 0 : 2);
@@ -193,7 +193,7 @@ struct MjEnv {
         }
         const double scale = P.p[2];
         for (int k = 0; k < NQ; k++) s[k] = M::qpos0[k] + (-scale + (scale - (-scale)) * rng.next_double());
-        if (HUMANOID_LIKE || PLANAR_WALKER || KIND == kInvertedPendulum)  // humanoid_v5.py:526-528, hopper_v5.py:318-331: uniform noise on the velocities as well
+        if (HUMANOID_LIKE || PLANAR_WALKER || KIND == kInvertedPendulum || KIND == kSwimmer)  // swimmer_v5.py:279-294, humanoid_v5.py:526-528, hopper_v5.py:318-331: uniform noise on the velocities as well
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-scale + (scale - (-scale)) * rng.next_double());
         else
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + scale * standard_normal(rng);
@@ -260,6 +260,8 @@ struct MjEnv {
             x.after[0] = d.xpos[sb][0] + t[0], x.after[1] = d.xpos[sb][2] + t[2];
         } else if (KIND == kHalfCheetah || PLANAR_WALKER || KIND == kInvertedPendulum)
             x.after[0] = d.qpos[0], x.after[1] = 0.0;
+        else if (KIND == kSwimmer)  // data.qpos[0:2] (swimmer_v5.py:226-228)
+            x.after[0] = d.qpos[0], x.after[1] = d.qpos[1];
         else if (KIND == kAnt)
             x.after[0] = d.xpos[1][0], x.after[1] = d.xpos[1][1];
         else
@@ -373,6 +375,19 @@ struct MjEnv {
             if (info)
                 info[0] = s[0], info[1] = s[1] - M::qpos0[1], info[2] = xv, info[3] = forward_reward, info[4] = -(double)ctrl_cost_f,
                 info[5] = healthy_reward;
+            return;
+        }
+        if (KIND == kSwimmer) {
+            // swimmer_v5.py:225-263: forward velocity of the root sliders, float32 control cost, never terminates
+            const double forward_reward = P.p[0] * xv;
+            reward = forward_reward - (double)ctrl_cost_f;
+            terminated = false;
+            const ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
+            write_obs(s, ox, P, obs);
+            if (info) {
+                info[0] = after[0], info[1] = after[1], info[2] = sqrt(after[0] * after[0] + after[1] * after[1]), info[3] = xv, info[4] = yv;
+                info[5] = forward_reward, info[6] = -(double)ctrl_cost_f;
+            }
             return;
         }
         if (KIND == kHalfCheetah) {

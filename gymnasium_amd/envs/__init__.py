@@ -15,6 +15,7 @@ from .mujoco.envs import (  # noqa: F401
     InvertedDoublePendulumVectorEnv,
     InvertedPendulumVectorEnv,
     ReacherVectorEnv,
+    SwimmerVectorEnv,
     Walker2dVectorEnv,
 )
 from .mujoco.envs import ENV_TABLE as _MUJOCO

@@ -14,7 +14,7 @@ from . import compiler
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc", "generated", "mjx_models.h")
 STRUCT = {"half_cheetah": "HalfCheetahModel", "ant": "AntModel", "humanoid": "HumanoidModel", "hopper": "HopperModel", "walker2d": "Walker2dModel",
-          "inverted_pendulum": "InvertedPendulumModel", "inverted_double_pendulum": "InvertedDoublePendulumModel", "reacher": "ReacherModel", "humanoid_standup": "HumanoidStandupModel"}
+          "inverted_pendulum": "InvertedPendulumModel", "inverted_double_pendulum": "InvertedDoublePendulumModel", "reacher": "ReacherModel", "humanoid_standup": "HumanoidStandupModel", "swimmer": "SwimmerModel"}
 
 
 def _arr(name, ctype, values, shape):
@@ -43,6 +43,7 @@ def emit_model(m) -> str:
           f"MAXCHAIN = {maxdepth};\n")
     s += f"    static constexpr int INTEGRATOR = {1 if m.integrator == 'RK4' else 0}, SOLVER = {1 if m.solver == 'PGS' else 0}, ITERATIONS = {m.iterations};\n"
     s += f"    static constexpr double TIMESTEP = {float(m.timestep).hex()}, MEANINERTIA = {float(m.meaninertia).hex()};\n"
+    s += f"    static constexpr double DENSITY = {float(m.density).hex()}, VISCOSITY = {float(m.viscosity).hex()};  // fluid (inertia-box model)\n"
     s += _arr("gravity", "double", m.gravity, (3,))
     for name, ct, val, shape in [
         ("body_parentid", "int", m.body_parentid, (nb,)), ("body_rootid", "int", m.body_rootid, (nb,)),
@@ -51,6 +52,7 @@ def emit_model(m) -> str:
         ("body_pos", "double", m.body_pos, (nb, 3)), ("body_quat", "double", m.body_quat, (nb, 4)),
         ("body_mass", "double", m.body_mass, (nb,)), ("body_ipos", "double", m.body_ipos, (nb, 3)),
         ("body_inertia", "double", m.body_inertia, (nb, 9)), ("body_invweight0", "double", m.body_invweight0, (nb, 2)),
+        ("body_fluidbox", "double", m.body_fluidbox, (nb, 3)), ("body_imat", "double", m.body_imat, (nb, 9)),
         ("jnt_type", "int", m.jnt_type, (nj,)), ("jnt_qposadr", "int", m.jnt_qposadr, (nj,)), ("jnt_dofadr", "int", m.jnt_dofadr, (nj,)),
         ("jnt_bodyid", "int", m.jnt_bodyid, (nj,)), ("jnt_limited", "int", m.jnt_limited, (nj,)),
         ("jnt_pos", "double", m.jnt_pos, (nj, 3)), ("jnt_axis", "double", m.jnt_axis, (nj, 3)), ("jnt_range", "double", m.jnt_range, (nj, 2)),

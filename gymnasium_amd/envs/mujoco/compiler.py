@@ -274,6 +274,26 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
     m.qpos0 = np.array(qpos0)
     m.qpos_spring = m.qpos0.copy()
 
+    # ---- fluid (option density / viscosity): equivalent inertia box of every body, in its principal frame ----------------
+    # MuJoCo's inertia-box fluid model (mj_passive): box[k] = sqrt(6 (I_i + I_j - I_k) / mass) from the principal moments;
+    # body_imat = principal axes as columns, expressed in the body frame (ximat = xmat @ body_imat)
+    m.density, m.viscosity = float(opt.get("density", 0.0)), float(opt.get("viscosity", 0.0))
+    m.body_fluidbox, m.body_imat = np.zeros((nbody, 3)), np.tile(np.eye(3).reshape(-1), (nbody, 1))
+    for bi in range(1, nbody):
+        if m.body_mass[bi] <= 0:
+            continue
+        I = np.asarray(m.body_inertia[bi], dtype=np.float64).reshape(3, 3)
+        if np.abs(I - np.diag(np.diag(I))).max() <= 1e-12 * np.trace(I):
+            w, V = np.diag(I).copy(), np.eye(3)   # already principal: keep the body axes (a degenerate pair would let eigh pick any rotation)
+        else:
+            w, V = np.linalg.eigh(I)
+            if np.linalg.det(V) < 0:
+                V[:, 2] = -V[:, 2]
+        I0, I1, I2 = w
+        mass = m.body_mass[bi]
+        m.body_fluidbox[bi] = [math.sqrt(max(MINVAL, I1 + I2 - I0) / mass * 6.0), math.sqrt(max(MINVAL, I0 + I2 - I1) / mass * 6.0),
+                               math.sqrt(max(MINVAL, I0 + I1 - I2) / mass * 6.0)]
+        m.body_imat[bi] = V.reshape(-1)
     # ---- sites: (body index, position in the body frame) ------------------------------------------------------------
     m.sites = [(m.body_names.index(b), tuple(float(x) for x in pos)) for _, b, pos in desc.get("sites", [])]
     # ---- actuators (motors on joints) ---------------------------------------------------------------------------

@@ -315,6 +315,34 @@ class ReacherVectorEnv(_PendulumVectorEnv):
         return 10
 
 
+class SwimmerVectorEnv(_MujocoVectorEnv):
+    """swimmer_v5.py:153-301: three links in a viscous medium (swimmer.xml: option density 4000, viscosity 0.1, RK4); obs = qpos[2:] + qvel
+    (float64[8]), action float32[2] in [-1, 1]; never terminates."""
+
+    KIND = "swimmer"
+    DEFAULT_MAX_EPISODE_STEPS = 1000
+    STOCK_XML = "swimmer.xml"
+    NQ, NV, NU, NBODY = 5, 5, 2, 4
+    CTRL_LOW, CTRL_HIGH = -1.0, 1.0
+    INFO_KEYS = ("x_position", "y_position", "distance_from_origin", "x_velocity", "y_velocity", "reward_forward", "reward_ctrl")
+    N_RESET_INFO_KEYS = 3
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "swimmer.xml", frame_skip: int = 4,
+                 forward_reward_weight: float = 1.0, ctrl_cost_weight: float = 1e-4, reset_noise_scale: float = 0.1,
+                 exclude_current_positions_from_observation: bool = True, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._exclude = bool(exclude_current_positions_from_observation)
+        self._params = (forward_reward_weight, ctrl_cost_weight, reset_noise_scale, float(self._exclude), float(frame_skip))
+        self.observation_structure = {"skipped_qpos": 2 * self._exclude, "qpos": self.NQ - 2 * self._exclude, "qvel": self.NV}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return self.NQ + self.NV - 2 * self._exclude
+
+    def _engine_params(self):
+        return self._params
+
+
 # id -> (creator, max_episode_steps, reward_threshold): gymnasium/envs/__init__.py:246-374
 ENV_TABLE = {
     "HalfCheetah-v5": (HalfCheetahVectorEnv, 1000, 4800.0),
@@ -326,4 +354,5 @@ ENV_TABLE = {
     "InvertedDoublePendulum-v5": (InvertedDoublePendulumVectorEnv, 1000, 9100.0),
     "Reacher-v5": (ReacherVectorEnv, 50, -3.75),
     "HumanoidStandup-v5": (HumanoidStandupVectorEnv, 1000, None),
+    "Swimmer-v5": (SwimmerVectorEnv, 1000, 360.0),
 }

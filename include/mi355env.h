@@ -62,7 +62,10 @@ typedef enum mi_env_kind {
                                             * [1] = reward_control_weight, [4] = frame_skip                                  */
     MI_ENV_HUMANOID_STANDUP = 15,          /* envs/mujoco/humanoidstandup_v5.py:266-486 + assets/humanoidstandup.xml; params as HUMANOID with
                                             * [0] uph_cost_weight (unused by the reference) [5] impact_cost_weight [10],[11] impact_cost_range */
-    MI_ENV_KIND_COUNT = 16
+    MI_ENV_SWIMMER = 16,                   /* envs/mujoco/swimmer_v5.py:153-301 + assets/swimmer.xml (fluid forces of the medium: option density,
+                                            * viscosity); params [0] forward_reward_weight [1] ctrl_cost_weight [2] reset_noise_scale
+                                            * [3] exclude_current_positions [4] frame_skip                                     */
+    MI_ENV_KIND_COUNT = 17
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */

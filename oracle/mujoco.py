@@ -20,9 +20,9 @@ _DLL = None
 def model_blob(m) -> np.ndarray:
     """Serialise a CompiledModel in the order mjo_model_from_blob (mujoco_core.c) reads it."""
     parts = [[m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, len(m.pair_geom1), 1 if m.integrator == "RK4" else 0,
-              1 if m.solver == "PGS" else 0, m.iterations, m.timestep], m.gravity, [m.meaninertia],
+              1 if m.solver == "PGS" else 0, m.iterations, m.timestep], m.gravity, [m.meaninertia, m.density, m.viscosity],
              m.body_parentid, m.body_rootid, m.body_jntadr, m.body_jntnum, m.body_dofadr, m.body_dofnum,
-             m.body_pos, m.body_quat, m.body_mass, m.body_ipos, m.body_inertia, m.body_invweight0,
+             m.body_pos, m.body_quat, m.body_mass, m.body_ipos, m.body_inertia, m.body_invweight0, m.body_fluidbox, m.body_imat,
              m.jnt_type, m.jnt_qposadr, m.jnt_dofadr, m.jnt_bodyid, m.jnt_limited,
              m.jnt_pos, m.jnt_axis, m.jnt_range, m.jnt_stiffness, m.jnt_margin, m.jnt_solref, m.jnt_solimp,
              m.dof_bodyid, m.dof_jntid, m.dof_parentid, m.dof_armature, m.dof_damping, m.dof_invweight0,

@@ -114,12 +114,12 @@ int mjo_model_from_blob(mjo_model *m, const double *blob, int n) {
         return -1;
     m->timestep = *p++;
     TAKE_D(m->gravity, 3);
-    m->meaninertia = *p++;
+    m->meaninertia = *p++, m->density = *p++, m->viscosity = *p++;
     int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, np = m->npair, nu = m->nu;
     TAKE_I(m->body_parentid, nb); TAKE_I(m->body_rootid, nb); TAKE_I(m->body_jntadr, nb); TAKE_I(m->body_jntnum, nb);
     TAKE_I(m->body_dofadr, nb); TAKE_I(m->body_dofnum, nb);
     TAKE_D(m->body_pos, 3 * nb); TAKE_D(m->body_quat, 4 * nb); TAKE_D(m->body_mass, nb); TAKE_D(m->body_ipos, 3 * nb);
-    TAKE_D(m->body_inertia, 9 * nb); TAKE_D(m->body_invweight0, 2 * nb);
+    TAKE_D(m->body_inertia, 9 * nb); TAKE_D(m->body_invweight0, 2 * nb); TAKE_D(m->body_fluidbox, 3 * nb); TAKE_D(m->body_imat, 9 * nb);
     TAKE_I(m->jnt_type, nj); TAKE_I(m->jnt_qposadr, nj); TAKE_I(m->jnt_dofadr, nj); TAKE_I(m->jnt_bodyid, nj); TAKE_I(m->jnt_limited, nj);
     TAKE_D(m->jnt_pos, 3 * nj); TAKE_D(m->jnt_axis, 3 * nj); TAKE_D(m->jnt_range, 2 * nj); TAKE_D(m->jnt_stiffness, nj);
     TAKE_D(m->jnt_margin, nj); TAKE_D(m->jnt_solref, 2 * nj); TAKE_D(m->jnt_solimp, 5 * nj);
@@ -551,6 +551,58 @@ static void com_vel(const mjo_model *m, mjo_data *d) {
     }
 }
 
+/* Fluid forces of the medium (option density / viscosity): MuJoCo's inertia-box model (mj_passive, engine_passive.c
+ * mj_inertiaBoxFluidModel; documentation "Computation" > passive forces): each body is replaced by the box with its mass and
+ * principal moments; in that box's frame (at the body's centre of mass) the velocity (w, v) produces
+ *   viscous:  torque -= pi d^3 mu w,              force -= 3 pi d mu v,                     d = mean box edge
+ *   drag:     torque_k -= rho b_k (b_i^4 + b_j^4) |w_k| w_k / 64,   force_k -= rho b_i b_j |v_k| v_k / 2
+ * and the wrench is applied at the centre of mass (mj_applyFT).  Needs cvel (com_vel) and the position stage. */
+static void fluid(const mjo_model *m, mjo_data *d) {
+    if (m->density <= 0 && m->viscosity <= 0) return;
+    const double PI = 3.14159265358979323846;
+    for (int b = 1; b < m->nbody; b++) {
+        if (m->body_mass[b] < 1e-15) continue;
+        double R[9]; /* ximat = xmat * imat */
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R[3 * i + j] = d->xmat[b][3 * i] * m->body_imat[b][j] + d->xmat[b][3 * i + 1] * m->body_imat[b][3 + j] + d->xmat[b][3 * i + 2] * m->body_imat[b][6 + j];
+        /* velocity of the body's centre of mass: cvel is [angular; linear at the tree com] */
+        const double off[3] = {d->xipos[b][0] - d->subtree_com[m->body_rootid[b]][0], d->xipos[b][1] - d->subtree_com[m->body_rootid[b]][1],
+                               d->xipos[b][2] - d->subtree_com[m->body_rootid[b]][2]};
+        const double *w = d->cvel[b], *vl = d->cvel[b] + 3;
+        const double vc[3] = {vl[0] + w[1] * off[2] - w[2] * off[1], vl[1] + w[2] * off[0] - w[0] * off[2], vl[2] + w[0] * off[1] - w[1] * off[0]};
+        double lw[3], lv[3], lt[3], lf[3];
+        for (int k = 0; k < 3; k++) {
+            lw[k] = R[k] * w[0] + R[3 + k] * w[1] + R[6 + k] * w[2];
+            lv[k] = R[k] * vc[0] + R[3 + k] * vc[1] + R[6 + k] * vc[2];
+            lt[k] = 0, lf[k] = 0;
+        }
+        const double *bx = m->body_fluidbox[b];
+        if (m->viscosity > 0) {
+            const double diam = (bx[0] + bx[1] + bx[2]) / 3.0;
+            for (int k = 0; k < 3; k++) lt[k] += -PI * diam * diam * diam * m->viscosity * lw[k], lf[k] += -3.0 * PI * diam * m->viscosity * lv[k];
+        }
+        if (m->density > 0) {
+            lf[0] -= 0.5 * m->density * bx[1] * bx[2] * fabs(lv[0]) * lv[0];
+            lf[1] -= 0.5 * m->density * bx[0] * bx[2] * fabs(lv[1]) * lv[1];
+            lf[2] -= 0.5 * m->density * bx[0] * bx[1] * fabs(lv[2]) * lv[2];
+            lt[0] -= m->density * bx[0] * (bx[1] * bx[1] * bx[1] * bx[1] + bx[2] * bx[2] * bx[2] * bx[2]) * fabs(lw[0]) * lw[0] / 64.0;
+            lt[1] -= m->density * bx[1] * (bx[0] * bx[0] * bx[0] * bx[0] + bx[2] * bx[2] * bx[2] * bx[2]) * fabs(lw[1]) * lw[1] / 64.0;
+            lt[2] -= m->density * bx[2] * (bx[0] * bx[0] * bx[0] * bx[0] + bx[1] * bx[1] * bx[1] * bx[1]) * fabs(lw[2]) * lw[2] / 64.0;
+        }
+        double gt[3], gf[3]; /* back to the world frame; torque about the tree com = torque + off x force */
+        for (int k = 0; k < 3; k++)
+            gt[k] = R[3 * k] * lt[0] + R[3 * k + 1] * lt[1] + R[3 * k + 2] * lt[2], gf[k] = R[3 * k] * lf[0] + R[3 * k + 1] * lf[1] + R[3 * k + 2] * lf[2];
+        const double tq[3] = {gt[0] + off[1] * gf[2] - off[2] * gf[1], gt[1] + off[2] * gf[0] - off[0] * gf[2], gt[2] + off[0] * gf[1] - off[1] * gf[0]};
+        int bb = b;
+        while (bb > 0 && m->body_dofnum[bb] == 0) bb = m->body_parentid[bb];
+        if (bb <= 0) continue;
+        for (int i = m->body_dofadr[bb] + m->body_dofnum[bb] - 1; i >= 0; i = m->dof_parentid[i])
+            d->qfrc_passive[i] += d->cdof[i][0] * tq[0] + d->cdof[i][1] * tq[1] + d->cdof[i][2] * tq[2] + d->cdof[i][3] * gf[0] + d->cdof[i][4] * gf[1] +
+                                  d->cdof[i][5] * gf[2];
+    }
+}
+
 static void passive(const mjo_model *m, mjo_data *d) {
     for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
     for (int j = 0; j < m->njnt; j++)
@@ -558,6 +610,7 @@ static void passive(const mjo_model *m, mjo_data *d) {
             int qa = m->jnt_qposadr[j];
             d->qfrc_passive[m->jnt_dofadr[j]] -= m->jnt_stiffness[j] * (d->qpos[qa] - m->qpos_spring[qa]);
         }
+    fluid(m, d);
 }
 
 /* recursive Newton-Euler with qacc = 0: Coriolis, centrifugal and gravitational forces */

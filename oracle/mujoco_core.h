@@ -36,11 +36,11 @@ enum { MJO_NEWTON = 0, MJO_PGS = 1 };
 
 typedef struct mjo_model {
     int nq, nv, nu, nbody, njnt, ngeom, npair, integrator, solver, iterations;
-    double timestep, gravity[3], meaninertia;
+    double timestep, gravity[3], meaninertia, density, viscosity;
     int body_parentid[MJO_MAXB], body_rootid[MJO_MAXB], body_jntadr[MJO_MAXB], body_jntnum[MJO_MAXB], body_dofadr[MJO_MAXB],
         body_dofnum[MJO_MAXB];
     double body_pos[MJO_MAXB][3], body_quat[MJO_MAXB][4], body_mass[MJO_MAXB], body_ipos[MJO_MAXB][3], body_inertia[MJO_MAXB][9],
-        body_invweight0[MJO_MAXB][2];
+        body_invweight0[MJO_MAXB][2], body_fluidbox[MJO_MAXB][3], body_imat[MJO_MAXB][9];
     int jnt_type[MJO_MAXJ], jnt_qposadr[MJO_MAXJ], jnt_dofadr[MJO_MAXJ], jnt_bodyid[MJO_MAXJ], jnt_limited[MJO_MAXJ];
     double jnt_pos[MJO_MAXJ][3], jnt_axis[MJO_MAXJ][3], jnt_range[MJO_MAXJ][2], jnt_stiffness[MJO_MAXJ], jnt_margin[MJO_MAXJ],
         jnt_solref[MJO_MAXJ][2], jnt_solimp[MJO_MAXJ][5];

@@ -108,6 +108,7 @@ int orc_mjenv_obs_dim(int which, const double *P) {
     if (which == ORC_MJ_REACHER) return 10;
     if (is_planar_walker(which)) return m->nq - (excl ? 1 : 0) + m->nv;
     if (which == ORC_MJ_HALF_CHEETAH) return m->nq - (excl ? 1 : 0) + m->nv;
+    if (which == ORC_MJ_SWIMMER) return m->nq - (excl ? 2 : 0) + m->nv; /* swimmer_v5.py:206-213 */
     if (which == ORC_MJ_ANT) return m->nq - (excl ? 2 : 0) + m->nv + (P[12] != 0.0 ? 6 * (m->nbody - 1) : 0);
     return m->nq - (excl ? 2 : 0) + m->nv + (P[12] != 0.0 ? 10 * (m->nbody - 1) : 0) + (P[13] != 0.0 ? 6 * (m->nbody - 1) : 0) +
            (P[14] != 0.0 ? m->nv - 6 : 0) + (P[15] != 0.0 ? 6 * (m->nbody - 1) : 0);
@@ -118,6 +119,7 @@ int orc_mjenv_info_dim(int which) {
     if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 3;
     if (which == ORC_MJ_REACHER) return 2;
     if (which == ORC_MJ_HUMANOID_STANDUP) return 6;
+    if (which == ORC_MJ_SWIMMER) return 7;
     return which == ORC_MJ_HALF_CHEETAH ? 4 : 9;
 }
 int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
@@ -151,6 +153,8 @@ static void tracked_xy(const orc_mjenv *e, double out[2]) {
         out[1] = e->d.xpos[b][2] + R[6] * tip[0] + R[7] * tip[1] + R[8] * tip[2];
     } else if (e->which == ORC_MJ_HALF_CHEETAH || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM)
         out[0] = e->d.qpos[0], out[1] = 0;
+    else if (e->which == ORC_MJ_SWIMMER)
+        out[0] = e->d.qpos[0], out[1] = e->d.qpos[1]; /* data.qpos[0:2] (swimmer_v5.py:226-228) */
     else if (e->which == ORC_MJ_ANT)
         out[0] = e->d.xpos[1][0], out[1] = e->d.xpos[1][1]; /* main_body = 1 (torso) */
     else
@@ -223,7 +227,7 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
     }
     /* qpos = init_qpos + uniform(-s, s, nq): Generator.uniform = low + (high - low) * next_double */
     for (int k = 0; k < m->nq; k++) qpos[k] = m->qpos0[k] + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
-    if (is_humanoid(e->which) || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM) /* humanoid_v5.py:526-528, hopper_v5.py:318-331, inverted_pendulum_v5.py:178-190: uniform noise on the velocities too */
+    if (is_humanoid(e->which) || is_planar_walker(e->which) || e->which == ORC_MJ_INVERTED_PENDULUM || e->which == ORC_MJ_SWIMMER) /* swimmer_v5.py:279-294,  humanoid_v5.py:526-528, hopper_v5.py:318-331, inverted_pendulum_v5.py:178-190: uniform noise on the velocities too */
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-scale + (scale - (-scale)) * orc_pcg64_double(rng));
     else /* init_qvel + scale * standard_normal(nv) */
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + scale * orc_standard_normal(rng);
@@ -308,6 +312,16 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         *terminated = !healthy && P[7] != 0.0;
         info[0] = d->qpos[0], info[1] = d->qpos[1] - m->qpos0[1], info[2] = xv, info[3] = forward_reward, info[4] = -(double)ctrl_cost,
         info[5] = healthy_reward;
+        return;
+    }
+    if (e->which == ORC_MJ_SWIMMER) { /* swimmer_v5.py:225-263: never terminates; the control cost is float32 like HalfCheetah's */
+        float sq[MJO_MAXU];
+        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
+        float ctrl_cost = (float)P[1] * orc_np_sum_f32(sq, nu);
+        *reward = forward_reward - (double)ctrl_cost;
+        *terminated = 0;
+        info[0] = after[0], info[1] = after[1], info[2] = sqrt(after[0] * after[0] + after[1] * after[1]), info[3] = xv, info[4] = yv;
+        info[5] = forward_reward, info[6] = -(double)ctrl_cost;
         return;
     }
     if (e->which == ORC_MJ_HALF_CHEETAH) {

@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 IDS = {"half_cheetah": "HalfCheetah-v5", "ant": "Ant-v5", "humanoid": "Humanoid-v5"}
 # more robots on the same physics core (one-lane kernel), their own glue
 MORE = {"hopper": "Hopper-v5", "walker2d": "Walker2d-v5", "inverted_pendulum": "InvertedPendulum-v5",
-        "inverted_double_pendulum": "InvertedDoublePendulum-v5", "reacher": "Reacher-v5", "humanoid_standup": "HumanoidStandup-v5"}
+        "inverted_double_pendulum": "InvertedDoublePendulum-v5", "reacher": "Reacher-v5", "humanoid_standup": "HumanoidStandup-v5", "swimmer": "Swimmer-v5"}
 ALL = {**IDS, **MORE}
-NSTATE = {"half_cheetah": 17, "ant": 27, "humanoid": 45, "hopper": 11, "walker2d": 17, "inverted_pendulum": 4, "inverted_double_pendulum": 0, "reacher": 0, "humanoid_standup": 45}
+NSTATE = {"half_cheetah": 17, "ant": 27, "humanoid": 45, "hopper": 11, "walker2d": 17, "inverted_pendulum": 4, "inverted_double_pendulum": 0, "reacher": 0, "humanoid_standup": 45, "swimmer": 8}
 FIRST_INFO = {"humanoid_standup": ("x_position", "reward_linup", "reward_quadctrl", "reward_impact"), "reacher": ("reward_dist", "reward_ctrl"), "inverted_pendulum": ("reward_survive",), "inverted_double_pendulum": ("reward_survive", "distance_penalty", "velocity_penalty")}
 
 

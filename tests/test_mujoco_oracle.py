@@ -370,3 +370,133 @@ def test_humanoid_standup_model_and_reward_identity(oracle_factory):
         np.testing.assert_allclose(ia["reward_linup"], o[:, 2] / 0.003, rtol=1e-12)
         assert not te.any() and o.shape == (3, 350)
     env.close()
+
+
+# ---- Swimmer-v5: the one robot whose dynamics come from the medium (option density / viscosity), not from contacts ---------------
+def _swimmer_fluid_reference(m, d, qpos, qvel):
+    """MuJoCo's inertia-box fluid model written independently of oracle/mujoco_core.c fluid(): body Jacobians by central differences of the
+    oracle's kinematics (xipos, planar yaw), forces from the documented formulas, generalised force = sum_b Jp^T f + Jr^T t."""
+    def kin(q):
+        d.set_state(q, qvel, np.zeros(m.nu))
+        d.forward()
+        xm = d.get("xmat").reshape(-1, 3, 3)
+        return d.get("xipos").copy(), np.arctan2(xm[:, 1, 0], xm[:, 0, 0]), xm
+    eps, nb = 1e-6, m.nbody
+    Jp, Jr = np.zeros((nb, 3, m.nv)), np.zeros((nb, m.nv))
+    for k in range(m.nv):
+        dq = np.zeros(m.nq)
+        dq[k] = eps
+        (pa, ya, _), (pb, yb, _) = kin(qpos + dq), kin(qpos - dq)
+        Jp[:, :, k] = (pa - pb) / (2 * eps)
+        Jr[:, k] = np.angle(np.exp(1j * (ya - yb))) / (2 * eps)
+    _, _, xm = kin(qpos)
+    out = np.zeros(m.nv)
+    for b in range(1, nb):
+        R = xm[b] @ m.body_imat[b].reshape(3, 3)
+        v, w = R.T @ (Jp[b] @ qvel), R.T @ np.array([0.0, 0.0, Jr[b] @ qvel])
+        bx = m.body_fluidbox[b]
+        diam = bx.sum() / 3
+        f = -3 * np.pi * diam * m.viscosity * v
+        t = -np.pi * diam ** 3 * m.viscosity * w
+        for i, (j, k) in enumerate(((1, 2), (0, 2), (0, 1))):
+            f[i] -= 0.5 * m.density * bx[j] * bx[k] * abs(v[i]) * v[i]
+            t[i] -= m.density * bx[i] * (bx[j] ** 4 + bx[k] ** 4) * abs(w[i]) * w[i] / 64
+        out += Jp[b].T @ (R @ f) + Jr[b] * (R @ t)[2]
+    return out
+
+
+def test_swimmer_model_and_fluid_forces():
+    """swimmer.xml:1-30: 3 capsules of density 1000 (length 1, radius 0.1) on two sliders + three hinges, no contact pair, RK4; the medium
+    (density 4000, viscosity 0.1) acts through each body's equivalent inertia box."""
+    m = cp.compile_model("swimmer")
+    assert (m.nq, m.nv, m.nu, m.nbody, m.njnt, len(m.pair_geom1)) == (5, 5, 2, 4, 5, 0) and m.integrator == "RK4" and m.timestep == 0.01
+    vol = np.pi * 0.1 ** 2 * 1.0 + 4 / 3 * np.pi * 0.1 ** 3  # capsule = cylinder + sphere
+    np.testing.assert_allclose(m.body_mass[1:], 1000 * vol, rtol=1e-14)
+    assert (m.density, m.viscosity) == (4000.0, 0.1) and (m.dof_armature == 0.1).all() and list(m.actuator_gear) == [150.0, 150.0]
+    np.testing.assert_allclose(m.jnt_range[3:], np.radians([[-100, 100]] * 2), rtol=1e-15)
+    # the box that has the capsule's mass and principal moments: long axis x, equal y / z edges
+    I = m.body_inertia[1].reshape(3, 3)
+    bx = m.body_fluidbox[1]
+    np.testing.assert_allclose(m.body_mass[1] * (bx[1] ** 2 + bx[2] ** 2) / 12, I[0, 0], rtol=1e-12)
+    np.testing.assert_allclose(m.body_mass[1] * (bx[0] ** 2 + bx[2] ** 2) / 12, I[1, 1], rtol=1e-12)
+    om = omj.OracleModel("swimmer")
+    d = om.make_data()
+    # straight body sliding along / across itself: closed forms
+    for axis, area in ((0, bx[1] * bx[2]), (1, bx[0] * bx[2])):
+        for v in (0.7, -1.3):
+            qv = np.zeros(5)
+            qv[axis] = v
+            d.reset(), d.set_state(np.zeros(5), qv, np.zeros(2)), d.forward()
+            want = 3 * (-3 * np.pi * bx.sum() / 3 * 0.1 * v - 0.5 * 4000 * area * abs(v) * v)
+            np.testing.assert_allclose(d.get("qfrc_passive")[axis], want, rtol=1e-13)
+            assert d.get("ncon") == 0 and d.get("nefc") == 0
+    rng = np.random.default_rng(3)
+    for _ in range(8):
+        qpos, qvel = rng.uniform(-1.5, 1.5, 5), rng.uniform(-3, 3, 5)
+        want = _swimmer_fluid_reference(m, d, qpos, qvel)
+        d.set_state(qpos, qvel, np.zeros(2)), d.forward()
+        got = d.get("qfrc_passive")
+        np.testing.assert_allclose(got, want, rtol=2e-7, atol=2e-7)
+        assert got @ qvel < 0  # the medium only dissipates
+        # yaw invariance: turning the swimmer and its velocity together turns the force on the sliders and leaves the hinge torques
+        th = 0.9
+        c, s = np.cos(th), np.sin(th)
+        q2, v2 = qpos.copy(), qvel.copy()
+        q2[2] += th
+        q2[:2], v2[:2] = [c * qpos[0] - s * qpos[1], s * qpos[0] + c * qpos[1]], [c * qvel[0] - s * qvel[1], s * qvel[0] + c * qvel[1]]
+        d.set_state(q2, v2, np.zeros(2)), d.forward()
+        g2 = d.get("qfrc_passive")
+        np.testing.assert_allclose(g2[:2], [c * got[0] - s * got[1], s * got[0] + c * got[1]], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(g2[2:], got[2:], rtol=1e-11, atol=1e-11)
+
+
+def test_swimmer_env_reset_stream_reward_and_info(oracle_factory):
+    m = cp.compile_model("swimmer")
+    env = gymnasium_amd.make_vec("Swimmer-v5", num_envs=3, _engine_factory=oracle_factory, exclude_current_positions_from_observation=False)
+    assert env.single_observation_space.shape == (10,) and env.single_action_space.shape == (2,)
+    obs, info = env.reset(seed=100)
+    for i in range(3):  # swimmer_v5.py:279-294: uniform noise on positions and velocities
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(100 + i)))
+        qpos = m.qpos0 + g.uniform(low=-0.1, high=0.1, size=5)
+        qvel = g.uniform(low=-0.1, high=0.1, size=5)
+        assert np.array_equal(obs[i], np.concatenate([qpos, qvel]))
+        assert np.array_equal(env.get_rng_state()[i], gymnasium_amd._native.pcg_words(g))
+    assert np.array_equal(info["x_position"], obs[:, 0]) and np.array_equal(info["y_position"], obs[:, 1])
+    np.testing.assert_allclose(info["distance_from_origin"], np.hypot(obs[:, 0], obs[:, 1]), rtol=1e-15)
+    env.action_space.seed(0)
+    prev = obs
+    for t in range(30):
+        act = env.action_space.sample()
+        obs, rew, term, trunc, info = env.step(act)
+        assert not term.any() and not trunc.any() and np.isfinite(obs).all()
+        assert np.array_equal(info["x_position"], obs[:, 0]) and np.array_equal(info["y_position"], obs[:, 1])  # test_mujoco_v5.py:48-77
+        assert np.array_equal(info["x_velocity"], (obs[:, 0] - prev[:, 0]) / 0.04) and np.array_equal(info["y_velocity"], (obs[:, 1] - prev[:, 1]) / 0.04)
+        assert np.array_equal(rew, info["reward_forward"] + info["reward_ctrl"])  # test_mujoco_v5.py:297-301
+        ctrl = np.float32(1e-4) * np.sum(np.square(act), axis=1, dtype=np.float32)
+        assert np.array_equal(info["reward_ctrl"], -ctrl.astype(np.float64)) and np.array_equal(info["reward_forward"], info["x_velocity"])
+        prev = obs
+    env.close()
+    env = gymnasium_amd.make_vec("Swimmer-v5", num_envs=2, _engine_factory=oracle_factory, max_episode_steps=7)
+    assert env.single_observation_space.shape == (8,) and env.spec.reward_threshold == 360.0 if env.spec is not None else True
+    env.reset(seed=1)
+    for t in range(7):
+        _, _, term, trunc, _ = env.step(np.zeros((2, 2), dtype=np.float32))
+    assert trunc.all() and not term.any()
+    env.close()
+
+
+def test_swimmer_swims():
+    """The gait that makes a three-link swimmer move: a travelling wave down the two joints propels it along its own axis, against the
+    drag of the medium (without the medium the centre of mass could not move at all: no external force)."""
+    om = omj.OracleModel("swimmer")
+    d = om.make_data()
+    d.reset()
+    x0 = None
+    for t in range(1500):
+        ph = 2 * np.pi * t * 0.01 / 1.0
+        d.set_state(None, None, np.array([np.sin(ph), np.sin(ph - 2.0)]) * 0.6)
+        d.step(1)
+        if t == 0:
+            x0 = d.get("subtree_com")[1].copy()
+    moved = d.get("subtree_com")[1] - x0
+    assert np.isfinite(d.get("qpos")).all() and np.hypot(moved[0], moved[1]) > 0.3
