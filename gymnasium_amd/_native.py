@@ -19,7 +19,7 @@ ABI_VERSION = 3
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
              "half_cheetah": 5, "ant": 6, "humanoid": 7, "tabular": 8,
-             "hopper": 9, "walker2d": 10, "inverted_pendulum": 11, "inverted_double_pendulum": 12, "blackjack": 13, "reacher": 14, "humanoid_standup": 15, "swimmer": 16}
+             "hopper": 9, "walker2d": 10, "inverted_pendulum": 11, "inverted_double_pendulum": 12, "blackjack": 13, "reacher": 14, "humanoid_standup": 15, "swimmer": 16, "pusher": 17}
 AUTORESET = {"NextStep": 0, "SameStep": 1, "Disabled": 2}
 NP_DTYPES = {MI_F32: np.float32, MI_F64: np.float64, MI_I64: np.int64}
 

@@ -1040,7 +1040,8 @@ typedef mjx::MjEnv<mjx::InvertedDoublePendulumModel, mjx::kInvertedDoublePendulu
 typedef mjx::MjEnv<mjx::ReacherModel, mjx::kReacher> ReacherEnv;
 typedef mjx::MjEnv<mjx::HumanoidStandupModel, mjx::kHumanoidStandup> HumanoidStandupEnv;
 typedef mjx::MjEnv<mjx::SwimmerModel, mjx::kSwimmer> SwimmerEnv;
-bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER || kind == MI_ENV_HUMANOID_STANDUP || kind == MI_ENV_SWIMMER; }
+typedef mjx::MjEnv<mjx::PusherModel, mjx::kPusher> PusherEnv;
+bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER || kind == MI_ENV_HUMANOID_STANDUP || kind == MI_ENV_SWIMMER || kind == MI_ENV_PUSHER; }
 bool is_tab(int kind) { return kind == MI_ENV_TABULAR || kind == MI_ENV_BLACKJACK; }  // Blackjack rides on the tabular kernels
 template <class F>
 int dispatch_mj(int kind, F &&f) {
@@ -1055,6 +1056,7 @@ int dispatch_mj(int kind, F &&f) {
     case MI_ENV_REACHER: return f(ReacherEnv());
     case MI_ENV_HUMANOID_STANDUP: return f(HumanoidStandupEnv());
     case MI_ENV_SWIMMER: return f(SwimmerEnv());
+    case MI_ENV_PUSHER: return f(PusherEnv());
     }
     return fail(MI_ERR_UNSUPPORTED, "this MuJoCo kind is not built into the HIP engine yet");
 }

@@ -45,7 +45,7 @@ namespace mjx {
 #endif
 
 enum { FREE = 0, BALL = 1, SLIDE = 2, HINGE = 3 };
-enum { PLANE = 0, SPHERE = 2, CAPSULE = 3 };
+enum { PLANE = 0, SPHERE = 2, CAPSULE = 3, CYLINDER = 5 };
 constexpr double kMinVal = 1e-15, kMinImp = 0.0001, kMaxImp = 0.9999;
 
 // ---- tiny vector algebra ---------------------------------------------------------------------------------------
@@ -455,6 +455,84 @@ MJX_DEV void sphere_pair(Data<M> &d, int pair, const double *p1, double r1, cons
     add_contact<M>(d, pair, dist - r1 - r2, pos, n, nullptr, flip);
 }
 
+// Signed distance from p to the solid cylinder (centre c, unit axis u, radius R, half height H) and its gradient: the same
+// case analysis as oracle/mujoco_core.c cylinder_sd().
+MJX_DEV double cylinder_sd(const double *p, const double *c, const double *u, double R, double H, double *grad) {
+    const double dv[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    const double a = dot3(dv, u);
+    double rv[3] = {dv[0] - a * u[0], dv[1] - a * u[1], dv[2] - a * u[2]};
+    const double rho = sqrt(dot3(rv, rv));
+    if (rho > kMinVal) {
+        rv[0] /= rho, rv[1] /= rho, rv[2] /= rho;
+    } else {
+        const double e[3] = {fabs(u[0]) < 0.5 ? 1.0 : 0.0, fabs(u[0]) < 0.5 ? 0.0 : 1.0, 0.0};
+        const double t = dot3(e, u);
+        rv[0] = e[0] - t * u[0], rv[1] = e[1] - t * u[1], rv[2] = e[2] - t * u[2];
+        normalize3(rv);
+    }
+    const double sa = a >= 0 ? 1.0 : -1.0, ea = fabs(a) - H, er = rho - R;
+    const bool cap = (ea <= 0 && er <= 0) ? (ea > er) : (er <= 0);   // nearest feature is a cap
+    const bool wall = (ea <= 0 && er <= 0) ? !(ea > er) : (ea <= 0);  // ... or the wall; neither: the rim
+    if (cap) {
+        grad[0] = sa * u[0], grad[1] = sa * u[1], grad[2] = sa * u[2];
+        return ea;
+    }
+    if (wall) {
+        grad[0] = rv[0], grad[1] = rv[1], grad[2] = rv[2];
+        return er;
+    }
+    const double sd = sqrt(ea * ea + er * er);
+#pragma unroll
+    for (int k = 0; k < 3; k++) grad[k] = (ea * sa * u[k] + er * rv[k]) / sd;
+    return sd;
+}
+
+// Capsule against cylinder: minimise the (convex) signed distance of the segment point P(t) to the cylinder by bisection on the sign
+// of grad . axis (oracle/mujoco_core.c capsule_cylinder()).
+template <class M>
+MJX_DEV void capsule_cylinder(Data<M> &d, int pair, const double *pc, const double *zc, double hc, double rc, const double *py, const double *zy,
+                              double R, double H, bool flip) {
+    const double cc[3] = {pc[0] - py[0], pc[1] - py[1], pc[2] - py[2]};
+    if (sqrt(dot3(cc, cc)) > hc + rc + sqrt(R * R + H * H) + M::pair_margin[pair]) return;
+    double lo = -hc, hi = hc, p[3], g[3], glo[3], ghi[3], t;
+    p[0] = pc[0] + lo * zc[0], p[1] = pc[1] + lo * zc[1], p[2] = pc[2] + lo * zc[2];
+    cylinder_sd(p, py, zy, R, H, glo);
+    if (dot3(glo, zc) >= 0) {
+        t = lo;
+        g[0] = glo[0], g[1] = glo[1], g[2] = glo[2];
+    } else {
+        p[0] = pc[0] + hi * zc[0], p[1] = pc[1] + hi * zc[1], p[2] = pc[2] + hi * zc[2];
+        cylinder_sd(p, py, zy, R, H, ghi);
+        if (dot3(ghi, zc) <= 0) {
+            t = hi;
+            g[0] = ghi[0], g[1] = ghi[1], g[2] = ghi[2];
+        } else {
+            for (int it = 0; it < 60; it++) {
+                const double mid = 0.5 * (lo + hi);
+                p[0] = pc[0] + mid * zc[0], p[1] = pc[1] + mid * zc[1], p[2] = pc[2] + mid * zc[2];
+                cylinder_sd(p, py, zy, R, H, g);
+                const bool left = dot3(g, zc) < 0;
+                lo = left ? mid : lo, hi = left ? hi : mid;
+#pragma unroll
+                for (int k = 0; k < 3; k++) glo[k] = left ? g[k] : glo[k], ghi[k] = left ? ghi[k] : g[k];
+            }
+            t = 0.5 * (lo + hi);
+            // on a kink of the distance: the subgradient element that is stationary along the segment (see the oracle)
+            const double a = dot3(glo, zc), b = dot3(ghi, zc), w = b / (b - a);
+#pragma unroll
+            for (int k = 0; k < 3; k++) g[k] = w * glo[k] + (1.0 - w) * ghi[k];
+            normalize3(g);
+        }
+    }
+    p[0] = pc[0] + t * zc[0], p[1] = pc[1] + t * zc[1], p[2] = pc[2] + t * zc[2];
+    double gt[3];
+    const double sd = cylinder_sd(p, py, zy, R, H, gt), dist = sd - rc;
+    double n[3], pos[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) n[k] = -g[k], pos[k] = p[k] - g[k] * (rc + 0.5 * dist);
+    add_contact<M>(d, pair, dist, pos, n, nullptr, flip);
+}
+
 template <class M>
 MJX_DEV void geom_pose(const Data<M> &d, int g, double *pos, double *axis_z) {
     const int b = M::geom_bodyid[g];
@@ -532,6 +610,8 @@ MJX_DEV void collision(Data<M> &d) {
 #pragma unroll
             for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * z1[k], c2[k] = p2[k] + x2 * z2[k];
             sphere_pair<M>(d, p, c1, r1, c2, r2, flip);
+        } else if (t1 == CAPSULE && t2 == CYLINDER) {
+            capsule_cylinder<M>(d, p, p1, z1, h1, r1, p2, z2, r2, h2, flip);
         }
     }
 }

@@ -61,7 +61,7 @@ MJX_DEV T np_sum(const T *a) {
     return res;
 }
 
-enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7, kHumanoidStandup = 8, kSwimmer = 9 };
+enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7, kHumanoidStandup = 8, kSwimmer = 9, kPusher = 10 };
 
 // quantities of the last forward pass that the observations read besides qpos / qvel (null pointer = zeros, which is
 // what mj_resetData leaves in cfrc_ext / qfrc_actuator)
@@ -71,7 +71,7 @@ struct ObsExtras {
     const double (*cvel)[6];
     const double *qfrc_actuator;
     const double *qfrc_constraint = nullptr;  // [NV], InvertedDoublePendulum's observation
-    const double *vec = nullptr;              // [3] fingertip - target, Reacher's observation
+    const double *vec = nullptr;              // Reacher: [3] fingertip - target; Pusher: [9] positions of tips_arm, object, goal
 };
 
 template <class M, int KIND>
@@ -83,15 +83,16 @@ struct MjEnv {
     static constexpr bool HUMANOID_LIKE = KIND == kHumanoid || KIND == kHumanoidStandup;  // same model family, same observation
     static constexpr bool PENDULUM = KIND == kInvertedPendulum || KIND == kInvertedDoublePendulum;
     static constexpr int INFO =
-        KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : (KIND == kHumanoidStandup ? 6 : (KIND == kSwimmer ? 7 : 9))))));
+        KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : (KIND == kHumanoidStandup ? 6 : (KIND == kSwimmer ? 7 : (KIND == kPusher ? 3 : 9)))))));
     static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || HUMANOID_LIKE;  // small robots: one-lane kernel only
     static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
-    static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : ((PENDULUM || KIND == kReacher) ? 0 : 2);
+    static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : ((PENDULUM || KIND == kReacher || KIND == kPusher) ? 0 : 2);
     static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (HUMANOID_LIKE ? 22 * (NB - 1) + NV - 6 : 0) +
-                                   (KIND == kInvertedDoublePendulum ? NQ : 0) + (KIND == kReacher ? 2 : 0);
+                                   (KIND == kInvertedDoublePendulum ? NQ : 0) + (KIND == kReacher ? 2 : 0) + (KIND == kPusher ? 9 : 0);
 
     static int obs_dim_host(const mi::EnvParams &P) {  // the same rule, host side (mi_create)
         if (KIND == kReacher) return 10;
+        if (KIND == kPusher) return 23;
         if (KIND == kInvertedPendulum) return NQ + NV;
         if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
@@ -103,6 +104,7 @@ struct MjEnv {
     }
     static MJX_DEV int obs_dim(const mi::EnvParams &P) {
         if (KIND == kReacher) return 10;
+        if (KIND == kPusher) return 23;
         if (KIND == kInvertedPendulum) return NQ + NV;
         if (KIND == kInvertedDoublePendulum) return 1 + 2 * (NQ - 1) + NV + 1;
         int n = NQ + NV - (P.p[3] != 0.0 ? SKIP : 0);
@@ -116,6 +118,12 @@ struct MjEnv {
     // ant_v5.py:393-404, half_cheetah_v5.py:248-257, humanoid_v5.py:430-466
     static MJX_DEV void write_obs(const double *s, const ObsExtras &x, const mi::EnvParams &P, double *o) {
         int n = 0;
+        if (KIND == kPusher) {
+            // pusher_v5.py:317-326: arm qpos[:7], arm qvel[:7], get_body_com of tips_arm, object, goal (= data.body(name).xpos)
+            for (int k = 0; k < 7; k++) o[k] = s[k], o[7 + k] = s[NQ + k];
+            for (int k = 0; k < 9; k++) o[14 + k] = x.vec ? x.vec[k] : 0.0;
+            return;
+        }
         if (KIND == kReacher) {
             // reacher_v5.py:232-245: cos(theta), sin(theta), target qpos, arm qvel, (fingertip - target)[:2]
             o[0] = cos(s[0]), o[1] = cos(s[1]), o[2] = sin(s[0]), o[3] = sin(s[1]), o[4] = s[2], o[5] = s[3], o[6] = s[NQ], o[7] = s[NQ + 1];
@@ -168,6 +176,33 @@ struct MjEnv {
 
     // reset_model + set_state (-> mj_forward); writes the reset observation when obs != nullptr
     static MJX_DEV void reset(mi::Pcg64 &rng, double *s, const mi::EnvParams &P, double *obs) {
+        if (KIND == kPusher) {
+            // pusher_v5.py:293-315: the arm starts at init_qpos; the object's sliders (y first, then x: joint order of the XML) are re-drawn
+            // until the object is farther than 0.17 from the goal; small arm velocities, object and goal at rest
+            for (int k = 0; k < NQ; k++) s[k] = M::qpos0[k];
+            for (;;) {
+                const double c0 = -0.3 + (0.0 - (-0.3)) * rng.next_double(), c1 = -0.2 + (0.2 - (-0.2)) * rng.next_double();
+                s[NQ - 4] = c0, s[NQ - 3] = c1;
+                if (sqrt(c0 * c0 + c1 * c1) > 0.17) break;
+            }
+            s[NQ - 2] = 0.0, s[NQ - 1] = 0.0;
+            for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * rng.next_double());
+            for (int k = NV - 4; k < NV; k++) s[NQ + k] = 0.0;
+            for (int k = 0; k < NV; k++) s[NQ + NV + k] = 0.0;
+            s[NQ + 2 * NV] = 0.0, s[NQ + 2 * NV + 1] = 0.0;
+            if (obs) {
+                Data<M> d;
+                for (int k = 0; k < NQ; k++) d.qpos[k] = s[k];
+                kinematics<M>(d);
+                double vec[9];
+                for (int b = 0; b < 3; b++)
+                    for (int k = 0; k < 3; k++) vec[3 * b + k] = d.xpos[NB - 3 + b][k];
+                ObsExtras x = {nullptr, nullptr, nullptr, nullptr};
+                x.vec = vec;
+                write_obs(s, x, P, obs);
+            }
+            return;
+        }
         if (KIND == kReacher) {
             // reacher_v5.py:209-226: arm + target noise, the goal re-drawn until it lies inside the 0.2 disc, small arm velocities
             for (int k = 0; k < NQ; k++) s[k] = (-0.1 + (0.1 - (-0.1)) * rng.next_double()) + M::qpos0[k];
@@ -231,7 +266,7 @@ struct MjEnv {
         const double (*cvel)[6];         // cvel[NB][6]
         const double *qfrc_actuator;     // [NV]
         const double *qfrc_constraint;   // [NV]
-        double vec[3];                   // Reacher: fingertip - target (body frames 3 and 4) of the last forward pass
+        double vec[9];                   // Reacher: fingertip - target (body frames 3 and 4) of the last forward pass; Pusher: xpos of the last three bodies
     };
 
     // One env.step() with the one-lane simulator (mjx_core.h): physics, then finish().
@@ -250,6 +285,10 @@ struct MjEnv {
         StepExtras x;
         if (KIND == kHumanoidStandup) {
             x.after[0] = x.after[1] = 0.0;
+        } else if (KIND == kPusher) {
+            x.after[0] = x.after[1] = 0.0;
+            for (int b = 0; b < 3; b++)
+                for (int k = 0; k < 3; k++) x.vec[3 * b + k] = d.xpos[NB - 3 + b][k];  // tips_arm, object, goal
         } else if (KIND == kReacher) {
             x.after[0] = x.after[1] = 0.0;
             for (int k = 0; k < 3; k++) x.vec[k] = d.xpos[3][k] - d.xpos[4][k];
@@ -320,6 +359,21 @@ struct MjEnv {
             write_obs(s, ox, P, obs);
             if (info)
                 info[0] = s[0], info[1] = s[1], info[2] = s[2] - M::qpos0[2], info[3] = uph_cost, info[4] = -quad_ctrl_cost, info[5] = -quad_impact_cost;
+            return;
+        }
+        if (KIND == kPusher) {
+            // pusher_v5.py:266-291: reward = -|object - goal| w_dist + (-sum(a^2) w_ctrl, float32) + (-|object - tips_arm| w_near); never terminates
+            const double *tip = x.vec, *ob = x.vec + 3, *goal = x.vec + 6;
+            const double v1[3] = {ob[0] - tip[0], ob[1] - tip[1], ob[2] - tip[2]}, v2[3] = {ob[0] - goal[0], ob[1] - goal[1], ob[2] - goal[2]};
+            const double reward_near = -sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) * P.p[0];
+            const double reward_dist = -sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]) * P.p[5];
+            const float reward_ctrl = -np_sum<float, NU>(sq) * (float)P.p[1];
+            reward = (reward_dist + (double)reward_ctrl) + reward_near;
+            terminated = false;
+            ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
+            ox.vec = x.vec;
+            write_obs(s, ox, P, obs);
+            if (info) info[0] = reward_dist, info[1] = (double)reward_ctrl, info[2] = reward_near;
             return;
         }
         if (KIND == kReacher) {
@@ -437,7 +491,7 @@ struct MjEnv {
     }
     static MJX_DEV void reset_info(const double *s, double *info) {
         for (int k = 0; k < INFO; k++) info[k] = 0.0;
-        if (PENDULUM || KIND == kReacher) return;  // _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
+        if (PENDULUM || KIND == kReacher || KIND == kPusher) return;  // _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
         info[0] = s[0];
         if (KIND == kHumanoidStandup) {
             info[1] = s[1], info[2] = s[2] - M::qpos0[2];  // humanoidstandup_v5.py:479-486

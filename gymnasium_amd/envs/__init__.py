@@ -14,6 +14,7 @@ from .mujoco.envs import (  # noqa: F401
     HumanoidVectorEnv,
     InvertedDoublePendulumVectorEnv,
     InvertedPendulumVectorEnv,
+    PusherVectorEnv,
     ReacherVectorEnv,
     SwimmerVectorEnv,
     Walker2dVectorEnv,

@@ -14,7 +14,7 @@ from . import compiler
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc", "generated", "mjx_models.h")
 STRUCT = {"half_cheetah": "HalfCheetahModel", "ant": "AntModel", "humanoid": "HumanoidModel", "hopper": "HopperModel", "walker2d": "Walker2dModel",
-          "inverted_pendulum": "InvertedPendulumModel", "inverted_double_pendulum": "InvertedDoublePendulumModel", "reacher": "ReacherModel", "humanoid_standup": "HumanoidStandupModel", "swimmer": "SwimmerModel"}
+          "inverted_pendulum": "InvertedPendulumModel", "inverted_double_pendulum": "InvertedDoublePendulumModel", "reacher": "ReacherModel", "humanoid_standup": "HumanoidStandupModel", "swimmer": "SwimmerModel", "pusher": "PusherModel"}
 
 
 def _arr(name, ctype, values, shape):

@@ -27,7 +27,7 @@ import numpy as np
 from . import models as _models
 
 FREE, BALL, SLIDE, HINGE = 0, 1, 2, 3          # mjtJoint
-PLANE, SPHERE, CAPSULE = 0, 2, 3               # mjtGeom values
+PLANE, SPHERE, CAPSULE, CYLINDER = 0, 2, 3, 5  # mjtGeom values
 MINVAL = 1e-15
 
 GEOM_DEFAULTS = dict(contype=1, conaffinity=1, condim=3, density=1000.0, friction=(1.0, 0.005, 0.0001), margin=0.0, gap=0.0,
@@ -135,7 +135,7 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
     geoms = []
     # a model without a ground plane still gets geom 0 (the engine's tables are never empty), with collisions switched off
     fl = dict(gdef, **(desc["floor"] if desc["floor"] is not None else dict(contype=0, conaffinity=0)))
-    geoms.append(dict(name="floor", type=PLANE, body=0, size=(0, 0, 0), pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), mass=0.0,
+    geoms.append(dict(name="floor", type=PLANE, body=0, size=(0, 0, 0), pos=np.array(fl.get("pos", (0, 0, 0)), dtype=np.float64), quat=np.array([1.0, 0, 0, 0]), mass=0.0,
                       inertia=np.zeros(3), **{k: fl[k] for k in ("contype", "conaffinity", "condim", "friction", "margin", "gap", "solref", "solimp", "solmix")}))
     for bi in range(1, nbody):
         for g in bodies[bi]["geoms"]:
@@ -179,6 +179,14 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
                 mass = p["density"] * vol
                 inertia = np.full(3, 2.0 * mass * radius * radius / 5.0)
                 gtype, gsize = SPHERE, (radius, 0.0, 0.0)
+            elif g["type"] == "cylinder":  # size = (radius, half height), axis = local z; solid cylinder inertia
+                half = float(size[1])
+                pos, quat = np.array(g["pos"] if g["pos"] is not None else (0, 0, 0), dtype=np.float64), np.array([1.0, 0, 0, 0])
+                height = 2 * half
+                mass = p["density"] * math.pi * radius * radius * height
+                ixx = mass * (3 * radius * radius + height * height) / 12.0
+                inertia = np.array([ixx, ixx, mass * radius * radius / 2.0])
+                gtype, gsize = CYLINDER, (radius, half, 0.0)
             else:
                 raise ValueError(g["type"])
             geoms.append(dict(name=g["name"], type=gtype, body=bi, size=gsize, pos=pos, quat=quat, mass=mass, inertia=inertia,
@@ -305,6 +313,7 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
 
     # ---- contact candidates -------------------------------------------------------------------------------------
     P = dict(g1=[], g2=[], condim=[], friction=[], margin=[], solref=[], solimp=[])
+    excluded = set(tuple(e) for e in desc.get("exclude_pairs", ()))  # geom-name pairs left out on purpose (the model says why)
     for a in range(ngeom):
         for b_ in range(a + 1, ngeom):
             ga, gb = geoms[a], geoms[b_]
@@ -317,6 +326,8 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
             if ba != 0 and bb != 0 and (m.body_parentid[ba] == bb or m.body_parentid[bb] == ba):
                 continue
             if ga["type"] == PLANE and gb["type"] == PLANE:
+                continue
+            if (ga["name"], gb["name"]) in excluded or (gb["name"], ga["name"]) in excluded:
                 continue
             mix = ga["solmix"] / (ga["solmix"] + gb["solmix"])
             P["g1"].append(a), P["g2"].append(b_)

@@ -315,6 +315,28 @@ class ReacherVectorEnv(_PendulumVectorEnv):
         return 10
 
 
+class PusherVectorEnv(_PendulumVectorEnv):
+    """pusher_v5.py:165-326: a 7-joint arm pushes a cylinder to a goal on a table (pusher_v5.xml: no gravity, Euler, frictionless
+    contacts); obs float64[23], action float32[7] in [-2, 2]; never terminates (TimeLimit 100)."""
+
+    KIND = "pusher"
+    DEFAULT_MAX_EPISODE_STEPS = 100
+    STOCK_XML = "pusher_v5.xml"
+    NQ, NV, NU, NBODY = 11, 11, 7, 13
+    CTRL_LOW, CTRL_HIGH = -2.0, 2.0
+    INFO_KEYS = ("reward_dist", "reward_ctrl", "reward_near")
+
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "pusher_v5.xml", frame_skip: int = 5,
+                 reward_near_weight: float = 0.5, reward_dist_weight: float = 1, reward_control_weight: float = 0.1, **kwargs):
+        self._check_common(xml_file, frame_skip, kwargs)
+        self._params = (reward_near_weight, reward_control_weight, 0.0, 0.0, float(frame_skip), reward_dist_weight)
+        self.observation_structure = {"qpos": 7, "qvel": 7, "tips_arm": 3, "object": 3, "goal": 3}
+        super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _obs_size(self):
+        return 23
+
+
 class SwimmerVectorEnv(_MujocoVectorEnv):
     """swimmer_v5.py:153-301: three links in a viscous medium (swimmer.xml: option density 4000, viscosity 0.1, RK4); obs = qpos[2:] + qvel
     (float64[8]), action float32[2] in [-1, 1]; never terminates."""
@@ -355,4 +377,5 @@ ENV_TABLE = {
     "Reacher-v5": (ReacherVectorEnv, 50, -3.75),
     "HumanoidStandup-v5": (HumanoidStandupVectorEnv, 1000, None),
     "Swimmer-v5": (SwimmerVectorEnv, 1000, 360.0),
+    "Pusher-v5": (PusherVectorEnv, 100, 0.0),
 }

@@ -65,7 +65,9 @@ typedef enum mi_env_kind {
     MI_ENV_SWIMMER = 16,                   /* envs/mujoco/swimmer_v5.py:153-301 + assets/swimmer.xml (fluid forces of the medium: option density,
                                             * viscosity); params [0] forward_reward_weight [1] ctrl_cost_weight [2] reset_noise_scale
                                             * [3] exclude_current_positions [4] frame_skip                                     */
-    MI_ENV_KIND_COUNT = 17
+    MI_ENV_PUSHER = 17,                    /* envs/mujoco/pusher_v5.py:165-326 + assets/pusher_v5.xml; params [0] reward_near_weight [1] reward_control_weight
+                                            * [4] frame_skip [5] reward_dist_weight                                            */
+    MI_ENV_KIND_COUNT = 18
 } mi_env_kind;
 
 /* vector/vector_env.py:34-39 AutoresetMode; semantics of vector/sync_vector_env.py:277-319. */

@@ -341,6 +341,88 @@ static void sphere_sphere_raw(const mjo_model *m, mjo_data *d, int pair, const d
     add_contact(m, d, pair, dist - r1 - r2, pos, n, tangent);
 }
 
+/* Signed distance from point p to the solid cylinder (centre c, unit axis u, radius R, half height H); grad = its gradient (the
+ * outward direction at the nearest surface point, which is p - sd * grad).  A convex function of p. */
+static double cylinder_sd(const double *p, const double *c, const double *u, double R, double H, double *grad) {
+    const double dv[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    const double a = dot3(dv, u);
+    double rv[3] = {dv[0] - a * u[0], dv[1] - a * u[1], dv[2] - a * u[2]};
+    const double rho = norm3(rv);
+    if (rho > MINVAL) {
+        for (int k = 0; k < 3; k++) rv[k] /= rho;
+    } else { /* on the axis: any direction orthogonal to it */
+        const double e[3] = {fabs(u[0]) < 0.5 ? 1.0 : 0.0, fabs(u[0]) < 0.5 ? 0.0 : 1.0, 0.0};
+        const double t = dot3(e, u);
+        for (int k = 0; k < 3; k++) rv[k] = e[k] - t * u[k];
+        normalize3(rv);
+    }
+    const double sa = a >= 0 ? 1.0 : -1.0, ea = fabs(a) - H, er = rho - R;
+    if (ea <= 0 && er <= 0) { /* inside: the nearer of the cap and the wall */
+        if (ea > er) {
+            for (int k = 0; k < 3; k++) grad[k] = sa * u[k];
+            return ea;
+        }
+        for (int k = 0; k < 3; k++) grad[k] = rv[k];
+        return er;
+    }
+    if (er <= 0) {
+        for (int k = 0; k < 3; k++) grad[k] = sa * u[k];
+        return ea;
+    }
+    if (ea <= 0) {
+        for (int k = 0; k < 3; k++) grad[k] = rv[k];
+        return er;
+    }
+    const double sd = sqrt(ea * ea + er * er); /* nearest point on the rim */
+    for (int k = 0; k < 3; k++) grad[k] = (ea * sa * u[k] + er * rv[k]) / sd;
+    return sd;
+}
+
+/* Capsule (segment centre pc, unit axis zc, half length hc, radius rc) against a cylinder.  MuJoCo has no analytic function for this
+ * pair (it runs its general convex collider); this is the exact geometry instead: the signed distance of the segment point P(t) to the
+ * cylinder is convex in t, so its minimiser is where the directional derivative grad . axis changes sign -- found by bisection. */
+static void capsule_cylinder(const mjo_model *m, mjo_data *d, int pair, const double *pc, const double *zc, double hc, double rc,
+                             const double *py, const double *zy, double R, double H) {
+    const double cc[3] = {pc[0] - py[0], pc[1] - py[1], pc[2] - py[2]};
+    if (norm3(cc) > hc + rc + sqrt(R * R + H * H) + m->pair_margin[pair]) return; /* bounding spheres apart */
+    double lo = -hc, hi = hc, p[3], g[3], glo[3], ghi[3], t;
+    for (int k = 0; k < 3; k++) p[k] = pc[k] + lo * zc[k];
+    cylinder_sd(p, py, zy, R, H, glo);
+    if (dot3(glo, zc) >= 0) {
+        t = lo;
+        memcpy(g, glo, sizeof g);
+    } else {
+        for (int k = 0; k < 3; k++) p[k] = pc[k] + hi * zc[k];
+        cylinder_sd(p, py, zy, R, H, ghi);
+        if (dot3(ghi, zc) <= 0) {
+            t = hi;
+            memcpy(g, ghi, sizeof g);
+        } else {
+            for (int it = 0; it < 60; it++) {
+                const double mid = 0.5 * (lo + hi);
+                for (int k = 0; k < 3; k++) p[k] = pc[k] + mid * zc[k];
+                cylinder_sd(p, py, zy, R, H, g);
+                if (dot3(g, zc) < 0)
+                    lo = mid, memcpy(glo, g, sizeof g);
+                else
+                    hi = mid, memcpy(ghi, g, sizeof g);
+            }
+            t = 0.5 * (lo + hi);
+            /* the minimiser may sit on a kink of the distance (cap and wall, or a face and the rim, equally near): take the element of
+             * the subgradient that is stationary along the segment -- the blend of the two one-sided gradients with zero slope */
+            const double a = dot3(glo, zc), b = dot3(ghi, zc), w = b / (b - a);
+            for (int k = 0; k < 3; k++) g[k] = w * glo[k] + (1.0 - w) * ghi[k];
+            normalize3(g);
+        }
+    }
+    for (int k = 0; k < 3; k++) p[k] = pc[k] + t * zc[k];
+    double gt[3];
+    const double sd = cylinder_sd(p, py, zy, R, H, gt), dist = sd - rc;
+    double n[3], pos[3];
+    for (int k = 0; k < 3; k++) n[k] = -g[k], pos[k] = p[k] - g[k] * (rc + 0.5 * dist); /* normal: capsule -> cylinder; midpoint of the gap */
+    add_contact(m, d, pair, dist, pos, n, 0);
+}
+
 static void collide_pair(const mjo_model *m, mjo_data *d, int pair) {
     int g1 = m->pair_geom1[pair], g2 = m->pair_geom2[pair];
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -407,6 +489,9 @@ static void collide_pair(const mjo_model *m, mjo_data *d, int pair) {
         double c1[3], c2[3];
         for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k], c2[k] = p2[k] + x2 * a2[k];
         sphere_sphere_raw(m, d, pair, c1, m->geom_size[g1][0], c2, m->geom_size[g2][0], 0);
+    } else if (t1 == MJO_CAPSULE && t2 == MJO_CYLINDER) {
+        const double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
+        capsule_cylinder(m, d, pair, p1, a1, m->geom_size[g1][1], m->geom_size[g1][0], p2, a2, m->geom_size[g2][0], m->geom_size[g2][1]);
     }
     if (g1 != m->pair_geom1[pair]) /* restore the model's geom order: normal points from pair_geom1 to pair_geom2 */
         for (int c = before; c < d->ncon; c++) {

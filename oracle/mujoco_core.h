@@ -30,7 +30,7 @@
 #define MJO_MAXEFC (4 * MJO_MAXCON + MJO_MAXJ)
 
 enum { MJO_FREE = 0, MJO_BALL = 1, MJO_SLIDE = 2, MJO_HINGE = 3 };
-enum { MJO_PLANE = 0, MJO_SPHERE = 2, MJO_CAPSULE = 3 };
+enum { MJO_PLANE = 0, MJO_SPHERE = 2, MJO_CAPSULE = 3, MJO_CYLINDER = 5 };
 enum { MJO_EULER = 0, MJO_RK4 = 1 };
 enum { MJO_NEWTON = 0, MJO_PGS = 1 };
 

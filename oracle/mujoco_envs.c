@@ -106,6 +106,7 @@ int orc_mjenv_obs_dim(int which, const double *P) {
     if (which == ORC_MJ_INVERTED_PENDULUM) return m->nq + m->nv;
     if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 1 + 2 * (m->nq - 1) + m->nv + 1;
     if (which == ORC_MJ_REACHER) return 10;
+    if (which == ORC_MJ_PUSHER) return 23;
     if (is_planar_walker(which)) return m->nq - (excl ? 1 : 0) + m->nv;
     if (which == ORC_MJ_HALF_CHEETAH) return m->nq - (excl ? 1 : 0) + m->nv;
     if (which == ORC_MJ_SWIMMER) return m->nq - (excl ? 2 : 0) + m->nv; /* swimmer_v5.py:206-213 */
@@ -120,6 +121,7 @@ int orc_mjenv_info_dim(int which) {
     if (which == ORC_MJ_REACHER) return 2;
     if (which == ORC_MJ_HUMANOID_STANDUP) return 6;
     if (which == ORC_MJ_SWIMMER) return 7;
+    if (which == ORC_MJ_PUSHER) return 3;
     return which == ORC_MJ_HALF_CHEETAH ? 4 : 9;
 }
 int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
@@ -143,7 +145,7 @@ static void mass_center_xy(const orc_mjenv *e, double out[2]) { /* humanoid_v5.p
 /* the position the env differentiates to get its velocity reward, read from the LAST forward pass (the reference reads
  * data.qpos / data.body().xpos / data.xipos after mj_step, and those Cartesian quantities lag qpos by one sub-step) */
 static void tracked_xy(const orc_mjenv *e, double out[2]) {
-    if (e->which == ORC_MJ_REACHER || e->which == ORC_MJ_HUMANOID_STANDUP) {
+    if (e->which == ORC_MJ_REACHER || e->which == ORC_MJ_HUMANOID_STANDUP || e->which == ORC_MJ_PUSHER) {
         out[0] = out[1] = 0;
     } else if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* data.site_xpos[0]: x and height of the tip (inverted_double_pendulum_v5.py:189) */
         const double tip[3] = {0, 0, 0.6}; /* <site name="tip" pos="0 0 .6"/> on pole2 = the last body */
@@ -165,6 +167,12 @@ void orc_mjenv_obs(const orc_mjenv *e, const double *P, double *o) {
     const mjo_model *m = e->m;
     const mjo_data *d = &e->d;
     int skip = P[3] != 0.0 ? ((e->which == ORC_MJ_HALF_CHEETAH || is_planar_walker(e->which)) ? 1 : 2) : 0, n = 0;
+    if (e->which == ORC_MJ_PUSHER) { /* pusher_v5.py:317-326; get_body_com = data.body(name).xpos of tips_arm, object, goal (the last three bodies) */
+        for (int k = 0; k < 7; k++) o[k] = d->qpos[k], o[7 + k] = d->qvel[k];
+        for (int b = 0; b < 3; b++)
+            for (int k = 0; k < 3; k++) o[14 + 3 * b + k] = d->xpos[m->nbody - 3 + b][k];
+        return;
+    }
     if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:232-245; get_body_com = data.body(name).xpos: fingertip = body 3, target = body 4 */
         o[0] = cos(d->qpos[0]), o[1] = cos(d->qpos[1]), o[2] = sin(d->qpos[0]), o[3] = sin(d->qpos[1]);
         o[4] = d->qpos[2], o[5] = d->qpos[3], o[6] = d->qvel[0], o[7] = d->qvel[1];
@@ -211,6 +219,21 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
     const mjo_model *m = e->m;
     double scale = P[2], qpos[MJO_MAXQ], qvel[MJO_MAXV];
     mjo_reset_data(m, &e->d); /* mj_resetData */
+    if (e->which == ORC_MJ_PUSHER) { /* pusher_v5.py:293-315 */
+        for (int k = 0; k < m->nq; k++) qpos[k] = m->qpos0[k];
+        for (;;) { /* the object is re-drawn until it is farther than 0.17 from the goal at the origin of its sliders (y slider first) */
+            const double c0 = -0.3 + (0.0 - (-0.3)) * orc_pcg64_double(rng), c1 = -0.2 + (0.2 - (-0.2)) * orc_pcg64_double(rng);
+            qpos[m->nq - 4] = c0, qpos[m->nq - 3] = c1;
+            if (sqrt(c0 * c0 + c1 * c1) > 0.17) break;
+        }
+        qpos[m->nq - 2] = 0.0, qpos[m->nq - 1] = 0.0;
+        for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * orc_pcg64_double(rng));
+        for (int k = m->nv - 4; k < m->nv; k++) qvel[k] = 0.0;
+        memcpy(e->d.qpos, qpos, sizeof(double) * m->nq), memcpy(e->d.qvel, qvel, sizeof(double) * m->nv);
+        mjo_forward(m, &e->d);
+        e->has_override = 0;
+        return;
+    }
     if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:209-226 */
         for (int k = 0; k < m->nq; k++) qpos[k] = (-0.1 + (0.1 - (-0.1)) * orc_pcg64_double(rng)) + m->qpos0[k];
         for (;;) { /* the goal is re-drawn until it lies inside the 0.2 disc (np.linalg.norm of 2 elements = sqrt(g0 g0 + g1 g1)) */
@@ -266,6 +289,19 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         *terminated = 0;
         info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = d->qpos[2] - m->qpos0[2], info[3] = uph_cost, info[4] = -quad_ctrl_cost,
         info[5] = -quad_impact_cost;
+        return;
+    }
+    if (e->which == ORC_MJ_PUSHER) { /* pusher_v5.py:266-291 */
+        const double *tip = d->xpos[m->nbody - 3], *ob = d->xpos[m->nbody - 2], *goal = d->xpos[m->nbody - 1];
+        const double v1[3] = {ob[0] - tip[0], ob[1] - tip[1], ob[2] - tip[2]}, v2[3] = {ob[0] - goal[0], ob[1] - goal[1], ob[2] - goal[2]};
+        const double reward_near = -sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) * P[0];
+        const double reward_dist = -sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]) * P[5];
+        float sq[MJO_MAXU];
+        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
+        const float reward_ctrl = -orc_np_sum_f32(sq, nu) * (float)P[1]; /* float32 array sum times a Python float: float32 */
+        *reward = (reward_dist + (double)reward_ctrl) + reward_near;
+        *terminated = 0;
+        info[0] = reward_dist, info[1] = (double)reward_ctrl, info[2] = reward_near;
         return;
     }
     if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:188-207 */
@@ -372,7 +408,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
 
 /* _get_reset_info of the scalar env: positions only */
 void orc_mjenv_reset_info(const orc_mjenv *e, double *row) {
-    if (is_pendulum(e->which) || e->which == ORC_MJ_REACHER) return; /* {} (inverted_pendulum_v5.py:198-199) */
+    if (is_pendulum(e->which) || e->which == ORC_MJ_REACHER || e->which == ORC_MJ_PUSHER) return; /* {} (inverted_pendulum_v5.py:198-199) */
     row[0] = e->d.qpos[0];
     if (e->which == ORC_MJ_HUMANOID_STANDUP)
         row[1] = e->d.qpos[1], row[2] = e->d.qpos[2] - e->m->qpos0[2]; /* humanoidstandup_v5.py:479-486 */

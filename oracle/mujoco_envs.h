@@ -5,7 +5,7 @@
 #include "pcg64.h"
 
 enum { ORC_MJ_HALF_CHEETAH = 0, ORC_MJ_ANT = 1, ORC_MJ_HUMANOID = 2, ORC_MJ_HOPPER = 3, ORC_MJ_WALKER2D = 4, ORC_MJ_INVERTED_PENDULUM = 5,
-       ORC_MJ_INVERTED_DOUBLE_PENDULUM = 6, ORC_MJ_REACHER = 7, ORC_MJ_HUMANOID_STANDUP = 8, ORC_MJ_SWIMMER = 9, ORC_MJ_COUNT = 10 };
+       ORC_MJ_INVERTED_DOUBLE_PENDULUM = 6, ORC_MJ_REACHER = 7, ORC_MJ_HUMANOID_STANDUP = 8, ORC_MJ_SWIMMER = 9, ORC_MJ_PUSHER = 10, ORC_MJ_COUNT = 11 };
 
 typedef struct orc_mjenv {
     int which;

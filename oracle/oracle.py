@@ -39,7 +39,7 @@ def _register_mujoco_models(lib):
 
     fn = lib.dll.orc_mj_register_model
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-    for which, name in enumerate(("half_cheetah", "ant", "humanoid", "hopper", "walker2d", "inverted_pendulum", "inverted_double_pendulum", "reacher", "humanoid_standup", "swimmer")):
+    for which, name in enumerate(("half_cheetah", "ant", "humanoid", "hopper", "walker2d", "inverted_pendulum", "inverted_double_pendulum", "reacher", "humanoid_standup", "swimmer", "pusher")):
         blob = omj.model_blob(compiler.compile_model(name))
         rc = fn(which, blob.ctypes.data, len(blob))
         assert rc == 0, f"oracle rejected the {name} model blob (rc={rc})"

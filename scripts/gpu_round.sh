@@ -25,7 +25,7 @@ done
 # MuJoCo family: Ant / Humanoid at the BASELINE.json sizes with the CPU oracle beside them, the others at 65536
 timeout 600 python bench.py --no-api --env Ant-v5 --num-envs 32768 --inner 4 --steps 5 --warmup 1 > gpurun_out/${TAG}_bench_Ant-v5_N32768.json 2>> gpurun_out/${TAG}_bench.err; show "Ant-v5 N=32768" gpurun_out/${TAG}_bench_Ant-v5_N32768.json
 timeout 600 python bench.py --no-api --env Humanoid-v5 --num-envs 32768 --inner 4 --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_Humanoid-v5_N32768.json 2>> gpurun_out/${TAG}_bench.err; show "Humanoid-v5 N=32768" gpurun_out/${TAG}_bench_Humanoid-v5_N32768.json
-for E in Ant-v5 HalfCheetah-v5 Hopper-v5 Walker2d-v5 InvertedPendulum-v5 InvertedDoublePendulum-v5 Reacher-v5 Swimmer-v5; do
+for E in Ant-v5 HalfCheetah-v5 Hopper-v5 Walker2d-v5 InvertedPendulum-v5 InvertedDoublePendulum-v5 Reacher-v5 Swimmer-v5 Pusher-v5; do
   timeout 600 python bench.py --no-api --no-cpu-baseline --env $E --num-envs 65536 --inner 4 --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_${E}_N65536.json 2>> gpurun_out/${TAG}_bench.err; show "$E N=65536" gpurun_out/${TAG}_bench_${E}_N65536.json
 done
 timeout 600 python bench.py --no-api --no-cpu-baseline --env HumanoidStandup-v5 --num-envs 32768 --inner 4 --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_HumanoidStandup-v5_N32768.json 2>> gpurun_out/${TAG}_bench.err; show "HumanoidStandup-v5 N=32768" gpurun_out/${TAG}_bench_HumanoidStandup-v5_N32768.json

@@ -99,9 +99,53 @@ int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsu
     delete bb;
     return ncon;
 }
+// The ONE-LANE simulator (mjx_core.h), compiled for the host as it is: nsub sub-steps (0: one forward pass), qacc and the contact count out.
+template <class M>
+int core_step(const double *qpos, const double *qvel, const double *ctrl, int nsub, double *qpos_out, double *qvel_out, double *qacc_out,
+              double *warm, double *contacts = nullptr) {
+    mjx::Data<M> *d = new mjx::Data<M>;
+    for (int k = 0; k < M::NQ; k++) d->qpos[k] = qpos[k];
+    for (int k = 0; k < M::NV; k++) d->qvel[k] = qvel[k], d->qacc_warm[k] = warm ? warm[k] : 0.0;
+    for (int k = 0; k < M::NU; k++) d->ctrl[k] = ctrl[k];
+    if (nsub == 0) mjx::forward<M>(*d);
+    for (int f = 0; f < nsub; f++) mjx::step<M>(*d);
+    for (int k = 0; k < M::NQ; k++) qpos_out[k] = d->qpos[k];
+    for (int k = 0; k < M::NV; k++) qvel_out[k] = d->qvel[k], qacc_out[k] = d->qacc[k];
+    if (warm)
+        for (int k = 0; k < M::NV; k++) warm[k] = d->qacc_warm[k];
+    const int ncon = d->ncon;
+    if (contacts)  // rows of 17: dist, pos[3], frame[9], pair, D, aref, normal force
+        for (int c = 0; c < ncon; c++) {
+            double *o = contacts + 17 * c;
+            o[0] = d->con[c].dist;
+            for (int k = 0; k < 3; k++) o[1 + k] = d->con[c].pos[k];
+            for (int k = 0; k < 9; k++) o[4 + k] = d->con[c].frame[k];
+            o[13] = d->con[c].pair, o[14] = d->con_D[c], o[15] = d->con_aref[c], o[16] = d->con_force[c][0];
+        }
+    delete d;
+    return ncon;
+}
 }  // namespace
 
 extern "C" {
+// the one-lane simulator; model ids follow oracle/mujoco_envs.h (0 half_cheetah .. 10 pusher)
+__attribute__((visibility("default"))) int core_emu_step(int model, const double *qpos, const double *qvel, const double *ctrl, int nsub,
+                                                          double *qpos_out, double *qvel_out, double *qacc_out, double *warm, double *contacts) {
+    switch (model) {
+        case 0: return core_step<HalfCheetahModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 1: return core_step<AntModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 2: return core_step<HumanoidModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 3: return core_step<HopperModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 4: return core_step<Walker2dModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 5: return core_step<InvertedPendulumModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 6: return core_step<InvertedDoublePendulumModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 7: return core_step<ReacherModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 8: return core_step<HumanoidStandupModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 9: return core_step<SwimmerModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+        case 10: return core_step<PusherModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm, contacts);
+    }
+    return -1;
+}
 // model: 0 half_cheetah, 1 ant, 2 humanoid.  nsub = 0: one forward pass only.  Returns the number of contacts of the last pass.
 __attribute__((visibility("default"))) int coop_emu_step(int model, const double *qpos, const double *qvel, const double *ctrl, int nsub,
                                                           double *qpos_out, double *qvel_out, double *extras, double *debug, double *warm) {

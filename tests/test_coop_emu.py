@@ -103,3 +103,54 @@ def test_env_steps_match_oracle_with_contacts(model):
             np.testing.assert_allclose(ex[4 + 16 * nb:4 + 22 * nb].reshape(nb, 6), d.get("cvel"), rtol=0, atol=1e-10)
             q, v = d.get("qpos"), d.get("qvel")
     assert seen_contacts > 0
+
+
+# ---- the ONE-LANE simulator (mjx_core.h, the product kernel of the nine smaller robots) compiled for the host ------------------------
+CORE_NAMES = ["half_cheetah", "ant", "humanoid", "hopper", "walker2d", "inverted_pendulum", "inverted_double_pendulum", "reacher",
+              "humanoid_standup", "swimmer", "pusher"]  # ids as in oracle/mujoco_envs.h
+
+
+def core(model, m, qpos, qvel, ctrl, nsub, warm=None):
+    qo, vo, ao = np.zeros(m.nq), np.zeros(m.nv), np.zeros(m.nv)
+    p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)
+    fn = lib().core_emu_step
+    fn.restype = C.c_int
+    ncon = fn(model, p(qpos), p(qvel), p(ctrl), nsub, p(qo), p(vo), p(ao), None if warm is None else warm.ctypes.data_as(C.c_void_p), None)
+    return qo, vo, ao, ncon
+
+
+@pytest.mark.parametrize("model", range(len(CORE_NAMES)), ids=CORE_NAMES)
+def test_one_lane_simulator_matches_oracle(model):
+    """States a random policy reaches on the oracle, then env steps (frame_skip sub-steps, warm start carried) on both implementations."""
+    name = CORE_NAMES[model]
+    om_ = om.OracleModel(name)
+    m, d = om_.m, om_.make_data()
+    free_root = name in ("ant", "humanoid", "humanoid_standup")
+    amp = 0.4 if name.startswith("humanoid") else (2.0 if name == "pusher" else 1.0)
+    nsub = {"inverted_pendulum": 2, "reacher": 2, "swimmer": 4, "hopper": 4, "walker2d": 4}.get(name, 5)
+    seen = 0
+    for trial in range(2):
+        rng = np.random.default_rng(10 * model + trial)
+        qpos = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
+        if free_root:
+            qpos[3:7] /= np.linalg.norm(qpos[3:7])
+        if name == "pusher":  # lower the arm towards the table and put the object in front of the wrist (tests/test_mujoco_oracle.py)
+            qpos[:] = 0
+            qpos[1], qpos[3], qpos[6] = rng.uniform(0.45, 0.62), rng.uniform(-0.45, -0.05), rng.uniform(-0.5, 0.5)
+            qpos[7], qpos[8] = -0.6 + rng.uniform(-0.12, 0.12) + 0.05, 0.80 + rng.uniform(-0.08, 0.06) - 0.45
+        d.reset(), d.set_state(qpos, 0.1 * rng.normal(size=m.nv), np.zeros(m.nu))
+        for _ in range(20 if name in ("pusher", "inverted_pendulum", "inverted_double_pendulum") else 60):
+            d.set_state(None, None, amp * rng.uniform(-1, 1, m.nu)), d.step(nsub)
+        q, v = d.get("qpos"), d.get("qvel")
+        warm = np.zeros(m.nv)
+        for _ in range(4):
+            ctrl = amp * rng.uniform(-1, 1, m.nu)
+            d.set_state(q, v, ctrl), d.step(nsub)
+            qo, vo, _, ncon = core(model, m, q, v, ctrl, nsub, warm)
+            assert ncon == d.get("ncon")
+            seen += ncon + d.get("nefc")
+            np.testing.assert_allclose(qo, d.get("qpos"), rtol=0, atol=1e-10 * max(1.0, np.abs(qo).max()))
+            np.testing.assert_allclose(vo, d.get("qvel"), rtol=0, atol=1e-9 * max(1.0, np.abs(vo).max()))
+            q, v = d.get("qpos"), d.get("qvel")
+    if name not in ("swimmer", "reacher", "inverted_pendulum", "inverted_double_pendulum"):
+        assert seen > 0, "these robots must have met their constraints (contacts / joint limits)"

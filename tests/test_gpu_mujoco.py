@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 IDS = {"half_cheetah": "HalfCheetah-v5", "ant": "Ant-v5", "humanoid": "Humanoid-v5"}
 # more robots on the same physics core (one-lane kernel), their own glue
 MORE = {"hopper": "Hopper-v5", "walker2d": "Walker2d-v5", "inverted_pendulum": "InvertedPendulum-v5",
-        "inverted_double_pendulum": "InvertedDoublePendulum-v5", "reacher": "Reacher-v5", "humanoid_standup": "HumanoidStandup-v5", "swimmer": "Swimmer-v5"}
+        "inverted_double_pendulum": "InvertedDoublePendulum-v5", "reacher": "Reacher-v5", "humanoid_standup": "HumanoidStandup-v5", "swimmer": "Swimmer-v5", "pusher": "Pusher-v5"}
 ALL = {**IDS, **MORE}
-NSTATE = {"half_cheetah": 17, "ant": 27, "humanoid": 45, "hopper": 11, "walker2d": 17, "inverted_pendulum": 4, "inverted_double_pendulum": 0, "reacher": 0, "humanoid_standup": 45, "swimmer": 8}
-FIRST_INFO = {"humanoid_standup": ("x_position", "reward_linup", "reward_quadctrl", "reward_impact"), "reacher": ("reward_dist", "reward_ctrl"), "inverted_pendulum": ("reward_survive",), "inverted_double_pendulum": ("reward_survive", "distance_penalty", "velocity_penalty")}
+NSTATE = {"half_cheetah": 17, "ant": 27, "humanoid": 45, "hopper": 11, "walker2d": 17, "inverted_pendulum": 4, "inverted_double_pendulum": 0, "reacher": 0, "humanoid_standup": 45, "swimmer": 8, "pusher": 14}
+FIRST_INFO = {"pusher": ("reward_dist", "reward_ctrl", "reward_near"), "humanoid_standup": ("x_position", "reward_linup", "reward_quadctrl", "reward_impact"), "reacher": ("reward_dist", "reward_ctrl"), "inverted_pendulum": ("reward_survive",), "inverted_double_pendulum": ("reward_survive", "distance_penalty", "velocity_penalty")}
 
 
 @pytest.mark.parametrize("name", list(ALL))
@@ -148,3 +148,38 @@ def test_cooperative_kernel_equals_one_lane_simulator(name, monkeypatch):
     assert np.array_equal(ser.get_rng_state(), coop.get_rng_state())
     print(f"{name}: cooperative vs one-lane max |obs diff| {worst:.3e} (resync every {window})")
     ser.close(), coop.close()
+
+
+def test_pusher_contacts_gpu_vs_oracle(oracle_factory):
+    """Pusher-v5 with the arm lowered onto the object and the table (capsule - cylinder and plane - capsule contacts active from the
+    first step): HIP vs oracle from identical states, 10 steps."""
+    n = 256
+    gpu = gymnasium_amd.make_vec("Pusher-v5", num_envs=n)
+    cpu = gymnasium_amd.make_vec("Pusher-v5", num_envs=n, _engine_factory=oracle_factory)
+    gpu.reset(seed=1), cpu.reset(seed=1)
+    st, el, fl = cpu.get_state()
+    rng = np.random.default_rng(0)
+    st = st.copy()
+    st[:, :] = 0.0
+    st[:, 1] = rng.uniform(0.45, 0.62, n)        # shoulder lift: the wrist comes down to the object's / the table's height
+    st[:, 3] = rng.uniform(-0.45, -0.05, n)      # elbow
+    st[:, 6] = rng.uniform(-0.5, 0.5, n)         # wrist roll
+    # the object just in front of the wrist (documented start pose of the tips: x = 0.821, y = -0.6): sliders are (y, x) offsets from (0.45, -0.05)
+    st[:, 7] = -0.6 + rng.uniform(-0.12, 0.12, n) - (-0.05)
+    st[:, 8] = 0.80 + rng.uniform(-0.08, 0.06, n) - 0.45
+    st[:, 11:18] = rng.uniform(-0.5, 0.5, (n, 7))  # arm joint velocities
+    gpu.set_state(st, el, fl), cpu.set_state(st, el, fl)
+    gpu.action_space.seed(3)
+    moved = np.zeros(n, dtype=bool)
+    worst = 0.0
+    for t in range(10):
+        a = gpu.action_space.sample()
+        og, rg, _, _, ig = gpu.step(a)
+        oc, rc, _, _, ic = cpu.step(a)
+        worst = max(worst, float(np.abs(og - oc).max()))
+        np.testing.assert_allclose(og, oc, rtol=1e-6, atol=1e-6, err_msg=f"t={t}")
+        np.testing.assert_allclose(rg, rc, rtol=1e-6, atol=1e-6)
+        moved |= np.abs(oc[:, 17] - (0.45 + st[:, 8])) > 1e-6
+    assert moved.sum() > n // 8, "the arm must actually push the object in a good share of the environments"
+    print(f"pusher contacts: max |obs diff| {worst:.3e} over 10 steps x {n} envs; object pushed in {int(moved.sum())} envs")
+    gpu.close(), cpu.close()

@@ -500,3 +500,126 @@ def test_swimmer_swims():
             x0 = d.get("subtree_com")[1].copy()
     moved = d.get("subtree_com")[1] - x0
     assert np.isfinite(d.get("qpos")).all() and np.hypot(moved[0], moved[1]) > 0.3
+
+
+# ---- Pusher-v5: arm + sliding cylinder; the one pair type MuJoCo itself has no analytic function for (capsule - cylinder) ---------
+def _segment_cylinder_distance(a, b, c, R, H):
+    """Independent formulation: signed distance of the segment a-b to the z-aligned solid cylinder (centre c), by scalar minimisation of the
+    point distance (outside: hypot of the axial / radial excess; inside: the larger, negative, of the two)."""
+    from scipy.optimize import minimize_scalar
+
+    def sd(t):
+        p = a + t * (b - a) - c
+        ea, er = abs(p[2]) - H, np.hypot(p[0], p[1]) - R
+        return max(ea, er) if (ea <= 0 and er <= 0) else float(np.hypot(max(ea, 0.0), max(er, 0.0)))
+    ts = np.linspace(0, 1, 4001)
+    vals = np.array([sd(t) for t in ts])
+    k = int(vals.argmin())
+    lo, hi = ts[max(k - 1, 0)], ts[min(k + 1, len(ts) - 1)]
+    res = minimize_scalar(sd, bounds=(lo, hi), method="bounded", options=dict(xatol=1e-13))
+    return min(res.fun, vals[k])
+
+
+def test_pusher_model_and_capsule_cylinder_contacts():
+    m = cp.compile_model("pusher")
+    assert (m.nq, m.nv, m.nu, m.nbody, m.njnt) == (11, 11, 7, 13, 11) and m.integrator == "Euler" and not m.gravity.any()
+    np.testing.assert_allclose(m.body_mass[11], 0.01 * np.pi * 0.05 ** 2 * 0.1, rtol=1e-14)  # the object: density 0.01 (pusher_v5.xml:77)
+    names = [(m.geom_names[a], m.geom_names[b]) for a, b in zip(m.pair_geom1, m.pair_geom2)]
+    assert names == [("floor", "wr0"), ("floor", "wr1"), ("floor", "wr2"), ("wr0", "object"), ("wr1", "object"), ("wr2", "object")]
+    assert (m.pair_condim == 1).all() and (m.pair_margin == 0.002).all()
+    om = omj.OracleModel("pusher")
+    d = om.make_data()
+    d.reset(), d.forward()
+    np.testing.assert_allclose(d.get("xpos")[10], [0.821, -0.6, 0.0], atol=1e-15)  # tips_arm of the documented start pose
+    assert d.get("ncon") == 0
+    rng = np.random.default_rng(5)
+    gi = {n: m.geom_names.index(n) for n in ("wr0", "wr1", "wr2", "object")}
+    seen = {"touching": 0, "penetrating": 0, "deep": 0}
+    for trial in range(60):
+        q = np.zeros(11)
+        q[:7] = [rng.uniform(lo, hi) for lo, hi in m.jnt_range[:7]]
+        d.set_state(q, np.zeros(11), np.zeros(7)), d.forward()
+        gx, gm = d.get("geom_xpos"), d.get("geom_xmat").reshape(-1, 3, 3)
+        # move the object next to one of the wrist capsules: a random point of the segment plus a random offset around the contact range
+        w = gi[("wr0", "wr1", "wr2")[trial % 3]]
+        half, axis = m.geom_size[w][1], gm[w][:, 2]
+        target = gx[w] + rng.uniform(-half, half) * axis + rng.normal(size=3) * (0.0 if trial % 4 == 0 else 0.05)
+        q[7], q[8] = target[1] - m.body_pos[11][1], target[0] - m.body_pos[11][0]  # slider y, then slider x
+        d.set_state(q, np.zeros(11), np.zeros(7)), d.forward()
+        gx = d.get("geom_xpos")
+        con = d.get("contact")
+        cyl = gx[gi["object"]]
+        for name in ("wr0", "wr1", "wr2"):
+            g = gi[name]
+            half, axis, rc = m.geom_size[g][1], gm[g][:, 2], m.geom_size[g][0]
+            want = _segment_cylinder_distance(gx[g] - half * axis, gx[g] + half * axis, cyl, 0.05, 0.05) - rc
+            rows = [r for r in con if int(r[13]) == g and int(r[14]) == gi["object"]]
+            if want < 0.002 - 1e-9:
+                assert len(rows) == 1
+                r = rows[0]
+                np.testing.assert_allclose(r[0], want, rtol=0, atol=2e-9)
+                n = r[4:7]
+                np.testing.assert_allclose(np.linalg.norm(n), 1.0, rtol=1e-12)
+                seen["touching" if want > 0 else ("penetrating" if want > -rc else "deep")] += 1
+                if want > -rc + 1e-3:  # the segment itself is outside the cylinder: the normal points from the capsule into the cylinder
+                    inside_pt = r[1:4] + n * 1e-3 * 0 + n * (abs(r[0]) * 0.5 + 1e-4)
+                    p = inside_pt - cyl
+                    assert abs(p[2]) <= 0.05 + 1e-9 and np.hypot(p[0], p[1]) <= 0.05 + 1e-9
+            elif want > 0.002 + 1e-9:
+                assert not rows
+    assert seen["touching"] > 0 and seen["penetrating"] > 5
+
+
+def test_pusher_arm_pushes_the_object():
+    """A wrist capsule overlapping the cylinder accelerates it away from the arm (frictionless contact, equal and opposite force)."""
+    m = cp.compile_model("pusher")
+    om = omj.OracleModel("pusher")
+    d = om.make_data()
+    q = np.zeros(11)
+    q[1], q[3] = 0.55, -0.45  # the arm reaches down to the table plane's height range
+    d.reset(), d.set_state(q, np.zeros(11), np.zeros(7)), d.forward()
+    gx = d.get("geom_xpos")
+    w = m.geom_names.index("wr0")
+    # place the object 0.06 in front (+x) of the wrist cross-bar: the gap between the surfaces is 0.06 - 0.05 - 0.02 < 0
+    q[7], q[8] = gx[w][1] - m.body_pos[11][1], gx[w][0] + 0.06 - m.body_pos[11][0]
+    d.set_state(q, np.zeros(11), np.zeros(7)), d.forward()
+    assert abs(gx[w][2] - (-0.275)) < 0.05 + 0.02  # the bar is at the cylinder's height: a contact must exist
+    assert d.get("ncon") >= 1 and d.get("nefc") >= 1
+    qacc = d.get("qacc")
+    assert qacc[8] > 0, "the object is pushed along +x, away from the bar"
+    d.step(20)
+    assert d.get("qpos")[8] > q[8]
+
+
+def test_pusher_env_reset_stream_reward_and_truncation(oracle_factory):
+    m = cp.compile_model("pusher")
+    env = gymnasium_amd.make_vec("Pusher-v5", num_envs=3, _engine_factory=oracle_factory)
+    assert env.single_observation_space.shape == (23,) and env.single_action_space.shape == (7,)
+    assert (env.single_action_space.low == -2).all() and (env.single_action_space.high == 2).all()
+    obs, info = env.reset(seed=100)
+    assert info == {}
+    for i in range(3):  # pusher_v5.py:293-315
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(100 + i)))
+        while True:
+            cyl = np.concatenate([g.uniform(low=-0.3, high=0, size=1), g.uniform(low=-0.2, high=0.2, size=1)])
+            if np.linalg.norm(cyl - np.asarray([0, 0])) > 0.17:
+                break
+        qvel = g.uniform(low=-0.005, high=0.005, size=11)
+        qvel[-4:] = 0
+        assert np.array_equal(obs[i, :7], np.zeros(7)) and np.array_equal(obs[i, 7:14], qvel[:7])
+        # object = body pos + (slider x, slider y); the FIRST draw drives the y slider (joint order of the XML)
+        np.testing.assert_allclose(obs[i, 17:20], m.body_pos[11] + [cyl[1], cyl[0], 0.0], rtol=0, atol=1e-16)
+        np.testing.assert_allclose(obs[i, 20:23], m.body_pos[12], rtol=0, atol=1e-16)
+        np.testing.assert_allclose(obs[i, 14:17], [0.821, -0.6, 0.0], rtol=0, atol=1e-15)
+        assert np.array_equal(env.get_rng_state()[i], gymnasium_amd._native.pcg_words(g))
+    env.action_space.seed(0)
+    for t in range(100):
+        act = env.action_space.sample()
+        obs, rew, term, trunc, info = env.step(act)
+        assert np.array_equal(rew, info["reward_dist"] + info["reward_ctrl"] + info["reward_near"])  # test_mujoco_v5.py:285-289
+        ctrl = -np.square(act).sum(axis=1, dtype=np.float32) * np.float32(0.1)
+        assert np.array_equal(info["reward_ctrl"], ctrl.astype(np.float64))
+        np.testing.assert_allclose(info["reward_near"], -np.linalg.norm(obs[:, 17:20] - obs[:, 14:17], axis=1) * 0.5, rtol=1e-14)
+        np.testing.assert_allclose(info["reward_dist"], -np.linalg.norm(obs[:, 17:20] - obs[:, 20:23], axis=1), rtol=1e-14)
+        assert not term.any() and trunc.all() == (t == 99) and np.isfinite(obs).all()
+    env.close()
