@@ -50,7 +50,7 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0):
     eng = env._engine
     eng.action_seed(_native.pcg_words(env.action_space.np_random))
     T = 4
-    obs = np.zeros((T, num_envs) if eng.obs_dtype is np.int64 else (T, num_envs, eng.obs_dim), eng.obs_dtype)
+    obs = np.zeros((T, num_envs) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (T, num_envs, eng.obs_dim), eng.obs_dtype)
     rew, te, tr = np.zeros((T, num_envs)), np.zeros((T, num_envs), np.bool_), np.zeros((T, num_envs), np.bool_)
     acts = np.zeros((T, num_envs) if eng.act_dtype is np.int64 else (T, num_envs, eng.act_dim), dtype=eng.act_dtype)
     t0 = time.perf_counter()
@@ -109,7 +109,7 @@ def main():
     act_dtype = torch.int64 if env._discrete else torch.float32
     obs_dtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
     acts = torch.empty((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=act_dtype, device=dev)
-    obs = torch.empty((inner, N) if eng.obs_dtype is np.int64 else (inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
+    obs = torch.empty((inner, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
     rew = torch.empty((inner, N), dtype=torch.float64, device=dev)
     te = torch.empty((inner, N), dtype=torch.bool, device=dev)
     tr = torch.empty((inner, N), dtype=torch.bool, device=dev)
@@ -128,17 +128,20 @@ def main():
         one_step()
     sync_all()
     eng.reset_stats()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    # One HIP event on either side of the K launches, on the stream they are queued on (env._bind_stream() = torch's current stream):
+    # the average launch duration is their distance / K.  (An event after every launch would put a marker packet between the kernels:
+    # measured +9 us per 96 us launch, which rocprofv3's kernel trace does not see.)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync_all()
     t0 = time.perf_counter()
-    ev[0].record()
+    ev0.record()
     for k in range(K):
         one_step()
-        ev[k + 1].record()
+    ev1.record()
     sync_all()
     elapsed = time.perf_counter() - t0
     st = env.statistics()
-    kernel_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(K)]
+    kernel_ms = [ev0.elapsed_time(ev1) / K]
     from gymnasium_amd import distributed as gd
 
     red = gd.reduce_statistics(st, elapsed_s=elapsed, device=dev)  # the only collective: a few dozen bytes over RCCL/xGMI
