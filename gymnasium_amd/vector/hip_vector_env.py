@@ -118,6 +118,17 @@ class HipVectorEnv(VectorEnv):
             self._episode_start = np.zeros(self.num_envs)
             self._prev_dones = np.zeros(self.num_envs, dtype=np.bool_)
 
+    def enable_episode_statistics(self):
+        """Switch on the on-device episode accounting after construction (what wrappers.vector.RecordEpisodeStatistics(env) does):
+        the step kernels start writing the finished episodes' return / length rows.  Call before reset()."""
+        if not self.record_episode_statistics:
+            self.record_episode_statistics = True
+            self.episode_count = 0
+            self._episode_start = np.zeros(self.num_envs)
+            self._prev_dones = np.zeros(self.num_envs, dtype=np.bool_)
+            self._alloc_buffers()
+            self._has_reset = False
+
     # -- buffers ---------------------------------------------------------------------------------------
     def _alloc_buffers(self):
         N, eng = self.num_envs, self._engine

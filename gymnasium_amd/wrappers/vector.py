@@ -121,6 +121,38 @@ class VectorWrapper:
         return t if was_tensor else t.cpu().numpy()
 
 
+class RecordEpisodeStatistics(VectorWrapper):
+    """gymnasium.wrappers.vector.RecordEpisodeStatistics (wrappers/vector/common.py:22-235) on the engine's own accounting: the step
+    kernels accumulate each sub-environment's return and length on the device (NEXT_STEP: the autoreset step does not count; SAME_STEP:
+    every step counts) and hand out the rows of the episodes that just ended; this class adds the reference's bookkeeping around them --
+    ``infos[stats_key] = {"r", "l", "t"}`` + ``infos["_" + stats_key]``, ``episode_count`` and the three bounded queues."""
+
+    def __init__(self, env, buffer_length: int = 100, stats_key: str = "episode"):
+        from collections import deque
+
+        super().__init__(env)
+        if not hasattr(env.unwrapped, "enable_episode_statistics"):
+            raise TypeError("RecordEpisodeStatistics of gymnasium_amd wraps a HipVectorEnv (use gymnasium's own wrapper for other vector envs)")
+        env.unwrapped.enable_episode_statistics()
+        self._stats_key = stats_key
+        self.time_queue, self.return_queue, self.length_queue = deque(maxlen=buffer_length), deque(maxlen=buffer_length), deque(maxlen=buffer_length)
+
+    @property
+    def episode_count(self):
+        return self.env.unwrapped.episode_count
+
+    def step(self, actions):
+        obs, rewards, terminations, truncations, infos = self.env.step(actions)
+        if "_episode" in infos:
+            stats, dones = infos.pop("episode"), infos.pop("_episode")
+            if self._stats_key in infos or f"_{self._stats_key}" in infos:
+                raise ValueError(f"Attempted to add episode stats with key '{self._stats_key}' but this key already exists in info: {list(infos.keys())}")
+            infos[self._stats_key], infos[f"_{self._stats_key}"] = stats, dones
+            idx = np.flatnonzero(dones)  # common.py:214-217: the queues take the finished episodes in sub-environment order
+            self.time_queue.extend(stats["t"][idx]), self.return_queue.extend(stats["r"][idx]), self.length_queue.extend(stats["l"][idx])
+        return obs, rewards, terminations, truncations, infos
+
+
 class NormalizeObservation(VectorWrapper):
     """stateful_observation.py:27-160."""
 

@@ -215,6 +215,18 @@ def make_episode_stats():
             else:
                 Rr.append(np.zeros(6)), Ll.append(np.zeros(6, dtype=int)), M.append(np.zeros(6, dtype=bool))
         out[f"{mode}_r"], out[f"{mode}_l"], out[f"{mode}_mask"] = np.stack(Rr), np.stack(Ll), np.stack(M)
+        out[f"{mode}_return_queue"], out[f"{mode}_length_queue"] = np.array(vec.return_queue), np.array(vec.length_queue)
+        out[f"{mode}_episode_count"] = np.array(vec.episode_count)
+        vec.close()
+        # the wrapper object itself with a short buffer and its own info key (wrappers/vector/common.py:72-109)
+        vec = gym.make_vec("CartPole-v1", num_envs=6, vectorization_mode="sync", vector_kwargs={"autoreset_mode": mode})
+        vec = RecordEpisodeStatistics(vec, buffer_length=7, stats_key="ep")
+        vec.reset(seed=3)
+        vec.action_space.seed(5)
+        for _ in range(300):
+            _, _, _, _, info = vec.step(vec.action_space.sample())
+            assert "episode" not in info
+        out[f"{mode}_short_return_queue"], out[f"{mode}_short_length_queue"] = np.array(vec.return_queue), np.array(vec.length_queue)
         vec.close()
     save("episode_stats.npz", **out)
 
@@ -398,6 +410,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--blackjack-only" in sys.argv:
         make_blackjack()
+        sys.exit(0)
+    if "--episode-stats-only" in sys.argv:
+        make_episode_stats()
         sys.exit(0)
     if "--wrappers-only" in sys.argv:
         make_wrappers()

@@ -228,6 +228,26 @@ def check_episode_stats(factory, tol):
                 assert "episode" not in info
         assert env.episode_count == count
         env.close()
+        # the wrapper class around a plain env: same rows under its own key, the reference's bounded queues (common.py:72-109,214-217)
+        from gymnasium_amd.wrappers import RecordEpisodeStatistics
+
+        for kw, tag in ((dict(), ""), (dict(buffer_length=7, stats_key="ep"), "short_")):
+            env = RecordEpisodeStatistics(make("cartpole", 6, factory, autoreset_mode=mode), **kw)
+            key = kw.get("stats_key", "episode")
+            env.reset(seed=3)
+            env.action_space.seed(5)
+            for t in range(300):
+                _, _, _, _, info = env.step(env.action_space.sample())
+                m = g[f"{mode}_mask"][t]
+                assert (key in info) == bool(m.any()) and (key == "episode" or "episode" not in info)
+                if m.any():
+                    assert np.array_equal(info["_" + key], m) and np.array_equal(info[key]["l"], g[f"{mode}_l"][t])
+                    _close(info[key]["r"], g[f"{mode}_r"][t], 0.0, "episode r (wrapper)")
+            assert env.episode_count == int(g[f"{mode}_episode_count"])
+            assert np.array_equal(np.array(env.return_queue), g[f"{mode}_{tag}return_queue"])
+            assert np.array_equal(np.array(env.length_queue), g[f"{mode}_{tag}length_queue"])
+            assert len(env.time_queue) == len(env.return_queue) and min(env.time_queue) >= 0
+            env.close()
 
 
 def check_teacher(key, factory, tol):
