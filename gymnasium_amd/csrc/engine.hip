@@ -30,6 +30,7 @@
 #include "pcg64_dev.h"
 #include "mjx_kernels.h"
 #include "mjx_coop.h"
+#include "mjx_physics.h"
 
 using namespace mi;
 
@@ -625,36 +626,8 @@ __global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtr
 }
 
 // ---- cooperative physics (mjx_coop.h): G lanes per sub-environment, 64 / G sub-environments per wavefront --------------
-// Advances qpos / qvel of every sub-environment that takes a real step this call by frame_skip sub-steps, in place, and
-// leaves what the reward / observation code needs in `extras`.  Sub-environments in their NEXT_STEP autoreset step (or
-// finished ones under DISABLED) are skipped: the step kernel that follows resets them / reports the error.
-template <class E, int MODE>
-__global__ __launch_bounds__(64) void mj_physics_kernel(DevEnv d, const float *actions, double *extras) {
-    typedef typename E::Model M;
-    constexpr int G = E::COOP_G, EPW = 64 / G;
-    typedef mjx::coop::Sim<M, G> S;
-    __shared__ typename S::B boards[EPW];
-    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
-    const int env = blockIdx.x * EPW + grp;
-    if (env >= d.N) return;
-    if (MODE != MI_AUTORESET_SAME_STEP && ((d.meta[env] >> kFlagShift) & kNeedsReset)) return;
-    typename S::B &bb = boards[grp];
-    typename S::R r;
-    S::init(bb, lane);
-    const size_t N = (size_t)d.N;
-    for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
-    for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
-    for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
-    r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
-    mjx::coop::coop_sync();
-    const int frame_skip = (int)d.P.p[4];
-    for (int f = 0; f < frame_skip; f++) S::step(bb, r, lane);
-    mjx::coop::coop_sync();
-    for (int k = lane; k < M::NQ; k += G) d.state[(size_t)k * N + env] = bb.qpos[k];
-    for (int k = lane; k < M::NV; k += G) d.state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
-    if (lane < M::NV) d.state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
-    S::write_extras(bb, r, lane, extras + (size_t)env * S::EX_TOTAL);
-}
+// mj_physics_kernel lives in mjx_physics.h and is instantiated in physics16.hip / physics32.hip (their own compiler settings); here it
+// is only launched: mi_phys::launch16 / launch32.
 
 // Box.sample() of the batched action space for step t of a rollout: draw number (t N + i) NU + u of the stream
 template <class E>
@@ -1127,13 +1100,12 @@ int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
         return MI_OK;
     } else {
     if (v->mj_coop) {
-        constexpr int EPW = 64 / E::COOP_G;
-        const dim3 pg((v->cfg.num_envs + EPW - 1) / EPW), pb(64);
-        switch (mode) {
-        case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((mj_physics_kernel<E, MI_AUTORESET_NEXT_STEP>), pg, pb, 0, v->stream, v->d, mp.actions, v->d_extras); break;
-        case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((mj_physics_kernel<E, MI_AUTORESET_SAME_STEP>), pg, pb, 0, v->stream, v->d, mp.actions, v->d_extras); break;
-        default: hipLaunchKernelGGL((mj_physics_kernel<E, MI_AUTORESET_DISABLED>), pg, pb, 0, v->stream, v->d, mp.actions, v->d_extras); break;
-        }
+        mi_phys::Args pa;
+        pa.state = v->d.state, pa.meta = v->d.meta, pa.needs_reset_mask = kNeedsReset << kFlagShift, pa.N = v->d.N, pa.frame_skip = (int)v->d.P.p[4];
+        const bool skip_resetting = mode != MI_AUTORESET_SAME_STEP;  // SAME_STEP: every sub-environment steps
+        const bool ok = E::COOP_G == 16 ? mi_phys::launch16(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream)
+                                        : mi_phys::launch32(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream);
+        if (!ok) return fail(MI_ERR_UNSUPPORTED, "no cooperative physics kernel for this env kind");
         mp.extras = v->d_extras;
     }
     if (v->mj_coop) {

@@ -28,6 +28,13 @@
 #pragma clang fp contract(fast)
 #endif
 
+#ifndef MJX_CHOL_LDS_FOR_16
+#define MJX_CHOL_LDS_FOR_16 0  // diagnostic switch: 16-lane groups on the LDS-exchange Cholesky as well (costs LDS: 3 instead of 4 wavefronts per CU)
+#endif
+#ifndef MJX_GROUP_SUM_SHFL
+#define MJX_GROUP_SUM_SHFL 0   // diagnostic switch: group reductions as __shfl_xor butterflies instead of DPP rotations
+#endif
+
 namespace mjx {
 namespace coop {
 
@@ -88,6 +95,10 @@ MJX_DEV void row_pair(double v, double &even_rows, double &odd_rows) {
 }
 template <int G>
 MJX_DEV double group_sum(double v, decltype(nullptr), int) {
+#if MJX_GROUP_SUM_SHFL
+    for (int off = G / 2; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+#endif
     if (G == 32) {
         double a, b;
         row_pair(v, a, b);
@@ -135,7 +146,7 @@ struct Board {
         } kin;
         struct {
             double L[NTRI];                                   // packed lower Cholesky factor (column access in back substitution)
-            double col[2][G_ == 16 ? 1 : NV];                 // pivot column / substitution exchange of the 32-lane variant (double buffered)
+            double col[2][(G_ == 16 && !MJX_CHOL_LDS_FOR_16) ? 1 : NV];                 // pivot column / substitution exchange of the 32-lane variant (double buffered)
             double vdir[NV];                                  // solution of the last solve (qacc_smooth, then the search directions)
         } sol;
     } A;
@@ -606,13 +617,13 @@ struct Sim {
 #define MJX_CHOL_LDS_FOR_32 1  // measured: the broadcast variant makes the 23-row Humanoid kernel spill 350 VGPRs (71 this way)
 #endif
     static MJX_DEV void chol_factor(B &bb, double *A, double &idiag, int lane) {
-        if constexpr (G == 16 || !MJX_CHOL_LDS_FOR_32)
+        if constexpr ((G == 16 && !MJX_CHOL_LDS_FOR_16) || (G == 32 && !MJX_CHOL_LDS_FOR_32))
             chol_factor_bcast(bb, A, idiag, lane);
         else
             chol_factor_lds(bb, A, idiag, lane);
     }
     static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
-        if constexpr (G == 16 || !MJX_CHOL_LDS_FOR_32)
+        if constexpr ((G == 16 && !MJX_CHOL_LDS_FOR_16) || (G == 32 && !MJX_CHOL_LDS_FOR_32))
             return chol_solve_bcast(bb, Lrow, idiag, rhs, lane);
         else
             return chol_solve_lds(bb, Lrow, idiag, rhs, lane);

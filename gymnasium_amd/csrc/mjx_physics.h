@@ -1,0 +1,73 @@
+// mjx_physics.h -- the cooperative physics kernel (mjx_coop.h) behind a plain launch function, so that it can live in its own
+// translation units: physics16.hip (16-lane groups: Ant, HalfCheetah) and physics32.hip (32-lane groups: Humanoid, HumanoidStandup) are
+// compiled with different instruction-scheduler settings than engine.hip (gymnasium_amd/csrc/build.py TU_FLAGS).
+//
+// Reference call sites replaced: gymnasium/envs/mujoco/mujoco_env.py:150 (mj_step(nstep = frame_skip)) and :155 (mj_rnePostConstraint),
+// for every sub-environment that takes a real step in this vector step.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/mi355env.h"
+#include "envs_classic.h"
+#include "pcg64_dev.h"
+#include "mjx_kernels.h"
+#include "mjx_coop.h"
+
+namespace mi_phys {
+
+// what the kernel needs of the engine's device state (engine.hip DevEnv): the component-major state rows [S][N] (qpos, qvel, the
+// qacc_warmstart slot), the per-env meta word whose `needs_reset_mask` bits mark a sub-environment that resets instead of stepping
+struct Args {
+    double *state;
+    const uint32_t *meta;
+    uint32_t needs_reset_mask;
+    int N, frame_skip;
+};
+
+// Advances qpos / qvel of every sub-environment that takes a real step this call by frame_skip sub-steps, in place, and leaves what
+// the reward / observation code needs in `extras`.  Sub-environments in their NEXT_STEP autoreset step (or finished ones under DISABLED)
+// are skipped: the step kernel that follows resets them / reports the error.
+template <class E, bool SKIP_RESETTING>
+__global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *actions, double *extras) {
+    typedef typename E::Model M;
+    constexpr int G = E::COOP_G, EPW = 64 / G;
+    typedef mjx::coop::Sim<M, G> S;
+    __shared__ typename S::B boards[EPW];
+    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+    const int env = blockIdx.x * EPW + grp;
+    if (env >= d.N) return;
+    if (SKIP_RESETTING && (d.meta[env] & d.needs_reset_mask)) return;
+    typename S::B &bb = boards[grp];
+    typename S::R r;
+    S::init(bb, lane);
+    const size_t N = (size_t)d.N;
+    for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
+    for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
+    for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
+    r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
+    mjx::coop::coop_sync();
+    for (int f = 0; f < d.frame_skip; f++) S::step(bb, r, lane);
+    mjx::coop::coop_sync();
+    for (int k = lane; k < M::NQ; k += G) d.state[(size_t)k * N + env] = bb.qpos[k];
+    for (int k = lane; k < M::NV; k += G) d.state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
+    if (lane < M::NV) d.state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
+    S::write_extras(bb, r, lane, extras + (size_t)env * S::EX_TOTAL);
+}
+
+template <class E>
+inline void launch_kind(const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream) {
+    constexpr int EPW = 64 / E::COOP_G;
+    const dim3 grid((a.N + EPW - 1) / EPW), block(64);
+    if (skip_resetting)
+        hipLaunchKernelGGL((mj_physics_kernel<E, true>), grid, block, 0, stream, a, actions, extras);
+    else
+        hipLaunchKernelGGL((mj_physics_kernel<E, false>), grid, block, 0, stream, a, actions, extras);
+}
+
+// defined in physics16.hip / physics32.hip; `kind` is an mi_env_kind; returns false for a kind the unit does not hold
+bool launch16(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream);
+bool launch32(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream);
+
+}  // namespace mi_phys

@@ -4,9 +4,12 @@
 // (s_memtime deltas summed over wavefronts).  Build + run (on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Igymnasium_amd/csrc scripts/coop_phase_bench.hip -o gpurun_out/coop_phase_bench
 //   gpurun_out/coop_phase_bench [ant|humanoid] [num_envs]
+#ifndef NO_PHASE_TIMING
 #define MJX_PHASE_TIMING 1
+#endif
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,21 +29,53 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     if (env >= N) return;
     typename S::B &bb = boards[grp];
     typename S::R r;
+#ifdef MJX_PHASE_TIMING
     for (int k = 0; k < 12; k++) r.tphase[k] = 0;
+#endif
     S::init(bb, lane);
     for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = state[(size_t)k * N + env];
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = lane < M::NV ? state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;
     coop::coop_sync();
+#ifdef MJX_PHASE_TIMING
     r.tmark = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < nsub; s++) S::step(bb, r, lane);
     coop::coop_sync();
     for (int k = lane; k < M::NQ; k += G) state[(size_t)k * N + env] = bb.qpos[k];
     for (int k = lane; k < M::NV; k += G) state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
     if (lane < M::NV) state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
+#ifdef MJX_PHASE_TIMING
     if (threadIdx.x == 0)
         for (int k = 0; k < 12; k++) atomicAdd(&phase[k], r.tphase[k]);
+#endif
+}
+
+// COOP_DEBUG: ONE forward pass from the initial state; per env 4 NV + NV^2 doubles: qacc, qacc_smooth, bias, qfrc_constraint, mass-matrix rows
+template <class M, int G>
+__global__ __launch_bounds__(64) void fwd_debug(const double *state, const float *actions, int N, double *out) {
+    typedef coop::Sim<M, G> S;
+    constexpr int EPW = 64 / G, NV = M::NV;
+    __shared__ typename S::B boards[EPW];
+    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+    const int env = blockIdx.x * EPW + grp;
+    if (env >= N) return;
+    typename S::B &bb = boards[grp];
+    typename S::R r;
+    S::init(bb, lane);
+    for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = state[(size_t)k * N + env];
+    for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
+    for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
+    r.warm = 0.0;
+    coop::coop_sync();
+    S::forward(bb, r, lane);
+    coop::coop_sync();
+    double *o = out + (size_t)env * (4 * NV + NV * NV);
+    if (lane < NV) {
+        o[lane] = r.qacc, o[NV + lane] = r.qacc_smooth, o[2 * NV + lane] = r.bias, o[3 * NV + lane] = r.qfrc_constraint;
+        for (int j = 0; j < NV; j++) o[4 * NV + lane * NV + j] = S::mrow(bb, r, lane, j);
+    }
 }
 
 template <class M, int G>
@@ -62,7 +97,23 @@ int run(int N, int nsub, float amp) {
     const dim3 grid((N + 64 / G - 1) / (64 / G)), block(64);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    const int warm = 40, timed = 6;
+    if (getenv("COOP_DEBUG")) {
+        const size_t W = 4 * M::NV + M::NV * M::NV;
+        double *d_out;
+        hipMalloc(&d_out, sizeof(double) * W * N);
+        hipMemset(d_out, 0, sizeof(double) * W * N);
+        for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
+        hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL((fwd_debug<M, G>), grid, block, 0, 0, d_st, d_act, N, d_out);
+        std::vector<double> out(W * N);
+        hipMemcpy(out.data(), d_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost);
+        FILE *f = fopen(getenv("COOP_DEBUG"), "wb");
+        fwrite(out.data(), sizeof(double), out.size(), f), fclose(f);
+        printf("wrote %zu doubles per env\n", W);
+        return 0;
+    }
+    const int warm = getenv("COOP_WARM") ? atoi(getenv("COOP_WARM")) : 40, timed = getenv("COOP_TIMED") ? atoi(getenv("COOP_TIMED")) : 6;
+    if (getenv("COOP_NSUB")) nsub = atoi(getenv("COOP_NSUB"));
     float ms = 0;
     for (int t = 0; t < warm + timed; t++) {
         for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
@@ -73,6 +124,18 @@ int run(int N, int nsub, float amp) {
     hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
     unsigned long long ph[12];
     hipMemcpy(ph, d_ph, sizeof ph, hipMemcpyDeviceToHost);
+    {  // fingerprint of the final state: lets two builds of this harness (compiler flags, code variants) be compared bit for bit
+        hipMemcpy(st.data(), d_st, sizeof(double) * st.size(), hipMemcpyDeviceToHost);
+        double sum = 0, asum = 0;
+        int bad = 0;
+        for (double v : st) sum += v, asum += fabs(v), bad += !(v == v);
+        printf("state fingerprint: sum %.17g abs-sum %.17g non-finite %d; env0 qpos[0..3] %.17g %.17g %.17g %.17g\n", sum, asum, bad, st[0], st[(size_t)N], st[(size_t)2 * N],
+               st[(size_t)3 * N]);
+        if (getenv("COOP_DUMP")) {
+            FILE *f = fopen(getenv("COOP_DUMP"), "wb");
+            fwrite(st.data(), sizeof(double), st.size(), f), fclose(f);
+        }
+    }
     const char *names[12] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "make_constraint",
                              "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other"};
     double tot = 0;
