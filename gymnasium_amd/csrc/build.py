@@ -19,13 +19,13 @@ SOURCES = {  # translation unit -> the headers it depends on
 }
 OUT = os.path.join(HERE, "libmi355env.so")
 ARCH = "gfx950"
-# Per translation unit, on top of FLAGS: LLVM's iterative GCN schedulers for the cooperative physics kernels.  With ONE wavefront per SIMD
-# they hide LDS / VALU latency better than the default max-occupancy scheduler (which trades ILP for an occupancy these kernels cannot have):
-#   physics32.hip  iterative-maxocc  Humanoid-v5 +30 %   results bit-identical to the default scheduler's
-#   physics16.hip  iterative-minreg  Ant-v5 +10 %        (scripts/coop_phase_bench.hip: 65536 / 32768 envs x 25 env-steps, every bit of the state)
-# NOT used where it was measured to be wrong: iterative-maxocc / -ilp produce wrong RK4 stage updates in the 16-lane kernels and a diverging
-# one-lane Humanoid kernel in engine.hip, so engine.hip stays on the default scheduler.
-TU_FLAGS = {"physics16.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"], "physics32.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]}
+# Per translation unit, on top of FLAGS: LLVM's iterative GCN scheduler for the cooperative physics kernels.  With ONE wavefront per SIMD it
+# hides LDS / VALU latency better than the default max-occupancy scheduler (which trades ILP for an occupancy these kernels cannot have):
+# Humanoid-v5 +33 %, Ant-v5 +19 %, results bit-identical to the default scheduler's (scripts/coop_phase_bench.hip: 65536 / 32768 envs x 25
+# env-steps, every bit of the state) -- PROVIDED the RK4 stage update stays out of line (mjx_coop.h rk4_stage), inlined it is miscompiled.
+# engine.hip stays on the default scheduler: built with iterative-maxocc its one-lane Humanoid kernel diverged.
+ITERATIVE = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
+TU_FLAGS = {"physics16.hip": ITERATIVE, "physics32.hip": ITERATIVE}
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
 
 

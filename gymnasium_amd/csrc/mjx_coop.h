@@ -1277,13 +1277,44 @@ struct Sim {
         coop_sync();
     }
 
+    // One stage of the RK4 tableau, as selects on the stage index: sub-diagonal (0.5, 0.5, 1) and weights (1/6, 1/3, 1/3, 1/6).
+    // Deliberately OUT OF LINE on the device: inlined into the stage loop, LLVM's iterative schedulers (build.py TU_FLAGS) produce wrong code
+    // for exactly this block in the 16-lane instantiation (every environment differs after one sub-step); as a function of its own the
+    // kernel is bit-identical to the default scheduler's and 18 % faster (scripts/coop_phase_bench.hip).  Four calls
+    // per sub-step cost nothing next to four forward passes.
+#if defined(MJX_HOST_EMU)
+    static inline void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {
+#else
+    static __device__ __attribute__((noinline)) void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {
+#endif
+        constexpr double h = M::TIMESTEP;
+        const bool isdof = lane < NV;
+        if (i == 0) {
+            if (isdof) v0 = bb.qvel[lane];
+            for (int k = lane; k < NQ; k += G) bb.q0[k] = bb.qpos[k];
+        }
+        const double fv = isdof ? bb.qvel[lane] : 0.0, fa = qacc;
+        const double bw = (i == 0 || i == 3) ? 1.0 / 6 : 1.0 / 3, anext = i == 2 ? 1.0 : 0.5;
+        if (i == 0)
+            sumv = bw * fv, suma = bw * fa;
+        else
+            sumv += bw * fv, suma += bw * fa;
+        const bool last = i == 3;
+        const double dv = last ? sumv : anext * fv, da = last ? suma : anext * fa;
+        coop_sync();  // every lane has read the stage's qpos / qvel
+        if (isdof) bb.dv[lane] = dv, bb.qvel[lane] = v0 + h * da;
+        if (i > 0)
+            for (int k = lane; k < NQ; k += G) bb.qpos[k] = bb.q0[k];
+        coop_sync();
+        integrate_pos(bb, bb.dv, h, lane);
+    }
+
     // one mj_step: semi-implicit Euler (one forward pass) or RK4 (four), through a single forward() call site
     static MJX_DEV void step(B &bb, R &r, int lane) {
         constexpr double h = M::TIMESTEP;
         constexpr int NSTAGE = M::INTEGRATOR == 0 ? 1 : 4;
         const bool isdof = lane < NV;
-        // RK4 tableau as selects on the stage index: sub-diagonal (0.5, 0.5, 1) and weights (1/6, 1/3, 1/3, 1/6)
-        double v0 = 0, sumv = 0, suma = 0;
+        double v0 = 0, sumv = 0, suma = 0;  // RK4: the first stage's velocity and the weighted sums (rk4_stage)
 #pragma unroll 1
         for (int i = 0; i < NSTAGE; i++) {
             forward(bb, r, lane);
@@ -1292,24 +1323,7 @@ struct Sim {
                 coop_sync();
                 integrate_pos(bb, bb.qvel, h, lane);
             } else {
-                if (i == 0) {
-                    if (isdof) v0 = bb.qvel[lane];
-                    for (int k = lane; k < NQ; k += G) bb.q0[k] = bb.qpos[k];
-                }
-                const double fv = isdof ? bb.qvel[lane] : 0.0, fa = r.qacc;
-                const double bw = (i == 0 || i == 3) ? 1.0 / 6 : 1.0 / 3, anext = i == 2 ? 1.0 : 0.5;
-                if (i == 0)
-                    sumv = bw * fv, suma = bw * fa;
-                else
-                    sumv += bw * fv, suma += bw * fa;
-                const bool last = i == NSTAGE - 1;
-                const double dv = last ? sumv : anext * fv, da = last ? suma : anext * fa;
-                coop_sync();  // every lane has read the stage's qpos / qvel
-                if (isdof) bb.dv[lane] = dv, bb.qvel[lane] = v0 + h * da;
-                if (i > 0)
-                    for (int k = lane; k < NQ; k += G) bb.qpos[k] = bb.q0[k];
-                coop_sync();
-                integrate_pos(bb, bb.dv, h, lane);
+                rk4_stage(bb, r.qacc, lane, i, v0, sumv, suma);
             }
         }
     }

@@ -1,7 +1,6 @@
 // physics16.hip -- cooperative physics kernels of the robots that use 16 lanes per sub-environment (mjx_coop.h, G = 16).
-// Compiled with -mllvm -amdgpu-sched-strategy=iterative-minreg (build.py TU_FLAGS): +10 % on Ant-v5, results bit-identical to the default
-// scheduler's.  NOT iterative-maxocc / -ilp: those are faster still (+19 %) but produce wrong RK4 stage updates for this instantiation
-// (found by tests/test_gpu_mujoco.py, narrowed down with scripts/coop_phase_bench.hip).
+// Compiled with -mllvm -amdgpu-sched-strategy=iterative-maxocc (build.py TU_FLAGS): +19 % on Ant-v5, results bit-identical to the default
+// scheduler's (scripts/coop_phase_bench.hip fingerprints, tests/test_gpu_mujoco.py) as long as mjx_coop.h rk4_stage() is not inlined.
 #include "mjx_physics.h"
 
 namespace mi_phys {
