@@ -33,7 +33,7 @@ STATE_BYTES = {"CartPole-v1": 96, "Pendulum-v1": 64, "Acrobot-v1": 96, "Mountain
 STEP_BYTES = {"CartPole-v1": 108, "Pendulum-v1": 68, "Acrobot-v1": 116, "MountainCar-v0": 68, "MountainCarContinuous-v0": 64}
 # MuJoCo family: which kernel dominates a rollout launch (Ant / Humanoid: `inner` x [mj_sample_kernel, mj_physics_kernel, mj_step_kernel];
 # the cooperative physics kernel is > 99 % of the time -- profiles/r01_k_ant_coop.txt)
-MJ_KERNEL = {"Ant-v5": "mj_physics_kernel", "Humanoid-v5": "mj_physics_kernel", "HalfCheetah-v5": "mj_rollout_kernel"}
+MJ_KERNEL = {"Ant-v5": "mj_physics_kernel", "Humanoid-v5": "mj_physics_kernel", "HumanoidStandup-v5": "mj_physics_kernel", "HalfCheetah-v5": "mj_physics_kernel"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 

@@ -10,29 +10,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def extract(path):
+def extract_all(path):
+    """Every gfx950 code object of the file: a library linked from several translation units carries one offload bundle per unit."""
     blob = open(path, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    at = blob.find(magic)
-    if at < 0:
-        raise SystemExit("no offload bundle in " + path)
-    (n,) = struct.unpack_from("<Q", blob, at + len(magic))
-    pos = at + len(magic) + 8
-    for _ in range(n):
-        off, size, tl = struct.unpack_from("<QQQ", blob, pos)
-        triple = blob[pos + 24:pos + 24 + tl].decode()
-        pos += 24 + tl
-        if "gfx950" in triple:
-            return blob[at + off:at + off + size]
-    raise SystemExit("no gfx950 code object")
+    out, at = [], blob.find(magic)
+    while at >= 0:
+        (n,) = struct.unpack_from("<Q", blob, at + len(magic))
+        pos = at + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, pos)
+            triple = blob[pos + 24:pos + 24 + tl].decode(errors="replace")
+            pos += 24 + tl
+            if "gfx950" in triple:
+                out.append(blob[at + off:at + off + size])
+        at = blob.find(magic, at + len(magic))
+    if not out:
+        raise SystemExit("no gfx950 code object in " + path)
+    return out
+
+
+def extract(path):
+    return extract_all(path)[0]
 
 
 def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gymnasium_amd", "csrc", "libmi355env.so")
     pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(extract(so)), f.flush()
-        notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True).stdout
+    notes = ""
+    for co in extract_all(so):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co), f.flush()
+            notes += subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True).stdout
     rows, cur = [], {}
     for line in notes.splitlines():
         m = re.match(r"\s*-?\s*\.(name|vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size|vgpr_spill_count):\s*(\S+)", line)
