@@ -116,12 +116,25 @@ MI_DEV void store_rng_state(const DevEnv &d, int i, const Pcg64 &r) {
 template <class E>
 struct ResetQueue {
     double u[E::NDRAWS];
+    double rs[E::S];  // the reset state those draws give under the default bounds (autoreset has no options): computed once per refill
     bool have;
     Pcg64 rng;
     MI_DEV void refill() {
 #pragma unroll
         for (int k = 0; k < E::NDRAWS; k++) u[k] = rng.next_double();
+        double b0, b1;
+        uint32_t f = 0;
+        E::default_bounds(b0, b1);
+        E::reset_u(u, rs, f, b0, b1);
         have = true;
+    }
+    // what reset_u does to the flag word does not depend on the draws: it sets or clears kStateF32 (envs_classic.h)
+    static MI_DEV uint32_t reset_flags(uint32_t flags) {
+        const double zero[E::NDRAWS] = {};
+        double tmp[E::S], b0, b1;
+        E::default_bounds(b0, b1);
+        E::reset_u(zero, tmp, flags, b0, b1);
+        return flags;
     }
 };
 constexpr int kRefillPeriod = 8;
@@ -225,11 +238,9 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
         *d.error = kErrInvalidAction;
         a = (typename E::Act)0;
     }
-    // the reset candidate (sync_vector_env.py:279-284)
-    double rs[E::S], b0, b1;
-    uint32_t rflags = L.flags & ~kNeedsReset;
-    E::default_bounds(b0, b1);
-    E::reset_u(q.u, rs, rflags, b0, b1);
+    // the reset candidate (sync_vector_env.py:279-284): the state was formed from the queued draws when they were drawn
+    const double (&rs)[E::S] = q.rs;
+    const uint32_t rflags = ResetQueue<E>::reset_flags(L.flags & ~kNeedsReset);
     // the step candidate
     double rew;
     bool te;

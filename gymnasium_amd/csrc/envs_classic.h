@@ -26,6 +26,15 @@ enum : uint32_t { kNeedsReset = 1u, kStateF32 = 2u };
 // band) needs no range reduction: minimax kernels on [-pi/4, pi/4] (the fdlibm k_sin / k_cos coefficient sets,
 // evaluated with FMAs; < 1 ulp).  Anything else goes through ocml's sincos.  The branch is wavefront-uniform in
 // practice, so a CartPole wavefront never pays for the reduction code.
+// a * b + c as ONE v_fma_f64 whose addend sits in its own VGPR pair.  Written as asm because the compiler turns a Horner chain with
+// constant addends into v_mov_b64 (copy the constant) + v_fmac_f64 (accumulate into the copy): two issue slots per step in a loop that is
+// issue-bound; this way the twelve coefficients stay in registers across the rollout loop and a step is one slot.
+MI_DEV double fma_vvv(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 MI_DEV void sincos_small_or_ocml(double x, double *sn, double *cs) {
     if (__builtin_expect(!(fabs(x) <= 0.7853981633974483), 0)) {
         sincos(x, sn, cs);
@@ -36,11 +45,11 @@ MI_DEV void sincos_small_or_ocml(double x, double *sn, double *cs) {
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double rs = fma(z, S6, S5);
-    rs = fma(z, rs, S4), rs = fma(z, rs, S3), rs = fma(z, rs, S2), rs = fma(z, rs, S1);
+    double rs = fma_vvv(z, S6, S5);
+    rs = fma_vvv(z, rs, S4), rs = fma_vvv(z, rs, S3), rs = fma_vvv(z, rs, S2), rs = fma_vvv(z, rs, S1);
     *sn = fma(z * x, rs, x);
-    double rc = fma(z, C6, C5);
-    rc = fma(z, rc, C4), rc = fma(z, rc, C3), rc = fma(z, rc, C2), rc = fma(z, rc, C1);
+    double rc = fma_vvv(z, C6, C5);
+    rc = fma_vvv(z, rc, C4), rc = fma_vvv(z, rc, C3), rc = fma_vvv(z, rc, C2), rc = fma_vvv(z, rc, C1);
     // 1 - (z/2 - z*z*rc), split so that the leading 1 - z/2 is exact-ish (fdlibm's qx trick is not needed at < 1 ulp)
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
