@@ -193,6 +193,9 @@ struct Lane {
 #if defined(MJX_PHASE_TIMING) && !defined(MJX_HOST_EMU)
     unsigned long long tphase[12], tmark;
 #endif
+#ifdef MJX_COUNT_WORK
+    int work;  // harness statistic: passes of the solver's state machine (factor / solve / assembly rounds) since it was cleared
+#endif
     double warm;  // qacc of the previous forward pass (mj qacc_warmstart): where the next constrained solve starts
     bool lim_on[2];
     double lim_D[2], lim_aref[2], lim_sign[2];
@@ -1091,6 +1094,9 @@ struct Sim {
         }
 #pragma unroll 1
         for (;;) {
+#ifdef MJX_COUNT_WORK
+            r.work++;
+#endif
             double rhs = 0;
             bool solve = true;
             if (st == ST_SMOOTH) {

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "mjx_coop.h"
@@ -37,6 +38,9 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = lane < M::NV ? state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;
+#ifdef MJX_COUNT_WORK
+    r.work = 0;
+#endif
     coop::coop_sync();
 #ifdef MJX_PHASE_TIMING
     r.tmark = __builtin_readcyclecounter();
@@ -46,6 +50,9 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     for (int k = lane; k < M::NQ; k += G) state[(size_t)k * N + env] = bb.qpos[k];
     for (int k = lane; k < M::NV; k += G) state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
     if (lane < M::NV) state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
+#ifdef MJX_COUNT_WORK
+    if (lane == 0) ((int *)phase)[32 + env] = r.work;  // per-env solver passes of this launch (the buffer is sized for it in run())
+#endif
 #ifdef MJX_PHASE_TIMING
     if (threadIdx.x == 0)
         for (int k = 0; k < 12; k++) atomicAdd(&phase[k], r.tphase[k]);
@@ -92,7 +99,7 @@ int run(int N, int nsub, float amp) {
     double *d_st;
     float *d_act;
     unsigned long long *d_ph;
-    hipMalloc(&d_st, sizeof(double) * st.size()), hipMalloc(&d_act, sizeof(float) * act.size()), hipMalloc(&d_ph, 12 * 8);
+    hipMalloc(&d_st, sizeof(double) * st.size()), hipMalloc(&d_act, sizeof(float) * act.size()), hipMalloc(&d_ph, 12 * 8 + 256 + sizeof(int) * (size_t)N);
     hipMemcpy(d_st, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice);
     const dim3 grid((N + 64 / G - 1) / (64 / G)), block(64);
     hipEvent_t e0, e1;
@@ -124,6 +131,25 @@ int run(int N, int nsub, float amp) {
     hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
     unsigned long long ph[12];
     hipMemcpy(ph, d_ph, sizeof ph, hipMemcpyDeviceToHost);
+#ifdef MJX_COUNT_WORK
+    {  // how unevenly the solver's work is spread over the sub-environments that share a wavefront (they wait for the slowest)
+        std::vector<int> w(N);
+        hipMemcpy(w.data(), (const char *)d_ph + 128, sizeof(int) * N, hipMemcpyDeviceToHost);
+        const int epw = 64 / G;
+        double sum = 0, waves = 0, sorted_waves = 0;
+        for (int i = 0; i < N; i++) sum += w[i];
+        for (int i = 0; i + epw <= N; i += epw) {
+            int m = 0;
+            for (int k = 0; k < epw; k++) m = w[i + k] > m ? w[i + k] : m;
+            waves += (double)m * epw;
+        }
+        std::vector<int> s2(w);
+        std::sort(s2.begin(), s2.end());
+        for (int i = 0; i + epw <= N; i += epw) sorted_waves += (double)s2[i + epw - 1] * epw;
+        printf("solver passes per env in the last launch: mean %.2f; wavefront-max grouping costs x%.3f of the mean, sorted grouping x%.3f\n", sum / N,
+               waves / sum, sorted_waves / sum);
+    }
+#endif
     {  // fingerprint of the final state: lets two builds of this harness (compiler flags, code variants) be compared bit for bit
         hipMemcpy(st.data(), d_st, sizeof(double) * st.size(), hipMemcpyDeviceToHost);
         double sum = 0, asum = 0;
