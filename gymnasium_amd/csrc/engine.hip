@@ -667,9 +667,21 @@ __global__ __launch_bounds__(kBlock) void mj_sample_kernel(DevEnv d, ActionStrea
 // ---------------------------------------------------------------------------------------------------------
 MI_DEV int tab_categorical(const double *csprob, int n, Pcg64 &rng) {
     const double u = rng.next_double();
-    for (int k = 0; k < n; k++)
+    // first index with csprob[k] > u (np.argmax(np.cumsum(p) > u); 0 when there is none).  The first entries by scan -- transition rows
+    // have <= 3 outcomes, FrozenLake / CliffWalking start in state 0 -- the rest of a long row (Taxi's 500-state initial distribution) by
+    // bisection, valid because cumulative sums are non-decreasing: 8 probes instead of a scan that costs a wavefront its slowest lane.
+    const int head = n < 4 ? n : 4;
+    for (int k = 0; k < head; k++)
         if (csprob[k] > u) return k;
-    return 0;  // np.argmax of an all-False array
+    int lo = head, hi = n;  // invariant: csprob[k] <= u for k < lo, csprob[k] > u for k >= hi
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (csprob[mid] > u)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo < n ? lo : 0;
 }
 struct TabLane {
     double s, prob;
@@ -756,17 +768,18 @@ MI_DEV void bj_step(Pcg64 &rng, double &s, double &aux, int64_t action, bool nat
     s = (double)(psum | (pace << 6) | (ptwo << 7) | (d0 << 8) | (d1 << 12));
 }
 
-MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L) {
-    Pcg64 rng = load_rng(d, i);
-    if (is_blackjack(d)) {
+// `held`: the lane's generator kept in registers by a fused rollout (loaded before its loop, stored after it); nullptr = the per-step
+// kernels, which load and store the stream around every use.
+MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L, Pcg64 *held = nullptr) {
+    Pcg64 local;
+    if (!held) local = load_rng(d, i);
+    Pcg64 &rng = held ? *held : local;
+    if (is_blackjack(d))
         bj_reset(rng, L.s, L.prob);
-        store_rng_state(d, i, rng);
-        L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
-        return;
-    }
-    L.s = (double)tab_categorical(d.tab.isd, d.tab.nS, rng);
-    store_rng_state(d, i, rng);
-    L.prob = 1.0, L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+    else
+        L.s = (double)tab_categorical(d.tab.isd, d.tab.nS, rng), L.prob = 1.0;
+    if (!held) store_rng_state(d, i, rng);
+    L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
 }
 // observation row of a tabular lane: the state index, or Blackjack's three integers
 MI_DEV void tab_write_obs(const DevEnv &d, double s, int64_t *base, size_t row) {
@@ -777,10 +790,10 @@ MI_DEV void tab_write_obs(const DevEnv &d, double s, int64_t *base, size_t row) 
 }
 template <int MODE>
 MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t &obs, int64_t &final_obs, bool &has_final, double &reward,
-                          bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st) {
+                          bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st, Pcg64 *held = nullptr) {
     te = tr = false, reward = 0.0, has_final = false;
     if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
-        tab_autoreset(d, i, L);
+        tab_autoreset(d, i, L, held);
         st.reset_steps++;
     } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
         *d.error = kErrDisabledStepped;
@@ -791,14 +804,16 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
             *d.error = kErrInvalidAction;
             a = 0;
         }
-        Pcg64 rng = load_rng(d, i);
+        Pcg64 local;
+        if (!held) local = load_rng(d, i);
+        Pcg64 &rng = held ? *held : local;
         if (is_blackjack(d)) {
             bj_step(rng, L.s, L.prob, a, d.P.p[0] != 0.0, d.P.p[1] != 0.0, reward, te);
-            store_rng_state(d, i, rng);
+            if (!held) store_rng_state(d, i, rng);
         } else {
             const size_t cell = (size_t)L.s * d.tab.nA + (size_t)a, row = cell * d.tab.K;
             const int k = tab_categorical(d.tab.csprob + row, d.tab.count[cell], rng);
-            store_rng_state(d, i, rng);
+            if (!held) store_rng_state(d, i, rng);
             L.s = (double)d.tab.next[row + k], L.prob = d.tab.prob[row + k];
             reward = d.tab.reward[row + k], te = d.tab.term[row + k] != 0;
         }
@@ -812,7 +827,7 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
     if (done) st.episodes++, st.return_sum += L.ep_ret, st.length_sum += (uint64_t)L.ep_len;
     if (MODE == MI_AUTORESET_SAME_STEP && done) {
         final_obs = (int64_t)L.s, has_final = true;
-        tab_autoreset(d, i, L);
+        tab_autoreset(d, i, L, held);
     }
     obs = (int64_t)L.s;
     if (done && MODE != MI_AUTORESET_SAME_STEP)
@@ -866,12 +881,30 @@ __global__ __launch_bounds__(kBlock) void tab_reset_kernel(DevEnv d, const uint8
     if (obs) tab_write_obs(d, L.s, obs, (size_t)i);
 }
 template <int MODE, bool SAMPLE>
-__global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
+__global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int lds_bytes) {
+    // The transition table is read once per env-step through three levels of dependent loads (count / cumulative probabilities -> branch
+    // -> successor, reward, flag); out of L2 that latency is the whole step (Taxi: 100 KB of tables).  When the launcher found that the
+    // table fits (lds_bytes > 0) the workgroup first copies it into LDS -- layout: the f64 arrays, then the i32 arrays, then the flags --
+    // and every lookup of the T steps is a 64-cycle LDS read instead.
+    extern __shared__ double tab_lds[];
+    if (lds_bytes > 0) {
+        const size_t cells = (size_t)d.tab.nS * d.tab.nA, rows = cells * d.tab.K;
+        double *cs = tab_lds, *pr = cs + rows, *rw = pr + rows, *isd = rw + rows;
+        int32_t *nx = reinterpret_cast<int32_t *>(isd + d.tab.nS), *cnt = nx + rows;
+        uint8_t *tm = reinterpret_cast<uint8_t *>(cnt + cells);
+        for (size_t k = threadIdx.x; k < rows; k += kBlock)
+            cs[k] = d.tab.csprob[k], pr[k] = d.tab.prob[k], rw[k] = d.tab.reward[k], nx[k] = d.tab.next[k], tm[k] = d.tab.term[k];
+        for (size_t k = threadIdx.x; k < cells; k += kBlock) cnt[k] = d.tab.count[k];
+        for (int k = threadIdx.x; k < d.tab.nS; k += kBlock) isd[k] = d.tab.isd[k];
+        __syncthreads();
+        d.tab.csprob = cs, d.tab.prob = pr, d.tab.reward = rw, d.tab.isd = isd, d.tab.next = nx, d.tab.count = cnt, d.tab.term = tm;
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     if (i < d.N) {
         TabLane L;
         tab_load(d, i, L);
+        Pcg64 rng = load_rng(d, i);  // the lane's own stream stays in registers for the whole rollout
         u128 astate = 0;
         if (SAMPLE) {
             astate = make_u128(as.state_hi, as.state_lo);
@@ -896,13 +929,14 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
             double reward, out_ret;
             int32_t out_len;
             bool te, tr, has_final;
-            tab_lane_step<MODE>(d, i, L, a, obs, fin, has_final, reward, te, tr, out_ret, out_len, st);
+            tab_lane_step<MODE>(d, i, L, a, obs, fin, has_final, reward, te, tr, out_ret, out_len, st, &rng);
             if (io.obs) tab_write_obs(d, (double)obs, static_cast<int64_t *>(io.obs), t * N + i);
             if (io.reward) io.reward[t * N + i] = reward;
             if (io.terminated) io.terminated[t * N + i] = te;
             if (io.truncated) io.truncated[t * N + i] = tr;
         }
         tab_store(d, i, L);
+        store_rng_state(d, i, rng);
     }
     block_accumulate(d, st);
 }
@@ -1536,14 +1570,23 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
     if (is_tab(v->cfg.kind)) {
         const dim3 g(v->grid), b(kBlock);
         const bool next = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
+        // table in LDS when it fits next to the 160 KB of a CU and the copy is amortised over enough steps (Blackjack has no table)
+        size_t lds = 0;
+        if (v->d.tab.nS > 0 && T >= 8) {
+            const size_t cells = (size_t)v->d.tab.nS * v->d.tab.nA, rows = cells * v->d.tab.K;
+            lds = (3 * rows + v->d.tab.nS) * sizeof(double) + (rows + cells) * sizeof(int32_t) + rows;
+            lds = (lds + 15) & ~(size_t)15;
+            if (lds > 150 * 1024) lds = 0;
+        }
+        const int lb = (int)lds;
         if (next && sample)
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, true>), g, b, lds, v->stream, v->d, p, as, T, lb);
         else if (next)
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, false>), g, b, lds, v->stream, v->d, p, as, T, lb);
         else if (sample)
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, p, as, T);
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, true>), g, b, lds, v->stream, v->d, p, as, T, lb);
         else
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, p, as, T);
+            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, false>), g, b, lds, v->stream, v->d, p, as, T, lb);
         HIP_TRY(hipGetLastError());
         rc = MI_OK;
     } else if (is_mj(v->cfg.kind)) {
