@@ -19,7 +19,7 @@ PY
 for N in 262144 1048576; do
   timeout 300 python bench.py --no-api --no-cpu-baseline --num-envs $N > gpurun_out/${TAG}_bench_N$N.json 2>> gpurun_out/${TAG}_bench.err; show "CartPole N=$N" gpurun_out/${TAG}_bench_N$N.json
 done
-for E in Pendulum-v1 Acrobot-v1 MountainCar-v0 MountainCarContinuous-v0 FrozenLake-v1 Taxi-v4 Blackjack-v1; do
+for E in Pendulum-v1 Acrobot-v1 MountainCar-v0 MountainCarContinuous-v0 FrozenLake-v1 FrozenLake8x8-v1 CliffWalking-v1 Taxi-v4 Blackjack-v1; do
   timeout 300 python bench.py --no-api --no-cpu-baseline --env $E > gpurun_out/${TAG}_bench_$E.json 2>> gpurun_out/${TAG}_bench.err; show $E gpurun_out/${TAG}_bench_$E.json
 done
 # MuJoCo family: Ant / Humanoid at the BASELINE.json sizes with the CPU oracle beside them, the others at 65536
