@@ -3,7 +3,7 @@
 // for a few env-steps (so that contacts and joint limits are active) and prints, per phase of forward(), the share of shader cycles
 // (s_memtime deltas summed over wavefronts).  Build + run (on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Igymnasium_amd/csrc scripts/coop_phase_bench.hip -o gpurun_out/coop_phase_bench
-//   gpurun_out/coop_phase_bench [ant|humanoid] [num_envs]
+//   gpurun_out/coop_phase_bench [ant|humanoid|standup|cheetah] [num_envs]
 #ifndef NO_PHASE_TIMING
 #define MJX_PHASE_TIMING 1
 #endif
@@ -177,5 +177,7 @@ int main(int argc, char **argv) {
     const char *which = argc > 1 ? argv[1] : "ant";
     const int N = argc > 2 ? atoi(argv[2]) : 32768;
     if (!strcmp(which, "humanoid")) return run<HumanoidModel, 32>(N, 5, 0.4f);
+    if (!strcmp(which, "standup")) return run<HumanoidStandupModel, 32>(N, 5, 0.4f);
+    if (!strcmp(which, "cheetah")) return run<HalfCheetahModel, 16>(N, 5, 1.0f);
     return run<AntModel, 16>(N, 5, 1.0f);
 }
