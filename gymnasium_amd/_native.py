@@ -78,7 +78,8 @@ class NativeError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmi355env.so")
+    """The in-tree build; MI355ENV_LIBRARY points at another build of the same ABI (A/B measurements of two builds on one GPU box)."""
+    return os.environ.get("MI355ENV_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmi355env.so")
 
 
 class NativeLib:
