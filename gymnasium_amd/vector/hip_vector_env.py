@@ -118,6 +118,17 @@ class HipVectorEnv(VectorEnv):
             self._episode_start = np.zeros(self.num_envs)
             self._prev_dones = np.zeros(self.num_envs, dtype=np.bool_)
 
+    def set_output(self, output: str):
+        """Switch between NumPy batches ("numpy": pinned staging + one copy per step) and device tensors ("torch": the engine writes
+        straight into torch tensors in HBM, nothing crosses PCIe) after construction -- what wrappers.vector.NumpyToTorch(env) does.
+        Call before reset()."""
+        if output not in ("numpy", "torch"):
+            raise ValueError(f"output must be 'numpy' or 'torch', got {output!r}")
+        if output != self.output:
+            self.output = output
+            self._alloc_buffers()
+            self._has_reset = False
+
     def enable_episode_statistics(self):
         """Switch on the on-device episode accounting after construction (what wrappers.vector.RecordEpisodeStatistics(env) does):
         the step kernels start writing the finished episodes' return / length rows.  Call before reset()."""

@@ -153,6 +153,42 @@ class RecordEpisodeStatistics(VectorWrapper):
         return obs, rewards, terminations, truncations, infos
 
 
+class NumpyToTorch(VectorWrapper):
+    """gymnasium.wrappers.vector.NumpyToTorch (wrappers/vector/numpy_to_torch.py:16-53) without the conversion: the wrapped HipVectorEnv is
+    switched to ``output="torch"``, so observations, rewards and flags ARE torch tensors the engine wrote in HBM (zero copy; the reference
+    wrapper converts NumPy batches with ``torch.from_numpy`` / DLPack after the fact) and actions may be device tensors.  ``device``: where
+    the caller wants the tensors -- None or the env's own GPU costs nothing, anything else (e.g. "cpu") is one ``.to(device)`` per array.
+    The arrays inside ``infos`` become tensors as well, like the reference's recursive conversion."""
+
+    def __init__(self, env, device=None):
+        super().__init__(env)
+        if not hasattr(env.unwrapped, "set_output"):
+            raise TypeError("NumpyToTorch of gymnasium_amd wraps a HipVectorEnv (use gymnasium's own wrapper for other vector envs)")
+        env.unwrapped.set_output("torch")
+        self.device = device
+
+    def _move(self, x):
+        torch = _torch()
+        if isinstance(x, dict):
+            return {k: self._move(v) for k, v in x.items()}
+        if isinstance(x, np.ndarray):
+            if x.dtype == object:  # final_obs under SAME_STEP: a ragged object array stays as it is
+                return x
+            x = torch.from_numpy(x)
+            return x.to(self.device if self.device is not None else f"cuda:{self._dev()}")
+        if isinstance(x, torch.Tensor) and self.device is not None and x.device != torch.device(self.device):
+            return x.to(self.device)
+        return x
+
+    def reset(self, *, seed=None, options=None):
+        obs, infos = self.env.reset(seed=seed, options=options)
+        return self._move(obs), self._move(infos)
+
+    def step(self, actions):
+        obs, rewards, terminations, truncations, infos = self.env.step(actions)
+        return self._move(obs), self._move(rewards), self._move(terminations), self._move(truncations), self._move(infos)
+
+
 class NormalizeObservation(VectorWrapper):
     """stateful_observation.py:27-160."""
 

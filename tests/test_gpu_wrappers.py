@@ -129,3 +129,30 @@ def test_full_size_wrapped_rollout_properties():
     z = (o.double().mean(0)).abs().max().item()
     assert z < 0.2, z
     env.close(), raw.close()
+
+
+def test_numpy_to_torch_wrapper_hands_out_device_tensors():
+    """wrappers.NumpyToTorch: same trajectory as the NumPy env, as tensors on the GPU (numpy_to_torch.py:16-53 semantics, zero copy)."""
+    import torch
+
+    import gymnasium_amd
+    from gymnasium_amd import wrappers
+
+    a = gymnasium_amd.make_vec("Ant-v5", num_envs=64)
+    b = wrappers.NumpyToTorch(gymnasium_amd.make_vec("Ant-v5", num_envs=64))
+    oa, _ = a.reset(seed=4)
+    ob, ib = b.reset(seed=4)
+    assert isinstance(ob, torch.Tensor) and ob.is_cuda and ob.dtype == torch.float64 and np.array_equal(ob.cpu().numpy(), oa)
+    assert all(isinstance(v, torch.Tensor) for v in ib.values())
+    a.action_space.seed(1)
+    for t in range(5):
+        act = a.action_space.sample()
+        oa, ra, tea, tra, ia = a.step(act)
+        ob, rb, teb, trb, ib = b.step(torch.from_numpy(act).cuda())
+        assert all(isinstance(x, torch.Tensor) and x.is_cuda for x in (ob, rb, teb, trb))
+        assert np.array_equal(ob.cpu().numpy(), oa) and np.array_equal(rb.cpu().numpy(), ra) and np.array_equal(teb.cpu().numpy(), tea)
+        assert set(ia) == set(ib) and np.array_equal(ib["x_position"].cpu().numpy(), ia["x_position"])
+    c = wrappers.NumpyToTorch(gymnasium_amd.make_vec("CartPole-v1", num_envs=8), device="cpu")
+    oc, _ = c.reset(seed=0)
+    assert isinstance(oc, torch.Tensor) and not oc.is_cuda and oc.dtype == torch.float32
+    a.close(), b.close(), c.close()
