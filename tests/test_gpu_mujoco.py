@@ -99,19 +99,21 @@ def test_fused_rollout_equals_stepping(name):
     a.close(), b.close()
 
 
-def test_ant_full_size_properties():
-    """BASELINE.json configs[3]: Ant-v5, num_envs = 32768: accounting identities, determinism, shard invariance."""
+@pytest.mark.parametrize("env_id", ["Ant-v5", "Humanoid-v5"])
+def test_full_size_properties(env_id):
+    """BASELINE.json configs[3] / configs[4] (per GPU): Ant-v5 / Humanoid-v5, num_envs = 32768: accounting identities, determinism, shard
+    invariance (the second half of the batch as its own engine with env_index_offset reproduces the same rows)."""
     import torch
 
-    N, T = 32768, 4
-    a = gymnasium_amd.make_vec("Ant-v5", num_envs=N, output="torch")
+    N, T = 32768, (4 if env_id == "Ant-v5" else 2)
+    a = gymnasium_amd.make_vec(env_id, num_envs=N, output="torch")
     a.reset(seed=0)
     a.action_space.seed(0)
     out = a.rollout(T)
     st = a.statistics()
     assert st["env_steps"] + st["reset_steps"] == N * T and torch.isfinite(out["obs"]).all()
     h = N // 2
-    c = gymnasium_amd.make_vec("Ant-v5", num_envs=h, output="torch", env_index_offset=h)
+    c = gymnasium_amd.make_vec(env_id, num_envs=h, output="torch", env_index_offset=h)
     c.reset(seed=0)
     out_c = c.rollout(T, actions=out["actions"][:, h:].contiguous())
     assert torch.equal(out["obs"][:, h:], out_c["obs"]) and torch.equal(out["rewards"][:, h:], out_c["rewards"])
