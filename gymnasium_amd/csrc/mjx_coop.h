@@ -194,7 +194,8 @@ struct Lane {
     unsigned long long tphase[12], tmark;
 #endif
 #ifdef MJX_COUNT_WORK
-    int work;  // harness statistic: passes of the solver's state machine (factor / solve / assembly rounds) since it was cleared
+    int work, work_wave;  // harness statistics: passes of the solver's state machine (factor / solve / assembly rounds) of this sub-environment
+                          // since they were cleared, and the same for the slowest sub-environment of the wavefront in every forward pass
 #endif
     double warm;  // qacc of the previous forward pass (mj qacc_warmstart): where the next constrained solve starts
     bool lim_on[2];
@@ -1092,10 +1093,13 @@ struct Sim {
             if (isdof) bb.A.sol.vdir[lane] = r.warm;
             coop_sync();
         }
+#ifdef MJX_COUNT_WORK
+        int passes = 0;
+#endif
 #pragma unroll 1
         for (;;) {
 #ifdef MJX_COUNT_WORK
-            r.work++;
+            passes++;
 #endif
             double rhs = 0;
             bool solve = true;
@@ -1251,6 +1255,13 @@ struct Sim {
             if (move * scale < 1e-16 || it >= 50) final_pass = true;  // one more assembly for the forces at the final iterate
             coop_sync();
         }
+#if defined(MJX_COUNT_WORK) && !defined(MJX_HOST_EMU)
+        {
+            int m = passes;
+            m = max(m, __shfl_xor(m, 16, 64)), m = max(m, __shfl_xor(m, 32, 64));  // the other sub-environments of this wavefront
+            r.work += passes, r.work_wave += m;
+        }
+#endif
         if (!damped_euler()) r.qacc_int = r.qacc;
         r.warm = r.qacc;
         coop_sync();

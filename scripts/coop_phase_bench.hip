@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = lane < M::NV ? state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;
 #ifdef MJX_COUNT_WORK
-    r.work = 0;
+    r.work = 0, r.work_wave = 0;
 #endif
     coop::coop_sync();
 #ifdef MJX_PHASE_TIMING
@@ -51,7 +51,8 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     for (int k = lane; k < M::NV; k += G) state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
     if (lane < M::NV) state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
 #ifdef MJX_COUNT_WORK
-    if (lane == 0) ((int *)phase)[32 + env] = r.work;  // per-env solver passes of this launch (the buffer is sized for it in run())
+    if (lane == 0) ((int *)phase)[32 + env] = r.work, atomicAdd((unsigned long long *)phase + 14, (unsigned long long)r.work),
+        atomicAdd((unsigned long long *)phase + 15, (unsigned long long)r.work_wave);  // per-env passes (buffer sized in run()) + totals
 #endif
 #ifdef MJX_PHASE_TIMING
     if (threadIdx.x == 0)
@@ -125,7 +126,7 @@ int run(int N, int nsub, float amp) {
     for (int t = 0; t < warm + timed; t++) {
         for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
         hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
-        if (t == warm) hipMemset(d_ph, 0, 12 * 8), hipEventRecord(e0);
+        if (t == warm) hipMemset(d_ph, 0, 16 * 8), hipEventRecord(e0);
         hipLaunchKernelGGL((phys<M, G>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph);
     }
     hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
@@ -148,6 +149,10 @@ int run(int N, int nsub, float amp) {
         for (int i = 0; i + epw <= N; i += epw) sorted_waves += (double)s2[i + epw - 1] * epw;
         printf("solver passes per env in the last launch: mean %.2f; wavefront-max grouping costs x%.3f of the mean, sorted grouping x%.3f\n", sum / N,
                waves / sum, sorted_waves / sum);
+        unsigned long long tot[2];
+        hipMemcpy(tot, (const char *)d_ph + 14 * 8, sizeof tot, hipMemcpyDeviceToHost);
+        printf("per forward pass: the slowest sub-environment of a wavefront does x%.3f the passes of the average one (all launches)\n",
+               (double)tot[1] / (double)tot[0]);
     }
 #endif
     {  // fingerprint of the final state: lets two builds of this harness (compiler flags, code variants) be compared bit for bit
