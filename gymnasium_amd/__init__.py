@@ -10,11 +10,13 @@ see INTEGRATION.md.
 """
 from . import gym_api
 from .envs import ENV_TABLE
+from .envs.mujoco.envs import ENV_TABLE as _MUJOCO_TABLE
 from .gym_api import AutoresetMode, VectorEnv, make_vec, register, registry, spaces  # noqa: F401
 from .vector import HipVectorEnv  # noqa: F401
 
 __version__ = "0.1.0"
 NAMESPACE = "MI355X"
+MUJOCO_IDS = frozenset(_MUJOCO_TABLE)
 
 
 def register_envs(override_stock_ids: bool = False) -> None:
@@ -30,7 +32,10 @@ def register_envs(override_stock_ids: bool = False) -> None:
             register(id=name, vector_entry_point=creator, max_episode_steps=max_steps, reward_threshold=threshold, kwargs=kw)
         if override_stock_ids or not gym_api.HAVE_GYMNASIUM:
             if env_id in registry:
-                if override_stock_ids:
+                if override_stock_ids and env_id in MUJOCO_IDS:
+                    # the stock id keeps Farama's `mujoco`-backed env: ours is not pinned against it
+                    gym_api.logger.warn(f"{env_id}: not overriding the stock id -- the MI355X restatement of MuJoCo is parity-unpinned; use {name}")
+                elif override_stock_ids:
                     registry[env_id].vector_entry_point = creator
             else:
                 register(id=env_id, vector_entry_point=creator, max_episode_steps=max_steps, reward_threshold=threshold, kwargs=kw)

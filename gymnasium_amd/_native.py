@@ -15,7 +15,7 @@ MI_OK = 0
 MI_HOST, MI_DEVICE = 0, 1
 MI_F32, MI_F64, MI_I64 = 0, 1, 2
 FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
              "half_cheetah": 5, "ant": 6, "humanoid": 7, "tabular": 8,
@@ -49,7 +49,7 @@ class MiLayout(C.Structure):
 class MiStepIO(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
                 ("truncated", C.c_void_p), ("final_obs", C.c_void_p), ("episode_return", C.c_void_p),
-                ("episode_length", C.c_void_p), ("info", C.c_void_p)]
+                ("episode_length", C.c_void_p), ("info", C.c_void_p), ("final_info", C.c_void_p)]
 
 
 class MiRolloutIO(C.Structure):
@@ -231,8 +231,9 @@ class Engine:
         self.lib.check(self.lib.reset(self.handle, _ptr(mask), _ptr(b), _ptr(obs), loc))
 
     def step(self, actions, obs, reward, terminated, truncated, final_obs=None, episode_return=None,
-             episode_length=None, loc=MI_HOST, info=None):
+             episode_length=None, loc=MI_HOST, info=None, final_info=None):
         io = self._step_io
+        io.final_info = _ptr(final_info)
         io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
         io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
         io.episode_return, io.episode_length, io.info = _ptr(episode_return), _ptr(episode_length), _ptr(info)

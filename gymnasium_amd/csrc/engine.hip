@@ -468,7 +468,7 @@ struct MjStepPtrs {
     uint8_t *terminated, *truncated;
     double *final_obs, *ep_ret;
     int32_t *ep_len;
-    double *info;
+    double *info, *final_info;
     int obs_dim;
     const double *extras;  // [N][EX_TOTAL] rows written by mj_physics_kernel, or nullptr (one-lane simulator inside the step kernel)
 };
@@ -507,7 +507,7 @@ MI_DEV void mj_autoreset(const DevEnv &d, int i, MjLane<E> &L, double *obs) {
 template <class E, int MODE, bool COOP = false>
 MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *action, double *obs, double *final_obs, double *info,
                          double &reward, bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st,
-                         const double *extras = nullptr) {
+                         const double *extras = nullptr, double *final_info = nullptr) {
     te = tr = false, reward = 0.0;
     if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
         mj_autoreset<E>(d, i, L, obs);
@@ -527,6 +527,7 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
             x.cvel = reinterpret_cast<const double (*)[6]>(extras + S::EX_CVEL);
             x.qfrc_actuator = extras + S::EX_QFA;
             x.qfrc_constraint = nullptr;
+            x.ten = extras + S::EX_TEN;
             const double before[2] = {L.s[E::NQ + 2 * E::NV], L.s[E::NQ + 2 * E::NV + 1]};
             E::finish(L.s, before, x, action, d.P, obs, reward, te, info);
         } else {
@@ -543,7 +544,10 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
     if (MODE == MI_AUTORESET_SAME_STEP && done) {
         if (final_obs)
             for (int k = 0; k < E::obs_dim(d.P); k++) final_obs[k] = obs[k];
+        if (info && final_info)  // sync_vector_env.py:309-317: the finishing step's info goes to "final_info" ...
+            for (int k = 0; k < E::INFO; k++) final_info[k] = info[k];
         mj_autoreset<E>(d, i, L, obs);
+        if (info) E::reset_info(L.s, info);  // ... and the top-level entries of this sub-env are its reset info (:319)
     }
     if (done && MODE != MI_AUTORESET_SAME_STEP)
         L.flags |= kNeedsReset;
@@ -564,7 +568,8 @@ __global__ __launch_bounds__(kBlock) void mj_step_kernel(DevEnv d, MjStepPtrs io
         mj_lane_step<E, MODE, COOP>(d, i, L, io.actions + (size_t)i * E::NU, io.obs + (size_t)i * io.obs_dim,
                               io.final_obs ? io.final_obs + (size_t)i * io.obs_dim : nullptr,
                               io.info ? io.info + (size_t)i * E::INFO : nullptr, reward, te, tr, out_ret, out_len, st,
-                              COOP ? io.extras + (size_t)i * mjx::coop::Sim<typename E::Model, E::COOP_G>::EX_TOTAL : nullptr);
+                              COOP ? io.extras + (size_t)i * mjx::coop::Sim<typename E::Model, E::COOP_G>::EX_TOTAL : nullptr,
+                              io.final_info ? io.final_info + (size_t)i * E::INFO : nullptr);
         mj_store<E>(d, i, L);
         if (io.reward) io.reward[i] = reward;
         if (io.terminated) io.terminated[i] = te;
@@ -790,7 +795,7 @@ MI_DEV void tab_write_obs(const DevEnv &d, double s, int64_t *base, size_t row) 
 }
 template <int MODE>
 MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t &obs, int64_t &final_obs, bool &has_final, double &reward,
-                          bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st, Pcg64 *held = nullptr) {
+                          bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st, Pcg64 *held = nullptr, double *final_prob = nullptr) {
     te = tr = false, reward = 0.0, has_final = false;
     if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
         tab_autoreset(d, i, L, held);
@@ -827,6 +832,7 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
     if (done) st.episodes++, st.return_sum += L.ep_ret, st.length_sum += (uint64_t)L.ep_len;
     if (MODE == MI_AUTORESET_SAME_STEP && done) {
         final_obs = (int64_t)L.s, has_final = true;
+        if (final_prob) *final_prob = L.prob;  // info["prob"] of the finishing transition ("final_info"); the reset then reports prob = 1
         tab_autoreset(d, i, L, held);
     }
     obs = (int64_t)L.s;
@@ -844,7 +850,7 @@ struct TabStepPtrs {
     int64_t *final_obs;
     double *ep_ret;
     int32_t *ep_len;
-    double *info;
+    double *info, *final_info;
 };
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void tab_step_kernel(DevEnv d, TabStepPtrs io) {
@@ -857,7 +863,8 @@ __global__ __launch_bounds__(kBlock) void tab_step_kernel(DevEnv d, TabStepPtrs 
         double reward, out_ret;
         int32_t out_len;
         bool te, tr, has_final;
-        tab_lane_step<MODE>(d, i, L, io.actions[i], obs, fin, has_final, reward, te, tr, out_ret, out_len, st);
+        double fin_prob = 0.0;
+        tab_lane_step<MODE>(d, i, L, io.actions[i], obs, fin, has_final, reward, te, tr, out_ret, out_len, st, nullptr, &fin_prob);
         tab_store(d, i, L);
         if (io.obs) tab_write_obs(d, (double)obs, io.obs, (size_t)i);
         if (io.reward) io.reward[i] = reward;
@@ -867,6 +874,7 @@ __global__ __launch_bounds__(kBlock) void tab_step_kernel(DevEnv d, TabStepPtrs 
         if (io.ep_ret) io.ep_ret[i] = out_ret;
         if (io.ep_len) io.ep_len[i] = out_len;
         if (io.info && !is_blackjack(d)) io.info[i] = L.prob;
+        if (io.final_info && has_final && !is_blackjack(d)) io.final_info[i] = fin_prob;
     }
     block_accumulate(d, st);
 }
@@ -1022,7 +1030,7 @@ struct mi_vecenv {
     int32_t *d_eplen;
     uint64_t *d_words;
     size_t act_bytes, obs_bytes;
-    double *d_info;
+    double *d_info, *d_final_info;
     size_t info_bytes;
     void *tab_bufs[7];
     bool tab_loaded;
@@ -1294,6 +1302,7 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     v->obs_bytes = N * (v->lay.obs_dtype == MI_F32 ? sizeof(float) : sizeof(double)) * v->lay.obs_dim;
     v->info_bytes = N * sizeof(double) * (v->lay.info_dim > 0 ? v->lay.info_dim : 1);
     HIP_TRY(hipMalloc(&v->d_info, v->info_bytes));
+    HIP_TRY(hipMalloc(&v->d_final_info, v->info_bytes));
     HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes));
     HIP_TRY(hipMalloc(&v->d_obs, v->obs_bytes));
     HIP_TRY(hipMalloc(&v->d_final, v->obs_bytes));
@@ -1322,7 +1331,7 @@ void mi_destroy(mi_vecenv *v) {
     (void)hipStreamSynchronize(v->stream);
     void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d.error,
                     v->d_pow2, v->d_actions, v->d_obs, v->d_final, v->d_reward, v->d_epret, v->d_eplen, v->d_term,
-                    v->d_trunc, v->d_mask, v->d_words, v->d_info, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
+                    v->d_trunc, v->d_mask, v->d_words, v->d_info, v->d_final_info, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : v->tab_bufs)
@@ -1469,10 +1478,11 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
         p.final_obs = (float *)io->final_obs, p.ep_ret = io->episode_return, p.ep_len = io->episode_length;
     }
     double *dinfo = loc == MI_HOST ? (io->info ? v->d_info : nullptr) : io->info;
+    double *dfinfo = loc == MI_HOST ? (io->final_info ? v->d_final_info : nullptr) : io->final_info;
     int rc;
     if (is_tab(v->cfg.kind)) {
         const TabStepPtrs tp = {(const int64_t *)p.actions, (int64_t *)p.obs, p.reward, p.terminated, p.truncated, (int64_t *)p.final_obs,
-                                p.ep_ret, p.ep_len, dinfo};
+                                p.ep_ret, p.ep_len, dinfo, dfinfo};
         const dim3 g(v->grid), b(kBlock);
         switch (v->cfg.autoreset_mode) {
         case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_NEXT_STEP>), g, b, 0, v->stream, v->d, tp); break;
@@ -1483,7 +1493,7 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
         rc = MI_OK;
     } else if (is_mj(v->cfg.kind)) {
         const MjStepPtrs mp = {(const float *)p.actions, (double *)p.obs, p.reward, p.terminated, p.truncated, (double *)p.final_obs,
-                               p.ep_ret, p.ep_len, dinfo, v->lay.obs_dim, nullptr};
+                               p.ep_ret, p.ep_len, dinfo, dfinfo, v->lay.obs_dim, nullptr};
         if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int { return launch_mj_step<decltype(env)>(v, mp); });
     } else {
@@ -1492,6 +1502,7 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
     if (rc) return rc;
     if (loc == MI_HOST) {
         if (io->info) HIP_TRY(hipMemcpyAsync(io->info, v->d_info, v->info_bytes, hipMemcpyDeviceToHost, v->stream));
+        if (io->final_info) HIP_TRY(hipMemcpyAsync(io->final_info, v->d_final_info, v->info_bytes, hipMemcpyDeviceToHost, v->stream));
         if (io->obs) HIP_TRY(hipMemcpyAsync(io->obs, v->d_obs, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
         if (io->reward) HIP_TRY(hipMemcpyAsync(io->reward, v->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost, v->stream));
         if (io->terminated) HIP_TRY(hipMemcpyAsync(io->terminated, v->d_term, N, hipMemcpyDeviceToHost, v->stream));

@@ -178,6 +178,7 @@ struct Board {
     int con_pair[MAXCON];
     unsigned cmask[KS], anyrow;
     int ncon;
+    double ten[M::NTENDON > 0 ? 2 * M::NTENDON : 1];  // fixed tendons at this forward pass: lengths, then velocities
 };
 
 // Everything a lane keeps in registers across phases.
@@ -1046,6 +1047,16 @@ struct Sim {
     static MJX_DEV void forward(B &bb, R &r, int lane) {
         const bool isdof = lane < NV;
         MJX_PHASE(r, 0);
+        if constexpr (M::NTENDON > 0) {  // lane t: tendon t at this pass's qpos / qvel (read by nobody before write_extras)
+            if (lane < M::NTENDON) {
+                double l = 0, v = 0;
+#pragma unroll
+                for (int k = 0; k < M::MAXWRAP; k++)
+                    if (k < M::tendon_num[lane])
+                        l += M::tendon_coef[lane][k] * bb.qpos[M::tendon_qposadr[lane][k]], v += M::tendon_coef[lane][k] * bb.qvel[M::tendon_dofadr[lane][k]];
+                bb.ten[lane] = l, bb.ten[M::NTENDON + lane] = v;
+            }
+        }
         kinematics(bb, r, lane);
         MJX_PHASE(r, 1);
         com_pos(bb, r, lane);
@@ -1367,9 +1378,9 @@ struct Sim {
 
     // What the per-env glue (mjx_kernels.h) reads from the last forward pass besides qpos / qvel, one row per environment:
     //   [0..1] world position (x, y) of body 1, [2..3] sum_b mass_b xipos_b (x, y)  (humanoid_v5.py:17-21 mass_center numerator),
-    //   cfrc_ext[NB][6], cinert[NB][10], cvel[NB][6], qfrc_actuator[NV]
+    //   cfrc_ext[NB][6], cinert[NB][10], cvel[NB][6], qfrc_actuator[NV], ten_length[NTENDON], ten_velocity[NTENDON]
     static constexpr int EX_XY = 0, EX_CFRC = 4, EX_CINERT = EX_CFRC + 6 * NB, EX_CVEL = EX_CINERT + 10 * NB, EX_QFA = EX_CVEL + 6 * NB,
-                         EX_TOTAL = EX_QFA + NV;
+                         EX_TEN = EX_QFA + NV, EX_TOTAL = EX_TEN + 2 * M::NTENDON;
     static MJX_DEV void write_extras(const B &bb, const R &r, int lane, double *ex) {
         if (lane == 0) {
             ex[EX_XY] = bb.xpos[1][0], ex[EX_XY + 1] = bb.xpos[1][1];
@@ -1392,6 +1403,8 @@ struct Sim {
             for (int k = 0; k < 10; k++) ex[EX_CINERT + 10 * b + k] = r.cinert[k];
         }
         if (lane < NV) ex[EX_QFA + lane] = r.qfrc_actuator;
+        if constexpr (M::NTENDON > 0)
+            if (lane < 2 * M::NTENDON) ex[EX_TEN + lane] = bb.ten[lane];
     }
 #undef MJX_RED
 };

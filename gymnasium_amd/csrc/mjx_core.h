@@ -185,7 +185,22 @@ struct Data {
     double lim_sign[NJ], lim_D[NJ], lim_aref[NJ], lim_force[NJ];
     // contact rows: per contact D (shared by its pyramid edges), aref (shared), force per edge
     double con_D[MAXCON], con_aref[MAXCON], con_force[MAXCON][4];
+    // fixed tendons (mj_tendon / mj_fwdVelocity for joint wraps): length and velocity at THIS forward pass's qpos / qvel
+    double ten_length[M::NTENDON > 0 ? M::NTENDON : 1], ten_velocity[M::NTENDON > 0 ? M::NTENDON : 1];
 };
+
+// ten_length[t] = sum_k coef_k qpos[joint_k], ten_velocity[t] = sum_k coef_k qvel[joint_k]  (humanoid.xml:91-100)
+template <class M>
+MJX_DEV void tendons(const double *qpos, const double *qvel, double *len, double *vel) {
+#pragma unroll
+    for (int t = 0; t < M::NTENDON; t++) {
+        double l = 0, v = 0;
+#pragma unroll
+        for (int k = 0; k < M::MAXWRAP; k++)
+            if (k < M::tendon_num[t]) l += M::tendon_coef[t][k] * qpos[M::tendon_qposadr[t][k]], v += M::tendon_coef[t][k] * qvel[M::tendon_dofadr[t][k]];
+        len[t] = l, vel[t] = v;
+    }
+}
 
 // ---- position stage -----------------------------------------------------------------------------------------------
 template <class M>
@@ -940,6 +955,7 @@ template <class M>
 MJX_DEVN void forward(Data<M> &d) {
     constexpr int NV = M::NV;
     kinematics<M>(d);
+    if constexpr (M::NTENDON > 0) tendons<M>(d.qpos, d.qvel, d.ten_length, d.ten_velocity);
     com_pos<M>(d);
     double bias[NV];
     com_vel_and_bias<M>(d, bias);  // uses the per-body cinert; crb() then turns cinert into composite inertias

@@ -82,8 +82,11 @@ struct MjEnv {
     static constexpr bool PLANAR_WALKER = KIND == kHopper || KIND == kWalker2d;
     static constexpr bool HUMANOID_LIKE = KIND == kHumanoid || KIND == kHumanoidStandup;  // same model family, same observation
     static constexpr bool PENDULUM = KIND == kInvertedPendulum || KIND == kInvertedDoublePendulum;
-    static constexpr int INFO =
+    // info row = the scalar entries of the env's info dict, then (humanoids) tendon_length[NTENDON], tendon_velocity[NTENDON]
+    // (humanoid_v5.py:486-487, humanoidstandup_v5.py:433-434)
+    static constexpr int INFO_SCALARS =
         KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : (KIND == kHumanoidStandup ? 6 : (KIND == kSwimmer ? 7 : (KIND == kPusher ? 3 : 9)))))));
+    static constexpr int INFO = INFO_SCALARS + 2 * M::NTENDON;
     static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || HUMANOID_LIKE;  // small robots: one-lane kernel only
     static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
     static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : ((PENDULUM || KIND == kReacher || KIND == kPusher) ? 0 : 2);
@@ -267,7 +270,13 @@ struct MjEnv {
         const double *qfrc_actuator;     // [NV]
         const double *qfrc_constraint;   // [NV]
         double vec[9];                   // Reacher: fingertip - target (body frames 3 and 4) of the last forward pass; Pusher: xpos of the last three bodies
+        const double *ten = nullptr;     // [2 NTENDON] data.ten_length, data.ten_velocity of the last forward pass
     };
+    // the tendon columns of an info row (data.ten_length / data.ten_velocity are views of the LAST forward pass's values)
+    static MJX_DEV void write_tendon_info(const double *ten, double *info) {
+#pragma unroll
+        for (int k = 0; k < 2 * M::NTENDON; k++) info[INFO_SCALARS + k] = ten[k];
+    }
 
     // One env.step() with the one-lane simulator (mjx_core.h): physics, then finish().
     static MJX_DEV void step(double *s, const float *action, const mi::EnvParams &P, double *obs, double &reward, bool &terminated,
@@ -311,6 +320,9 @@ struct MjEnv {
         if (KIND == kAnt || HUMANOID_LIKE) contact_forces<M>(d, cfrc);
         if (HUMANOID_LIKE) com_pos<M>(d);  // crb() folded the per-body inertias into composites: restore them for the obs
         x.cfrc = cfrc, x.cinert = d.cinert, x.cvel = d.cvel, x.qfrc_actuator = d.qfrc_actuator, x.qfrc_constraint = d.qfrc_constraint;
+        double ten[M::NTENDON > 0 ? 2 * M::NTENDON : 1];
+        for (int t = 0; t < M::NTENDON; t++) ten[t] = d.ten_length[t], ten[M::NTENDON + t] = d.ten_velocity[t];
+        x.ten = ten;
         finish(s, before, x, action, P, obs, reward, terminated, info);
     }
 
@@ -357,8 +369,10 @@ struct MjEnv {
             terminated = false;
             const ObsExtras ox = {x.cfrc, x.cinert, x.cvel, x.qfrc_actuator};
             write_obs(s, ox, P, obs);
-            if (info)
+            if (info) {
                 info[0] = s[0], info[1] = s[1], info[2] = s[2] - M::qpos0[2], info[3] = uph_cost, info[4] = -quad_ctrl_cost, info[5] = -quad_impact_cost;
+                write_tendon_info(x.ten, info);
+            }
             return;
         }
         if (KIND == kPusher) {
@@ -487,12 +501,18 @@ struct MjEnv {
         if (info) {
             info[0] = s[0], info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]), info[3] = xv, info[4] = yv;
             info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
+            if (HUMANOID_LIKE) write_tendon_info(x.ten, info);
         }
     }
     static MJX_DEV void reset_info(const double *s, double *info) {
         for (int k = 0; k < INFO; k++) info[k] = 0.0;
         if (PENDULUM || KIND == kReacher || KIND == kPusher) return;  // _get_reset_info is empty (inverted_pendulum_v5.py:198-199)
         info[0] = s[0];
+        if constexpr (M::NTENDON > 0) {  // mj_forward at the reset state: humanoid_v5.py:534-541
+            double ten[2 * M::NTENDON];
+            tendons<M>(s, s + NQ, ten, ten + M::NTENDON);
+            write_tendon_info(ten, info);
+        }
         if (KIND == kHumanoidStandup) {
             info[1] = s[1], info[2] = s[2] - M::qpos0[2];  // humanoidstandup_v5.py:479-486
             return;

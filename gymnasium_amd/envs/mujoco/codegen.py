@@ -75,6 +75,14 @@ def emit_model(m) -> str:
     s += f"    static constexpr int NSITE = {len(sites)};\n"
     s += _arr("site_bodyid", "int", [b for b, _ in sites], (len(sites),))
     s += _arr("site_pos", "double", [p for _, p in sites], (len(sites), 3))
+    nt = m.ntendon
+    maxwrap = max([len(w) for w in m.tendon_wraps], default=0)
+    s += f"    static constexpr int NTENDON = {nt}, MAXWRAP = {max(maxwrap, 1)};  // fixed tendons (joint wraps): info values only\n"
+    pad = lambda rows, fill: [list(r) + [fill] * (max(maxwrap, 1) - len(r)) for r in rows]  # noqa: E731
+    s += _arr("tendon_num", "int", [len(w) for w in m.tendon_wraps], (nt,))
+    s += _arr("tendon_qposadr", "int", pad([[x[0] for x in w] for w in m.tendon_wraps], 0), (nt, max(maxwrap, 1)))
+    s += _arr("tendon_dofadr", "int", pad([[x[1] for x in w] for w in m.tendon_wraps], 0), (nt, max(maxwrap, 1)))
+    s += _arr("tendon_coef", "double", pad([[x[2] for x in w] for w in m.tendon_wraps], 0.0), (nt, max(maxwrap, 1)))
     s += "};\n"
     return s
 

@@ -302,6 +302,12 @@ def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
         m.body_fluidbox[bi] = [math.sqrt(max(MINVAL, I1 + I2 - I0) / mass * 6.0), math.sqrt(max(MINVAL, I0 + I2 - I1) / mass * 6.0),
                                math.sqrt(max(MINVAL, I0 + I1 - I2) / mass * 6.0)]
         m.body_imat[bi] = V.reshape(-1)
+    # ---- fixed tendons: length = sum_k coef_k qpos[joint_k], velocity = sum_k coef_k qvel[joint_k] (mj_tendon / mj_fwdVelocity for
+    # mjWRAP_JOINT wraps); humanoid.xml:91-100.  No stiffness / limits / actuators hang on them in any asset: info values only.
+    m.tendon_names = [t[0] for t in desc.get("tendons", [])]
+    m.ntendon = len(m.tendon_names)
+    m.tendon_wraps = [[(int(m.jnt_qposadr[J["name"].index(j)]), int(m.jnt_dofadr[J["name"].index(j)]), float(c)) for j, c in t[1]]
+                      for t in desc.get("tendons", [])]
     # ---- sites: (body index, position in the body frame) ------------------------------------------------------------
     m.sites = [(m.body_names.index(b), tuple(float(x) for x in pos)) for _, b, pos in desc.get("sites", [])]
     # ---- actuators (motors on joints) ---------------------------------------------------------------------------

@@ -16,21 +16,42 @@ from __future__ import annotations
 
 import numpy as np
 
-from ...gym_api import error, spaces
+from ...gym_api import error, logger, spaces
 from ...vector.hip_vector_env import HipVectorEnv
+from . import models as _models
+
+_WARNED_UNPINNED = False
 
 
 class _MujocoVectorEnv(HipVectorEnv):
     STOCK_XML = ""
     NQ = NV = NU = NBODY = 0
     CTRL_LOW = CTRL_HIGH = 0.0
+    TENDONS: tuple = ()  # ((qpos address, dof address, coefficient), ...) per fixed tendon (humanoid.xml:91-100)
 
     def _check_common(self, xml_file, frame_skip, kwargs):
+        global _WARNED_UNPINNED
         if xml_file != self.STOCK_XML:
             raise error.Error(f"gymnasium_amd runs the stock {self.STOCK_XML} model compiled into the engine; got xml_file={xml_file!r}")
         for k in ("default_camera_config", "width", "height", "camera_id", "camera_name", "max_geom", "visual_options"):
             kwargs.pop(k, None)  # rendering-only arguments of MujocoEnv (mujoco_env.py:38-55)
         self.frame_skip = int(frame_skip)
+        if not _WARNED_UNPINNED:  # once per process
+            _WARNED_UNPINNED = True
+            logger.warn("gymnasium_amd MuJoCo-family environments run a from-scratch restatement of MuJoCo's published pipeline; no fixture "
+                        "from a real `mujoco` build pins it yet (DESIGN.md section 7), so trajectories and rewards are NOT guaranteed to equal "
+                        "the reference's within a tolerance.")
+
+    @property
+    def dt(self) -> float:
+        """MujocoEnv.dt (mujoco_env.py:189-191): model.opt.timestep * frame_skip."""
+        return _models.MODELS[self.KIND]()["option"]["timestep"] * self.frame_skip
+
+    def _tendon_values(self, qpos, qvel):
+        """data.ten_length / data.ten_velocity of mj_forward at (qpos, qvel): fixed tendons are linear in both."""
+        ln = np.stack([sum(c * qpos[:, qa] for qa, _, c in t) for t in self.TENDONS], axis=1)
+        vl = np.stack([sum(c * qvel[:, da] for _, da, c in t) for t in self.TENDONS], axis=1)
+        return ln, vl
 
     def _single_spaces(self):
         obs = spaces.Box(low=-np.inf, high=np.inf, shape=(self._obs_size(),), dtype=np.float64)
@@ -47,9 +68,17 @@ class _MujocoVectorEnv(HipVectorEnv):
         qpos = self.get_state()[0]
         infos = {"x_position": np.where(sel, qpos[:, 0], 0.0), "_x_position": sel}
         if self.N_RESET_INFO_KEYS == 3:
-            infos.update({"y_position": np.where(sel, qpos[:, 1], 0.0), "_y_position": sel.copy(),
-                          "distance_from_origin": np.where(sel, np.sqrt(qpos[:, 0] ** 2 + qpos[:, 1] ** 2), 0.0), "_distance_from_origin": sel.copy()})
+            infos.update({"y_position": np.where(sel, qpos[:, 1], 0.0), "_y_position": sel.copy()})
+            infos.update(self._reset_tendon_infos(qpos, sel))  # key order of humanoid_v5.py:534-541
+            infos.update({"distance_from_origin": np.where(sel, np.sqrt(qpos[:, 0] ** 2 + qpos[:, 1] ** 2), 0.0), "_distance_from_origin": sel.copy()})
         return infos
+
+    def _reset_tendon_infos(self, state, sel):
+        if not self.TENDONS:
+            return {}
+        ln, vl = self._tendon_values(state[:, :self.NQ], state[:, self.NQ:self.NQ + self.NV])
+        return {"tendon_length": np.where(sel[:, None], ln, 0.0), "_tendon_length": sel.copy(),
+                "tendon_velocity": np.where(sel[:, None], vl, 0.0), "_tendon_velocity": sel.copy()}
 
 
 class HalfCheetahVectorEnv(_MujocoVectorEnv):
@@ -119,6 +148,9 @@ class HumanoidVectorEnv(_MujocoVectorEnv):
     CTRL_LOW, CTRL_HIGH = -0.4, 0.4
     INFO_KEYS = AntVectorEnv.INFO_KEYS
     N_RESET_INFO_KEYS = 3
+    INFO_VECTOR_KEYS = (("tendon_length", 2), ("tendon_velocity", 2))  # data.ten_length / data.ten_velocity (humanoid_v5.py:486-487)
+    # <tendon><fixed name="left_hipknee"> -left_hip_y + left_knee, "right_hipknee" likewise (humanoid.xml:91-100): (qpos adr, dof adr, coef)
+    TENDONS = (((16, 15, -1.0), (17, 16, 1.0)), ((12, 11, -1.0), (13, 12, 1.0)))
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "humanoid.xml", frame_skip: int = 5,
                  forward_reward_weight: float = 1.25, ctrl_cost_weight: float = 0.1, contact_cost_weight: float = 5e-7,
@@ -177,8 +209,10 @@ class HumanoidStandupVectorEnv(HumanoidVectorEnv):
     def _reset_infos(self, mask):
         sel = np.ones(self.num_envs, dtype=np.bool_) if mask is None else mask.view(np.bool_).copy()
         qpos = self.get_state()[0]
-        return {"x_position": np.where(sel, qpos[:, 0], 0.0), "_x_position": sel, "y_position": np.where(sel, qpos[:, 1], 0.0), "_y_position": sel.copy(),
-                "z_distance_from_origin": np.where(sel, qpos[:, 2] - 0.105, 0.0), "_z_distance_from_origin": sel.copy()}
+        infos = {"x_position": np.where(sel, qpos[:, 0], 0.0), "_x_position": sel, "y_position": np.where(sel, qpos[:, 1], 0.0), "_y_position": sel.copy(),
+                 "z_distance_from_origin": np.where(sel, qpos[:, 2] - 0.105, 0.0), "_z_distance_from_origin": sel.copy()}
+        infos.update(self._reset_tendon_infos(qpos, sel))  # humanoidstandup_v5.py:479-486
+        return infos
 
 
 class _PlanarWalkerVectorEnv(_MujocoVectorEnv):

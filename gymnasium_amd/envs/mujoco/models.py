@@ -105,7 +105,7 @@ def ant():
 
     torso = body(
         "torso", (0, 0, 0.75),
-        joints=[joint("root", "free", armature=0, damping=0, limited=False)],   # :24
+        joints=[joint("root", "free", armature=0, damping=0, limited=False, margin=0.01)],   # :24
         geoms=[sphere("torso_geom", 0.25)],                                      # :23
         children=[
             leg("front_left_leg", "aux_1", +1, +1, "hip_1", "ankle_1", (-1, 1, 0), (30, 70), "aux_1_geom", "left_leg_geom", "left_ankle_geom"),
@@ -338,7 +338,7 @@ def reacher():
     target = body("target", (0.1, -0.1, 0.01),                                                                                # :30
                   joints=[joint("target_x", "slide", axis=(1, 0, 0), pos=(0, 0, 0), range=(-.27, .27), ref=0.1, **free),      # :31
                           joint("target_y", "slide", axis=(0, 1, 0), pos=(0, 0, 0), range=(-.27, .27), ref=-0.1, **free)],    # :32
-                  geoms=[sphere("target", 0.009)])                                                                            # :33
+                  geoms=[sphere("target", 0.009, contype=0, conaffinity=0)])                                                                            # :33
     return dict(
         name="reacher", angle="radian", settotalmass=None,
         option=dict(timestep=0.01, gravity=(0, 0, -9.81), integrator="RK4", solver="Newton", iterations=100),

@@ -70,8 +70,11 @@ class TabularVectorEnv(HipVectorEnv):
         # Reference quirk, mirrored: VectorEnv._add_info (vector_env.py:277-338) types a key's array after the FIRST sub-env
         # that supplies it in a step.  When sub-env 0 is in its autoreset step its info is the reset info {"prob": 1} -- an
         # int -- so the whole "prob" array becomes int64 and the other sub-envs' probabilities are truncated (1/3 -> 0).
-        env0_resetting = bool(self._was_done[0]) and self.autoreset_mode.value == "NextStep"
+        # The same happens under SAME_STEP when sub-env 0 finishes: its top-level entry is then the reset info (sync_vector_env.py:319).
+        pending0 = bool(self._was_done[0])
         infos = super()._build_infos()
+        mode = self.autoreset_mode.value
+        env0_resetting = pending0 if mode == "NextStep" else (bool(infos["_final_info"][0]) if (mode == "SameStep" and "_final_info" in infos) else False)
         if self.RESET_PROB_IS_INT and env0_resetting:
             infos["prob"] = infos["prob"].astype(np.int64)
         return infos
@@ -244,7 +247,13 @@ class TaxiVectorEnv(TabularVectorEnv):
         return infos
 
     def _build_infos(self):
-        return self._with_action_mask(TabularVectorEnv._build_infos(self))
+        infos = self._with_action_mask(TabularVectorEnv._build_infos(self))
+        if "final_info" in infos:  # SAME_STEP: the finishing step's info carries the mask of the final state (taxi.py:470)
+            dones = infos["_final_info"]
+            final = self._host(self._final).reshape(-1)
+            infos["final_info"]["action_mask"] = np.where(dones[:, None], self._action_mask[np.where(dones, final, 0)], 0).astype(np.int8)
+            infos["final_info"]["_action_mask"] = dones.copy()
+        return infos
 
     def _reset_infos(self, mask):
         return self._with_action_mask(super()._reset_infos(mask))
@@ -281,8 +290,11 @@ class BlackjackVectorEnv(HipVectorEnv):
 
     def step(self, actions):
         obs, r, te, tr, info = super().step(actions)
-        if "final_obs" in info:
-            info["final_obs"] = np.array([None if f is None else tuple(int(x) for x in f) for f in info["final_obs"]], dtype=object)
+        if "final_obs" in info:  # a 1-D object array of tuples, also when every sub-env finished (np.array would build (N, 3))
+            out = np.empty(self.num_envs, dtype=object)
+            for i, f in enumerate(info["final_obs"]):
+                out[i] = None if f is None else tuple(int(x) for x in f)
+            info["final_obs"] = out
         return self._tuple(obs), r, te, tr, info
 
 

@@ -59,8 +59,9 @@ class HipVectorEnv(VectorEnv):
 
     KIND: str = ""
     DEFAULT_MAX_EPISODE_STEPS: int | None = None
-    INFO_KEYS: tuple = ()        # names of the engine's info columns (MuJoCo envs); the first N_RESET_INFO_KEYS are also
+    INFO_KEYS: tuple = ()        # names of the engine's scalar info columns (MuJoCo envs); the first N_RESET_INFO_KEYS are also
     N_RESET_INFO_KEYS: int = 0   # what the scalar env's reset() reports (_get_reset_info), i.e. valid on autoreset steps
+    INFO_VECTOR_KEYS: tuple = () # (name, width) array-valued info entries stored after the scalar columns; reported by step AND reset
     metadata: dict[str, Any] = {"render_modes": [], "autoreset_mode": AutoresetMode.NEXT_STEP}
 
     # -- to be provided by subclasses ------------------------------------------------------------------
@@ -112,6 +113,7 @@ class HipVectorEnv(VectorEnv):
         self._act_shape = (self.num_envs,) if self._discrete else (self.num_envs, eng.act_dim)
         self._seeded = False
         self._has_reset = False
+        self._was_done = np.zeros(self.num_envs, dtype=np.bool_)  # mirror of the device's needs-reset flags (SyncVectorEnv._autoreset_envs)
         self._alloc_buffers()
         if self.record_episode_statistics:
             self.episode_count = 0
@@ -157,6 +159,7 @@ class HipVectorEnv(VectorEnv):
             self._trunc = torch.zeros((N,), dtype=torch.bool, device=dev)
             self._final = torch.zeros(self._obs_shape, dtype=self._obs_tdtype, device=dev) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
             self._info = torch.zeros((N, eng.info_dim), dtype=torch.float64, device=dev) if eng.info_dim else None
+            self._final_info = torch.zeros((N, eng.info_dim), dtype=torch.float64, device=dev) if (eng.info_dim and self._final is not None) else None
             self._ep_r = torch.zeros((N,), dtype=torch.float64, device=dev) if self.record_episode_statistics else None
             self._ep_l = torch.zeros((N,), dtype=torch.int32, device=dev) if self.record_episode_statistics else None
             self._loc = _native.MI_DEVICE
@@ -168,6 +171,7 @@ class HipVectorEnv(VectorEnv):
             self._trunc = np.zeros((N,), dtype=np.bool_)
             self._final = np.zeros(self._obs_shape, dtype=eng.obs_dtype) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
             self._info = np.zeros((N, eng.info_dim), dtype=np.float64) if eng.info_dim else None
+            self._final_info = np.zeros((N, eng.info_dim), dtype=np.float64) if (eng.info_dim and self._final is not None) else None
             self._ep_r = np.zeros((N,), dtype=np.float64) if self.record_episode_statistics else None
             self._ep_l = np.zeros((N,), dtype=np.int32) if self.record_episode_statistics else None
             self._loc = _native.MI_HOST
@@ -256,7 +260,10 @@ class HipVectorEnv(VectorEnv):
         else:
             self._engine.reset(mask, bounds, self._obs, _native.MI_HOST)
         self._has_reset = True
-        self._was_done = np.zeros(self.num_envs, dtype=np.bool_)
+        if mask is None:
+            self._was_done[:] = False
+        else:  # sync_vector_env.py:232-234: only the reset sub-envs leave the pending-autoreset set
+            self._was_done[mask.view(np.bool_)] = False
         if self.record_episode_statistics:
             now = time.perf_counter()
             if mask is None:
@@ -304,7 +311,8 @@ class HipVectorEnv(VectorEnv):
         self._bind_stream()
         try:
             self._engine.step(aptr, self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc),
-                              self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc, self._p(self._info))
+                              self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc, self._p(self._info),
+                              self._p(self._final_info))
         except _native.NativeError as e:
             if e.code == -1:  # MI_ERR_INVALID_ARGUMENT: action outside the space (cartpole.py:165-167 asserts)
                 raise AssertionError(e.message) from e
@@ -315,38 +323,65 @@ class HipVectorEnv(VectorEnv):
         infos = self._build_infos()
         return self._out(self._obs), self._out(self._rew), self._out(self._term), self._out(self._trunc), infos
 
+    def _info_columns(self):
+        """[(name, first column, width, in_reset_info)] of the engine's info row."""
+        cols = [(name, k, 0, k < self.N_RESET_INFO_KEYS) for k, name in enumerate(self.INFO_KEYS)]
+        start = len(self.INFO_KEYS)
+        for name, width in self.INFO_VECTOR_KEYS:
+            cols.append((name, start, width, True))
+            start += width
+        return cols
+
+    def _info_dict(self, rows, supplied, reset_rows) -> dict:
+        """VectorEnv._add_info (vector_env.py:277-338) over an info matrix: one array per key plus the `_key` mask of the
+        sub-envs that supplied it.  `supplied`: rows that have an info at all; `reset_rows`: rows whose info is the scalar
+        env's RESET info, which carries only the reset keys.  A key no sub-env supplied does not appear."""
+        out: dict[str, Any] = {}
+        for name, start, width, in_reset in self._info_columns():
+            mask = supplied if in_reset else (supplied & ~reset_rows)
+            if not mask.any():
+                continue
+            col = rows[:, start] if width == 0 else rows[:, start:start + width]
+            val = np.where(mask if width == 0 else mask[:, None], col, 0.0)
+            out[name], out["_" + name] = val, mask.copy()
+        return out
+
+    def _host(self, buf):
+        return buf.cpu().numpy() if self.output == "torch" else buf
+
     def _build_infos(self) -> dict:
         infos: dict[str, Any] = {}
-        need_final = self.autoreset_mode == AutoresetMode.SAME_STEP
+        N = self.num_envs
+        same_step = self.autoreset_mode == AutoresetMode.SAME_STEP
+        if not (self.INFO_KEYS or same_step or self.record_episode_statistics):
+            return infos  # nothing to report: with device tensors the step stays asynchronous (no read-back of the flags)
+        dones = np.logical_or(self._host(self._term), self._host(self._trunc))
+        every = np.ones(N, dtype=np.bool_)
         if self.INFO_KEYS and self._info is not None:
-            # VectorEnv._add_info (vector_env.py:277-338): one array per key plus a `_key` mask of the envs that supplied
-            # it; an env in its NEXT_STEP autoreset step supplies only its reset info (sync_vector_env.py:279-284)
-            info = self._info.cpu().numpy() if self.output == "torch" else self._info
-            stepping = ~self._was_done if self.autoreset_mode == AutoresetMode.NEXT_STEP else np.ones(self.num_envs, dtype=np.bool_)
-            for k, name in enumerate(self.INFO_KEYS):
-                infos[name] = info[:, k].copy()
-                infos["_" + name] = np.ones(self.num_envs, dtype=np.bool_) if k < self.N_RESET_INFO_KEYS else stepping.copy()
-            if self.output == "torch":
-                self._was_done = (self._term | self._trunc).cpu().numpy()
+            # an env in its NEXT_STEP autoreset step supplies only its reset info (sync_vector_env.py:279-284); under SAME_STEP a
+            # finished env's top-level entries are its reset info and the finishing step's info goes to "final_info" (:309-319)
+            if self.autoreset_mode == AutoresetMode.NEXT_STEP:
+                reset_rows = self._was_done
+            elif same_step:
+                reset_rows = dones
             else:
-                self._was_done = np.logical_or(self._term, self._trunc)
-        if not need_final and not self.record_episode_statistics:
-            return infos
-        if self.output == "torch":
-            dones = (self._term | self._trunc).cpu().numpy()
-        else:
-            dones = np.logical_or(self._term, self._trunc)
-        any_done = bool(dones.any())
-        if need_final and any_done:
-            # sync_vector_env.py:309-317 via VectorEnv._add_info: object array of per-env observations
-            final = self._final.cpu().numpy() if self.output == "torch" else self._final
-            arr = np.full(self.num_envs, None, dtype=object)
+                reset_rows = np.zeros(N, dtype=np.bool_)
+            infos.update(self._info_dict(self._host(self._info), every, reset_rows))
+        if same_step and dones.any():
+            # sync_vector_env.py:309-317 via VectorEnv._add_info: object array of per-env observations + nested final_info
+            final = self._host(self._final)
+            arr = np.full(N, None, dtype=object)
             for i in np.flatnonzero(dones):
                 arr[i] = final[i].copy()
             infos["final_obs"], infos["_final_obs"] = arr, dones.copy()
-            infos["final_info"], infos["_final_info"] = {}, dones.copy()
+            finfo = {}
+            if self.INFO_KEYS and self._final_info is not None:
+                finfo = self._info_dict(self._host(self._final_info), dones, np.zeros(N, dtype=np.bool_))
+            infos["final_info"], infos["_final_info"] = finfo, dones.copy()
+        self._was_done = dones if self.autoreset_mode != AutoresetMode.SAME_STEP else np.zeros(N, dtype=np.bool_)
         if self.record_episode_statistics:
             now = time.perf_counter()
+            any_done = bool(dones.any())
             if self.autoreset_mode != AutoresetMode.SAME_STEP:
                 self._episode_start[self._prev_dones] = now
             self._prev_dones = dones
@@ -405,6 +440,8 @@ class HipVectorEnv(VectorEnv):
             out["actions"] = a_in
         # the vector env's "current" buffers follow the last step, as after T step() calls
         self._obs.copy_(obs[-1]); self._rew.copy_(rew[-1]); self._term.copy_(term[-1]); self._trunc.copy_(trunc[-1])
+        if self.autoreset_mode == AutoresetMode.NEXT_STEP:  # the sub-envs that finished in the last step reset in the next one
+            self._was_done = (term[-1] | trunc[-1]).cpu().numpy()
         return out
 
     # -- bookkeeping -----------------------------------------------------------------------------------
@@ -422,6 +459,8 @@ class HipVectorEnv(VectorEnv):
     def set_state(self, state=None, elapsed_steps=None, flags=None):
         self._engine.set_state(state, elapsed_steps, flags)
         self._has_reset = True
+        if flags is not None:  # keep the host mirror of the pending-autoreset set in step with the device flags
+            self._was_done = (np.asarray(flags, dtype=np.uint8) & _native.FLAG_NEEDS_RESET) != 0
 
     def get_rng_state(self) -> np.ndarray:
         """Per-env PCG64 words [N, 4] = {state_hi, state_lo, inc_hi, inc_lo}."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355ENV_ABI_VERSION 3
+#define MI355ENV_ABI_VERSION 4
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -121,7 +121,8 @@ typedef struct mi_layout {
     int32_t info_dim;     /* per-env info row length (float64), 0 for classic control; MuJoCo columns:
                              HALF_CHEETAH: x_position, x_velocity, reward_forward, reward_ctrl   (half_cheetah_v5.py:230,241-246)
                              ANT / HUMANOID: x_position, y_position, distance_from_origin, x_velocity, y_velocity,
-                                             reward_forward, reward_ctrl, reward_contact, reward_survive (ant_v5.py:359-366,384-389) */
+                                             reward_forward, reward_ctrl, reward_contact, reward_survive (ant_v5.py:359-366,384-389)
+                             HUMANOID / HUMANOID_STANDUP append tendon_length[2], tendon_velocity[2] (humanoid_v5.py:486-487) */
     int32_t reserved[2];
 } mi_layout;
 
@@ -136,7 +137,11 @@ typedef struct mi_layout {
  *   final_obs        out  [N][obs_dim]  SAME_STEP only: rows of envs that finished this step (others untouched)
  *   episode_return   out  [N] f64      vector RecordEpisodeStatistics "r" (wrappers/vector/common.py:156-235):
  *   episode_length   out  [N] i32      "l"; both 0 where the env did not finish an episode this step
- *   info             out  [N][info_dim] f64   the numeric entries of the scalar env's info dict (layout.info_dim columns)
+ *   info             out  [N][info_dim] f64   the numeric entries of the scalar env's info dict (layout.info_dim columns);
+ *                                               rows of sub-envs that RESET in this call (NEXT_STEP autoreset step, SAME_STEP after a
+ *                                               finished episode) hold the scalar env's reset info instead (_get_reset_info)
+ *   final_info       out  [N][info_dim] f64   SAME_STEP only: the info of the step that finished the episode, for the rows of
+ *                                               envs that finished this step (sync_vector_env.py:309-317 "final_info"; others untouched)
  */
 typedef struct mi_step_io {
     const void *actions;
@@ -148,6 +153,7 @@ typedef struct mi_step_io {
     double *episode_return;
     int32_t *episode_length;
     double *info;
+    double *final_info;
 } mi_step_io;
 
 /* Buffers of one fused rollout() call: T consecutive step()s in one launch, time-major [T][N][dim].

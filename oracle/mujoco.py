@@ -28,7 +28,8 @@ def model_blob(m) -> np.ndarray:
              m.dof_bodyid, m.dof_jntid, m.dof_parentid, m.dof_armature, m.dof_damping, m.dof_invweight0,
              m.qpos0, m.qpos_spring, m.geom_type, m.geom_bodyid, m.geom_size, m.geom_pos, m.geom_mat,
              m.pair_geom1, m.pair_geom2, m.pair_condim, m.pair_friction, m.pair_margin, m.pair_solref, m.pair_solimp,
-             m.actuator_dofadr, m.actuator_gear, m.actuator_ctrlrange]
+             m.actuator_dofadr, m.actuator_gear, m.actuator_ctrlrange,
+             [m.ntendon], *[[len(w)] + [x for wrap in w for x in wrap] for w in m.tendon_wraps]]
     return np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in parts])
 
 

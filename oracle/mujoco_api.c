@@ -51,7 +51,7 @@ static const field_t FIELDS[] = {
     F(qfrc_smooth, 2, 0, 1, 1), F(qacc_smooth, 2, 0, 1, 1), F(qfrc_constraint, 2, 0, 1, 1), F(qacc, 2, 0, 1, 1),
     F(qacc_warmstart, 2, 0, 1, 1), F(cfrc_ext, 3, 0, 6, 6), F(efc_J, 5, 0, -2, MJO_MAXV), F(efc_pos, 5, 0, 1, 1),
     F(efc_margin, 5, 0, 1, 1), F(efc_D, 5, 0, 1, 1), F(efc_R, 5, 0, 1, 1), F(efc_vel, 5, 0, 1, 1), F(efc_aref, 5, 0, 1, 1),
-    F(efc_force, 5, 0, 1, 1), F(efc_KBIP, 5, 0, 4, 4),
+    F(efc_force, 5, 0, 1, 1), F(efc_KBIP, 5, 0, 4, 4), F(ten_length, 0, MJO_MAXT, 1, 1), F(ten_velocity, 0, MJO_MAXT, 1, 1),
 };
 
 /* Copies field `name` as a dense row-major [rows][cols] array into out; returns rows*cols, or -1 for an unknown name. */

@@ -132,6 +132,13 @@ int mjo_model_from_blob(mjo_model *m, const double *blob, int n) {
     TAKE_D(m->pair_friction, 3 * np); TAKE_D(m->pair_margin, np); TAKE_D(m->pair_solref, 2 * np); TAKE_D(m->pair_solimp, 5 * np);
     TAKE_I(m->actuator_dofadr, nu);
     TAKE_D(m->actuator_gear, nu); TAKE_D(m->actuator_ctrlrange, 2 * nu);
+    m->ntendon = (int)*p++;
+    if (m->ntendon > MJO_MAXT) return -1;
+    for (int t = 0; t < m->ntendon; t++) {
+        m->tendon_num[t] = (int)*p++;
+        if (m->tendon_num[t] > MJO_MAXWRAP) return -1;
+        for (int k = 0; k < m->tendon_num[t]; k++) m->wrap_qposadr[t][k] = (int)*p++, m->wrap_dofadr[t][k] = (int)*p++, m->wrap_coef[t][k] = *p++;
+    }
     return (int)(p - blob) == n ? 0 : -2;
 }
 
@@ -912,9 +919,20 @@ static void solve_pgs(const mjo_model *m, mjo_data *d) {
 }
 
 /* ---- forward -------------------------------------------------------------------------------------------------- */
+/* fixed tendons: length = sum coef qpos[joint], velocity = sum coef qvel[joint] (mjWRAP_JOINT wraps of mj_tendon; ten_J qvel) */
+static void tendons(const mjo_model *m, mjo_data *d) {
+    for (int t = 0; t < m->ntendon; t++) {
+        double l = 0, v = 0;
+        for (int k = 0; k < m->tendon_num[t]; k++)
+            l += m->wrap_coef[t][k] * d->qpos[m->wrap_qposadr[t][k]], v += m->wrap_coef[t][k] * d->qvel[m->wrap_dofadr[t][k]];
+        d->ten_length[t] = l, d->ten_velocity[t] = v;
+    }
+}
+
 void mjo_forward(const mjo_model *m, mjo_data *d) {
     int nv = m->nv;
     kinematics(m, d);
+    tendons(m, d);
     com_pos(m, d);
     crb(m, d);
     chol_factor(nv, d->qM, d->qL);

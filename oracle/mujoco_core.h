@@ -28,6 +28,8 @@
 #define MJO_MAXPAIR 136
 #define MJO_MAXCON 40
 #define MJO_MAXEFC (4 * MJO_MAXCON + MJO_MAXJ)
+#define MJO_MAXT 4    /* fixed tendons */
+#define MJO_MAXWRAP 4 /* joints per fixed tendon */
 
 enum { MJO_FREE = 0, MJO_BALL = 1, MJO_SLIDE = 2, MJO_HINGE = 3 };
 enum { MJO_PLANE = 0, MJO_SPHERE = 2, MJO_CAPSULE = 3, MJO_CYLINDER = 5 };
@@ -53,6 +55,9 @@ typedef struct mjo_model {
     double pair_friction[MJO_MAXPAIR][3], pair_margin[MJO_MAXPAIR], pair_solref[MJO_MAXPAIR][2], pair_solimp[MJO_MAXPAIR][5];
     int actuator_dofadr[MJO_MAXU];
     double actuator_gear[MJO_MAXU], actuator_ctrlrange[MJO_MAXU][2];
+    /* fixed tendons (humanoid.xml:91-100): joint wraps only, no dynamics attached */
+    int ntendon, tendon_num[MJO_MAXT], wrap_qposadr[MJO_MAXT][MJO_MAXWRAP], wrap_dofadr[MJO_MAXT][MJO_MAXWRAP];
+    double wrap_coef[MJO_MAXT][MJO_MAXWRAP];
 } mjo_model;
 
 typedef struct mjo_contact {
@@ -77,6 +82,7 @@ typedef struct mjo_data {
     double qfrc_passive[MJO_MAXV], qfrc_bias[MJO_MAXV], qfrc_actuator[MJO_MAXV], qfrc_smooth[MJO_MAXV], qacc_smooth[MJO_MAXV];
     double qfrc_constraint[MJO_MAXV], qacc[MJO_MAXV], qacc_warmstart[MJO_MAXV];
     double cfrc_ext[MJO_MAXB][6];
+    double ten_length[MJO_MAXT], ten_velocity[MJO_MAXT]; /* mj_tendon / mj_fwdVelocity: fixed tendons, at this forward pass's state */
     int solver_iter;
 } mjo_data;
 

@@ -119,10 +119,16 @@ int orc_mjenv_info_dim(int which) {
     if (which == ORC_MJ_INVERTED_PENDULUM) return 1;
     if (which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) return 3;
     if (which == ORC_MJ_REACHER) return 2;
-    if (which == ORC_MJ_HUMANOID_STANDUP) return 6;
+    if (which == ORC_MJ_HUMANOID_STANDUP) return 6 + 2 * g_models[which]->ntendon; /* + tendon_length, tendon_velocity (humanoidstandup_v5.py:433-434) */
     if (which == ORC_MJ_SWIMMER) return 7;
     if (which == ORC_MJ_PUSHER) return 3;
+    if (which == ORC_MJ_HUMANOID) return 9 + 2 * g_models[which]->ntendon; /* humanoid_v5.py:486-487 */
     return which == ORC_MJ_HALF_CHEETAH ? 4 : 9;
+}
+/* the tendon columns of an info row: data.ten_length, data.ten_velocity of the last forward pass */
+static void tendon_info(const orc_mjenv *e, double *cols) {
+    const int nt = e->m->ntendon;
+    for (int t = 0; t < nt; t++) cols[t] = e->d.ten_length[t], cols[nt + t] = e->d.ten_velocity[t];
 }
 int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
 
@@ -289,6 +295,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         *terminated = 0;
         info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = d->qpos[2] - m->qpos0[2], info[3] = uph_cost, info[4] = -quad_ctrl_cost,
         info[5] = -quad_impact_cost;
+        tendon_info(e, info + 6);
         return;
     }
     if (e->which == ORC_MJ_PUSHER) { /* pusher_v5.py:266-291 */
@@ -404,12 +411,14 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     *terminated = !healthy && P[7] != 0.0;
     info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = sqrt(d->qpos[0] * d->qpos[0] + d->qpos[1] * d->qpos[1]);
     info[3] = xv, info[4] = yv, info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
+    if (e->which == ORC_MJ_HUMANOID) tendon_info(e, info + 9);
 }
 
 /* _get_reset_info of the scalar env: positions only */
 void orc_mjenv_reset_info(const orc_mjenv *e, double *row) {
     if (is_pendulum(e->which) || e->which == ORC_MJ_REACHER || e->which == ORC_MJ_PUSHER) return; /* {} (inverted_pendulum_v5.py:198-199) */
     row[0] = e->d.qpos[0];
+    if (is_humanoid(e->which)) tendon_info(e, row + (e->which == ORC_MJ_HUMANOID ? 9 : 6)); /* humanoid_v5.py:534-541 */
     if (e->which == ORC_MJ_HUMANOID_STANDUP)
         row[1] = e->d.qpos[1], row[2] = e->d.qpos[2] - e->m->qpos0[2]; /* humanoidstandup_v5.py:479-486 */
     else if (is_planar_walker(e->which))

@@ -20,6 +20,8 @@ weak-scalar promotion) and records
   toytext_<env>.npz         FrozenLake / CliffWalking / Taxi: the reference's transition table P and initial distribution,
                             plus a gym.make_vec(id, 8, "sync") trajectory with the info dict entries (prob, action_mask)
 
+  infos_*.npz               SAME_STEP info dicts (final_info / reset info at top level) and a partial reset during a pending autoreset
+
 Nothing here is read at run time by the product; tests compare the oracle (oracle/) and the HIP engine to it.
 """
 import os
@@ -352,6 +354,59 @@ def make_blackjack():
         v.close()
 
 
+def make_same_step_infos():
+    """infos_<env>.npz: the info dict of SyncVectorEnv under SAME_STEP (sync_vector_env.py:302-319: final_obs / final_info, the
+    finished sub-env's top-level entries are its RESET info) for FrozenLake-v1 / Taxi-v4, and a NEXT_STEP recording with a partial
+    reset (options["reset_mask"]) issued while another sub-env is waiting for its autoreset step (:232-234)."""
+    for key, env_id in (("frozenlake", "FrozenLake-v1"), ("taxi", "Taxi-v4")):
+        n, T = 6, 250
+        v = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync", vector_kwargs=dict(autoreset_mode=AutoresetMode.SAME_STEP))
+        o0, _ = v.reset(seed=13)
+        v.action_space.seed(5)
+        rec = {k: [] for k in ("actions", "obs", "reward", "term", "trunc", "prob", "prob_is_int", "prob_mask", "has_final", "final_mask", "final_obs",
+                               "final_prob", "final_prob_mask", "action_mask", "final_action_mask", "final_action_mask_mask")}
+        for _ in range(T):
+            a = v.action_space.sample()
+            o, r, te, tr, info = v.step(a)
+            rec["actions"].append(a), rec["obs"].append(o), rec["reward"].append(r), rec["term"].append(te), rec["trunc"].append(tr)
+            rec["prob"].append(np.asarray(info["prob"], dtype=np.float64)), rec["prob_is_int"].append(np.issubdtype(np.asarray(info["prob"]).dtype, np.integer))
+            rec["prob_mask"].append(info["_prob"])
+            has = "final_info" in info
+            rec["has_final"].append(has)
+            rec["final_mask"].append(info["_final_info"] if has else np.zeros(n, np.bool_))
+            rec["final_obs"].append(np.array([-1 if (not has or x is None) else int(x) for x in (info["final_obs"] if has else [None] * n)], dtype=np.int64))
+            rec["final_prob"].append(np.asarray(info["final_info"]["prob"], dtype=np.float64) if has else np.zeros(n))
+            rec["final_prob_mask"].append(info["final_info"]["_prob"] if has else np.zeros(n, np.bool_))
+            if "action_mask" in info:
+                rec["action_mask"].append(np.stack([np.asarray(m) for m in info["action_mask"]]))
+                fam = info["final_info"]["action_mask"] if has else np.zeros((n, 6), np.int8)
+                rec["final_action_mask"].append(np.stack([np.asarray(m) for m in fam]))
+                rec["final_action_mask_mask"].append(info["final_info"]["_action_mask"] if has else np.zeros(n, np.bool_))
+        save(f"infos_same_step_{key}.npz", obs0=o0, **{k: np.stack(x) for k, x in rec.items() if x})
+        v.close()
+    # NEXT_STEP + partial reset while sub-env 1 is pending its autoreset: CliffWalking with a 5-step TimeLimit makes every sub-env
+    # truncate at the same step; then only sub-envs {0, 2} are reset explicitly
+    n = 4
+    v = gym.make_vec("FrozenLake-v1", num_envs=n, vectorization_mode="sync", max_episode_steps=5)
+    v.reset(seed=3)
+    v.action_space.seed(9)
+    rec = {k: [] for k in ("actions", "obs", "reward", "term", "trunc", "prob", "prob_is_int", "prob_mask")}
+    mask = np.array([True, False, True, False])
+    reset_at, reset_obs = [], []
+    for t in range(40):
+        a = v.action_space.sample()
+        o, r, te, tr, info = v.step(a)
+        rec["actions"].append(a), rec["obs"].append(o), rec["reward"].append(r), rec["term"].append(te), rec["trunc"].append(tr)
+        rec["prob"].append(np.asarray(info["prob"], dtype=np.float64)), rec["prob_is_int"].append(np.issubdtype(np.asarray(info["prob"]).dtype, np.integer))
+        rec["prob_mask"].append(info["_prob"])
+        if (te | tr).any() and len(reset_at) < 3:  # someone is now pending: reset half of the batch by hand
+            ro, _ = v.reset(options={"reset_mask": mask})
+            reset_at.append(t), reset_obs.append(ro)
+    save("infos_partial_reset_frozenlake.npz", reset_mask=mask, reset_at=np.array(reset_at), reset_obs=np.stack(reset_obs),
+         **{k: np.stack(x) for k, x in rec.items()})
+    v.close()
+
+
 def make_wrappers():
     """The reference's stateful vector wrappers on its own SyncVectorEnv: raw batches (inputs) and wrapped outputs.
 
@@ -417,6 +472,9 @@ if __name__ == "__main__":
     if "--wrappers-only" in sys.argv:
         make_wrappers()
         sys.exit(0)
+    if "--infos-only" in sys.argv:
+        make_same_step_infos()
+        sys.exit(0)
     print("reference gymnasium", gym.__version__, "numpy", np.__version__)
     make_rng()
     make_rollouts()
@@ -429,3 +487,4 @@ if __name__ == "__main__":
     make_toytext()
     make_wrappers()
     make_blackjack()
+    make_same_step_infos()

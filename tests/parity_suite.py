@@ -388,3 +388,59 @@ def check_blackjack(key, factory):
     with pytest.raises(AssertionError):
         env.step(np.full(8, 2))
     env.close()
+
+
+def check_same_step_infos(key, factory):
+    """SAME_STEP info dicts against the reference recording (tests/golden/infos_same_step_<key>.npz): the finished sub-env's top-level
+    entries are its RESET info, the finishing step's info sits under final_info with its own masks (sync_vector_env.py:302-319)."""
+    g = golden(f"infos_same_step_{key}.npz")
+    n = g["obs0"].shape[0]
+    env = gymnasium_amd.make_vec(TOYTEXT_IDS[key], num_envs=n, autoreset_mode="SameStep", _engine_factory=factory)
+    obs, _ = env.reset(seed=13)
+    assert np.array_equal(obs, g["obs0"])
+    env.action_space.seed(5)
+    finals = 0
+    for t in range(g["actions"].shape[0]):
+        a = env.action_space.sample()
+        assert np.array_equal(a, g["actions"][t])
+        o, r, te, tr, info = env.step(a)
+        assert np.array_equal(o, g["obs"][t]) and np.array_equal(r, g["reward"][t]) and np.array_equal(te, g["term"][t]) and np.array_equal(tr, g["trunc"][t]), t
+        assert np.array_equal(info["prob"], g["prob"][t]) and np.array_equal(info["_prob"], g["prob_mask"][t]), t
+        assert bool(np.issubdtype(info["prob"].dtype, np.integer)) == bool(g["prob_is_int"][t]), t
+        assert ("final_info" in info) == bool(g["has_final"][t]), t
+        if "action_mask" in g.files:
+            assert np.array_equal(info["action_mask"], g["action_mask"][t]), t
+        if g["has_final"][t]:
+            finals += 1
+            assert np.array_equal(info["_final_info"], g["final_mask"][t]) and np.array_equal(info["_final_obs"], g["final_mask"][t])
+            fo = np.array([-1 if x is None else int(x) for x in info["final_obs"]])
+            assert np.array_equal(fo, g["final_obs"][t]), t
+            fi = info["final_info"]
+            assert np.array_equal(fi["prob"], g["final_prob"][t]) and np.array_equal(fi["_prob"], g["final_prob_mask"][t]), t
+            assert fi["prob"].dtype == np.float64
+            if "final_action_mask" in g.files:
+                assert np.array_equal(fi["action_mask"], g["final_action_mask"][t]) and np.array_equal(fi["_action_mask"], g["final_action_mask_mask"][t]), t
+    assert finals > 0
+    env.close()
+
+
+def check_partial_reset_infos(factory):
+    """NEXT_STEP: an explicit reset of SOME sub-envs (options['reset_mask']) while another one is waiting for its autoreset step
+    (sync_vector_env.py:232-234 clears only the masked entries): the un-reset sub-env still supplies its reset info next step."""
+    g = golden("infos_partial_reset_frozenlake.npz")
+    n = g["actions"].shape[1]
+    env = gymnasium_amd.make_vec("FrozenLake-v1", num_envs=n, max_episode_steps=5, _engine_factory=factory)
+    env.reset(seed=3)
+    env.action_space.seed(9)
+    resets = list(g["reset_at"])
+    for t in range(g["actions"].shape[0]):
+        a = env.action_space.sample()
+        assert np.array_equal(a, g["actions"][t])
+        o, r, te, tr, info = env.step(a)
+        assert np.array_equal(o, g["obs"][t]) and np.array_equal(te, g["term"][t]) and np.array_equal(tr, g["trunc"][t]), t
+        assert np.array_equal(info["prob"], g["prob"][t]) and np.array_equal(info["_prob"], g["prob_mask"][t]), t
+        assert bool(np.issubdtype(info["prob"].dtype, np.integer)) == bool(g["prob_is_int"][t]), t
+        if t in resets:
+            ro, _ = env.reset(options={"reset_mask": g["reset_mask"]})
+            assert np.array_equal(ro, g["reset_obs"][resets.index(t)])
+    env.close()

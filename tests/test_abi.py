@@ -41,7 +41,7 @@ def test_struct_layouts_match_header():
 
     assert ctypes.sizeof(n.MiConfig) == 8 * 4 + 16 * 8
     assert ctypes.sizeof(n.MiLayout) == 8 * 4
-    assert ctypes.sizeof(n.MiStepIO) == 9 * 8
+    assert ctypes.sizeof(n.MiStepIO) == 10 * 8
     assert ctypes.sizeof(n.MiRolloutIO) == 6 * 8
     assert ctypes.sizeof(n.MiStats) == 5 * 8
 

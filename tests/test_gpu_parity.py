@@ -237,6 +237,15 @@ def test_blackjack_fused_rollout_and_full_size():
     a.close(), b.close()
 
 
+@pytest.mark.parametrize("key", ["frozenlake", "taxi"])
+def test_same_step_info_layout(key):
+    ps.check_same_step_infos(key, None)
+
+
+def test_partial_reset_during_pending_autoreset():
+    ps.check_partial_reset_infos(None)
+
+
 @pytest.mark.parametrize("key", ["frozenlake", "taxi", "cliffwalking_slippery"])
 def test_toytext_fused_rollout_and_full_size(key):
     import torch
