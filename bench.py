@@ -3,23 +3,41 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--env CartPole-v1] [--num-envs 65536] [--inner 128]
 
-Workload (BASELINE.json configs[1]): CartPole-v1, num_envs = 65536 PER GPU, random policy.  One bench "step" is one
-launch of the hot path over the whole batch: `rollout(inner)` = `inner` lockstep vector steps of all 65536
-sub-environments with the random policy `action_space.sample()` evaluated on device (bit-identical to the host
-policy) and the full trajectory (actions, observations, rewards, terminated, truncated) written to HBM.  Inputs are
-resident in HBM when the timed region starts; nothing crosses PCIe inside it.
+Primary workload (BASELINE.json configs[1]): CartPole-v1, num_envs = 65536 PER GPU, random policy.  One bench "step" is one
+launch of the hot path over the whole batch: `rollout(inner)` = `inner` lockstep vector steps of all sub-environments with the
+random policy `action_space.sample()` evaluated on device (bit-identical to the host policy) and the full trajectory (actions,
+observations, rewards, terminated, truncated) written to HBM.  Inputs are resident in HBM when the timed region starts; nothing
+crosses PCIe inside it.
 
-value = env-steps/s counted like the reference's benchmark_vector_step (gymnasium/utils/performance.py:88-90: NEXT_STEP
-autoreset steps are not counted), whole job over all ranks.  Also reported: the per-launch step() API with device
-tensors and the NumPy API (PCIe-inclusive) -- never as `value`.
+value = env-steps/s counted like the reference's benchmark_vector_step (gymnasium/utils/performance.py:88-90: NEXT_STEP autoreset
+steps are not counted), whole job over all ranks.  The same JSON line also carries (rank 0, --gpus 1):
 
-N > 1: one process per GPU (torchrun), each rank owns its own 65536 sub-environments (global indices
-rank*65536 ...; no data-path collective), one RCCL all-reduce of {env_steps, episodes, return_sum} at the end.
+  sustained_value   the same launch repeated for >= --sustained seconds (clock / thermal steady state; the K-step burst is ~2 ms)
+  secondary         BASELINE.json configs[2..4]: Pendulum / Acrobot / MountainCarContinuous @65536, Ant-v5 @32768 and @65536,
+                    Humanoid-v5 @32768 (per GPU), each with its own roofline and cpu_baseline
+  roofline          dominant kernel: HBM-bound classic kernels as algorithmic bytes / launch time vs 8 TB/s with `traffic` from
+                    rocprofv3 PMC passes run BY THIS COMMAND on a short child invocation (FETCH_SIZE x2 + WRITE_SIZE, separate
+                    passes); the cooperative MuJoCo kernels are VALU / latency bound: `bound: "valu"`, frac = SQ_ACTIVE_INST_VALU /
+                    SQ_WAVE_CYCLES of the same kind of pass, plus the scratch-inclusive traffic ratio
+  cpu_baseline      the C oracle (kind "port", 1 thread) on the host cores, bounded sample
+  cpu_reference     Gymnasium's own AsyncVectorEnv (num_envs = os.cpu_count()) / SyncVectorEnv / NumPy CartPoleVectorEnv timed in
+                    this run when `import gymnasium` works (GYM_REFERENCE or an installed package); the GPU box has neither, so there
+                    the numbers measured in the build container are carried as cpu_reference_recorded (hardware stated)
+  api_step_device / api_step_numpy   the per-launch step() API -- never `value`
+
+N > 1: one process per GPU (torchrun), each rank owns its own num_envs sub-environments (global indices rank*num_envs ...; no
+data-path collective), one RCCL all-reduce of {env_steps, episodes, return_sum} at the end.  BASELINE.json configs[4]
+(Humanoid-v5, 262144 envs over 8 GPUs) is `torchrun --nproc-per-node 8 bench.py --gpus 8 --env Humanoid-v5 --num-envs 32768 --inner 4`.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,15 +49,29 @@ sys.path.insert(0, ROOT)
 ROLLOUT_BYTES = {"CartPole-v1": 34, "Pendulum-v1": 26, "Acrobot-v1": 42, "MountainCar-v0": 26, "MountainCarContinuous-v0": 22}
 STATE_BYTES = {"CartPole-v1": 96, "Pendulum-v1": 64, "Acrobot-v1": 96, "MountainCar-v0": 64, "MountainCarContinuous-v0": 64}
 STEP_BYTES = {"CartPole-v1": 108, "Pendulum-v1": 68, "Acrobot-v1": 116, "MountainCar-v0": 68, "MountainCarContinuous-v0": 64}
-# MuJoCo family: which kernel dominates a rollout launch (Ant / Humanoid: `inner` x [mj_sample_kernel, mj_physics_kernel, mj_step_kernel];
-# the cooperative physics kernel is > 99 % of the time -- profiles/r01_k_ant_coop.txt)
-MJ_KERNEL = {"Ant-v5": "mj_physics_kernel", "Humanoid-v5": "mj_physics_kernel", "HumanoidStandup-v5": "mj_physics_kernel", "HalfCheetah-v5": "mj_physics_kernel"}
+# MuJoCo family on the cooperative kernel: a rollout launch = `inner` x [mj_sample_kernel, mj_physics_kernel, mj_step_kernel]; the
+# physics kernel is > 98 % of the time (profiles/r01_z_ant_coop_physics.txt)
+MJ_COOP = ("Ant-v5", "Humanoid-v5", "HumanoidStandup-v5", "HalfCheetah-v5")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# (env, num_envs per GPU, vector steps per launch, launches) of the secondary lines: BASELINE.json configs[2..4] + the north_star's Ant @65536
+SECONDARY = [("Pendulum-v1", 65536, 128, 20), ("Acrobot-v1", 65536, 128, 10), ("MountainCarContinuous-v0", 65536, 128, 20),
+             ("Ant-v5", 32768, 4, 6), ("Ant-v5", 65536, 4, 4), ("Humanoid-v5", 32768, 4, 3)]
+# the reference itself, measured in the build container (no gymnasium on the GPU box)
+CPU_REFERENCE_RECORDED = {
+    "hardware": "8 vCPU Intel Xeon @ 2.10 GHz (build container), Python 3.10.12, NumPy 2.2.6, reference gymnasium v1.4.0",
+    "how": "gymnasium.utils.performance.benchmark_vector_step, 2-3 s runs (BASELINE.md section 2)", "unit": "env-steps/s",
+    "AsyncVectorEnv CartPole-v1": {"num_envs=4": 10.0e3, "num_envs=8": 14.6e3, "num_envs=16": 16.8e3, "cores": 8},
+    "SyncVectorEnv CartPole-v1": {"num_envs=4": 51e3, "num_envs=64": 74e3, "num_envs=1024": 84e3, "cores": 1},
+    "NumPy CartPoleVectorEnv (vector_entry_point)": {"num_envs=1024": 7.3e6, "num_envs=65536": 13.7e6, "cores": 1},
+    "single env gym.make": {"CartPole-v1": 82e3, "MountainCar-v0": 70e3, "MountainCarContinuous-v0": 35e3, "Pendulum-v1": 20e3, "Acrobot-v1": 16e3, "cores": 1},
+    "MuJoCo ids": "unavailable: `mujoco` is not installed in the build container either",
+}
 
 
+# ---- CPU legs -----------------------------------------------------------------------------------------------------------------
 def cpu_baseline(env_id, num_envs, budget_s=12.0):
-    """The CPU oracle (C restatement of the reference's CartPole + SyncVectorEnv semantics, 1 thread) on the same workload,
-    bounded to ~budget_s of CPU time.  kind="port": the Python reference itself is not present on the GPU box."""
+    """The CPU oracle (C restatement of the reference's env + SyncVectorEnv semantics, 1 thread) on the same workload, bounded to
+    ~budget_s of CPU time.  kind="port": the Python reference itself is not present on the GPU box."""
     import gymnasium_amd
     from gymnasium_amd import _native
     from oracle import oracle
@@ -49,14 +81,14 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0):
     env.action_space.seed(0)
     eng = env._engine
     eng.action_seed(_native.pcg_words(env.action_space.np_random))
-    T = 4
+    T = 1 if env_id in MJ_COOP else 4
     obs = np.zeros((T, num_envs) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (T, num_envs, eng.obs_dim), eng.obs_dtype)
     rew, te, tr = np.zeros((T, num_envs)), np.zeros((T, num_envs), np.bool_), np.zeros((T, num_envs), np.bool_)
     acts = np.zeros((T, num_envs) if eng.act_dtype is np.int64 else (T, num_envs, eng.act_dim), dtype=eng.act_dtype)
     t0 = time.perf_counter()
     eng.rollout(T, None, acts, obs, rew, te, tr)
-    per_step = (time.perf_counter() - t0) / T
-    reps = max(1, int(budget_s / (per_step * T)))
+    per_call = time.perf_counter() - t0
+    reps = max(1, int(budget_s / per_call) - 1)
     eng.reset_stats()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -69,6 +101,184 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0):
                       "rollout (same random policy, same outputs materialised), 1 thread"}
 
 
+def cpu_reference(budget_s=4.0):
+    """Gymnasium's own vectorisers on this host's cores, if the package is importable (utils/performance.py:57-103).  Returns None
+    where it is not (the GPU box): the caller then carries the numbers recorded in the build container."""
+    ref = os.environ.get("GYM_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref, "gymnasium")) and ref not in sys.path:
+        sys.path.append(ref)
+    try:
+        import gymnasium as gym
+        from gymnasium.utils.performance import benchmark_vector_step
+    except Exception:
+        return None
+    cores = os.cpu_count() or 1
+    out = {"cores": cores, "unit": "env-steps/s", "gymnasium": gym.__version__, "how": f"benchmark_vector_step, target_duration={budget_s} s"}
+    for label, kw in ((f"AsyncVectorEnv CartPole-v1 num_envs={cores}", dict(num_envs=cores, vectorization_mode="async")),
+                      ("SyncVectorEnv CartPole-v1 num_envs=1024", dict(num_envs=1024, vectorization_mode="sync")),
+                      ("NumPy CartPoleVectorEnv num_envs=65536", dict(num_envs=65536, vectorization_mode="vector_entry_point"))):
+        try:
+            env = gym.make_vec("CartPole-v1", **kw)
+            out[label] = benchmark_vector_step(env, target_duration=budget_s, seed=0)
+            env.close()
+        except Exception as e:  # a missing optional dependency must not cost the GPU numbers
+            out[label] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
+# ---- live PMC passes (rocprofv3 on a short child invocation of this file) --------------------------------------------------------
+def _rocprof_counters(args, counters, kernel_like, timeout_s):
+    """Run `rocprofv3 --pmc <counters> -- python bench.py --child <args>` and return {counter: (avg value per dispatch, dispatches)} of
+    the kernels whose name contains `kernel_like`; None if rocprofv3 is absent or the pass fails."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--child", *args]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        dbs = sorted(glob.glob(tmp + "/**/*.db", recursive=True))
+        if not dbs:
+            return None
+        db = sqlite3.connect(dbs[-1])
+        rows = db.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by counter_name",
+                          (f"%{kernel_like}%",)).fetchall()
+        return {c: (float(v), int(n)) for c, v, n in rows} or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
+
+
+def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150):
+    """HBM traffic per dispatch of `kernel` (WRITE_SIZE + 2 FETCH_SIZE, in KiB on gfx950; MI355X_MICROARCH.md HBM section: separate
+    passes, FETCH_SIZE doubled) and, for the VALU-bound kernels, the SQ activity counters as shares of SQ_WAVE_CYCLES."""
+    args = ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", "1"]
+    out = {}
+    if want_traffic:
+        f = _rocprof_counters(args, ["FETCH_SIZE"], kernel, timeout_s)
+        w = _rocprof_counters(args, ["WRITE_SIZE"], kernel, timeout_s) if f else None
+        if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
+            out["traffic"] = 1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0])
+            out["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, FETCH_SIZE doubled) on a child invocation in this run, "
+                                     f"{f['FETCH_SIZE'][1]} dispatches of {kernel}")
+    if want_sq:
+        sq = _rocprof_counters(args, SQ_COUNTERS, kernel, timeout_s)
+        if sq and sq.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
+            wc = sq["SQ_WAVE_CYCLES"][0]
+            out["sq"] = {k[3:].lower() + "_frac": sq[k][0] / wc for k in SQ_COUNTERS[1:] if k in sq}
+            out["sq_source"] = "rocprofv3 --pmc " + " ".join(SQ_COUNTERS) + " on a child invocation in this run"
+    return out
+
+
+def recorded_traffic(env_id, N, inner):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path)).get(f"{env_id}:{N}:{inner}")
+    except Exception:
+        return None
+
+
+# ---- one configuration on this rank's GPU --------------------------------------------------------------------------------------
+class Config:
+    def __init__(self, env_id, N, inner, local_rank, rank):
+        import torch
+
+        import gymnasium_amd
+        from gymnasium_amd import _native
+
+        self.torch, self.env_id, self.N, self.inner = torch, env_id, N, inner
+        dev = torch.device("cuda", local_rank)
+        env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", env_index_offset=rank * N)
+        env.reset(seed=0)
+        env.action_space.seed(rank)
+        eng = env._engine
+        self.env, self.eng = env, eng
+        # preallocated trajectory buffers, reused every launch (a real collector would hand them to the learner)
+        act_dtype = torch.int64 if env._discrete else torch.float32
+        obs_dtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
+        self.acts = torch.empty((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=act_dtype, device=dev)
+        self.obs = torch.empty((inner, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
+        self.rew = torch.empty((inner, N), dtype=torch.float64, device=dev)
+        self.te = torch.empty((inner, N), dtype=torch.bool, device=dev)
+        self.tr = torch.empty((inner, N), dtype=torch.bool, device=dev)
+        env._bind_stream()
+        eng.action_seed(_native.pcg_words(env.action_space.np_random))
+
+    def launch(self):
+        self.eng.rollout(self.inner, None, self.acts.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(), self.te.data_ptr(), self.tr.data_ptr())
+
+    def timed(self, K, sync):
+        """K launches between two HIP events on the engine's stream (env._bind_stream() = torch's current stream).  One event on either
+        side: an event after every launch would put a marker packet between the kernels (+9 us per 96 us launch, measured)."""
+        t = self.torch
+        ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        sync()
+        self.eng.reset_stats()
+        sync()
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(K):
+            self.launch()
+        ev1.record()
+        sync()
+        elapsed = time.perf_counter() - t0
+        return elapsed, ev0.elapsed_time(ev1) * 1e-3 / K, self.env.statistics()
+
+    def algorithmic_bytes_per_launch(self):
+        eng, env = self.eng, self.env
+        if self.env_id in ROLLOUT_BYTES:
+            per_step, per_launch = ROLLOUT_BYTES[self.env_id], STATE_BYTES[self.env_id]
+        else:  # float32 / int64 action row + obs row + reward + 2 flags per env-step
+            per_step = (8 if env._discrete else 4 * eng.act_dim) + (8 if eng.obs_dtype is not np.float32 else 4) * eng.obs_dim + 8 + 2
+            per_launch = 2 * (8 * eng.state_dim + 4 + 8 + 4)
+            if self.env_id in MJ_COOP:  # every vector step is its own set of launches: the state row is read and written per step
+                per_step, per_launch = per_step + per_launch, 0
+        return (per_step * self.inner + per_launch) * self.N
+
+    def dominant_kernel(self):
+        if self.env_id in ROLLOUT_BYTES:
+            return "rollout_kernel"
+        if self.eng.obs_dtype is np.int64:
+            return "tab_rollout_kernel"
+        return "mj_physics_kernel" if self.env_id in MJ_COOP else "mj_rollout_kernel"
+
+    def roofline(self, kernel_s, pmc=()):
+        """kernel_s = average duration of one rollout launch; pmc = which live counter passes to run ("traffic", "sq").  HBM-bound kernels: algorithmic bytes per launch / kernel_s against
+        8 TB/s.  The cooperative MuJoCo kernels are VALU / latency bound (one wavefront per SIMD): frac is the
+        measured share of wave cycles that issue VALU work, and the HBM side is reported as a traffic ratio."""
+        algo = self.algorithmic_bytes_per_launch()
+        achieved = algo / kernel_s / 1e9
+        kernel = self.dominant_kernel()
+        coop = self.env_id in MJ_COOP
+        per = self.inner if coop else 1  # dispatches of the dominant kernel per rollout launch
+        live = live_counters(self.env_id, self.N, self.inner, kernel, "traffic" in pmc, "sq" in pmc and coop) if pmc else {}
+        traffic, src = live.get("traffic"), live.get("traffic_source")
+        if traffic is not None:
+            traffic *= per
+        else:
+            traffic, src = recorded_traffic(self.env_id, self.N, self.inner), "profiles/pmc_traffic.json (recorded by an earlier rocprofv3 run of the same command; no live pass in this run)"
+            if traffic is None:
+                src = None
+        base = {"kernel": kernel, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": kernel_s * 1e3,
+                "traffic_over_algorithmic": (traffic / algo) if traffic else None}
+        if coop:
+            sq = live.get("sq")
+            return {"bound": "valu", "achieved": (sq or {}).get("active_inst_valu_frac"), "peak": 1.0, "unit": "share of wave cycles issuing VALU instructions (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), one wavefront per SIMD",
+                    "frac": (sq or {}).get("active_inst_valu_frac"), "sq": sq, "sq_source": live.get("sq_source"), "hbm_frac": achieved / HBM_PEAK_GBS,
+                    "avg_vector_step_ms": kernel_s * 1e3 / self.inner, **base}
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **base}
+
+    def close(self):
+        self.env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,13 +287,17 @@ def main():
     ap.add_argument("--env", default="CartPole-v1")
     ap.add_argument("--num-envs", type=int, default=65536, help="sub-environments PER GPU")
     ap.add_argument("--inner", type=int, default=128, help="vector steps fused into one launch (one bench step)")
+    ap.add_argument("--sustained", type=float, default=1.5, help="seconds of back-to-back launches for sustained_value (0 = skip)")
+    ap.add_argument("--pmc", choices=["auto", "full", "off"], default="auto",
+                    help="live rocprofv3 counter passes on a child invocation: auto = primary traffic + SQ activity of the MuJoCo secondaries, "
+                         "full = traffic for every line, off = recorded values only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-api", action="store_true", help="skip the secondary per-launch step() API measurements")
+    ap.add_argument("--no-api", action="store_true", help="skip the per-launch step() API measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (BASELINE.json configs[2..4])")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
     args = ap.parse_args()
 
     import torch
-
-    import gymnasium_amd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,77 +312,37 @@ def main():
     dev = torch.device("cuda", local_rank)
     N, K, W, inner = args.num_envs, args.steps, args.warmup, args.inner
 
-    env = gymnasium_amd.make_vec(args.env, num_envs=N, device=local_rank, output="torch", env_index_offset=rank * N)
-    env.reset(seed=0)
-    env.action_space.seed(rank)
-    eng = env._engine
-
-    # preallocated trajectory buffers, reused every step (a real collector would hand them to the learner)
-    from gymnasium_amd import _native
-
-    act_dtype = torch.int64 if env._discrete else torch.float32
-    obs_dtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
-    acts = torch.empty((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=act_dtype, device=dev)
-    obs = torch.empty((inner, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
-    rew = torch.empty((inner, N), dtype=torch.float64, device=dev)
-    te = torch.empty((inner, N), dtype=torch.bool, device=dev)
-    tr = torch.empty((inner, N), dtype=torch.bool, device=dev)
-    env._bind_stream()
-    eng.action_seed(_native.pcg_words(env.action_space.np_random))
-
-    def one_step():
-        eng.rollout(inner, None, acts.data_ptr(), obs.data_ptr(), rew.data_ptr(), te.data_ptr(), tr.data_ptr())
-
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def sync_local():
+        torch.cuda.synchronize()
+
+    cfg = Config(args.env, N, inner, local_rank, rank)
     for _ in range(W):
-        one_step()
-    sync_all()
-    eng.reset_stats()
-    # One HIP event on either side of the K launches, on the stream they are queued on (env._bind_stream() = torch's current stream):
-    # the average launch duration is their distance / K.  (An event after every launch would put a marker packet between the kernels:
-    # measured +9 us per 96 us launch, which rocprofv3's kernel trace does not see.)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sync_all()
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(K):
-        one_step()
-    ev1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    st = env.statistics()
-    kernel_ms = [ev0.elapsed_time(ev1) / K]
+        cfg.launch()
+    if args.child:
+        for _ in range(K):
+            cfg.launch()
+        torch.cuda.synchronize()
+        cfg.close()
+        return
+    elapsed, kernel_s, st = cfg.timed(K, sync_all)
     from gymnasium_amd import distributed as gd
 
     red = gd.reduce_statistics(st, elapsed_s=elapsed, device=dev)  # the only collective: a few dozen bytes over RCCL/xGMI
     elapsed = red["elapsed_s"]
     env_steps, episodes, return_sum = float(red["env_steps"]), float(red["episodes"]), float(red["return_sum"])
+    single = rank == 0 and world == 1
+    pmc_primary = ("traffic", "sq") if (single and args.pmc != "off") else ()
 
     result = None
     if rank == 0:
-        value = env_steps / elapsed
-        avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-        if args.env in ROLLOUT_BYTES:
-            rollout_b, state_b = ROLLOUT_BYTES[args.env], STATE_BYTES[args.env]
-        else:  # MuJoCo family: float32 action row + float64 obs row + reward + 2 flags per env-step; state row R+W per launch
-            rollout_b = (8 if env._discrete else 4 * eng.act_dim) + 8 * eng.obs_dim + 8 + 2
-            state_b = 2 * (8 * eng.state_dim + 4 + 8 + 4)
-        bytes_per_launch = (rollout_b * inner + state_b) * N
-        achieved = bytes_per_launch / avg_kernel_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.env}:{N}:{inner}")
-            except Exception:
-                traffic = None
         result = {
             "metric": "env-steps/sec at num_envs=65536 (1/2/4/8 MI355X) vs CPU AsyncVectorEnv",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.env} num_envs={N} per GPU, random policy (on-device action_space.sample()), "
@@ -177,13 +351,24 @@ def main():
                        "env": args.env, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
                        "parallelism": f"env-sharded x{world} (no data-path collective)"},
             "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
-            "roofline": {"bound": "hbm", "kernel": "rollout_kernel" if args.env in ROLLOUT_BYTES else ("tab_rollout_kernel" if eng.obs_dtype is np.int64 else MJ_KERNEL.get(args.env, "mj_rollout_kernel")), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3},
         }
 
-    # ---- secondary numbers (rank 0, N=1 only): per-launch step() API ---------------------------------------
-    if rank == 0 and world == 1 and not args.no_api:
+    # ---- sustained: the same launch back to back for >= args.sustained seconds (all ranks, same barrier discipline) ----------------
+    if args.sustained > 0:
+        Ks = max(K, int(args.sustained / max(kernel_s, 1e-7)) + 1)
+        el_s, k_s, st_s = cfg.timed(Ks, sync_all)
+        red_s = gd.reduce_statistics(st_s, elapsed_s=el_s, device=dev)
+        if rank == 0:
+            result["sustained_value"] = float(red_s["env_steps"]) / red_s["elapsed_s"]
+            result["sustained"] = {"launches": Ks, "seconds": red_s["elapsed_s"], "avg_kernel_ms": k_s * 1e3}
+    if rank == 0:
+        result["roofline"] = cfg.roofline(kernel_s, pmc_primary)
+
+    # ---- the per-launch step() API (rank 0, one GPU): device tensors and the NumPy path ----------------------------------------------
+    if single and not args.no_api:
+        import gymnasium_amd
+
+        env, eng = cfg.env, cfg.eng
         a_dev = torch.randint(0, 2, (N,), device=dev) if env._discrete else (torch.rand((N, eng.act_dim), device=dev) * 0.8 - 0.4)
         env.copy = False
         for _ in range(20):
@@ -205,23 +390,55 @@ def main():
         env_np = gymnasium_amd.make_vec(args.env, num_envs=N, device=local_rank, copy=False)
         env_np.reset(seed=0)
         env_np.action_space.seed(0)
-        for _ in range(5):
-            env_np.step(env_np.action_space.sample())
+        actions = [env_np.action_space.sample() for _ in range(8)]
         t0 = time.perf_counter()
+        for _ in range(40):
+            env_np.action_space.sample()
+        sample_us = (time.perf_counter() - t0) / 40 * 1e6
+        for k in range(5):
+            env_np.step(actions[k % 8])
         reps = 100
-        for _ in range(reps):
-            env_np.step(env_np.action_space.sample())
+        t0 = time.perf_counter()
+        for k in range(reps):
+            env_np.step(actions[k % 8])
         dt = time.perf_counter() - t0
-        result["api_step_numpy"] = {"value": N * reps / dt, "unit": "vector-env lanes/s (NumPy in/out over PCIe, host action sampling)",
-                                    "us_per_step_wall": dt / reps * 1e6}
+        result["api_step_numpy"] = {"value": N * reps / dt, "unit": "vector-env lanes/s (NumPy in / NumPy out over PCIe; host action sampling excluded)",
+                                    "us_per_step_wall": dt / reps * 1e6, "host_action_space_sample_us": sample_us}
         env_np.close()
+    cfg.close()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.env, N)
-    elif rank == 0:
-        result["cpu_baseline"] = None
+    # ---- secondary configurations (rank 0, one GPU) -------------------------------------------------------------------------------------
+    if single and not args.no_secondary and args.env == "CartPole-v1":
+        result["secondary"] = []
+        for env_id, n2, inner2, k2 in SECONDARY:
+            c2 = Config(env_id, n2, inner2, local_rank, 0)
+            for _ in range(2):
+                c2.launch()
+            el2, ks2, st2 = c2.timed(k2, sync_local)
+            line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": st2["env_steps"] / el2,
+                    "unit": "env-steps/s", "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64"}
+            if args.sustained > 0:
+                ks_n = max(k2, int(min(args.sustained, 1.0) / max(ks2, 1e-7)) + 1)
+                el3, _, st3 = c2.timed(ks_n, sync_local)
+                line["sustained_value"] = st3["env_steps"] / el3
+            # auto: one SQ-activity pass for the VALU-bound MuJoCo kernels (their traffic ratio from the recorded profile); full: everything live
+            want = ("traffic", "sq") if args.pmc == "full" else (("sq",) if (args.pmc == "auto" and env_id in MJ_COOP) else ())
+            line["roofline"] = c2.roofline(ks2, want)
+            c2.close()
+            if not args.no_cpu_baseline:  # MuJoCo: a 512-env sample (the oracle's per-env cost does not depend on the batch size)
+                line["cpu_baseline"] = cpu_baseline(env_id, 512 if env_id in MJ_COOP else n2, budget_s=3.0)
+            result["secondary"].append(line)
 
-    env.close()
+    # ---- CPU legs: the oracle port on rank 0 (every N), the reference's own vectorisers where importable -------------------------------
+    if rank == 0:
+        result["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.env, 512 if args.env in MJ_COOP else N)
+        if not args.no_cpu_baseline and world == 1:
+            ref = cpu_reference()
+            if ref is not None:
+                result["cpu_reference"] = ref
+            else:
+                result["cpu_reference"] = None
+                result["cpu_reference_recorded"] = CPU_REFERENCE_RECORDED
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -46,17 +46,28 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every stale translation unit to an object file (hipcc, gfx950 only) and link libmi355env.so."""
+OUT_REF = os.path.join(HERE, "libmi355env_ref.so")
+
+
+def build(force: bool = False, verbose: bool = True, reference_scheduler: bool = False) -> str:
+    """Compile every stale translation unit to an object file (hipcc, gfx950 only) and link libmi355env.so.
+
+    ``reference_scheduler=True`` builds libmi355env_ref.so instead: the SAME sources with hipcc's default instruction scheduler in every
+    translation unit (no TU_FLAGS).  It is test infrastructure for tests/test_gpu_scheduler_guard.py, which requires the shipped
+    (iterative-scheduler) cooperative kernels to be bit-identical to it -- the guard against the miscompile described above."""
     generate_models()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs, relink = [], force or not os.path.exists(OUT)
+    out = OUT_REF if reference_scheduler else OUT
+    objs, relink = [], force or not os.path.exists(out)
     jobs = []
     for src, headers in SOURCES.items():
-        obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
+        tu_flags = [] if reference_scheduler else TU_FLAGS.get(src, [])
+        # translation units whose flags do not differ between the two builds share one object file
+        suffix = "_ref.o" if (reference_scheduler and TU_FLAGS.get(src)) else ".o"
+        obj = os.path.join(HERE, os.path.splitext(src)[0] + suffix)
         objs.append(obj)
         if force or _stale(obj, [src, "build.py"] + headers):
-            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *TU_FLAGS.get(src, []), *os.environ.get("MI355ENV_HIPCC_FLAGS", "").split(), "-c", "-o", obj,
+            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *tu_flags, *os.environ.get("MI355ENV_HIPCC_FLAGS", "").split(), "-c", "-o", obj,
                    os.path.join(HERE, src)]
             if verbose:
                 print(" ".join(cmd), flush=True)
@@ -65,14 +76,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for cmd, proc in jobs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    if relink or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs
+    if relink or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=HERE)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    print(build(force="--force" in sys.argv))
+    if "--ref" in sys.argv:
+        print(build(force="--force" in sys.argv, reference_scheduler=True))
