@@ -899,6 +899,96 @@ MJX_DEV int solve_newton(Data<M> &d) {
     return it;
 }
 
+// ---- dual projected Gauss-Seidel (humanoid.xml:8 `solver="PGS" iterations="50"`) ----------------------------------------------
+// The same rows as solve_newton, solved the way mj_solPGS does: forces f >= 0 of the unilateral rows (limits, frictionless contacts,
+// pyramid edges) are relaxed one at a time in row order, f_r <- max(0, f_r - res_r / AR_rr) with res = (J M^-1 J^T + R) f + b, for at most
+// M::ITERATIONS sweeps or until the scaled cost improvement of a sweep drops below the tolerance (1e-8).  Matrix-free in acceleration
+// space: a = qacc_smooth + M^-1 J^T f is carried along, so res_r = J_r a - aref_r + R_r f_r and a row update adds (M^-1 J_r^T) delta.
+// Warm start (mj's dual warmstart): forces implied by qacc_warmstart, dropped for zero if their dual cost is positive.
+// d.qL must hold the Cholesky factor of M and d.qacc_smooth the unconstrained acceleration.  One-lane cross-check of mjx_coop.h pgs().
+template <class M>
+MJX_DEV int solve_pgs(Data<M> &d) {
+    constexpr int NV = M::NV, MAXROW = M::NJNT + 4 * Data<M>::MAXCON;
+    double aref[MAXROW], jar[MAXROW], Rr[MAXROW], f[MAXROW], b[MAXROW], ARd[MAXROW];
+    double MiJT[MAXROW][NV];
+    RowView<M>::for_each(d, aref, [&](int r, double D, double, const double *J) {
+        Rr[r] = 1.0 / D;
+        if (r < d.nlimit) {
+            aref[r] = d.lim_aref[r];
+        } else {
+            double v = 0;
+#pragma unroll
+            for (int i = 0; i < NV; i++) v += J[i] * d.qvel[i];
+            jar[r] = v;  // stash J qvel
+        }
+    });
+    int nrow = d.nlimit;
+    for (int c = 0; c < d.ncon; c++) {
+        const int rows = M::pair_condim[d.con[c].pair] == 1 ? 1 : 4;
+        for (int e = 0; e < rows; e++, nrow++) aref[nrow] = -d.con_force[c][0] * jar[nrow] + d.con_aref[c];
+    }
+    double a[NV], qfrc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) a[i] = 0, qfrc[i] = 0;
+    double cost = 0;
+    RowView<M>::for_each(d, aref, [&](int r, double D, double ar, const double *J) {
+        double js = -ar, jw = -ar, diag = 0;
+#pragma unroll
+        for (int i = 0; i < NV; i++) MiJT[r][i] = J[i];
+        chol_solve<NV>(d.qL, MiJT[r]);
+#pragma unroll
+        for (int i = 0; i < NV; i++) js += J[i] * d.qacc_smooth[i], jw += J[i] * d.qacc_warm[i], diag += J[i] * MiJT[r][i];
+        b[r] = js, ARd[r] = diag + Rr[r];
+        f[r] = jw < 0 ? -D * jw : 0.0;  // mj_constraintUpdate at qacc_warmstart
+        cost += f[r] * (0.5 * Rr[r] * f[r] + b[r]);
+#pragma unroll
+        for (int i = 0; i < NV; i++) a[i] += MiJT[r][i] * f[r], qfrc[i] += J[i] * f[r];
+    });
+#pragma unroll
+    for (int i = 0; i < NV; i++) cost += 0.5 * qfrc[i] * a[i];  // f' J M^-1 J' f
+    if (cost > 0) {
+        for (int r = 0; r < nrow; r++) f[r] = 0;
+#pragma unroll
+        for (int i = 0; i < NV; i++) a[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) a[i] += d.qacc_smooth[i];
+    const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
+    int it = 0;
+    for (; it < M::ITERATIONS;) {
+        double improvement = 0;
+        RowView<M>::for_each(d, aref, [&](int r, double, double ar, const double *J) {
+            double res = Rr[r] * f[r] - ar;
+#pragma unroll
+            for (int i = 0; i < NV; i++) res += J[i] * a[i];
+            double nw = f[r] - res / ARd[r];
+            nw = nw < 0 ? 0.0 : nw;
+            const double delta = nw - f[r];
+            f[r] = nw;
+            improvement -= delta * (0.5 * delta * ARd[r] + res);
+#pragma unroll
+            for (int i = 0; i < NV; i++) a[i] += MiJT[r][i] * delta;
+        });
+        it++;
+        if (improvement * scale < 1e-8) break;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) d.qacc[i] = a[i], d.qfrc_constraint[i] = 0;
+    RowView<M>::for_each(d, aref, [&](int r, double, double, const double *J) {
+        if (f[r] != 0.0)
+#pragma unroll
+            for (int i = 0; i < NV; i++) d.qfrc_constraint[i] += J[i] * f[r];
+    });
+    for (int n = 0; n < d.nlimit; n++) d.lim_force[n] = f[n];
+    int row = d.nlimit;
+    for (int c = 0; c < d.ncon; c++) {
+        const int rows = M::pair_condim[d.con[c].pair] == 1 ? 1 : 4;
+        for (int e = 0; e < 4; e++) d.con_force[c][e] = e < rows ? f[row + e] : 0.0;
+        row += rows;
+    }
+    return it;
+}
+
 // ---- fluid forces of the medium (option density / viscosity), MuJoCo's inertia-box model ---------------------------------
 // Every body is replaced by the box with its mass and principal moments (M::body_fluidbox, axes M::body_imat); in that frame,
 // at the body's centre of mass, the velocity (w, v) gives  viscous: t -= pi d^3 mu w, f -= 3 pi d mu v  (d = mean edge) and
@@ -951,7 +1041,10 @@ MJX_DEV void fluid(const Data<M> &d, double *qfrc) {
 }
 
 // ---- forward dynamics -------------------------------------------------------------------------------------------------
-template <class M>
+// PGS: the reference's solver choice for this model (M::SOLVER, humanoid.xml:8); false = the primal Newton method for every model.
+// With PGS the warm start follows MuJoCo's rule -- qacc_warmstart is what the previous mj_step left (saved after the integrator), the
+// same for every RK4 stage -- so forward() does not touch d.qacc_warm; step() does.
+template <class M, bool PGS = (M::SOLVER == 1)>
 MJX_DEVN void forward(Data<M> &d) {
     constexpr int NV = M::NV;
     kinematics<M>(d);
@@ -988,11 +1081,17 @@ MJX_DEVN void forward(Data<M> &d) {
         chol_solve<NV>(d.qL, d.qacc_smooth);
 #pragma unroll
         for (int i = 0; i < NV; i++) d.qacc[i] = d.qacc_smooth[i], d.qfrc_constraint[i] = 0;
+    } else if constexpr (PGS) {
+        chol_factor<NV>(d.qM, d.qL);
+        chol_solve<NV>(d.qL, d.qacc_smooth);
+        solve_pgs<M>(d);
     } else {  // constrained: Newton from the warm start, M is never factorised by itself (see mjx_coop.h forward())
         solve_newton<M>(d);
     }
+    if constexpr (!PGS) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) d.qacc_warm[i] = d.qacc[i];
+        for (int i = 0; i < NV; i++) d.qacc_warm[i] = d.qacc[i];
+    }
 }
 
 template <class M>
@@ -1014,11 +1113,11 @@ MJX_DEV void integrate_pos(double *qpos, const double *qvel, double h) {
 }
 
 // one mj_step: forward + integrator (semi-implicit Euler with implicit joint damping, or RK4)
-template <class M>
+template <class M, bool PGS = (M::SOLVER == 1)>
 MJX_DEV void step(Data<M> &d) {
     constexpr int NV = M::NV, NQ = M::NQ;
     constexpr double h = M::TIMESTEP;
-    forward<M>(d);
+    forward<M, PGS>(d);
     if (M::INTEGRATOR == 0) {
         double qacc[NV];
         bool damped = false;
@@ -1055,7 +1154,7 @@ MJX_DEV void step(Data<M> &d) {
             integrate_pos<M>(d.qpos, dv, h);
 #pragma unroll
             for (int k = 0; k < NV; k++) d.qvel[k] = v0[k] + h * da[k];
-            forward<M>(d);
+            forward<M, PGS>(d);
 #pragma unroll
             for (int k = 0; k < NV; k++) Fv[i][k] = d.qvel[k], Fa[i][k] = d.qacc[k];
         }
@@ -1068,6 +1167,10 @@ MJX_DEV void step(Data<M> &d) {
 #pragma unroll
         for (int k = 0; k < NV; k++) d.qvel[k] = v0[k] + h * da[k];
         integrate_pos<M>(d.qpos, dv, h);
+    }
+    if constexpr (PGS) {  // mj_advance: "save qacc for next step warmstart" -- the last forward pass's qacc, once per step
+#pragma unroll
+        for (int i = 0; i < NV; i++) d.qacc_warm[i] = d.qacc[i];
     }
 }
 

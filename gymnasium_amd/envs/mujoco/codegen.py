@@ -41,7 +41,7 @@ def emit_model(m) -> str:
     s = f"struct {STRUCT[m.name]} {{\n"
     s += (f"    static constexpr int NQ = {m.nq}, NV = {nv}, NU = {nu}, NBODY = {nb}, NJNT = {nj}, NGEOM = {ng}, NPAIR = {npair}, "
           f"MAXCHAIN = {maxdepth};\n")
-    s += f"    static constexpr int INTEGRATOR = {1 if m.integrator == 'RK4' else 0}, SOLVER = {1 if m.solver == 'PGS' else 0}, ITERATIONS = {m.iterations};\n"
+    s += f"    static constexpr int INTEGRATOR = {1 if m.integrator == 'RK4' else 0}, SOLVER = {1 if m.reference_solver == 'PGS' else 0}, ITERATIONS = {m.iterations};\n"
     s += f"    static constexpr double TIMESTEP = {float(m.timestep).hex()}, MEANINERTIA = {float(m.meaninertia).hex()};\n"
     s += f"    static constexpr double DENSITY = {float(m.density).hex()}, VISCOSITY = {float(m.viscosity).hex()};  // fluid (inertia-box model)\n"
     s += _arr("gravity", "double", m.gravity, (3,))

@@ -88,11 +88,11 @@ class CompiledModel:
         return f"<CompiledModel {self.name} nq={self.nq} nv={self.nv} nu={self.nu} nbody={self.nbody} ngeom={self.ngeom} npair={len(self.pair_geom1)}>"
 
 
-def compile_model(desc, faithful_solver: bool = False) -> CompiledModel:
-    """``faithful_solver=False`` (default): constraints are always solved to convergence with the primal Newton method, also for
-    the humanoid, whose MJCF asks for ``solver="PGS" iterations="50"`` (humanoid.xml:8).  Both solvers minimise the same
-    convex cost; PGS truncated at 50 sweeps leaves a ~1e-4 relative residual that is a property of that solver run, not of
-    the model.  ``faithful_solver=True`` keeps PGS/50 (CPU oracle only; used to measure that residual in the tests)."""
+def compile_model(desc, faithful_solver: bool = True) -> CompiledModel:
+    """``faithful_solver=True`` (default): the constraint solver is the one the MJCF asks for -- ``solver="PGS" iterations="50"`` for
+    the two humanoids (humanoid.xml:8), MuJoCo's default Newton for everything else.  ``faithful_solver=False`` solves every model
+    to convergence with the primal Newton method (the opt-in ``solver="Newton"`` of the humanoid envs): both minimise the same convex
+    cost, PGS truncated at 50 sweeps leaves a ~1e-5 relative residual in qacc that belongs to that solver run, not to the model."""
     if isinstance(desc, str):
         desc = _models.MODELS[desc]()
     m = CompiledModel()

@@ -108,9 +108,13 @@ typedef struct mi_config {
     int32_t num_envs;            /* N >= 1 (sub-environments owned by THIS device / rank) */
     int32_t max_episode_steps;   /* TimeLimit (wrappers/common.py:116-150); <= 0 disables truncation */
     int32_t autoreset_mode;      /* mi_autoreset_mode */
-    int32_t reserved[3];
+    int32_t reserved[3];         /* reserved[0]: option bits (MI_CFG_*), the others 0 */
     double params[16];
 } mi_config;
+/* mi_config.reserved[0] bits.  MI_CFG_SOLVER_NEWTON: the MuJoCo kinds whose MJCF asks for `solver="PGS" iterations="50"` (HUMANOID,
+ * HUMANOID_STANDUP: assets/humanoid.xml:8) run that solver by default; this bit selects the converged primal Newton solver instead (the
+ * same convex problem solved to 1e-10 -- a deliberate, faster deviation from the reference, opt-in only). */
+#define MI_CFG_SOLVER_NEWTON 1
 
 typedef struct mi_layout {
     int32_t obs_dim;      /* observation row length (elements) */

@@ -960,7 +960,10 @@ void mjo_forward(const mjo_model *m, mjo_data *d) {
     } else {
         solve_newton(m, d);
     }
-    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+    /* Newton (converged): the next pass starts from this one's solution.  PGS is truncated, so its iterates depend on the start: there
+     * MuJoCo's rule is kept exactly -- qacc_warmstart is saved once per mj_step, after the integrator (mj_advance), and every forward
+     * pass of an RK4 step (and a bare mj_forward) starts from that same vector. */
+    if (m->solver != MJO_PGS) memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
 }
 
 /* ---- integration ---------------------------------------------------------------------------------------------- */
@@ -1030,6 +1033,7 @@ void mjo_step(const mjo_model *m, mjo_data *d, int nstep) {
             rk4(m, d);
         else
             euler(m, d);
+        if (m->solver == MJO_PGS) memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * m->nv); /* mj_advance: save qacc for the next step's warm start */
     }
 }
 

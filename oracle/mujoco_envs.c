@@ -133,9 +133,14 @@ static void tendon_info(const orc_mjenv *e, double *cols) {
 int orc_mjenv_state_dim(int which) { return g_models[which]->nq + 2 * g_models[which]->nv + 2; }
 
 /* ---- per-env glue ----------------------------------------------------------------------------------------------- */
-orc_mjenv *orc_mjenv_create(int which) {
+orc_mjenv *orc_mjenv_create(int which, int force_newton) {
     orc_mjenv *e = (orc_mjenv *)calloc(1, sizeof *e);
     e->which = which, e->m = g_models[which];
+    if (force_newton && g_models[which]->solver != MJO_NEWTON) { /* the humanoid envs' solver="Newton" opt-in */
+        e->own = (mjo_model *)malloc(sizeof(mjo_model));
+        memcpy(e->own, g_models[which], sizeof(mjo_model));
+        e->own->solver = MJO_NEWTON, e->m = e->own;
+    }
     mjo_reset_data(e->m, &e->d);
     return e;
 }

@@ -10,6 +10,7 @@ enum { ORC_MJ_HALF_CHEETAH = 0, ORC_MJ_ANT = 1, ORC_MJ_HUMANOID = 2, ORC_MJ_HOPP
 typedef struct orc_mjenv {
     int which;
     const mjo_model *m;
+    mjo_model *own; /* private copy of the model when the env overrides the solver (solver="Newton" opt-in), else NULL */
     mjo_data d;
     double track_override[2];
     int has_override;
@@ -22,7 +23,7 @@ const mjo_model *orc_mj_model(int which);
 int orc_mjenv_obs_dim(int which, const double *params);
 int orc_mjenv_info_dim(int which);
 int orc_mjenv_state_dim(int which);
-orc_mjenv *orc_mjenv_create(int which);
+orc_mjenv *orc_mjenv_create(int which, int force_newton);
 void orc_mjenv_obs(const orc_mjenv *e, const double *params, double *obs);
 void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *params);
 void orc_mjenv_step(orc_mjenv *e, const float *action, const double *params, double *reward, int *terminated, double *info);

@@ -44,7 +44,10 @@ def test_reset_bit_exact_and_windowed_parity(name, oracle_factory):
         worst, worst_r = max(worst, float(np.abs(og - oc).max())), max(worst_r, float(np.abs(rg - rc).max()))
         np.testing.assert_allclose(og, oc, rtol=1e-5, atol=1e-5, err_msg=f"{name} obs t={t}")
         np.testing.assert_allclose(rg, rc, rtol=1e-5, atol=1e-5, err_msg=f"{name} reward t={t}")
+        assert set(ig) == set(ic), f"{name} t={t}: info keys differ"  # a key no sub-env supplied this step does not appear at all
         for k in FIRST_INFO.get(name, ("x_position", "x_velocity", "reward_forward", "reward_ctrl")):
+            if k not in ic:
+                continue
             np.testing.assert_allclose(ig[k], ic[k], rtol=1e-5, atol=1e-5, err_msg=k)
             assert np.array_equal(ig["_" + k], ic["_" + k])
         if (t + 1) % window == 0:
