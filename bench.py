@@ -156,10 +156,10 @@ def _rocprof_counters(args, counters, kernel_like, timeout_s):
 SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
 
 
-def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150):
+def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150, env_kwargs=None):
     """HBM traffic per dispatch of `kernel` (WRITE_SIZE + 2 FETCH_SIZE, in KiB on gfx950; MI355X_MICROARCH.md HBM section: separate
     passes, FETCH_SIZE doubled) and, for the VALU-bound kernels, the SQ activity counters as shares of SQ_WAVE_CYCLES."""
-    args = ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", "1"]
+    args = ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", "1", "--env-kwargs", json.dumps(env_kwargs or {})]
     out = {}
     if want_traffic:
         f = _rocprof_counters(args, ["FETCH_SIZE"], kernel, timeout_s)
@@ -187,15 +187,15 @@ def recorded_traffic(env_id, N, inner):
 
 # ---- one configuration on this rank's GPU --------------------------------------------------------------------------------------
 class Config:
-    def __init__(self, env_id, N, inner, local_rank, rank):
+    def __init__(self, env_id, N, inner, local_rank, rank, env_kwargs=None):
         import torch
 
         import gymnasium_amd
         from gymnasium_amd import _native
 
-        self.torch, self.env_id, self.N, self.inner = torch, env_id, N, inner
+        self.torch, self.env_id, self.N, self.inner, self.env_kwargs = torch, env_id, N, inner, env_kwargs
         dev = torch.device("cuda", local_rank)
-        env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", env_index_offset=rank * N)
+        env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", env_index_offset=rank * N, **(env_kwargs or {}))
         env.reset(seed=0)
         env.action_space.seed(rank)
         eng = env._engine
@@ -258,7 +258,7 @@ class Config:
         kernel = self.dominant_kernel()
         coop = self.env_id in MJ_COOP
         per = self.inner if coop else 1  # dispatches of the dominant kernel per rollout launch
-        live = live_counters(self.env_id, self.N, self.inner, kernel, "traffic" in pmc, "sq" in pmc and coop) if pmc else {}
+        live = live_counters(self.env_id, self.N, self.inner, kernel, "traffic" in pmc, "sq" in pmc and coop, env_kwargs=self.env_kwargs) if pmc else {}
         traffic, src = live.get("traffic"), live.get("traffic_source")
         if traffic is not None:
             traffic *= per
@@ -294,6 +294,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the per-launch step() API measurements")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (BASELINE.json configs[2..4])")
+    ap.add_argument("--env-kwargs", default="{}", help='JSON constructor kwargs of the env, e.g. \'{"solver": "Newton"}\' (Humanoid: opt-in solver)')
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
     args = ap.parse_args()
 
@@ -320,7 +321,8 @@ def main():
     def sync_local():
         torch.cuda.synchronize()
 
-    cfg = Config(args.env, N, inner, local_rank, rank)
+    env_kwargs = json.loads(args.env_kwargs)
+    cfg = Config(args.env, N, inner, local_rank, rank, env_kwargs)
     for _ in range(W):
         cfg.launch()
     if args.child:
@@ -348,7 +350,7 @@ def main():
             "config": {"workload": f"{args.env} num_envs={N} per GPU, random policy (on-device action_space.sample()), "
                                    f"NEXT_STEP autoreset, TimeLimit, fused rollout of {inner} vector steps per launch, "
                                    "trajectory (actions, obs, rewards, terminated, truncated) written to HBM",
-                       "env": args.env, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
+                       "env": args.env, "env_kwargs": env_kwargs, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
                        "parallelism": f"env-sharded x{world} (no data-path collective)"},
             "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
         }

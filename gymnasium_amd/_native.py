@@ -15,6 +15,7 @@ MI_OK = 0
 MI_HOST, MI_DEVICE = 0, 1
 MI_F32, MI_F64, MI_I64 = 0, 1, 2
 FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
+CFG_SOLVER_NEWTON = 1  # MI_CFG_SOLVER_NEWTON
 ABI_VERSION = 4
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
@@ -186,9 +187,10 @@ class Engine:
     """One mi_vecenv handle.  Thin, allocation-free wrappers; pointers are NumPy arrays or raw device addresses."""
 
     def __init__(self, lib: NativeLib, kind: str, num_envs: int, max_episode_steps: int | None, autoreset_mode: str,
-                 params=(), device: int = 0):
+                 params=(), device: int = 0, options: int = 0):
         self.lib = lib
         cfg = MiConfig()
+        cfg.reserved[0] = int(options)  # MI_CFG_* bits (include/mi355env.h)
         cfg.struct_size = C.sizeof(MiConfig)
         cfg.kind = ENV_KINDS[kind]
         cfg.num_envs = int(num_envs)

@@ -60,6 +60,7 @@ struct DevEnv {
     int *error;          // sticky device error word
     int N;
     int max_steps;
+    int solver_newton;   // MI_CFG_SOLVER_NEWTON (one-lane MuJoCo kernels; the cooperative kernel is chosen at launch)
     EnvParams P;
     TabTable tab;
 };
@@ -531,7 +532,7 @@ MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *acti
             const double before[2] = {L.s[E::NQ + 2 * E::NV], L.s[E::NQ + 2 * E::NV + 1]};
             E::finish(L.s, before, x, action, d.P, obs, reward, te, info);
         } else {
-            E::step(L.s, action, d.P, obs, reward, te, info);
+            E::step(L.s, action, d.P, obs, reward, te, info, d.solver_newton != 0);
         }
         L.elapsed += 1;
         tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;
@@ -1038,6 +1039,7 @@ struct mi_vecenv {
     bool mj_coop;
     int extras_dim;
     double *d_extras;       // [N][EX_TOTAL]
+    double *d_pgs_spill;    // PGS kinds: [N][Sim::SPILL_DOUBLES] overflow store of the cooperative solver (mjx_coop.h pgs())
     float *d_act_scratch;   // [N][NU] actions of the current rollout step when the caller does not keep them
     void *d_obs_scratch;    // [N][obs_dim] observations of the current rollout step when the caller does not keep them
 };
@@ -1155,6 +1157,7 @@ int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
     if (v->mj_coop) {
         mi_phys::Args pa;
         pa.state = v->d.state, pa.meta = v->d.meta, pa.needs_reset_mask = kNeedsReset << kFlagShift, pa.N = v->d.N, pa.frame_skip = (int)v->d.P.p[4];
+        pa.pgs_spill = v->d_pgs_spill, pa.newton = v->d.solver_newton;
         const bool skip_resetting = mode != MI_AUTORESET_SAME_STEP;  // SAME_STEP: every sub-environment steps
         const bool ok = E::COOP_G == 16 ? mi_phys::launch16(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream)
                                         : mi_phys::launch32(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream);
@@ -1280,6 +1283,7 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     v->grid = (int)((N + kBlock - 1) / kBlock);
     DevEnv &d = v->d;
     d.N = cfg->num_envs, d.max_steps = cfg->max_episode_steps;
+    d.solver_newton = (cfg->reserved[0] & MI_CFG_SOLVER_NEWTON) ? 1 : 0;
     for (int k = 0; k < 16; k++) d.P.p[k] = cfg->params[k];
     HIP_TRY(hipMalloc(&d.state, sizeof(double) * v->lay.state_dim * N));
     HIP_TRY(hipMalloc(&d.meta, sizeof(uint32_t) * N));
@@ -1319,6 +1323,8 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         HIP_TRY(hipMalloc(&v->d_act_scratch, v->act_bytes));
         HIP_TRY(hipMalloc(&v->d_obs_scratch, v->obs_bytes));
         HIP_TRY(hipMemsetAsync(v->d_extras, 0, sizeof(double) * v->extras_dim * N, v->stream));
+        const size_t spill = v->mj_coop && !d.solver_newton ? mi_phys::pgs_spill_doubles(cfg->kind) : 0;
+        if (spill) HIP_TRY(hipMalloc(&v->d_pgs_spill, sizeof(double) * spill * N));
     }
     HIP_TRY(hipStreamSynchronize(v->stream));
     *out = v;
@@ -1331,7 +1337,7 @@ void mi_destroy(mi_vecenv *v) {
     (void)hipStreamSynchronize(v->stream);
     void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d.error,
                     v->d_pow2, v->d_actions, v->d_obs, v->d_final, v->d_reward, v->d_epret, v->d_eplen, v->d_term,
-                    v->d_trunc, v->d_mask, v->d_words, v->d_info, v->d_final_info, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
+                    v->d_trunc, v->d_mask, v->d_words, v->d_info, v->d_final_info, v->d_pgs_spill, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : v->tab_bufs)

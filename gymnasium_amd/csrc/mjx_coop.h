@@ -177,6 +177,7 @@ struct Board {
     double Mt[M_IN_LDS ? NV : 1][M_IN_LDS ? NV : 1];
     int con_pair[MAXCON];
     unsigned cmask[KS], anyrow;
+    unsigned limmask[2];  // dofs whose lower / upper joint-limit row is active in this forward pass (PGS visits them in dof order)
     int ncon;
     double ten[M::NTENDON > 0 ? 2 * M::NTENDON : 1];  // fixed tendons at this forward pass: lengths, then velocities
 };
@@ -205,9 +206,14 @@ struct Lane {
     bool c_on[KC];
     int c_b1[KC], c_b2[KC], c_dim[KC];
     double c_mu[KC], c_D[KC], c_kterm[KC], c_b[KC], c_jv[KC][3], c_jx[KC][3], c_jd[KC][3], c_gw[KC][8];
+    // dual PGS (Sim<.., PGS = true>): forces of this lane's limit rows and contact rows, the 3x3 contact-frame block A = J_c M^-1 J_c^T
+    // (A00 A01 A02 A11 A12 A22), the reciprocals 1 / (E A E^T + R) of its rows, J_c qacc_smooth, and where contacts beyond the LDS
+    // capacity keep their M^-1 J_c^T block (global memory, per environment)
+    double p_lf[2], p_lari[2], p_f[KC][4], p_A[KC][6], p_ari[KC][4], p_js[KC][3];
+    double *spill;
 };
 
-template <class M, int G>
+template <class M, int G, bool PGS = (M::SOLVER == 1)>
 struct Sim {
     typedef Board<M, G> B;
     typedef Lane<M, G> R;
@@ -753,7 +759,7 @@ struct Sim {
     // their rank (slot order = the order in which the serial code emits contacts), truncated at MAXCON
     static MJX_DEV void collision(B &bb, int lane) {
         if (lane < KS) bb.cmask[lane] = 0;
-        if (lane == 0) bb.anyrow = 0;
+        if (lane == 0) bb.anyrow = 0, bb.limmask[0] = 0, bb.limmask[1] = 0;
         coop_sync();
         unsigned mine = 0;
 #pragma unroll 1
@@ -870,6 +876,7 @@ struct Sim {
                         row_params<M>(M::jnt_solref[jp], M::jnt_solimp[jp], dist, margin, M::dof_invweight0[lane], k, b, imp, Rr);
                         r.lim_on[sd] = true, r.lim_sign[sd] = -side, r.lim_D[sd] = 1.0 / Rr;
                         r.lim_aref[sd] = -b * (-side * bb.qvel[lane]) - k * imp * (dist - margin);
+                        if (PGS) lds_or(&bb.limmask[sd], 1u << lane);
                         any = true;
                     }
                 }
@@ -1033,6 +1040,311 @@ struct Sim {
         }
     }
 
+    // ---- dual projected Gauss-Seidel (humanoid.xml:8 `solver="PGS" iterations="50"`) ---------------------------------------------
+    // What mj_solPGS does, laid out for a group of lanes.  Unknowns: forces f >= 0 of the unilateral rows (joint limits, frictionless
+    // contacts, the 4 edges of a pyramidal contact), relaxed ONE ROW AT A TIME in MuJoCo's row order (limits in joint order, then
+    // contacts in detection order): f_r <- max(0, f_r - res_r / AR_rr), res = (J M^-1 J^T + R) f + J qacc_smooth - aref, for at most
+    // M::ITERATIONS sweeps or until a sweep's scaled cost improvement is below the tolerance 1e-8.  The iteration is sequential by
+    // definition, so the parallelism is inside a row:
+    //   * matrix-free in acceleration space: dof lane i carries a_i, a = qacc_smooth + M^-1 J^T f; res_r = J_r a - aref_r + R_r f_r;
+    //   * M^-1 is formed once per forward pass (row i on lane i, in the registers of the Hessian row the Newton solver would use);
+    //   * a limit row has J = +-e_i: its residual is local to lane i, its update adds column i of M^-1 times the broadcast step;
+    //   * the rows of a contact share the 3 x NV contact-frame Jacobian J_c: v = J_c a is three group reductions, the (up to) four edge
+    //     updates then happen on the owner lane alone in the 3-dim contact frame against the block A = J_c M^-1 J_c^T (v += A E^T d),
+    //     and a += (M^-1 J_c^T) (sum of E^T d) closes the contact: one exchange per contact and sweep, not one per row;
+    //   * M^-1 J_c^T (3 x NV per contact) is computed once per pass; the first BCAP contacts keep it in the LDS storage of M (dead after
+    //     the factorisation), later ones in global memory (r.spill).
+    // Warm start = mj's dual warmstart: the forces implied by qacc_warmstart (r.warm), dropped for zero if their dual cost is positive.
+    static constexpr int BCAP = B::M_IN_LDS ? NV / 3 : 0;
+    static constexpr int SPILL_DOUBLES = (MAXCON > BCAP ? MAXCON - BCAP : 0) * 3 * NV;
+    static MJX_DEV void store_b(B &bb, const R &r, int c, int lane, const double *b) {
+        if (lane >= NV) return;
+        double *p = r.spill + (size_t)(c - BCAP) * 3 * NV;
+        if constexpr (B::M_IN_LDS) {
+            if (c < BCAP) p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+        }
+        p[lane] = b[0], p[NV + lane] = b[1], p[2 * NV + lane] = b[2];
+    }
+    static MJX_DEV void load_b(const B &bb, const R &r, int c, int lane, double *b) {
+        b[0] = b[1] = b[2] = 0;
+        if (lane >= NV) return;
+        const double *p = r.spill + (size_t)(c - BCAP) * 3 * NV;
+        if constexpr (B::M_IN_LDS) {
+            if (c < BCAP) p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+        }
+        b[0] = p[lane], b[1] = p[NV + lane], b[2] = p[2 * NV + lane];
+    }
+    // r.Hrow: row `lane` of L (M = L L^T) -> row `lane` of M^-1.  L^-1 row by row through the storage of M (dead), then L^-T L^-1.
+    static MJX_DEV void invert(B &bb, R &r, int lane) {
+        static_assert(B::M_IN_LDS, "the explicit inverse goes through the blackboard storage of M");
+        double acc[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) acc[j] = 0;
+        double (&S)[NV][NV] = bb.Mt;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            if (lane == k) {
+#pragma unroll
+                for (int j = 0; j <= k; j++) S[k][j] = ((j == k ? 1.0 : 0.0) - acc[j]) * r.idiag;
+            }
+            coop_sync();
+            if (lane > k && lane < NV) {
+                const double lik = r.Hrow[k];
+#pragma unroll
+                for (int j = 0; j <= k; j++) acc[j] += lik * S[k][j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) r.Hrow[j] = 0;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const double ski = (lane <= k) ? S[k][lane < NV ? lane : 0] : 0.0;
+#pragma unroll
+            for (int j = 0; j <= k; j++) r.Hrow[j] += ski * S[k][j];
+        }
+        coop_sync();  // S is dead from here on: the storage becomes the M^-1 J_c^T store
+    }
+    // The rows of contact (kc, owner lane) against the contact-frame acceleration v = J_c a: relax them in order, keep v current, return the
+    // frame-space force step dl = sum E^T delta and the cost improvement.  Runs on every lane (SIMD), meaningful on the owner.
+    static MJX_DEV void pgs_contact(R &r, int kc, double *v, double *dl, double &impr) {
+        const double Rr = 1.0 / r.c_D[kc];
+        const double *A = r.p_A[kc];
+        dl[0] = dl[1] = dl[2] = 0;
+        if (r.c_dim[kc] == 1) {
+            const double aref = -r.c_b[kc] * r.c_jv[kc][0] + r.c_kterm[kc];
+            const double f0 = r.p_f[kc][0], res = (v[0] - aref) + Rr * f0;
+            double nw = f0 - res * r.p_ari[kc][0];
+            nw = nw < 0 ? 0.0 : nw;
+            const double dd = nw - f0;
+            r.p_f[kc][0] = nw, impr -= dd * (0.5 * dd * (A[0] + Rr) + res);
+            v[0] += A[0] * dd, v[1] += A[1] * dd, v[2] += A[2] * dd, dl[0] = dd;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const double sg = (e & 1) ? -r.c_mu[kc] : r.c_mu[kc];
+                const int t = 1 + e / 2;
+                const double A0t = t == 1 ? A[1] : A[2], Att = t == 1 ? A[3] : A[5], Aot = A[4];  // A[other][t] = A12 either way
+                const double AR = (A[0] + 2 * sg * A0t + sg * sg * Att) + Rr;
+                const double fe = r.p_f[kc][e], res = ((v[0] + sg * v[t]) - edge_aref(r, kc, sg, t)) + Rr * fe;
+                double nw = fe - res * r.p_ari[kc][e];
+                nw = nw < 0 ? 0.0 : nw;
+                const double dd = nw - fe;
+                r.p_f[kc][e] = nw, impr -= dd * (0.5 * dd * AR + res);
+                // v += A (e_0 + sg e_t) dd
+                v[0] += (A[0] + sg * A0t) * dd;
+                v[t] += (A0t + sg * Att) * dd;
+                v[3 - t] += ((t == 1 ? A[2] : A[1]) + sg * Aot) * dd;
+                dl[0] += dd, dl[t] += sg * dd;
+            }
+        }
+    }
+    // limit rows of dof I (static: column I of M^-1 is entry I of every lane's register row), lower side then upper side
+    template <int I, bool WARM>
+    static MJX_DEV void pgs_limits(B &bb, R &r, int lane, unsigned lm0, unsigned lm1, double &a, double &qf, double &impr) {
+        if constexpr (M::jnt_limited[M::dof_jntid[I]] && (M::jnt_type[M::dof_jntid[I]] == HINGE || M::jnt_type[M::dof_jntid[I]] == SLIDE)) {
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                if (((sd == 0 ? lm0 : lm1) >> I) & 1u) {  // group-uniform
+                    double step = 0;  // sign * delta of this row, on lane I
+                    if (lane == I) {
+                        const double s = r.lim_sign[sd], f0 = r.p_lf[sd];
+                        if (WARM) {  // a, qf accumulate M^-1 J^T f and J^T f of the warm-start forces
+                            step = s * f0, qf += s * f0;
+                        } else {
+                            const double Rr = 1.0 / r.lim_D[sd], res = (s * a - r.lim_aref[sd]) + Rr * f0;
+                            double nw = f0 - res * r.p_lari[sd];
+                            nw = nw < 0 ? 0.0 : nw;
+                            const double dd = nw - f0;
+                            r.p_lf[sd] = nw, impr -= dd * (0.5 * dd / r.p_lari[sd] + res), step = s * dd;
+                        }
+                    }
+                    const double bs = bcast<I>(step, bb, lane);
+                    a += r.Hrow[I] * bs;
+                }
+            }
+        }
+        if constexpr (I + 1 < NV) pgs_limits<I + 1, WARM>(bb, r, lane, lm0, lm1, a, qf, impr);
+    }
+    // in: r.qfrc_smooth, the constraint rows of make_constraint(), r.warm.  out: r.qacc, r.qacc_smooth, contact forces on the blackboard.
+    static MJX_DEV void pgs(B &bb, R &r, int lane, bool anyrow) {
+        const bool isdof = lane < NV;
+#pragma unroll
+        for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
+        chol_factor(bb, r.Hrow, r.idiag, lane);
+        const double qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
+        r.qacc_smooth = qs, r.qfrc_constraint = 0;
+        if (!anyrow) {
+            r.qacc = qs;
+            return;
+        }
+        // contact-frame images of qacc_smooth (vdir, left there by the solve) and of the warm start
+        double jw[KC][3];
+        twist(bb, bb.A.sol.vdir, lane);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            r.p_js[kc][0] = r.p_js[kc][1] = r.p_js[kc][2] = 0;
+            if (r.c_on[kc]) contact_vel(bb, bb.C.sol.tw, kc * G + lane, r.c_b1[kc], r.c_b2[kc], r.p_js[kc]);
+        }
+        coop_sync();
+        if (isdof) bb.A.sol.vdir[lane] = r.warm;
+        coop_sync();
+        twist(bb, bb.A.sol.vdir, lane);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            jw[kc][0] = jw[kc][1] = jw[kc][2] = 0;
+            if (r.c_on[kc]) contact_vel(bb, bb.C.sol.tw, kc * G + lane, r.c_b1[kc], r.c_b2[kc], jw[kc]);
+        }
+        coop_sync();
+        invert(bb, r, lane);  // r.Hrow = row `lane` of M^-1
+        const unsigned lm0 = bb.limmask[0], lm1 = bb.limmask[1];
+        const int ncon = bb.ncon;
+        // ---- rows: diagonal, warm-start force, dual cost pieces --------------------------------------------------------------------
+        double cost = 0;  // this lane's share of sum_r f_r (R_r f_r / 2 + b_r)
+        if (isdof) {
+            double mii = 0;
+#pragma unroll
+            for (int j = 0; j < NV; j++) mii = (j == lane) ? r.Hrow[j] : mii;
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                r.p_lf[sd] = 0, r.p_lari[sd] = 0;
+                if (r.lim_on[sd]) {
+                    const double s = r.lim_sign[sd], Rr = 1.0 / r.lim_D[sd];
+                    r.p_lari[sd] = 1.0 / (mii + Rr);
+                    const double jar = s * r.warm - r.lim_aref[sd];
+                    const double f0 = jar < 0 ? -r.lim_D[sd] * jar : 0.0;
+                    r.p_lf[sd] = f0, cost += f0 * (0.5 * Rr * f0 + (s * qs - r.lim_aref[sd]));
+                }
+            }
+        } else {
+            r.p_lf[0] = r.p_lf[1] = 0, r.p_lari[0] = r.p_lari[1] = 0;
+        }
+        double w = 0, qf = 0, dummy = 0;  // (M^-1 J^T f)_lane and (J^T f)_lane of the warm-start forces
+        pgs_limits<0, true>(bb, r, lane, lm0, lm1, w, qf, dummy);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+#pragma unroll 1
+            for (int owner = 0; owner < G; owner++) {
+                const int c = kc * G + owner;
+                if (c >= ncon) break;
+                double jcol[3] = {0, 0, 0};
+                double (&J)[3][NV] = bb.C.sol.jc[c & 1];
+                double (&gw)[8] = bb.C.sol.gw[c & 1];
+                if (isdof) {
+                    jac_col(bb, r, c, lane, jcol);
+                    J[0][lane] = jcol[0], J[1][lane] = jcol[1], J[2][lane] = jcol[2];
+                }
+                if (lane == owner) {  // warm-start forces of the contact's rows and their frame-space sum
+                    const double D = r.c_D[kc], Rr = 1.0 / D;
+                    double lam[3] = {0, 0, 0};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) r.p_f[kc][e] = 0;
+                    if (r.c_dim[kc] == 1) {
+                        const double aref = -r.c_b[kc] * r.c_jv[kc][0] + r.c_kterm[kc], jar = jw[kc][0] - aref;
+                        const double f0 = jar < 0 ? -D * jar : 0.0;
+                        r.p_f[kc][0] = f0, lam[0] = f0, cost += f0 * (0.5 * Rr * f0 + (r.p_js[kc][0] - aref));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const double sg = (e & 1) ? -r.c_mu[kc] : r.c_mu[kc];
+                            const int t = 1 + e / 2;
+                            const double aref = edge_aref(r, kc, sg, t), jar = (jw[kc][0] + sg * jw[kc][t]) - aref;
+                            const double fe = jar < 0 ? -D * jar : 0.0;
+                            r.p_f[kc][e] = fe, lam[0] += fe, lam[t] += sg * fe;
+                            cost += fe * (0.5 * Rr * fe + ((r.p_js[kc][0] + sg * r.p_js[kc][t]) - aref));
+                        }
+                    }
+                    gw[0] = lam[0], gw[1] = lam[1], gw[2] = lam[2];
+                }
+                coop_sync();
+                double b[3] = {0, 0, 0};
+                if (isdof) {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) b[0] += r.Hrow[j] * J[0][j], b[1] += r.Hrow[j] * J[1][j], b[2] += r.Hrow[j] * J[2][j];
+                }
+                store_b(bb, r, c, lane, b);
+                // A = J_c (M^-1 J_c^T): six reductions, kept by the owner together with the reciprocal row diagonals
+                const double a00 = group_sum<G>(jcol[0] * b[0], MJX_RED(bb), lane), a01 = group_sum<G>(jcol[0] * b[1], MJX_RED(bb), lane),
+                             a02 = group_sum<G>(jcol[0] * b[2], MJX_RED(bb), lane), a11 = group_sum<G>(jcol[1] * b[1], MJX_RED(bb), lane),
+                             a12 = group_sum<G>(jcol[1] * b[2], MJX_RED(bb), lane), a22 = group_sum<G>(jcol[2] * b[2], MJX_RED(bb), lane);
+                if (lane == owner) {
+                    double *A = r.p_A[kc];
+                    A[0] = a00, A[1] = a01, A[2] = a02, A[3] = a11, A[4] = a12, A[5] = a22;
+                    const double Rr = 1.0 / r.c_D[kc];
+                    if (r.c_dim[kc] == 1) {
+                        r.p_ari[kc][0] = 1.0 / (a00 + Rr);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const double sg = (e & 1) ? -r.c_mu[kc] : r.c_mu[kc];
+                            const double A0t = e < 2 ? a01 : a02, Att = e < 2 ? a11 : a22;
+                            r.p_ari[kc][e] = 1.0 / ((a00 + 2 * sg * A0t + sg * sg * Att) + Rr);
+                        }
+                    }
+                }
+                w += b[0] * gw[0] + b[1] * gw[1] + b[2] * gw[2];
+                qf += jcol[0] * gw[0] + jcol[1] * gw[1] + jcol[2] * gw[2];
+            }
+        }
+        // dual cost of the warm start: f'(A + R) f / 2 + f' b = (J^T f)' (M^-1 J^T f) / 2 + sum_r f_r (R_r f_r / 2 + b_r)
+        const double wcost = group_sum<G>(cost + 0.5 * qf * w, MJX_RED(bb), lane);
+        double a = qs;
+        if (wcost > 0) {  // the warm start is worse than zero forces: start from f = 0, a = qacc_smooth
+            r.p_lf[0] = r.p_lf[1] = 0;
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) r.p_f[kc][e] = 0;
+        } else {
+            a += w;
+        }
+        // ---- sweeps ---------------------------------------------------------------------------------------------------------------------
+        const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
+#pragma unroll 1
+        for (int it = 0; it < M::ITERATIONS; it++) {
+            double impr = 0, unused = 0;
+            pgs_limits<0, false>(bb, r, lane, lm0, lm1, a, unused, impr);
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+#pragma unroll 1
+                for (int owner = 0; owner < G; owner++) {
+                    const int c = kc * G + owner;
+                    if (c >= ncon) break;
+                    double jcol[3] = {0, 0, 0}, v[3], dl[3], b[3];
+                    if (isdof) jac_col(bb, r, c, lane, jcol);
+                    v[0] = group_sum<G>(jcol[0] * a, MJX_RED(bb), lane), v[1] = group_sum<G>(jcol[1] * a, MJX_RED(bb), lane),
+                    v[2] = group_sum<G>(jcol[2] * a, MJX_RED(bb), lane);
+                    double (&gw)[8] = bb.C.sol.gw[c & 1];
+                    if (lane == owner) {
+                        pgs_contact(r, kc, v, dl, impr);
+                        gw[0] = dl[0], gw[1] = dl[1], gw[2] = dl[2];
+                    }
+                    load_b(bb, r, c, lane, b);
+                    coop_sync();
+                    a += b[0] * gw[0] + b[1] * gw[1] + b[2] * gw[2];
+                }
+            }
+            const double imp = group_sum<G>(impr, MJX_RED(bb), lane);
+#if defined(MJX_HOST_EMU)
+            if (lane == 0) g_stat[3]++;
+#endif
+            if (imp * scale < 1e-8) break;
+        }
+        r.qacc = a;
+        // world-frame contact forces for cfrc_ext: frame^T (sum f, mu (f0 - f1), mu (f2 - f3))  (mj_contactForce for pyramids)
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            if (r.c_on[kc]) {
+                const int c = kc * G + lane;
+                const double *F = bb.con_frame[c], *f = r.p_f[kc], mu = r.c_mu[kc];
+                const double lf0 = r.c_dim[kc] == 1 ? f[0] : ((f[0] + f[1]) + f[2]) + f[3], lf1 = r.c_dim[kc] == 1 ? 0.0 : (f[0] - f[1]) * mu,
+                             lf2 = r.c_dim[kc] == 1 ? 0.0 : (f[2] - f[3]) * mu;
+#pragma unroll
+                for (int k = 0; k < 3; k++) bb.C.sol.con_F[c][k] = F[k] * lf0 + F[3 + k] * lf1 + F[6 + k] * lf2;
+            }
+        }
+        coop_sync();
+    }
+
     // ---- forward dynamics -------------------------------------------------------------------------------------------------
     // in: bb.qpos, bb.qvel, bb.ctrl.  out (dof lanes): r.qacc, r.qacc_int (the acceleration the Euler integrator uses: implicit
     // in the joint damping), r.qfrc_actuator; on the blackboard: poses, cvel, contact frames and world-frame contact forces.
@@ -1090,6 +1402,14 @@ struct Sim {
 #if defined(MJX_HOST_EMU)
         if (lane == 0) g_stat[0]++, g_stat[1] += anyrow;
 #endif
+        if constexpr (PGS) {  // the model's own solver (humanoid.xml:8); r.warm is advanced by step(): MuJoCo saves qacc_warmstart once per mj_step
+            static_assert(!damped_euler(), "PGS models of the family integrate with RK4");
+            pgs(bb, r, lane, anyrow);
+            r.qacc_int = r.qacc;
+            coop_sync();
+            MJX_PHASE(r, 11);
+            return;
+        }
         const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
         constexpr double h = M::TIMESTEP;
         int st = ST_SMOOTH, it = 0;
@@ -1354,6 +1674,7 @@ struct Sim {
                 rk4_stage(bb, r.qacc, lane, i, v0, sumv, suma);
             }
         }
+        if constexpr (PGS) r.warm = r.qacc;  // mj_advance: "save qacc for next step warmstart" -- the LAST forward pass's qacc, once per step
     }
 
     // mj_rnePostConstraint, the part the envs read: cfrc_ext of body `lane + 1` from the contact forces of the LAST forward pass

@@ -280,7 +280,7 @@ struct MjEnv {
 
     // One env.step() with the one-lane simulator (mjx_core.h): physics, then finish().
     static MJX_DEV void step(double *s, const float *action, const mi::EnvParams &P, double *obs, double &reward, bool &terminated,
-                             double *info) {
+                             double *info, bool newton = false) {
         Data<M> d;
         for (int k = 0; k < NQ; k++) d.qpos[k] = s[k];
         for (int k = 0; k < NV; k++) d.qvel[k] = s[NQ + k];
@@ -288,7 +288,14 @@ struct MjEnv {
         for (int k = 0; k < NV; k++) d.qacc_warm[k] = s[NQ + NV + k];  // the qacc_warmstart slot of the state row
         const double before[2] = {s[NQ + 2 * NV], s[NQ + 2 * NV + 1]};
         const int frame_skip = (int)P.p[4];
-        for (int f = 0; f < frame_skip; f++) mjx::step<M>(d);
+        if constexpr (M::SOLVER == 1) {  // the MJCF's PGS / 50, or the opt-in Newton solver (MI_CFG_SOLVER_NEWTON)
+            if (newton)
+                for (int f = 0; f < frame_skip; f++) mjx::step<M, false>(d);
+            else
+                for (int f = 0; f < frame_skip; f++) mjx::step<M, true>(d);
+        } else {
+            for (int f = 0; f < frame_skip; f++) mjx::step<M>(d);
+        }
         for (int k = 0; k < NV; k++) s[NQ + NV + k] = d.qacc_warm[k];
         // Cartesian quantities of the LAST forward pass (they lag qpos by one sub-step, as in the reference)
         StepExtras x;

@@ -24,16 +24,20 @@ struct Args {
     const uint32_t *meta;
     uint32_t needs_reset_mask;
     int N, frame_skip;
+    double *pgs_spill;   // PGS: per-environment overflow store of M^-1 J_c^T for contacts beyond the LDS capacity (Sim::SPILL_DOUBLES each)
+    int newton;          // MI_CFG_SOLVER_NEWTON: run the Newton instantiation although the model's MJCF asks for PGS
 };
 
 // Advances qpos / qvel of every sub-environment that takes a real step this call by frame_skip sub-steps, in place, and leaves what
 // the reward / observation code needs in `extras`.  Sub-environments in their NEXT_STEP autoreset step (or finished ones under DISABLED)
 // are skipped: the step kernel that follows resets them / reports the error.
-template <class E, bool SKIP_RESETTING>
+// PGS: the constraint solver of the model's MJCF (M::SOLVER == 1: humanoid.xml:8 `solver="PGS" iterations="50"`) or, false, the converged
+// primal Newton solver (every other robot's MJCF default; opt-in for the humanoids, MI_CFG_SOLVER_NEWTON).
+template <class E, bool SKIP_RESETTING, bool PGS>
 __global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *actions, double *extras) {
     typedef typename E::Model M;
     constexpr int G = E::COOP_G, EPW = 64 / G;
-    typedef mjx::coop::Sim<M, G> S;
+    typedef mjx::coop::Sim<M, G, PGS> S;
     __shared__ typename S::B boards[EPW];
     const int grp = threadIdx.x / G, lane = threadIdx.x % G;
     const int env = blockIdx.x * EPW + grp;
@@ -47,6 +51,7 @@ __global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *act
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
+    r.spill = PGS ? d.pgs_spill + (size_t)env * S::SPILL_DOUBLES : nullptr;
     mjx::coop::coop_sync();
     for (int f = 0; f < d.frame_skip; f++) S::step(bb, r, lane);
     mjx::coop::coop_sync();
@@ -60,11 +65,23 @@ template <class E>
 inline void launch_kind(const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream) {
     constexpr int EPW = 64 / E::COOP_G;
     const dim3 grid((a.N + EPW - 1) / EPW), block(64);
+    if constexpr (E::Model::SOLVER == 1) {
+        if (!a.newton) {
+            if (skip_resetting)
+                hipLaunchKernelGGL((mj_physics_kernel<E, true, true>), grid, block, 0, stream, a, actions, extras);
+            else
+                hipLaunchKernelGGL((mj_physics_kernel<E, false, true>), grid, block, 0, stream, a, actions, extras);
+            return;
+        }
+    }
     if (skip_resetting)
-        hipLaunchKernelGGL((mj_physics_kernel<E, true>), grid, block, 0, stream, a, actions, extras);
+        hipLaunchKernelGGL((mj_physics_kernel<E, true, false>), grid, block, 0, stream, a, actions, extras);
     else
-        hipLaunchKernelGGL((mj_physics_kernel<E, false>), grid, block, 0, stream, a, actions, extras);
+        hipLaunchKernelGGL((mj_physics_kernel<E, false, false>), grid, block, 0, stream, a, actions, extras);
 }
+
+// doubles of pgs_spill one environment of `kind` needs (0: the kind does not use PGS)
+size_t pgs_spill_doubles(int kind);
 
 // defined in physics16.hip / physics32.hip; `kind` is an mi_env_kind; returns false for a kind the unit does not hold
 bool launch16(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream);

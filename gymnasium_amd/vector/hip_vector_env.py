@@ -71,6 +71,10 @@ class HipVectorEnv(VectorEnv):
     def _engine_params(self) -> tuple:
         return ()
 
+    def _engine_options(self) -> int:
+        """MI_CFG_* option bits of mi_config.reserved[0]."""
+        return 0
+
     def _parse_reset_options(self, options):
         """Return the env-specific (b0, b1) reset bounds or None for defaults; raise ValueError like the reference."""
         return None
@@ -104,10 +108,10 @@ class HipVectorEnv(VectorEnv):
         if _engine_factory is None:
             lib = _native.load_library()  # raises ImportError if the HIP library was not built
             self._engine = _native.Engine(lib, self.KIND, self.num_envs, self.max_episode_steps, self.autoreset_mode.value,
-                                          self._engine_params(), self._device_index)
+                                          self._engine_params(), self._device_index, options=self._engine_options())
         else:  # test seam: tests drive this host class against a checker backend; never used by the package itself
             self._engine = _engine_factory(self.KIND, self.num_envs, self.max_episode_steps, self.autoreset_mode.value,
-                                           self._engine_params(), self._device_index)
+                                           self._engine_params(), self._device_index, options=self._engine_options())
         eng = self._engine
         self._discrete = eng.act_dtype is np.int64
         self._act_shape = (self.num_envs,) if self._discrete else (self.num_envs, eng.act_dim)

@@ -45,6 +45,6 @@ def _register_mujoco_models(lib):
         assert rc == 0, f"oracle rejected the {name} model blob (rc={rc})"
 
 
-def engine_factory(kind, num_envs, max_episode_steps, autoreset_mode, params, device):
+def engine_factory(kind, num_envs, max_episode_steps, autoreset_mode, params, device, options=0):
     """Drop-in for HipVectorEnv(_engine_factory=...): the oracle behind the product's host class."""
-    return _native.Engine(load(), kind, num_envs, max_episode_steps, autoreset_mode, params, device)
+    return _native.Engine(load(), kind, num_envs, max_episode_steps, autoreset_mode, params, device, options=options)

@@ -63,16 +63,18 @@ void mjx::coop::coop_sync() {
 namespace {
 using namespace mjx;
 
-template <class M, int G>
+template <class M, int G, bool PGS = (M::SOLVER == 1)>
 int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsub, double *qpos_out, double *qvel_out, double *extras,
              double *debug, double *warm) {
-    typedef coop::Sim<M, G> S;
+    typedef coop::Sim<M, G, PGS> S;
     auto *bb = new typename S::B();
     std::memset((void *)bb, 0, sizeof(*bb));
+    std::vector<double> spill(S::SPILL_DOUBLES + 1);
     g_syncs = 0;
     run_group(G, [&](int lane) {
         typename S::R r;
         std::memset((void *)&r, 0, sizeof(r));
+        r.spill = spill.data();
         if (warm && lane < M::NV) r.warm = warm[lane];
         S::init(*bb, lane);
         for (int k = lane; k < M::NQ; k += G) bb->qpos[k] = qpos[k];
@@ -125,6 +127,23 @@ int core_step(const double *qpos, const double *qvel, const double *ctrl, int ns
     delete d;
     return ncon;
 }
+// the one-lane simulator with the opt-in Newton solver for a model whose MJCF asks for PGS
+template <class M>
+int core_step_newton(const double *qpos, const double *qvel, const double *ctrl, int nsub, double *qpos_out, double *qvel_out, double *qacc_out, double *warm) {
+    mjx::Data<M> *d = new mjx::Data<M>;
+    for (int k = 0; k < M::NQ; k++) d->qpos[k] = qpos[k];
+    for (int k = 0; k < M::NV; k++) d->qvel[k] = qvel[k], d->qacc_warm[k] = warm ? warm[k] : 0.0;
+    for (int k = 0; k < M::NU; k++) d->ctrl[k] = ctrl[k];
+    if (nsub == 0) mjx::forward<M, false>(*d);
+    for (int f = 0; f < nsub; f++) mjx::step<M, false>(*d);
+    for (int k = 0; k < M::NQ; k++) qpos_out[k] = d->qpos[k];
+    for (int k = 0; k < M::NV; k++) qvel_out[k] = d->qvel[k], qacc_out[k] = d->qacc[k];
+    if (warm)
+        for (int k = 0; k < M::NV; k++) warm[k] = d->qacc_warm[k];
+    const int ncon = d->ncon;
+    delete d;
+    return ncon;
+}
 }  // namespace
 
 extern "C" {
@@ -152,7 +171,18 @@ __attribute__((visibility("default"))) int coop_emu_step(int model, const double
     switch (model) {  // warm: in/out qacc_warmstart[nv] (NULL = start from zero)
         case 0: return emu_step<HalfCheetahModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
         case 1: return emu_step<AntModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
-        case 2: return emu_step<HumanoidModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
+        case 2: return emu_step<HumanoidModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);  // the MJCF's solver: PGS / 50
+        case 12: return emu_step<HumanoidModel, 32, false>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);  // opt-in Newton
+        case 8: return emu_step<HumanoidStandupModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);  // lying on the floor: many contacts
+        case 18: return emu_step<HumanoidStandupModel, 32, false>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
+    }
+    return -1;
+}
+__attribute__((visibility("default"))) int core_emu_step_newton(int model, const double *qpos, const double *qvel, const double *ctrl, int nsub,
+                                                                 double *qpos_out, double *qvel_out, double *qacc_out, double *warm) {
+    switch (model) {
+        case 2: return core_step_newton<HumanoidModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm);
+        case 8: return core_step_newton<HumanoidStandupModel>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, qacc_out, warm);
     }
     return -1;
 }
@@ -161,6 +191,7 @@ __attribute__((visibility("default"))) int coop_emu_extras_dim(int model) {
         case 0: return coop::Sim<HalfCheetahModel, 16>::EX_TOTAL;
         case 1: return coop::Sim<AntModel, 16>::EX_TOTAL;
         case 2: return coop::Sim<HumanoidModel, 32>::EX_TOTAL;
+        case 8: return coop::Sim<HumanoidStandupModel, 32>::EX_TOTAL;
     }
     return -1;
 }

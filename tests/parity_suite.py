@@ -300,7 +300,7 @@ def check_action_samples():
         env.close()
 
 
-def _dummy_factory(kind, num_envs, *a):
+def _dummy_factory(kind, num_envs, *a, **kw):
     class _E:
         act_dtype = np.int64 if kind in ("cartpole", "acrobot", "mountain_car") else np.float32
         obs_dtype = np.float32

@@ -17,7 +17,17 @@ from oracle import mujoco as om
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(HERE, "coop_emu")
 NAMES = ["half_cheetah", "ant", "humanoid"]
+# emulator model id -> (robot, solver): the humanoid runs its MJCF's PGS / 50 (id 2) or the opt-in Newton solver (id 12)
+VARIANTS = {0: ("half_cheetah", None), 1: ("ant", None), 2: ("humanoid", "PGS"), 12: ("humanoid", "Newton"),
+            8: ("humanoid_standup", "PGS"), 18: ("humanoid_standup", "Newton")}
 _LIB = None
+
+
+def oracle_model(model):
+    from gymnasium_amd.envs.mujoco import compiler as cp
+
+    name, solver = VARIANTS[model]
+    return om.OracleModel(cp.compile_model(name, faithful_solver=(solver != "Newton")))
 
 
 def lib():
@@ -40,15 +50,15 @@ def lib():
 
 def emu(model, m, qpos, qvel, ctrl, nsub, warm=None):
     qo, vo = np.zeros(m.nq), np.zeros(m.nv)
-    ex, dbg = np.zeros(lib().coop_emu_extras_dim(model)), np.zeros(4 * m.nv + m.nv * m.nv)
+    ex, dbg = np.zeros(lib().coop_emu_extras_dim(model % 10)), np.zeros(4 * m.nv + m.nv * m.nv)
     p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)
     ncon = lib().coop_emu_step(model, p(qpos), p(qvel), p(ctrl), nsub, p(qo), p(vo), p(ex), p(dbg), None if warm is None else warm.ctypes.data_as(C.c_void_p))
     return qo, vo, ex, dbg, ncon
 
 
-@pytest.mark.parametrize("model", [0, 1, 2], ids=NAMES)
+@pytest.mark.parametrize("model", list(VARIANTS), ids=[f"{n}-{s}" if s else n for n, s in VARIANTS.values()])
 def test_forward_matches_oracle(model):
-    om_ = om.OracleModel(NAMES[model])
+    om_ = oracle_model(model)
     m, d = om_.m, om_.make_data()
     rng = np.random.default_rng(model)
     nv = m.nv
@@ -63,37 +73,41 @@ def test_forward_matches_oracle(model):
         _, _, _, dbg, ncon = emu(model, m, qpos, qvel, ctrl, 0)
         assert ncon == d.get("ncon")
         scale = max(1.0, np.abs(d.get("qacc")).max())
-        np.testing.assert_allclose(dbg[4 * nv:].reshape(nv, nv), d.get("qM"), rtol=0, atol=1e-13)
+        pgs = VARIANTS[model][1] == "PGS"
+        if not pgs:  # the PGS path reuses the blackboard storage of M for M^-1 once M is factorised
+            np.testing.assert_allclose(dbg[4 * nv:].reshape(nv, nv), d.get("qM"), rtol=0, atol=1e-13)
         np.testing.assert_allclose(dbg[2 * nv:3 * nv], d.get("qfrc_bias"), rtol=0, atol=1e-11)
-        if d.get("nefc") == 0:  # with constraint rows the solver starts from the warm start and never forms qacc_smooth
+        if d.get("nefc") == 0 or pgs:  # Newton with constraint rows starts from the warm start and never forms qacc_smooth
             np.testing.assert_allclose(dbg[nv:2 * nv], d.get("qacc_smooth"), rtol=0, atol=1e-12 * scale)
         np.testing.assert_allclose(dbg[:nv], d.get("qacc"), rtol=0, atol=1e-11 * scale)
-        np.testing.assert_allclose(dbg[3 * nv:4 * nv], d.get("qfrc_constraint"), rtol=0, atol=1e-9 * scale)
+        if not pgs:
+            np.testing.assert_allclose(dbg[3 * nv:4 * nv], d.get("qfrc_constraint"), rtol=0, atol=1e-9 * scale)
 
 
-@pytest.mark.parametrize("model", [0, 1, 2], ids=NAMES)
+@pytest.mark.parametrize("model", list(VARIANTS), ids=[f"{n}-{s}" if s else n for n, s in VARIANTS.values()])
 def test_env_steps_match_oracle_with_contacts(model):
     """frame_skip sub-steps (Euler with implicit damping / RK4) from states the oracle reached under a random policy."""
-    om_ = om.OracleModel(NAMES[model])
+    om_ = oracle_model(model)
     m, d = om_.m, om_.make_data()
-    nb, amp = m.nbody, (0.4 if model == 2 else 1.0)
-    seen_contacts = 0
+    nb, amp = m.nbody, (0.4 if model >= 2 else 1.0)
+    seen_contacts = most_contacts = 0
     for trial in range(2):
         rng = np.random.default_rng(100 + trial)
         qpos = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
         if model > 0:
             qpos[3:7] /= np.linalg.norm(qpos[3:7])
         d.reset(), d.set_state(qpos, 0.1 * rng.normal(size=m.nv), np.zeros(m.nu))
-        for _ in range(120 if model == 2 else 60):
+        for _ in range(120 if model in (2, 12) else (20 if model in (8, 18) else 60)):
             d.set_state(None, None, amp * rng.uniform(-1, 1, m.nu)), d.step(5)
         q, v = d.get("qpos"), d.get("qvel")
-        warm = np.zeros(m.nv)  # carried across env steps like the kernel's qacc_warmstart slot
+        warm = d.get("qacc_warmstart").copy()  # carried across env steps like the kernel's qacc_warmstart slot (PGS results depend on it)
         for _ in range(4):
             ctrl = amp * rng.uniform(-1, 1, m.nu)
             d.set_state(q, v, ctrl), d.step(5), d.rne_post_constraint()
             qo, vo, ex, _, ncon = emu(model, m, q, v, ctrl, 5, warm)
             assert ncon == d.get("ncon")
             seen_contacts += ncon
+            most_contacts = max(most_contacts, ncon)
             np.testing.assert_allclose(qo, d.get("qpos"), rtol=0, atol=1e-11)
             np.testing.assert_allclose(vo, d.get("qvel"), rtol=0, atol=1e-10)
             cf = ex[4:4 + 6 * nb].reshape(nb, 6)
@@ -102,7 +116,31 @@ def test_env_steps_match_oracle_with_contacts(model):
             np.testing.assert_allclose(ex[4 + 6 * nb:4 + 16 * nb].reshape(nb, 10), d.get("cinert"), rtol=0, atol=1e-12)
             np.testing.assert_allclose(ex[4 + 16 * nb:4 + 22 * nb].reshape(nb, 6), d.get("cvel"), rtol=0, atol=1e-10)
             q, v = d.get("qpos"), d.get("qvel")
-    assert seen_contacts > 0
+    assert seen_contacts > 0 and most_contacts > 0
+
+
+def test_pgs_more_contacts_than_the_lds_store_holds():
+    """The cooperative PGS keeps M^-1 J_c^T of the first 7 contacts in LDS and spills the rest to global memory: a humanoid pressed flat
+    into the floor (>= 10 contacts) must still equal the oracle, forward pass and sub-steps."""
+    om_ = oracle_model(8)
+    m, d = om_.m, om_.make_data()
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        qpos = m.qpos0 + rng.uniform(-0.05, 0.05, m.nq)
+        qpos[3:7] = m.qpos0[3:7]
+        qpos[2] = m.qpos0[2] - 0.03 - 0.02 * trial  # lying on its back, pushed into the plane
+        qvel, ctrl = 0.3 * rng.normal(size=m.nv), 0.4 * rng.uniform(-1, 1, m.nu)
+        d.reset(), d.set_state(qpos, qvel, ctrl), d.forward()
+        assert d.get("ncon") >= 10, d.get("ncon")
+        _, _, _, dbg, ncon = emu(8, m, qpos, qvel, ctrl, 0)
+        assert ncon == d.get("ncon")
+        np.testing.assert_allclose(dbg[:m.nv], d.get("qacc"), rtol=0, atol=1e-10 * max(1.0, np.abs(d.get("qacc")).max()))
+        d.reset(), d.set_state(qpos, qvel, ctrl), d.step(2), d.rne_post_constraint()
+        qo, vo, ex, _, _ = emu(8, m, qpos, qvel, ctrl, 2, np.zeros(m.nv))
+        np.testing.assert_allclose(qo, d.get("qpos"), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(vo, d.get("qvel"), rtol=0, atol=1e-8 * max(1.0, np.abs(vo).max()))
+        cf = ex[4:4 + 6 * m.nbody].reshape(m.nbody, 6)
+        np.testing.assert_allclose(cf, d.get("cfrc_ext"), rtol=0, atol=1e-8 * max(1.0, np.abs(cf).max()))
 
 
 # ---- the ONE-LANE simulator (mjx_core.h, the product kernel of the nine smaller robots) compiled for the host ------------------------
@@ -142,7 +180,7 @@ def test_one_lane_simulator_matches_oracle(model):
         for _ in range(20 if name in ("pusher", "inverted_pendulum", "inverted_double_pendulum") else 60):
             d.set_state(None, None, amp * rng.uniform(-1, 1, m.nu)), d.step(nsub)
         q, v = d.get("qpos"), d.get("qvel")
-        warm = np.zeros(m.nv)
+        warm = d.get("qacc_warmstart").copy()
         for _ in range(4):
             ctrl = amp * rng.uniform(-1, 1, m.nu)
             d.set_state(q, v, ctrl), d.step(nsub)

@@ -188,3 +188,31 @@ def test_pusher_contacts_gpu_vs_oracle(oracle_factory):
     assert moved.sum() > n // 8, "the arm must actually push the object in a good share of the environments"
     print(f"pusher contacts: max |obs diff| {worst:.3e} over 10 steps x {n} envs; object pushed in {int(moved.sum())} envs")
     gpu.close(), cpu.close()
+
+
+@pytest.mark.parametrize("env_id", ["Humanoid-v5", "HumanoidStandup-v5"])
+def test_humanoid_solver_choice(env_id, oracle_factory):
+    """The humanoids run their MJCF's solver by default -- `solver="PGS" iterations="50"` (humanoid.xml:8), restated in mjx_coop.h pgs() --
+    and the converged Newton solver only on request (solver="Newton").  Each agrees with the oracle's solver of the same name; the two differ
+    from each other by what a truncated PGS leaves (~1e-5 relative in qacc per forward pass)."""
+    n = 96
+    envs = {(dev, s): gymnasium_amd.make_vec(env_id, num_envs=n, solver=s, **({} if dev == "gpu" else dict(_engine_factory=oracle_factory)))
+            for dev in ("gpu", "cpu") for s in ("PGS", "Newton")}
+    for e in envs.values():
+        e.reset(seed=8)
+    envs["gpu", "PGS"].action_space.seed(1)
+    gap = 0.0
+    for t in range(8):
+        a = envs["gpu", "PGS"].action_space.sample()
+        out = {k: e.step(a) for k, e in envs.items()}
+        for s in ("PGS", "Newton"):
+            np.testing.assert_allclose(out["gpu", s][0], out["cpu", s][0], rtol=1e-6, atol=1e-6, err_msg=f"{env_id} {s} obs t={t}")
+            np.testing.assert_allclose(out["gpu", s][1], out["cpu", s][1], rtol=1e-6, atol=1e-6, err_msg=f"{env_id} {s} reward t={t}")
+            assert np.array_equal(out["gpu", s][2], out["cpu", s][2])
+        gap = max(gap, float(np.abs(out["gpu", "PGS"][0] - out["gpu", "Newton"][0]).max()))
+    assert gap > 0.0, "PGS / 50 and converged Newton must not be the same computation"
+    print(f"{env_id}: max |obs(PGS) - obs(Newton)| over 8 steps = {gap:.3e}")
+    with pytest.raises(Exception):
+        gymnasium_amd.make_vec(env_id, num_envs=1, solver="CG")
+    for e in envs.values():
+        e.close()
