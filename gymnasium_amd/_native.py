@@ -34,6 +34,8 @@ SYMBOLS = [
 
 # The device-side vector wrappers (include/mi355env.h, gymnasium_amd/csrc/wrappers.hip); their checker is NumPy code
 # (oracle/wrappers.py), so they are not part of the orc_-prefixed checker ABI.
+# Host stepping through the engine's pinned staging block (mi_step_async / mi_step_wait / mi_host_buffers): product library only.
+HOST_SYMBOLS = ["step_async", "step_wait", "host_buffers"]
 WRAPPER_SYMBOLS = ["rms_create", "rms_destroy", "rms_get", "rms_set", "normalize_observation", "normalize_reward", "clip_reward"]
 
 
@@ -122,6 +124,9 @@ class NativeLib:
             self.normalize_observation = f("normalize_observation", [vp, vp, vp, i32, i32, dbl, i32, vp], i32)
             self.normalize_reward = f("normalize_reward", [vp, vp, vp, vp, vp, vp, vp, i32, dbl, dbl, i32, i32, vp], i32)
             self.clip_reward = f("clip_reward", [i32, vp, vp, i32, vp, vp, vp], i32)
+            self.step_async = f("step_async", [vp, C.POINTER(MiStepIO)], i32)
+            self.step_wait = f("step_wait", [vp], i32)
+            self.host_buffers = f("host_buffers", [vp, C.POINTER(MiStepIO)], i32)
 
     def _fn(self, name, argtypes, restype):
         fn = getattr(self.dll, self.prefix + name)
@@ -240,6 +245,47 @@ class Engine:
         io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
         io.episode_return, io.episode_length, io.info = _ptr(episode_return), _ptr(episode_length), _ptr(info)
         self.lib.check(self.lib.step(self.handle, C.byref(io), loc))
+
+    def _fill_io(self, actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info):
+        io = self._step_io
+        io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
+        io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
+        io.episode_return, io.episode_length, io.info, io.final_info = _ptr(episode_return), _ptr(episode_length), _ptr(info), _ptr(final_info)
+        return io
+
+    def step_async(self, actions, obs, reward, terminated, truncated, final_obs=None, episode_return=None, episode_length=None, info=None,
+                   final_info=None):
+        """Enqueue a host step (H2D, kernel, one D2H) without waiting; the arrays are filled by step_wait()."""
+        io = self._fill_io(actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info)
+        self.lib.check(self.lib.step_async(self.handle, C.byref(io)))
+
+    def step_wait(self):
+        self.lib.check(self.lib.step_wait(self.handle))
+
+    def host_buffers(self):
+        """The engine's pinned host arrays as NumPy views (valid until close()), or None for a backend without them (the checker)."""
+        if not hasattr(self.lib, "host_buffers"):
+            return None
+        io = MiStepIO()
+        self.lib.check(self.lib.host_buffers(self.handle, C.byref(io)))
+        N = self.num_envs
+
+        def view(ptr, ctype, dtype, count, shape):
+            return np.ctypeslib.as_array((ctype * count).from_address(ptr)).view(dtype).reshape(shape)
+
+        oct_, odt = {np.float32: (C.c_float, np.float32), np.float64: (C.c_double, np.float64), np.int64: (C.c_int64, np.int64)}[self.obs_dtype]
+        act_ct, act_dt = (C.c_int64, np.int64) if self.act_dtype is np.int64 else (C.c_float, np.float32)
+        obs_shape = (N,) if (self.obs_dtype is np.int64 and self.obs_dim == 1) else (N, self.obs_dim)
+        act_shape = (N,) if self.act_dtype is np.int64 else (N, self.act_dim)
+        out = {"actions": view(io.actions, act_ct, act_dt, N * self.act_dim, act_shape),
+               "obs": view(io.obs, oct_, odt, N * self.obs_dim, obs_shape), "final_obs": view(io.final_obs, oct_, odt, N * self.obs_dim, obs_shape),
+               "reward": view(io.reward, C.c_double, np.float64, N, (N,)), "episode_return": view(io.episode_return, C.c_double, np.float64, N, (N,)),
+               "terminated": view(io.terminated, C.c_uint8, np.bool_, N, (N,)), "truncated": view(io.truncated, C.c_uint8, np.bool_, N, (N,)),
+               "episode_length": view(io.episode_length, C.c_int32, np.int32, N, (N,))}
+        if self.info_dim:
+            out["info"] = view(io.info, C.c_double, np.float64, N * self.info_dim, (N, self.info_dim))
+            out["final_info"] = view(io.final_info, C.c_double, np.float64, N * self.info_dim, (N, self.info_dim))
+        return out
 
     def action_seed(self, words):
         w = np.ascontiguousarray(words, dtype=np.uint64)

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1023,8 +1024,13 @@ struct mi_vecenv {
     Pcg64 act_rng;          // host copy of the action-space generator
     PcgJump *d_pow2;        // [64] device jump table for act_rng.inc
     PcgJump jump_n;
-    // staging for the MI_HOST entry points
-    void *d_actions;
+    // Staging for the MI_HOST entry points (SURVEY 8(b) "Ownership"): every step output lives in ONE device block and ONE pinned host
+    // block of the same layout -- [error word | obs | reward | terminated | truncated | info | episode_return | episode_length | final_obs |
+    // final_info], 256-byte aligned sections -- so a host step is one H2D (actions), one launch and one D2H of the prefix in use.
+    // d_obs ... d_final_info / h_* are views into the two blocks.
+    char *d_out, *h_out;
+    size_t out_bytes, off_end[9];  // end offset of each section in the order above (after the header)
+    void *d_actions, *h_actions;
     void *d_obs, *d_final;
     double *d_reward, *d_epret;
     uint8_t *d_term, *d_trunc, *d_mask;
@@ -1033,6 +1039,10 @@ struct mi_vecenv {
     size_t act_bytes, obs_bytes;
     double *d_info, *d_final_info;
     size_t info_bytes;
+    mi_step_io h_io;        // the pinned host arrays (mi_host_buffers)
+    mi_step_io pending;     // user pointers of a step that was enqueued by mi_step_async and not waited for yet
+    size_t pending_bytes;
+    bool has_pending;
     void *tab_bufs[7];
     bool tab_loaded;
     // MuJoCo family: cooperative physics kernel (default) or the one-lane simulator (MI355ENV_MJ_SERIAL=1, cross-check)
@@ -1090,9 +1100,9 @@ int dispatch_mj(int kind, F &&f) {
 }
 
 int check_device_error(mi_vecenv *v) {
-    int err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, v->d.error, sizeof err, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(v->h_out, v->d.error, sizeof(int), hipMemcpyDeviceToHost, v->stream));
     HIP_TRY(hipStreamSynchronize(v->stream));
+    const int err = *reinterpret_cast<const int *>(v->h_out);
     if (!err) return MI_OK;
     HIP_TRY(hipMemsetAsync(v->d.error, 0, sizeof(int), v->stream));
     if (err == kErrInvalidAction) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
@@ -1277,8 +1287,23 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         v->lay = kLayouts[cfg->kind];
     }
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&v->own_stream, hipStreamNonBlocking));
-    v->stream = v->own_stream;
+    // One engine stream per DEVICE, shared by every env of the process and never destroyed.  A stream is a hardware queue with its own
+    // scratch-memory reservation, sized for the hungriest kernel launched on it (the one-lane MuJoCo kernels keep ~20 KB per lane there):
+    // a stream per env made a long-lived process that creates and closes many envs (the GPU test-suite: > 100) abort inside the runtime
+    // at the first large-scratch launch of some later env.  Sub-environments of different envs are independent, so sharing only serialises
+    // launches that a caller wanting overlap can still separate with mi_set_stream.
+    {
+        static std::mutex mu;
+        static hipStream_t shared[64] = {};
+        std::lock_guard<std::mutex> lock(mu);
+        if (device < 64) {
+            if (!shared[device]) HIP_TRY(hipStreamCreateWithFlags(&shared[device], hipStreamNonBlocking));
+            v->stream = shared[device];
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&v->own_stream, hipStreamNonBlocking));
+            v->stream = v->own_stream;
+        }
+    }
     const size_t N = (size_t)cfg->num_envs;
     v->grid = (int)((N + kBlock - 1) / kBlock);
     DevEnv &d = v->d;
@@ -1292,7 +1317,6 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     HIP_TRY(hipMalloc(&d.ep_len, sizeof(int32_t) * N));
     HIP_TRY(hipMalloc(&d.blk_count, sizeof(uint64_t) * 4 * v->grid));
     HIP_TRY(hipMalloc(&d.blk_ret, sizeof(double) * v->grid));
-    HIP_TRY(hipMalloc(&d.error, sizeof(int)));
     HIP_TRY(hipMalloc(&v->d_pow2, sizeof(PcgJump) * 64));
     HIP_TRY(hipMemsetAsync(d.state, 0, sizeof(double) * v->lay.state_dim * N, v->stream));
     HIP_TRY(hipMemsetAsync(d.meta, 0, sizeof(uint32_t) * N, v->stream));
@@ -1301,23 +1325,33 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     HIP_TRY(hipMemsetAsync(d.ep_len, 0, sizeof(int32_t) * N, v->stream));
     HIP_TRY(hipMemsetAsync(d.blk_count, 0, sizeof(uint64_t) * 4 * v->grid, v->stream));
     HIP_TRY(hipMemsetAsync(d.blk_ret, 0, sizeof(double) * v->grid, v->stream));
-    HIP_TRY(hipMemsetAsync(d.error, 0, sizeof(int), v->stream));
     v->act_bytes = N * (v->lay.act_dtype == MI_I64 ? 8 : 4) * v->lay.act_dim;
     v->obs_bytes = N * (v->lay.obs_dtype == MI_F32 ? sizeof(float) : sizeof(double)) * v->lay.obs_dim;
     v->info_bytes = N * sizeof(double) * (v->lay.info_dim > 0 ? v->lay.info_dim : 1);
-    HIP_TRY(hipMalloc(&v->d_info, v->info_bytes));
-    HIP_TRY(hipMalloc(&v->d_final_info, v->info_bytes));
-    HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes));
-    HIP_TRY(hipMalloc(&v->d_obs, v->obs_bytes));
-    HIP_TRY(hipMalloc(&v->d_final, v->obs_bytes));
-    HIP_TRY(hipMalloc(&v->d_reward, sizeof(double) * N));
-    HIP_TRY(hipMalloc(&v->d_epret, sizeof(double) * N));
-    HIP_TRY(hipMalloc(&v->d_eplen, sizeof(int32_t) * N));
-    HIP_TRY(hipMalloc(&v->d_term, N));
-    HIP_TRY(hipMalloc(&v->d_trunc, N));
+    {
+        const size_t sizes[9] = {v->obs_bytes, sizeof(double) * N, N, N, v->info_bytes, sizeof(double) * N, sizeof(int32_t) * N, v->obs_bytes, v->info_bytes};
+        size_t off = 256, start[9];  // the first 256 bytes hold the sticky device error word
+        for (int k = 0; k < 9; k++) start[k] = off, off = (off + sizes[k] + 255) & ~(size_t)255, v->off_end[k] = start[k] + sizes[k];
+        v->out_bytes = off;
+        HIP_TRY(hipMalloc(&v->d_out, v->out_bytes));
+        HIP_TRY(hipHostMalloc((void **)&v->h_out, v->out_bytes, hipHostMallocDefault));
+        HIP_TRY(hipMemsetAsync(v->d_out, 0, v->out_bytes, v->stream));
+        memset(v->h_out, 0, v->out_bytes);
+        d.error = reinterpret_cast<int *>(v->d_out);
+        char *D = v->d_out, *H = v->h_out;
+        v->d_obs = D + start[0], v->d_reward = (double *)(D + start[1]), v->d_term = (uint8_t *)(D + start[2]), v->d_trunc = (uint8_t *)(D + start[3]);
+        v->d_info = (double *)(D + start[4]), v->d_epret = (double *)(D + start[5]), v->d_eplen = (int32_t *)(D + start[6]);
+        v->d_final = D + start[7], v->d_final_info = (double *)(D + start[8]);
+        HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes));
+        HIP_TRY(hipHostMalloc(&v->h_actions, v->act_bytes, hipHostMallocDefault));
+        memset(v->h_actions, 0, v->act_bytes);
+        v->h_io.actions = v->h_actions, v->h_io.obs = H + start[0], v->h_io.reward = (double *)(H + start[1]);
+        v->h_io.terminated = (uint8_t *)(H + start[2]), v->h_io.truncated = (uint8_t *)(H + start[3]), v->h_io.info = (double *)(H + start[4]);
+        v->h_io.episode_return = (double *)(H + start[5]), v->h_io.episode_length = (int32_t *)(H + start[6]);
+        v->h_io.final_obs = H + start[7], v->h_io.final_info = (double *)(H + start[8]);
+    }
     HIP_TRY(hipMalloc(&v->d_mask, N));
     HIP_TRY(hipMalloc(&v->d_words, sizeof(uint64_t) * 4 * N));
-    HIP_TRY(hipMemsetAsync(v->d_obs, 0, v->obs_bytes, v->stream));
     if (is_mj(cfg->kind)) {
         HIP_TRY(hipMalloc(&v->d_extras, sizeof(double) * v->extras_dim * N));
         HIP_TRY(hipMalloc(&v->d_act_scratch, v->act_bytes));
@@ -1335,11 +1369,12 @@ void mi_destroy(mi_vecenv *v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
     (void)hipStreamSynchronize(v->stream);
-    void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d.error,
-                    v->d_pow2, v->d_actions, v->d_obs, v->d_final, v->d_reward, v->d_epret, v->d_eplen, v->d_term,
-                    v->d_trunc, v->d_mask, v->d_words, v->d_info, v->d_final_info, v->d_pgs_spill, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
+    void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d_out,
+                    v->d_pow2, v->d_actions, v->d_mask, v->d_words, v->d_pgs_spill, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (v->h_out) (void)hipHostFree(v->h_out);
+    if (v->h_actions) (void)hipHostFree(v->h_actions);
     for (void *p : v->tab_bufs)
         if (p) (void)hipFree(p);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
@@ -1457,10 +1492,13 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
     return MI_OK;
 }
 
-int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
+// Enqueue one vector step.  loc == MI_HOST: actions go through the pinned staging block (one H2D), the kernel writes the device output
+// block, and ONE D2H brings back the prefix of it that the caller asked for (error word included); nothing is synchronised here.
+static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     if (!v || !io) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     if (!v->was_reset) return fail(MI_ERR_STATE, "step before reset");
     if (!io->actions) return fail(MI_ERR_INVALID_ARGUMENT, "actions is NULL");
+    if (v->has_pending) return fail(MI_ERR_STATE, "mi_step_async: the previous asynchronous step has not been waited for (mi_step_wait)");
     if (set_device(v)) return MI_ERR_HIP;
     const size_t N = (size_t)v->cfg.num_envs;
     StepPtrs p;
@@ -1472,7 +1510,8 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
             for (size_t i = 0; i < N; i++)
                 if (a[i] < 0 || a[i] >= na) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
         }
-        HIP_TRY(hipMemcpyAsync(v->d_actions, io->actions, v->act_bytes, hipMemcpyHostToDevice, v->stream));
+        if (io->actions != v->h_actions) memcpy(v->h_actions, io->actions, v->act_bytes);  // callers that fill the pinned array skip this
+        HIP_TRY(hipMemcpyAsync(v->d_actions, v->h_actions, v->act_bytes, hipMemcpyHostToDevice, v->stream));
         p.actions = v->d_actions;
         p.obs = (float *)v->d_obs, p.reward = v->d_reward, p.terminated = v->d_term, p.truncated = v->d_trunc;
         p.final_obs = io->final_obs ? (float *)v->d_final : nullptr;
@@ -1507,19 +1546,58 @@ int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
     }
     if (rc) return rc;
     if (loc == MI_HOST) {
-        if (io->info) HIP_TRY(hipMemcpyAsync(io->info, v->d_info, v->info_bytes, hipMemcpyDeviceToHost, v->stream));
-        if (io->final_info) HIP_TRY(hipMemcpyAsync(io->final_info, v->d_final_info, v->info_bytes, hipMemcpyDeviceToHost, v->stream));
-        if (io->obs) HIP_TRY(hipMemcpyAsync(io->obs, v->d_obs, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
-        if (io->reward) HIP_TRY(hipMemcpyAsync(io->reward, v->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost, v->stream));
-        if (io->terminated) HIP_TRY(hipMemcpyAsync(io->terminated, v->d_term, N, hipMemcpyDeviceToHost, v->stream));
-        if (io->truncated) HIP_TRY(hipMemcpyAsync(io->truncated, v->d_trunc, N, hipMemcpyDeviceToHost, v->stream));
-        if (io->final_obs) HIP_TRY(hipMemcpyAsync(io->final_obs, v->d_final, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
-        if (io->episode_return)
-            HIP_TRY(hipMemcpyAsync(io->episode_return, v->d_epret, sizeof(double) * N, hipMemcpyDeviceToHost, v->stream));
-        if (io->episode_length)
-            HIP_TRY(hipMemcpyAsync(io->episode_length, v->d_eplen, sizeof(int32_t) * N, hipMemcpyDeviceToHost, v->stream));
-        return check_device_error(v);  // synchronises
+        // one copy: the block prefix up to the last section somebody wants (sections in h_io order: obs, reward, terminated, truncated,
+        // info, episode_return, episode_length, final_obs, final_info)
+        const void *want[9] = {io->obs, io->reward, io->terminated, io->truncated, io->info, io->episode_return, io->episode_length, io->final_obs, io->final_info};
+        size_t n = 256;
+        for (int k = 0; k < 9; k++)
+            if (want[k]) n = v->off_end[k];
+        HIP_TRY(hipMemcpyAsync(v->h_out, v->d_out, n, hipMemcpyDeviceToHost, v->stream));
+        v->pending = *io, v->pending_bytes = n, v->has_pending = true;
     }
+    return MI_OK;
+}
+
+// Wait for the step enqueued by step_enqueue(MI_HOST): synchronise, raise the device error word that came back with the block, and hand the
+// sections to the caller's arrays (a plain memcpy out of pinned memory; skipped for arrays that ARE the pinned ones, mi_host_buffers).
+static int step_finish(mi_vecenv *v) {
+    if (!v->has_pending) return MI_OK;
+    v->has_pending = false;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    const int err = *reinterpret_cast<const int *>(v->h_out);
+    if (err) {
+        HIP_TRY(hipMemsetAsync(v->d.error, 0, sizeof(int), v->stream));
+        if (err == kErrInvalidAction) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
+        return fail(MI_ERR_STATE, "DISABLED autoreset: a finished sub-environment was stepped without reset");
+    }
+    const size_t N = (size_t)v->cfg.num_envs;
+    const mi_step_io &u = v->pending, &h = v->h_io;
+    auto out = [](void *dst, const void *src, size_t n) {
+        if (dst && dst != src) memcpy(dst, src, n);
+    };
+    out(u.obs, h.obs, v->obs_bytes), out(u.reward, h.reward, sizeof(double) * N), out(u.terminated, h.terminated, N), out(u.truncated, h.truncated, N);
+    out(u.info, h.info, v->info_bytes), out(u.episode_return, h.episode_return, sizeof(double) * N), out(u.episode_length, h.episode_length, sizeof(int32_t) * N);
+    out(u.final_obs, h.final_obs, v->obs_bytes), out(u.final_info, h.final_info, v->info_bytes);
+    return MI_OK;
+}
+
+int mi_step(mi_vecenv *v, const mi_step_io *io, int loc) {
+    if (int rc = step_enqueue(v, io, loc)) return rc;
+    return loc == MI_HOST ? step_finish(v) : (int)MI_OK;
+}
+
+int mi_step_async(mi_vecenv *v, const mi_step_io *io) { return step_enqueue(v, io, MI_HOST); }
+
+int mi_step_wait(mi_vecenv *v) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (!v->has_pending) return fail(MI_ERR_STATE, "mi_step_wait without a pending mi_step_async");
+    if (set_device(v)) return MI_ERR_HIP;
+    return step_finish(v);
+}
+
+int mi_host_buffers(mi_vecenv *v, mi_step_io *out) {
+    if (!v || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    *out = v->h_io;
     return MI_OK;
 }
 

@@ -28,6 +28,11 @@
 #pragma clang fp contract(fast)
 #endif
 
+#if defined(MJX_HOST_EMU)
+#define MJX_SCHED_FENCE() ((void)0)
+#else
+#define MJX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef MJX_CHOL_LDS_FOR_16
 #define MJX_CHOL_LDS_FOR_16 0  // diagnostic switch: 16-lane groups on the LDS-exchange Cholesky as well (costs LDS: 3 instead of 4 wavefronts per CU)
 #endif
@@ -1074,8 +1079,15 @@ struct Sim {
         }
         b[0] = p[lane], b[1] = p[NV + lane], b[2] = p[2 * NV + lane];
     }
-    // r.Hrow: row `lane` of L (M = L L^T) -> row `lane` of M^-1.  L^-1 row by row through the storage of M (dead), then L^-T L^-1.
-    static MJX_DEV void invert(B &bb, R &r, int lane) {
+    // Row `lane` of M^-1 from the factor M = L L^T (packed copy on the blackboard, idiag = 1 / L[lane][lane]): L^-1 row by row through the
+    // storage of M (dead), then L^-T L^-1.  OUT OF LINE on the device: inlined, this block alone drives the 32-lane kernel from 19 to 540
+    // spilled registers (measured by compiling with and without it) and slows every other phase of the forward pass down with it; as a
+    // function it has its own register allocation and costs one save / restore of the caller's live registers per forward pass.
+#if defined(MJX_HOST_EMU)
+    static inline void invert(B &bb, double idiag, int lane, double *minv) {
+#else
+    static __device__ __attribute__((noinline)) void invert(B &bb, double idiag, int lane, double *minv) {
+#endif
         static_assert(B::M_IN_LDS, "the explicit inverse goes through the blackboard storage of M");
         double acc[NV];
 #pragma unroll
@@ -1085,23 +1097,28 @@ struct Sim {
         for (int k = 0; k < NV; k++) {
             if (lane == k) {
 #pragma unroll
-                for (int j = 0; j <= k; j++) S[k][j] = ((j == k ? 1.0 : 0.0) - acc[j]) * r.idiag;
+                for (int j = 0; j <= k; j++) S[k][j] = ((j == k ? 1.0 : 0.0) - acc[j]) * idiag;
             }
             coop_sync();
             if (lane > k && lane < NV) {
-                const double lik = r.Hrow[k];
+                const double lik = bb.A.sol.L[tri(lane < NV ? lane : 0, 0) + k];  // L[lane][k] from the packed copy: the register row is free for M^-1
 #pragma unroll
                 for (int j = 0; j <= k; j++) acc[j] += lik * S[k][j];
             }
+            MJX_SCHED_FENCE();  // keep the scheduler from hoisting the LDS reads of later rows (hundreds of live values -> spills)
         }
+        double row[NV];
 #pragma unroll
-        for (int j = 0; j < NV; j++) r.Hrow[j] = 0;
+        for (int j = 0; j < NV; j++) row[j] = 0;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const double ski = (lane <= k) ? S[k][lane < NV ? lane : 0] : 0.0;
 #pragma unroll
-            for (int j = 0; j <= k; j++) r.Hrow[j] += ski * S[k][j];
+            for (int j = 0; j <= k; j++) row[j] += ski * S[k][j];
+            MJX_SCHED_FENCE();
         }
+#pragma unroll
+        for (int j = 0; j < NV; j++) minv[j] = row[j];
         coop_sync();  // S is dead from here on: the storage becomes the M^-1 J_c^T store
     }
     // The rows of contact (kc, owner lane) against the contact-frame acceleration v = J_c a: relax them in order, keep v current, return the
@@ -1173,6 +1190,7 @@ struct Sim {
         chol_factor(bb, r.Hrow, r.idiag, lane);
         const double qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
         r.qacc_smooth = qs, r.qfrc_constraint = 0;
+        MJX_PHASE(r, 8);
         if (!anyrow) {
             r.qacc = qs;
             return;
@@ -1195,7 +1213,14 @@ struct Sim {
             if (r.c_on[kc]) contact_vel(bb, bb.C.sol.tw, kc * G + lane, r.c_b1[kc], r.c_b2[kc], jw[kc]);
         }
         coop_sync();
-        invert(bb, r, lane);  // r.Hrow = row `lane` of M^-1
+        MJX_PHASE(r, 9);
+        {
+            double minv[NV];
+            invert(bb, r.idiag, lane, minv);
+#pragma unroll
+            for (int j = 0; j < NV; j++) r.Hrow[j] = minv[j];  // r.Hrow = row `lane` of M^-1
+        }
+        MJX_PHASE(r, 7);
         const unsigned lm0 = bb.limmask[0], lm1 = bb.limmask[1];
         const int ncon = bb.ncon;
         // ---- rows: diagonal, warm-start force, dual cost pieces --------------------------------------------------------------------
@@ -1297,6 +1322,7 @@ struct Sim {
         } else {
             a += w;
         }
+        MJX_PHASE(r, 6);
         // ---- sweeps ---------------------------------------------------------------------------------------------------------------------
         const double scale = 1.0 / (M::MEANINERTIA * (NV > 1 ? NV : 1));
 #pragma unroll 1
@@ -1330,6 +1356,7 @@ struct Sim {
             if (imp * scale < 1e-8) break;
         }
         r.qacc = a;
+        MJX_PHASE(r, 10);
         // world-frame contact forces for cfrc_ext: frame^T (sum f, mu (f0 - f1), mu (f2 - f3))  (mj_contactForce for pyramids)
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {

@@ -125,7 +125,7 @@ class HipVectorEnv(VectorEnv):
             self._prev_dones = np.zeros(self.num_envs, dtype=np.bool_)
 
     def set_output(self, output: str):
-        """Switch between NumPy batches ("numpy": pinned staging + one copy per step) and device tensors ("torch": the engine writes
+        """Switch between NumPy batches ("numpy": the engine's pinned host block, one H2D + one D2H per step) and device tensors ("torch": the engine writes
         straight into torch tensors in HBM, nothing crosses PCIe) after construction -- what wrappers.vector.NumpyToTorch(env) does.
         Call before reset()."""
         if output not in ("numpy", "torch"):
@@ -169,15 +169,21 @@ class HipVectorEnv(VectorEnv):
             self._loc = _native.MI_DEVICE
         else:
             self._obs_shape = (N,) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (N, eng.obs_dim)
-            self._obs = np.zeros(self._obs_shape, dtype=eng.obs_dtype)
-            self._rew = np.zeros((N,), dtype=np.float64)
-            self._term = np.zeros((N,), dtype=np.bool_)
-            self._trunc = np.zeros((N,), dtype=np.bool_)
-            self._final = np.zeros(self._obs_shape, dtype=eng.obs_dtype) if self.autoreset_mode == AutoresetMode.SAME_STEP else None
-            self._info = np.zeros((N, eng.info_dim), dtype=np.float64) if eng.info_dim else None
-            self._final_info = np.zeros((N, eng.info_dim), dtype=np.float64) if (eng.info_dim and self._final is not None) else None
-            self._ep_r = np.zeros((N,), dtype=np.float64) if self.record_episode_statistics else None
-            self._ep_l = np.zeros((N,), dtype=np.int32) if self.record_episode_statistics else None
+            same = self.autoreset_mode == AutoresetMode.SAME_STEP
+            # The engine's own PINNED host arrays (mi_host_buffers): the step's single D2H lands directly in what step() returns
+            # (copy=False) or copies from (copy=True, like SyncVectorEnv's deepcopy).  A backend without them (the checker): plain arrays.
+            hb = eng.host_buffers() if hasattr(eng, "host_buffers") else None
+            self._pinned = hb is not None
+            self.action_buffer = hb["actions"] if hb else None  # sample / write actions here to skip the staging memcpy of step()
+            self._obs = hb["obs"] if hb else np.zeros(self._obs_shape, dtype=eng.obs_dtype)
+            self._rew = hb["reward"] if hb else np.zeros((N,), dtype=np.float64)
+            self._term = hb["terminated"] if hb else np.zeros((N,), dtype=np.bool_)
+            self._trunc = hb["truncated"] if hb else np.zeros((N,), dtype=np.bool_)
+            self._final = (hb["final_obs"] if hb else np.zeros(self._obs_shape, dtype=eng.obs_dtype)) if same else None
+            self._info = (hb["info"] if hb else np.zeros((N, eng.info_dim), dtype=np.float64)) if eng.info_dim else None
+            self._final_info = (hb["final_info"] if hb else np.zeros((N, eng.info_dim), dtype=np.float64)) if (eng.info_dim and same) else None
+            self._ep_r = (hb["episode_return"] if hb else np.zeros((N,), dtype=np.float64)) if self.record_episode_statistics else None
+            self._ep_l = (hb["episode_length"] if hb else np.zeros((N,), dtype=np.int32)) if self.record_episode_statistics else None
             self._loc = _native.MI_HOST
 
     def _p(self, buf):
@@ -352,6 +358,44 @@ class HipVectorEnv(VectorEnv):
 
     def _host(self, buf):
         return buf.cpu().numpy() if self.output == "torch" else buf
+
+    # -- asynchronous stepping (AsyncVectorEnv.step_async / step_wait, vector/async_vector_env.py:440-521) ----------------------------
+    def step_async(self, actions):
+        """Enqueue one step (actions H2D, kernel, one D2H into the pinned block) and return at once; ``step_wait()`` collects it.
+        With device tensors (``output="torch"``) every step is already asynchronous: this is then ``step()`` with the result parked."""
+        self._check_open()
+        if not self._has_reset:
+            raise AssertionError("Call reset before using step method.")
+        if getattr(self, "_async_pending", None) is not None:
+            raise error.Error("Calling `step_async` while waiting for a pending call to `step_async` to complete.")  # AlreadyPendingCallError upstream
+        if self.output == "torch" or not self._pinned:
+            self._async_pending = ("done", self.step(actions))
+            return
+        keep, aptr = self._coerce_actions(actions)
+        self._bind_stream()
+        try:
+            self._engine.step_async(aptr, self._obs, self._rew, self._term, self._trunc, self._final, self._ep_r, self._ep_l, self._info, self._final_info)
+        except _native.NativeError as e:
+            if e.code in (-1, -5):
+                raise AssertionError(e.message) from e
+            raise
+        self._async_pending = ("engine", keep)
+
+    def step_wait(self, timeout=None):
+        pending = getattr(self, "_async_pending", None)
+        if pending is None:
+            raise error.Error("Calling `step_wait` without any prior call to `step_async`.")  # NoAsyncCallError upstream
+        self._async_pending = None
+        if pending[0] == "done":
+            return pending[1]
+        try:
+            self._engine.step_wait()
+        except _native.NativeError as e:
+            if e.code in (-1, -5):
+                raise AssertionError(e.message) from e
+            raise
+        infos = self._build_infos()
+        return self._out(self._obs), self._out(self._rew), self._out(self._term), self._out(self._trunc), infos
 
     def _build_infos(self) -> dict:
         infos: dict[str, Any] = {}

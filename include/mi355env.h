@@ -196,7 +196,7 @@ void mi_destroy(mi_vecenv *env);
 int mi_get_layout(const mi_vecenv *env, mi_layout *out);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work.  NULL means the legacy
  * default stream (what torch.cuda.current_stream().cuda_stream is by default).  Until this is called the env
- * uses a private non-blocking stream created by mi_create. */
+ * uses the engine's non-blocking stream of its device (one per device and process, shared by all envs). */
 int mi_set_stream(mi_vecenv *env, void *hip_stream);
 int mi_synchronize(mi_vecenv *env);
 
@@ -217,6 +217,21 @@ int mi_reset(mi_vecenv *env, const uint8_t *mask, const double *bounds, void *ob
 /* Replaces SyncVectorEnv.step (vector/sync_vector_env.py:266-337) with TimeLimit (wrappers/common.py:129-133)
  * and the scalar env's step() folded into one kernel launch. */
 int mi_step(mi_vecenv *env, const mi_step_io *io, int loc);
+
+/*
+ * Asynchronous host stepping (SURVEY.md 8(b) "Threading"): replaces AsyncVectorEnv.step_async / step_wait
+ * (vector/async_vector_env.py:440-521).  mi_step_async enqueues actions H2D -> step kernel -> ONE D2H of the output block and returns
+ * without synchronising; mi_step_wait synchronises, reports errors and fills the arrays given to mi_step_async (host pointers).  One step
+ * may be pending per env.  mi_step(io, MI_HOST) is exactly mi_step_async + mi_step_wait.
+ *
+ * mi_host_buffers: the env's own PINNED host arrays, laid out like the device output block (actions, obs, reward, terminated,
+ * truncated, info, episode_return, episode_length, final_obs, final_info; valid until mi_destroy).  Passing these pointers to
+ * mi_step / mi_step_async makes the host path zero-copy: the D2H lands where the caller reads, the actions are uploaded from where the
+ * caller wrote them (SURVEY.md 8(b) "Ownership").
+ */
+int mi_step_async(mi_vecenv *env, const mi_step_io *io);
+int mi_step_wait(mi_vecenv *env);
+int mi_host_buffers(mi_vecenv *env, mi_step_io *out);
 
 /* Transition table of a MI_ENV_TABULAR environment (host pointers, copied to the device).  Replaces the `P` dict and
  * `initial_state_distrib` the toy-text constructors build (frozen_lake.py:255-303, cliffwalking.py:118-135, taxi.py:281-334):

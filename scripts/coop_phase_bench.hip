@@ -20,9 +20,9 @@
 
 using namespace mjx;
 
-template <class M, int G>
-__global__ __launch_bounds__(64) void phys(double *state, const float *actions, int N, int nsub, unsigned long long *phase) {
-    typedef coop::Sim<M, G> S;
+template <class M, int G, bool PGS>
+__global__ __launch_bounds__(64) void phys(double *state, const float *actions, int N, int nsub, unsigned long long *phase, double *spill) {
+    typedef coop::Sim<M, G, PGS> S;
     constexpr int EPW = 64 / G;
     __shared__ typename S::B boards[EPW];
     const int grp = threadIdx.x / G, lane = threadIdx.x % G;
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = lane < M::NV ? state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;
+    r.spill = spill + (size_t)env * S::SPILL_DOUBLES;
 #ifdef MJX_COUNT_WORK
     r.work = 0, r.work_wave = 0;
 #endif
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
 
 // COOP_DEBUG: ONE forward pass from the initial state; per env 4 NV + NV^2 doubles: qacc, qacc_smooth, bias, qfrc_constraint, mass-matrix rows
 template <class M, int G>
-__global__ __launch_bounds__(64) void fwd_debug(const double *state, const float *actions, int N, double *out) {
+__global__ __launch_bounds__(64) void fwd_debug(const double *state, const float *actions, int N, double *out, double *spill) {
     typedef coop::Sim<M, G> S;
     constexpr int EPW = 64 / G, NV = M::NV;
     __shared__ typename S::B boards[EPW];
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(64) void fwd_debug(const double *state, const float
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = 0.0;
+    r.spill = spill + (size_t)env * S::SPILL_DOUBLES;
     coop::coop_sync();
     S::forward(bb, r, lane);
     coop::coop_sync();
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(64) void fwd_debug(const double *state, const float
     }
 }
 
-template <class M, int G>
+template <class M, int G, bool PGS = (M::SOLVER == 1)>
 int run(int N, int nsub, float amp) {
     const int S = M::NQ + 2 * M::NV;
     std::vector<double> st((size_t)S * N, 0.0);
@@ -102,6 +104,8 @@ int run(int N, int nsub, float amp) {
     unsigned long long *d_ph;
     hipMalloc(&d_st, sizeof(double) * st.size()), hipMalloc(&d_act, sizeof(float) * act.size()), hipMalloc(&d_ph, 12 * 8 + 256 + sizeof(int) * (size_t)N);
     hipMemcpy(d_st, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice);
+    double *d_spill;
+    hipMalloc(&d_spill, sizeof(double) * ((size_t)coop::Sim<M, G, PGS>::SPILL_DOUBLES * N + 1));
     const dim3 grid((N + 64 / G - 1) / (64 / G)), block(64);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
@@ -112,7 +116,7 @@ int run(int N, int nsub, float amp) {
         hipMemset(d_out, 0, sizeof(double) * W * N);
         for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
         hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL((fwd_debug<M, G>), grid, block, 0, 0, d_st, d_act, N, d_out);
+        hipLaunchKernelGGL((fwd_debug<M, G>), grid, block, 0, 0, d_st, d_act, N, d_out, d_spill);
         std::vector<double> out(W * N);
         hipMemcpy(out.data(), d_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost);
         FILE *f = fopen(getenv("COOP_DEBUG"), "wb");
@@ -127,7 +131,7 @@ int run(int N, int nsub, float amp) {
         for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
         hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
         if (t == warm) hipMemset(d_ph, 0, 16 * 8), hipEventRecord(e0);
-        hipLaunchKernelGGL((phys<M, G>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph);
+        hipLaunchKernelGGL((phys<M, G, PGS>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph, d_spill);
     }
     hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
     unsigned long long ph[12];
@@ -167,8 +171,11 @@ int run(int N, int nsub, float amp) {
             fwrite(st.data(), sizeof(double), st.size(), f), fclose(f);
         }
     }
-    const char *names[12] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "make_constraint",
-                             "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other"};
+    const char *newton_names[12] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "make_constraint",
+                                    "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other"};
+    const char *pgs_names[12] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "pgs: rows (M^-1 J^T, A, warm start) + make_constraint",
+                                 "pgs: M^-1", "pgs: factor M + qacc_smooth", "pgs: J qacc_smooth, J warm", "pgs: sweeps", "other"};
+    const char **names = PGS ? pgs_names : newton_names;
     double tot = 0;
     for (int k = 0; k < 12; k++) tot += (double)ph[k];
     printf("%d envs, %d sub-steps per launch: %.3f ms per launch (incl. host action upload), %.4g env-steps/s\n", N, nsub, ms / timed, N / (ms / timed * 1e-3));
@@ -181,8 +188,10 @@ int run(int N, int nsub, float amp) {
 int main(int argc, char **argv) {
     const char *which = argc > 1 ? argv[1] : "ant";
     const int N = argc > 2 ? atoi(argv[2]) : 32768;
-    if (!strcmp(which, "humanoid")) return run<HumanoidModel, 32>(N, 5, 0.4f);
+    if (!strcmp(which, "humanoid")) return run<HumanoidModel, 32>(N, 5, 0.4f);              // the MJCF's solver: PGS / 50
+    if (!strcmp(which, "humanoid-newton")) return run<HumanoidModel, 32, false>(N, 5, 0.4f);  // opt-in Newton
     if (!strcmp(which, "standup")) return run<HumanoidStandupModel, 32>(N, 5, 0.4f);
+    if (!strcmp(which, "standup-newton")) return run<HumanoidStandupModel, 32, false>(N, 5, 0.4f);
     if (!strcmp(which, "cheetah")) return run<HalfCheetahModel, 16>(N, 5, 1.0f);
     return run<AntModel, 16>(N, 5, 1.0f);
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 19
     for name in declared:
         assert hasattr(lib.dll, name), f"{name} declared in include/mi355env.h but not exported"
-    assert sorted("mi_" + s for s in _native.SYMBOLS + _native.WRAPPER_SYMBOLS) == declared
+    assert sorted("mi_" + s for s in _native.SYMBOLS + _native.WRAPPER_SYMBOLS + _native.HOST_SYMBOLS) == declared
     assert lib.abi_version() == _native.ABI_VERSION
 
 

@@ -266,3 +266,48 @@ def test_toytext_fused_rollout_and_full_size(key):
     sa, sb = a.statistics(), b.statistics()
     assert sa == sb and sa["env_steps"] + sa["reset_steps"] == 65536 * 24
     a.close(), b.close()
+
+
+def test_step_async_wait_and_pinned_buffers():
+    """The NumPy path steps through the engine's pinned host block: step_async / step_wait (AsyncVectorEnv's API, async_vector_env.py:440-521)
+    equal step(); actions written into env.action_buffer (the pinned upload array) give the same results as a pageable array; copy=False
+    returns views of the pinned block itself."""
+    n = 2048
+    a = ps.make("cartpole", n, None)
+    b = ps.make("cartpole", n, None, copy=False)
+    oa, _ = a.reset(seed=9)
+    ob, _ = b.reset(seed=9)
+    assert np.array_equal(oa, ob) and b.action_buffer is not None and b.action_buffer.shape == (n,) and b.action_buffer.dtype == np.int64
+    a.action_space.seed(2)
+    for t in range(60):
+        act = a.action_space.sample()
+        ra = a.step(act)
+        b.action_buffer[:] = act
+        b.step_async(b.action_buffer)
+        with pytest.raises(Exception):
+            b.step_async(act)  # one step may be pending
+        rb = b.step_wait()
+        for x, y in zip(ra[:4], rb[:4]):
+            assert np.array_equal(x, y), t
+        assert np.shares_memory(rb[0], b._obs) and not np.shares_memory(ra[0], a._obs)
+    with pytest.raises(Exception):
+        b.step_wait()
+    with pytest.raises(AssertionError):
+        b.step_async(np.full(n, 7))
+    a.close(), b.close()
+
+
+def test_step_async_mujoco_infos():
+    n = 64
+    a = gymnasium_amd.make_vec("Ant-v5", num_envs=n)
+    b = gymnasium_amd.make_vec("Ant-v5", num_envs=n)
+    a.reset(seed=1), b.reset(seed=1)
+    a.action_space.seed(0)
+    for _ in range(5):
+        act = a.action_space.sample()
+        ra = a.step(act)
+        b.step_async(act)
+        rb = b.step_wait()
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        assert set(ra[4]) == set(rb[4]) and all(np.array_equal(ra[4][k], rb[4][k]) for k in ra[4])
+    a.close(), b.close()

@@ -3,51 +3,62 @@ gymnasium_amd/csrc/build.py TU_FLAGS) against the SAME sources under hipcc's def
 product by __graft_entry__.build()).
 
 Why this is a test: the iterative schedulers were measured to MISCOMPILE the 16-lane instantiation when the RK4 stage update is inlined
-(every environment differs after one sub-step); keeping `rk4_stage` out of line makes all four instantiations
+(every environment differs after one sub-step); keeping `rk4_stage` out of line makes all instantiations
 bit-identical to the default scheduler's output.  A compiler update, a source change or a new flag can silently bring that back, and a
-tolerance-level parity test might not notice -- so the two builds must agree on EVERY BIT of the state after 25 env-steps x 4096
-sub-environments (Ant, HalfCheetah, Humanoid, HumanoidStandup: 100 / 25 / 100 / 100 forward passes each).
+tolerance-level parity test might not notice -- so the two builds must agree on EVERY BIT of the trajectory and of the final state after
+25 env-steps x 4096 sub-environments (Ant, HalfCheetah, Humanoid and HumanoidStandup with both of their solvers).
+
+Each build runs in its own child process (MI355ENV_LIBRARY selects the library): two HIP libraries carrying the same kernels in one
+long-lived process was measured (round 2) to abort the runtime.
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gymnasium_amd", "csrc")
+REF = os.path.join(CSRC, "libmi355env_ref.so")
+
+CHILD = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
 import gymnasium_amd
 from gymnasium_amd import _native
+assert _native.load_library().path == {lib!r}
+env = gymnasium_amd.make_vec({env_id!r}, num_envs=4096, **{kw!r})
+obs, _ = env.reset(seed=17)
+env.action_space.seed(3)
+out = [obs]
+for t in range(25):
+    o, r, te, tr, _ = env.step(env.action_space.sample())
+    out += [o, r, te, tr]
+st, el, fl = env.get_state()
+np.savez({path!r}, *out, st, el, fl)
+env.close()
+"""
 
-pytestmark = pytest.mark.gpu
-REF = os.path.join(os.path.dirname(os.path.abspath(_native.__file__)), "csrc", "libmi355env_ref.so")
-_REF_LIB = None
 
-
-def ref_factory(kind, num_envs, max_episode_steps, autoreset_mode, params, device, options=0):
-    global _REF_LIB
-    if _REF_LIB is None:
-        _REF_LIB = _native.NativeLib(REF, "mi_")
-    return _native.Engine(_REF_LIB, kind, num_envs, max_episode_steps, autoreset_mode, params, device, options=options)
+def run_build(lib, env_id, kw, path):
+    env = dict(os.environ, MI355ENV_LIBRARY=lib)
+    p = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, lib=lib, env_id=env_id, kw=kw, path=path)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return np.load(path)
 
 
 @pytest.mark.parametrize("env_id,solver", [("Ant-v5", None), ("HalfCheetah-v5", None), ("Humanoid-v5", "PGS"), ("HumanoidStandup-v5", "PGS"),
                                            ("Humanoid-v5", "Newton"), ("HumanoidStandup-v5", "Newton")])
-def test_iterative_scheduler_build_is_bit_identical_to_default_scheduler_build(env_id, solver):
+def test_iterative_scheduler_build_is_bit_identical_to_default_scheduler_build(env_id, solver, tmp_path):
     assert os.path.exists(REF), f"{REF} missing: run __graft_entry__.build() (python -m gymnasium_amd.csrc.build --ref)"
-    n, T = 4096, 25
     kw = {} if env_id in ("HalfCheetah-v5", "HumanoidStandup-v5") else dict(terminate_when_unhealthy=False)  # keep every env stepping real physics
     if solver:
         kw["solver"] = solver  # both shipped instantiations of the 32-lane kernel: the MJCF's PGS / 50 and the opt-in Newton
-    a = gymnasium_amd.make_vec(env_id, num_envs=n, **kw)
-    b = gymnasium_amd.make_vec(env_id, num_envs=n, _engine_factory=ref_factory, **kw)
-    assert a._engine.lib.path != b._engine.lib.path
-    oa, _ = a.reset(seed=17)
-    ob, _ = b.reset(seed=17)
-    assert np.array_equal(oa, ob)
-    a.action_space.seed(3)
-    for t in range(T):
-        act = a.action_space.sample()
-        ra, rb = a.step(act), b.step(act)
-        for x, y, what in zip(ra[:4], rb[:4], ("obs", "reward", "terminated", "truncated")):
-            assert np.array_equal(x, y), f"{env_id}: {what} differs between the two builds at step {t} ({int((np.asarray(x) != np.asarray(y)).sum())} entries)"
-    sa, sb = a.get_state(), b.get_state()
-    assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), f"{env_id}: final state differs"
-    a.close(), b.close()
+    a = run_build(os.path.join(CSRC, "libmi355env.so"), env_id, kw, str(tmp_path / "product.npz"))
+    b = run_build(REF, env_id, kw, str(tmp_path / "reference.npz"))
+    assert a.files == b.files and len(a.files) == 1 + 4 * 25 + 3
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), f"{env_id} {solver}: array {k} differs between the two builds ({int((a[k] != b[k]).sum())} entries)"
