@@ -16,6 +16,7 @@ MI_HOST, MI_DEVICE = 0, 1
 MI_F32, MI_F64, MI_I64 = 0, 1, 2
 FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
 CFG_SOLVER_NEWTON = 1  # MI_CFG_SOLVER_NEWTON
+CFG_FAST_MATH = 2  # MI_CFG_FAST_MATH (classic control: device sin / cos and x * x instead of the libm restatements)
 ABI_VERSION = 4
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,

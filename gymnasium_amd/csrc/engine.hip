@@ -344,6 +344,7 @@ struct StepPtrs {
 
 template <class E, int MODE>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io) {
+    tables_init<E>();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     if (i < d.N) {
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io) {
 template <class E>
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevEnv d, const uint8_t *mask, int has_bounds, double b0, double b1,
                                                        float *obs) {
+    tables_init<E>();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= d.N) return;
     if (mask && !mask[i]) return;
@@ -407,6 +409,7 @@ struct RolloutPtrs {
 // wavefront that runs alone on its SIMD) disappear from the loop.
 template <class E, int MODE, bool SAMPLE, bool FULL>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
+    tables_init<E>();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     if (i < d.N) {
@@ -1056,16 +1059,21 @@ struct mi_vecenv {
 
 namespace {
 
-template <class F>
-int dispatch_kind(int kind, F &&f) {
+template <class M, class F>
+int dispatch_kind_math(int kind, F &&f) {
     switch (kind) {
-    case MI_ENV_CARTPOLE: return f(CartPole());
-    case MI_ENV_PENDULUM: return f(Pendulum());
-    case MI_ENV_ACROBOT: return f(Acrobot());
-    case MI_ENV_MOUNTAIN_CAR: return f(MountainCar());
-    case MI_ENV_MOUNTAIN_CAR_CONTINUOUS: return f(MountainCarContinuous());
+    case MI_ENV_CARTPOLE: return f(CartPoleT<M>());
+    case MI_ENV_PENDULUM: return f(PendulumT<M>());
+    case MI_ENV_ACROBOT: return f(AcrobotT<M>());
+    case MI_ENV_MOUNTAIN_CAR: return f(MountainCarT<M>());
+    case MI_ENV_MOUNTAIN_CAR_CONTINUOUS: return f(MountainCarContinuousT<M>());
     }
     return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
+}
+// fast_math: MI_CFG_FAST_MATH (envs_classic.h FastMath); the default is the reference's libm bit for bit
+template <class F>
+int dispatch_kind(int kind, bool fast_math, F &&f) {
+    return fast_math ? dispatch_kind_math<FastMath>(kind, f) : dispatch_kind_math<ExactMath>(kind, f);
 }
 
 typedef mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah> HalfCheetahEnv;
@@ -1477,7 +1485,7 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
         hipLaunchKernelGGL((mj_reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, (double *)dobs, v->lay.obs_dim);
         HIP_TRY(hipGetLastError());
         return (int)MI_OK;
-    }) : dispatch_kind(v->cfg.kind, [&](auto env) -> int {
+    }) : dispatch_kind(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, [&](auto env) -> int {
         using E = decltype(env);
         hipLaunchKernelGGL((reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, has_bounds, b0, b1, (float *)dobs);
         HIP_TRY(hipGetLastError());
@@ -1542,7 +1550,7 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
         if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int { return launch_mj_step<decltype(env)>(v, mp); });
     } else {
-        rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
+        rc = dispatch_kind(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
     }
     if (rc) return rc;
     if (loc == MI_HOST) {
@@ -1702,7 +1710,7 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
             return (int)MI_OK;
         });
     } else {
-        rc = dispatch_kind(v->cfg.kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
+        rc = dispatch_kind(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
     }
     if (rc) return rc;
     if (sample) {  // the host copy of the generator moves past the T*N draws the kernel consumes

@@ -5,14 +5,21 @@
 // promotion makes the reference round to float32.  The translation unit is compiled with
 // -ffp-contract=off so that no a*b+c is fused: the reference rounds every product.
 //
-// Differences from the CPU reference that remain (and are covered by the stated tolerance rtol=atol=1e-5,
-// gymnasium/utils/env_checker.py:68): ocml sin/cos/fmod instead of glibc's (<= 1-2 ulp), and x*x where NumPy's
-// scalar `**2` calls libm pow (x*x is the correctly rounded value; glibc pow is within 1 ulp of it).
+// Every environment is a template over a math policy:
+//   ExactMath (default): sin / cos are the reference's libm bit for bit (sincos_exact.h) and `x ** 2` on NumPy scalars is libm's pow / powf
+//     bit for bit (pow_exact.h); fmod is exact by definition and everything else is IEEE arithmetic in the reference's order, so state,
+//     rewards and flags equal the reference's float64 / float32 values EXACTLY, for whole episodes (tests/test_gpu_parity.py: array_equal).
+//     The one place that cannot be reproduced is Acrobot's observation right after a reset, where NumPy evaluates cos / sin of a float32
+//     array with its own SIMD float32 kernels (<= 1 float32 ulp; oracle and engine return the correctly rounded value there).
+//   FastMath (opt-in, MI_CFG_FAST_MATH): ocml's sin / cos (<= 1 ulp from libm's) and x * x (correctly rounded, where glibc's pow is off by
+//     one ulp on ~0.09 % of arguments).  Differences from the reference start at 1e-16 and grow with the system's own error amplification.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "pcg64_dev.h"
+#include "pow_exact.h"
+#include "sincos_exact.h"
 
 namespace mi {
 
@@ -22,38 +29,78 @@ constexpr double kPi = 3.141592653589793;
 
 enum : uint32_t { kNeedsReset = 1u, kStateF32 = 2u };
 
-// sin and cos of one argument.  |x| <= pi/4 (always the case for a CartPole inside its 12-degree termination
-// band) needs no range reduction: minimax kernels on [-pi/4, pi/4] (the fdlibm k_sin / k_cos coefficient sets,
-// evaluated with FMAs; < 1 ulp).  Anything else goes through ocml's sincos.  The branch is wavefront-uniform in
-// practice, so a CartPole wavefront never pays for the reduction code.
-// a * b + c as ONE v_fma_f64 whose addend sits in its own VGPR pair.  Written as asm because the compiler turns a Horner chain with
-// constant addends into v_mov_b64 (copy the constant) + v_fmac_f64 (accumulate into the copy): two issue slots per step in a loop that is
-// issue-bound; this way the twelve coefficients stay in registers across the rollout loop and a step is one slot.
-MI_DEV double fma_vvv(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// The tables of sincos_exact.h / pow_exact.h live in LDS for the lifetime of a kernel (5.2 KB + 5 KB + 0.5 KB; a kernel allocates only the
+// ones its environment reads): every kernel that steps / resets / observes a classic env calls tables_init<E>() first.  A per-lane table
+// index into global memory inside the rollout loop would tie the loop's loads to its stores (one in-order vmcnt on gfx950).
+static __shared__ double g_trig6[660];
+static __shared__ double g_pow_log[384];
+static __shared__ uint64_t g_pow_exp[256];
+static __shared__ double g_powf_log2[32];
+static __shared__ uint64_t g_powf_exp2[32];
 
-MI_DEV void sincos_small_or_ocml(double x, double *sn, double *cs) {
-    if (__builtin_expect(!(fabs(x) <= 0.7853981633974483), 0)) {
-        sincos(x, sn, cs);
-        return;
+struct ExactMath {
+    static constexpr bool EXACT = true;
+    template <bool POW, bool POWF>
+    static MI_DEV void init() {
+        for (int e = threadIdx.x; e < 110; e += blockDim.x) mi_sincos::expand6(mi_sincos::kTable, g_trig6, e);
+        if (POW) {
+            for (int k = threadIdx.x; k < 384; k += blockDim.x) g_pow_log[k] = mi_pow::kLogTab[k];
+            for (int k = threadIdx.x; k < 256; k += blockDim.x) g_pow_exp[k] = mi_pow::kExpTab[k];
+        }
+        if (POWF) {
+            for (int k = threadIdx.x; k < 32; k += blockDim.x) g_powf_log2[k] = mi_pow::kLog2fTab[k], g_powf_exp2[k] = mi_pow::kExp2fTab[k];
+        }
+        __syncthreads();
     }
-    const double z = x * x;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double rs = fma_vvv(z, S6, S5);
-    rs = fma_vvv(z, rs, S4), rs = fma_vvv(z, rs, S3), rs = fma_vvv(z, rs, S2), rs = fma_vvv(z, rs, S1);
-    *sn = fma(z * x, rs, x);
-    double rc = fma_vvv(z, C6, C5);
-    rc = fma_vvv(z, rc, C4), rc = fma_vvv(z, rc, C3), rc = fma_vvv(z, rc, C2), rc = fma_vvv(z, rc, C1);
-    // 1 - (z/2 - z*z*rc), split so that the leading 1 - z/2 is exact-ish (fdlibm's qx trick is not needed at < 1 ulp)
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    *cs = w + (((1.0 - w) - hz) + z * (z * rc));
+    static MI_DEV double sin(double x) { return mi_sincos::sin_bf(g_trig6, x); }
+    static MI_DEV double cos(double x) { return mi_sincos::cos_bf(g_trig6, x); }
+    static MI_DEV void sincos(double x, double &s, double &c) { mi_sincos::sincos_bf(g_trig6, x, s, c); }
+    // for angles the environment wraps or clips (|x| far below 1e8): no hand-over to the platform's huge-argument routine, and lanes
+    // spread over all ranges (no wavefront-uniform short cut)
+    static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true>(g_trig6, x); }
+    static MI_DEV double cos_bounded(double x) { return mi_sincos::cos_bf<true>(g_trig6, x); }
+    static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false>(g_trig6, x, s, c); }
+    static MI_DEV double sq(double x) { return mi_pow::square(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
+    static MI_DEV float sqf(float x) { return mi_pow::squaref(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2
+};
+struct FastMath {
+    static constexpr bool EXACT = false;
+    template <bool POW, bool POWF>
+    static MI_DEV void init() {}
+    static MI_DEV double sin(double x) { return ::sin(x); }
+    static MI_DEV double cos(double x) { return ::cos(x); }
+    // |x| <= pi/4 (always the case for a CartPole inside its 12-degree termination band) needs no range reduction: minimax kernels on
+    // [-pi/4, pi/4] (the fdlibm k_sin / k_cos coefficient sets, evaluated with FMAs; < 1 ulp).  Anything else goes through ocml's sincos.
+    // The branch is wavefront-uniform in practice, so a CartPole wavefront never pays for the reduction code.
+    static MI_DEV void sincos(double x, double &sn, double &cs) {
+        if (__builtin_expect(!(fabs(x) <= 0.7853981633974483), 0)) {
+            ::sincos(x, &sn, &cs);
+            return;
+        }
+        using mi_sincos::fma_k;
+        const double z = x * x;
+        const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                     S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+        const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                     C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+        double rs = fma_k(z, S6, S5);
+        rs = fma_k(z, rs, S4), rs = fma_k(z, rs, S3), rs = fma_k(z, rs, S2), rs = fma_k(z, rs, S1);
+        sn = fma(z * x, rs, x);
+        double rc = fma_k(z, C6, C5);
+        rc = fma_k(z, rc, C4), rc = fma_k(z, rc, C3), rc = fma_k(z, rc, C2), rc = fma_k(z, rc, C1);
+        const double hz = 0.5 * z;
+        const double w = 1.0 - hz;
+        cs = w + (((1.0 - w) - hz) + z * (z * rc));
+    }
+    static MI_DEV double sin_bounded(double x) { return ::sin(x); }
+    static MI_DEV double cos_bounded(double x) { return ::cos(x); }
+    static MI_DEV void sincos_bounded(double x, double &s, double &c) { ::sincos(x, &s, &c); }
+    static MI_DEV double sq(double x) { return x * x; }
+    static MI_DEV float sqf(float x) { return x * x; }
+};
+template <class E>
+MI_DEV void tables_init() {
+    E::Math::template init<E::USES_POW, E::USES_POWF>();
 }
 
 // x / C for a compile-time constant C, bit-identical to the IEEE division for every |x| in [1e-300, 1e300]:
@@ -80,7 +127,10 @@ struct EnvParams {
 struct CartPoleTotalMass {
     static constexpr double value = 0.1 + 1.0;  // masspole + masscart (cartpole.py:127)
 };
-struct CartPole {
+template <class M>
+struct CartPoleT {
+    typedef M Math;
+    static constexpr bool USES_POW = false, USES_POWF = false;
     typedef CartPoleTotalMass TotalMass;
     static constexpr int S = 4, OBS = 4, N_ACTIONS = 2;
     static constexpr bool DISCRETE = true;
@@ -115,8 +165,8 @@ struct CartPole {
         const double x_threshold = 2.4;
         double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const double force = action == 1 ? force_mag : -force_mag;
-        double sintheta, costheta;
-        sincos_small_or_ocml(theta, &sintheta, &costheta);
+        double costheta, sintheta;  // cartpole.py:180-181 np.cos / np.sin
+        M::sincos(theta, sintheta, costheta);
         const double temp = div_by_constant(force + polemass_length * (theta_dot * theta_dot) * sintheta, TotalMass());
         const double thetaacc = (gravity * sintheta - costheta * temp) /
                                 (length * (4.0 / 3.0 - div_by_constant(masspole * (costheta * costheta), TotalMass())));
@@ -135,7 +185,10 @@ struct CartPole {
 // ---------------------------------------------------------------------------------------------------------
 // Pendulum-v1: gymnasium/envs/classic_control/pendulum.py:102-171,281-282
 // ---------------------------------------------------------------------------------------------------------
-struct Pendulum {
+template <class M>
+struct PendulumT {
+    typedef M Math;
+    static constexpr bool USES_POW = true, USES_POWF = true;
     static constexpr int S = 2, OBS = 3;
     static constexpr bool DISCRETE = false;
     typedef float Act;
@@ -149,8 +202,8 @@ struct Pendulum {
         s[1] = -y_init + (y_init - (-y_init)) * u[1];
     }
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
-        double sn, cs;
-        sincos(s[0], &sn, &cs);
+        double cs, sn;
+        M::sincos(s[0], sn, cs);
         o[0] = (float)cs, o[1] = (float)sn, o[2] = (float)s[1];
     }
     static MI_DEV bool valid(Act) { return true; }
@@ -173,10 +226,10 @@ struct Pendulum {
             md = 0.0;
         }
         const double an = md - kPi;
-        const float cu = 0.001f * (u * u);            // float32: 0.001 * (u ** 2)
-        const double costs = an * an + 0.1 * (thdot * thdot) + (double)cu;
+        const float cu = 0.001f * M::sqf(u);  // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
+        const double costs = M::sq(an) + 0.1 * M::sq(thdot) + (double)cu;
         const float tu = (float)(3.0 / (m * (l * l))) * u;  // float32: 3.0 / (m l^2) * u
-        double sn = sin(th);
+        double sn = M::sin(th);
         double newthdot = thdot + (3 * g / (2 * l) * sn + (double)tu) * dt;
         newthdot = newthdot < -max_speed ? -max_speed : newthdot;
         newthdot = newthdot > max_speed ? max_speed : newthdot;
@@ -190,7 +243,10 @@ struct Pendulum {
 // ---------------------------------------------------------------------------------------------------------
 // Acrobot-v1: gymnasium/envs/classic_control/acrobot.py:172-279,375-461
 // ---------------------------------------------------------------------------------------------------------
-struct Acrobot {
+template <class M>
+struct AcrobotT {
+    typedef M Math;
+    static constexpr bool USES_POW = true, USES_POWF = false;
     static constexpr int S = 4, OBS = 6, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
     typedef int64_t Act;
@@ -207,9 +263,9 @@ struct Acrobot {
     }
     // acrobot.py:232-237 (after a reset NumPy evaluates these in float32; we return the correctly rounded value)
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
-        double s1, c1, s2, c2;
-        sincos(s[0], &s1, &c1);
-        sincos(s[1], &s2, &c2);
+        double c1, s1, c2, s2;
+        M::sincos_bounded(s[0], s1, c1);
+        M::sincos_bounded(s[1], s2, c2);
         o[0] = (float)c1, o[1] = (float)s1, o[2] = (float)c2, o[3] = (float)s2, o[4] = (float)s[2], o[5] = (float)s[3];
     }
     static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
@@ -217,31 +273,32 @@ struct Acrobot {
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
-    // acrobot.py:244-279, "book" dynamics; y = (theta1, theta2, dtheta1, dtheta2), a = torque
+    // acrobot.py:244-279, "book" dynamics; y = (theta1, theta2, dtheta1, dtheta2), a = torque.  The `** 2` on Python floats (lc1**2 = 0.25, ...)
+    // are exact; the ones on np.float64 state components go through libm pow (M::sq).
     static MI_DEV void dsdt(const double y[4], double a, double d[4]) {
         const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
         const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
-        double s2, c2;
-        sincos(theta2, &s2, &c2);
+        double c2, s2;
+        M::sincos_bounded(theta2, s2, c2);
         const double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
         const double d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
-        const double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - kPi / 2.0);
-        const double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
-                            (m1 * lc1 + m2 * l1) * g * cos(theta1 - kPi / 2) + phi2;
-        const double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
-                                (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+        const double phi2 = m2 * lc2 * g * M::cos_bounded(theta1 + theta2 - kPi / 2.0);
+        const double phi1 = -m2 * l1 * lc2 * M::sq(dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+                            (m1 * lc1 + m2 * l1) * g * M::cos_bounded(theta1 - kPi / 2) + phi2;
+        const double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * M::sq(dtheta1) * s2 - phi2) /
+                                (m2 * (lc2 * lc2) + I2 - M::sq(d2) / d1);
         const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
         d[0] = dtheta1, d[1] = dtheta2, d[2] = ddtheta1, d[3] = ddtheta2;
     }
-    static MI_DEV double wrap(double x, double m, double M) {
-        const double diff = M - m;
-        while (x > M) x = x - diff;
-        while (x < m) x = x + diff;
+    static MI_DEV double wrap(double x, double lo, double hi) {
+        const double diff = hi - lo;
+        while (x > hi) x = x - diff;
+        while (x < lo) x = x + diff;
         return x;
     }
-    static MI_DEV double bound(double x, double m, double M) {
-        const double t = (m > x) ? m : x;
-        return (M < t) ? M : t;
+    static MI_DEV double bound(double x, double lo, double hi) {
+        const double t = (lo > x) ? lo : x;
+        return (hi < t) ? hi : t;
     }
     // acrobot.py:202-230 with rk4 (:415-461) over t = [0, 0.2]; the torque component has derivative 0
     static MI_DEV void step(double s[S], uint32_t &flags, Act action, const EnvParams &, double &reward, bool &terminated) {
@@ -268,7 +325,7 @@ struct Acrobot {
 #pragma unroll
         for (int i = 0; i < 4; i++) s[i] = ns[i];
         flags &= ~kStateF32;
-        terminated = (-cos(ns[0]) - cos(ns[1] + ns[0])) > 1.0;
+        terminated = (-M::cos_bounded(ns[0]) - M::cos_bounded(ns[1] + ns[0])) > 1.0;
         reward = terminated ? 0.0 : -1.0;
     }
 };
@@ -276,7 +333,10 @@ struct Acrobot {
 // ---------------------------------------------------------------------------------------------------------
 // MountainCar-v0: gymnasium/envs/classic_control/mountain_car.py:108-170
 // ---------------------------------------------------------------------------------------------------------
-struct MountainCar {
+template <class M>
+struct MountainCarT {
+    typedef M Math;
+    static constexpr bool USES_POW = false, USES_POWF = false;
     static constexpr int S = 2, OBS = 2, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
     typedef int64_t Act;
@@ -298,7 +358,7 @@ struct MountainCar {
         const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5;
         const double force = 0.001, gravity = 0.0025;
         double position = s[0], velocity = s[1];
-        velocity += (double)(action - 1) * force + cos(3 * position) * (-gravity);
+        velocity += (double)(action - 1) * force + M::cos_bounded(3 * position) * (-gravity);
         velocity = velocity < -max_speed ? -max_speed : velocity;
         velocity = velocity > max_speed ? max_speed : velocity;
         position += velocity;
@@ -316,7 +376,10 @@ struct MountainCar {
 // The state is a float64 array right after reset and a float32 array from the first step on (":178"); NumPy-2
 // promotion then makes most of the update float32 arithmetic.
 // ---------------------------------------------------------------------------------------------------------
-struct MountainCarContinuous {
+template <class M>
+struct MountainCarContinuousT {
+    typedef M Math;
+    static constexpr bool USES_POW = false, USES_POWF = false;
     static constexpr int S = 2, OBS = 2;
     static constexpr bool DISCRETE = false;
     typedef float Act;
@@ -346,7 +409,7 @@ struct MountainCarContinuous {
         if (flags & kStateF32) {
             float p = (float)s[0], v = (float)s[1];
             const float three_p = 3.0f * p;
-            const double g = 0.0025 * cos((double)three_p);
+            const double g = 0.0025 * M::cos_bounded((double)three_p);
             if (force_is_py)
                 v = v + (float)(force_py * power - g);
             else
@@ -361,7 +424,7 @@ struct MountainCarContinuous {
             position = p, velocity = v;
         } else {
             double p = s[0], v = s[1];
-            const double g = 0.0025 * cos(3 * p);
+            const double g = 0.0025 * M::cos_bounded(3 * p);
             if (force_is_py)
                 v = v + (force_py * power - g);
             else
@@ -381,5 +444,11 @@ struct MountainCarContinuous {
         flags |= kStateF32;
     }
 };
+
+typedef CartPoleT<ExactMath> CartPole;
+typedef PendulumT<ExactMath> Pendulum;
+typedef AcrobotT<ExactMath> Acrobot;
+typedef MountainCarT<ExactMath> MountainCar;
+typedef MountainCarContinuousT<ExactMath> MountainCarContinuous;
 
 }  // namespace mi

@@ -24,7 +24,22 @@ DEFAULT_X = np.pi  # pendulum.py:14-15
 DEFAULT_Y = 1.0
 
 
-class CartPoleVectorEnv(HipVectorEnv):
+class _ClassicControlVectorEnv(HipVectorEnv):
+    """``fast_math=False`` (default): sin / cos / ``** 2`` are the reference's libm bit for bit, trajectories are ``array_equal`` to
+    ``SyncVectorEnv``'s.  ``fast_math=True`` (MI_CFG_FAST_MATH) trades that for the device's own sin / cos and ``x * x``: results within
+    1 ulp per call of the reference's, more env-steps/s."""
+
+    def __init__(self, *args, fast_math: bool = False, **kwargs):
+        self.fast_math = bool(fast_math)
+        super().__init__(*args, **kwargs)
+
+    def _engine_options(self) -> int:
+        from .. import _native
+
+        return _native.CFG_FAST_MATH if self.fast_math else 0
+
+
+class CartPoleVectorEnv(_ClassicControlVectorEnv):
     KIND = "cartpole"
     DEFAULT_MAX_EPISODE_STEPS = 500
 
@@ -45,7 +60,7 @@ class CartPoleVectorEnv(HipVectorEnv):
         return parse_low_high(options, -0.05, 0.05)
 
 
-class PendulumVectorEnv(HipVectorEnv):
+class PendulumVectorEnv(_ClassicControlVectorEnv):
     KIND = "pendulum"
     DEFAULT_MAX_EPISODE_STEPS = 200
 
@@ -69,7 +84,7 @@ class PendulumVectorEnv(HipVectorEnv):
         return (x, y)
 
 
-class AcrobotVectorEnv(HipVectorEnv):
+class AcrobotVectorEnv(_ClassicControlVectorEnv):
     KIND = "acrobot"
     DEFAULT_MAX_EPISODE_STEPS = 500
 
@@ -84,7 +99,7 @@ class AcrobotVectorEnv(HipVectorEnv):
         return parse_low_high(options, -0.1, 0.1)
 
 
-class _MountainCarBase(HipVectorEnv):
+class _MountainCarBase(_ClassicControlVectorEnv):
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, goal_velocity: float = 0, **kwargs):
         self.goal_velocity = goal_velocity
         super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)

@@ -115,6 +115,11 @@ typedef struct mi_config {
  * HUMANOID_STANDUP: assets/humanoid.xml:8) run that solver by default; this bit selects the converged primal Newton solver instead (the
  * same convex problem solved to 1e-10 -- a deliberate, faster deviation from the reference, opt-in only). */
 #define MI_CFG_SOLVER_NEWTON 1
+/* MI_CFG_FAST_MATH: the classic-control kinds (CARTPOLE .. MOUNTAIN_CAR_CONTINUOUS) reproduce the reference's libm by default -- sin / cos /
+ * pow(x, 2) / powf(x, 2) bit for bit, so whole trajectories are array_equal to SyncVectorEnv's (classic_control/cartpole.py:180-181,
+ * pendulum.py:131, acrobot.py:263-283).  This bit selects the device's own sin / cos (<= 1 ulp away) and x * x instead: ~1.2-2x the
+ * env-steps/s, results within the tolerances of tests/test_gpu_parity.py's fast-math cases.  Opt-in only. */
+#define MI_CFG_FAST_MATH 2
 
 typedef struct mi_layout {
     int32_t obs_dim;      /* observation row length (elements) */

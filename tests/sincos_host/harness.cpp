@@ -1,0 +1,37 @@
+// TEST INFRASTRUCTURE: gymnasium_amd/csrc/sincos_exact.h compiled for the host (g++ -mfma -ffp-contract=off: the header spells out every
+// fused multiply-add), so that tests/test_sincos_exact.py can compare it with the running libm on millions of arguments.
+#include "../../gymnasium_amd/csrc/sincos_exact.h"
+
+extern "C" {
+__attribute__((visibility("default"))) void sin_exact_batch(const double *x, double *out, long n) {
+    for (long i = 0; i < n; i++) out[i] = mi_sincos::sin_exact(mi_sincos::kTable, x[i]);
+}
+__attribute__((visibility("default"))) void cos_exact_batch(const double *x, double *out, long n) {
+    for (long i = 0; i < n; i++) out[i] = mi_sincos::cos_exact(mi_sincos::kTable, x[i]);
+}
+static const double *table6() {
+    static double t6[660];
+    static bool done = false;
+    if (!done) {
+        for (int e = 0; e < 110; e++) mi_sincos::expand6(mi_sincos::kTable, t6, e);
+        done = true;
+    }
+    return t6;
+}
+// the branch-free forms the kernels call
+__attribute__((visibility("default"))) void sin_bf_batch(const double *x, double *out, long n) {
+    const double *t6 = table6();
+    for (long i = 0; i < n; i++) out[i] = mi_sincos::sin_bf(t6, x[i]);
+}
+__attribute__((visibility("default"))) void cos_bf_batch(const double *x, double *out, long n) {
+    const double *t6 = table6();
+    for (long i = 0; i < n; i++) out[i] = mi_sincos::cos_bf(t6, x[i]);
+}
+__attribute__((visibility("default"))) void sincos_bf_batch(const double *x, double *s, double *c, long n) {
+    const double *t6 = table6();
+    for (long i = 0; i < n; i++) mi_sincos::sincos_bf(t6, x[i], s[i], c[i]);
+}
+__attribute__((visibility("default"))) void table_copy(double *out) {
+    for (int i = 0; i < 440; i++) out[i] = mi_sincos::kTable[i];
+}
+}

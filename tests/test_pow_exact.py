@@ -1,0 +1,89 @@
+"""gymnasium_amd/csrc/pow_exact.h restates glibc's pow(x, 2.0) / powf(x, 2.0f) (what NumPy's scalar `x ** 2` calls) so that the squares the
+reference takes through `**` (pendulum.py:131,135; acrobot.py:263-275) are reproduced bit for bit on the device.  Here the header is compiled
+for the host and compared with the RUNNING libm on millions of arguments, including the ones where pow(x, 2) != x * x."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+libm = C.CDLL("libm.so.6")
+libm.pow.restype, libm.pow.argtypes = C.c_double, [C.c_double, C.c_double]
+libm.powf.restype, libm.powf.argtypes = C.c_float, [C.c_float, C.c_float]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        d = os.path.join(HERE, "pow_host")
+        so, src = os.path.join(d, "libpow_host.so"), os.path.join(d, "harness.cpp")
+        hdr = [os.path.join(HERE, "..", "gymnasium_amd", "csrc", f) for f in ("pow_exact.h", "pow_tables.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in [src] + hdr):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-o", so, src], check=True, cwd=d)
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def expected_libm():
+    return math.pow(1.3, 2.0).hex() == "0x1.b0a3d70a3d70bp+0" and "fma" in open("/proc/cpuinfo").read()
+
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/proc/cpuinfo") or not expected_libm(), reason="host libm is not glibc's FMA pow: nothing to compare against")
+
+
+def square(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().square_batch(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_long(x.size))
+    return out
+
+
+def squaref(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().squaref_batch(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_long(x.size))
+    return out
+
+
+def test_numpy_scalar_power_is_libm_pow():
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-10, 10, 200000)
+    ref = np.array([libm.pow(v, 2.0) for v in x])
+    assert np.array_equal(np.array([float(np.float64(v) ** 2) for v in x]), ref)
+    assert (ref != x * x).sum() > 50, "pow(x, 2) is expected to differ from x * x now and then: that is why this header exists"
+    xf = rng.uniform(-2, 2, 100000).astype(np.float32)
+    reff = np.array([libm.powf(float(v), 2.0) for v in xf], dtype=np.float32)
+    assert np.array_equal(np.array([np.float32(v) ** 2 for v in xf], dtype=np.float32), reff)
+
+
+@pytest.mark.parametrize("lo,hi,n", [(-10.0, 10.0, 1_500_000), (-1.0, 1.0, 1_000_000), (0.99, 1.01, 500_000), (-1e-3, 1e-3, 300_000), (-1e5, 1e5, 300_000)])
+def test_square_is_bit_identical_to_libm_pow(lo, hi, n):
+    x = np.random.default_rng(int(abs(hi) * 977) % 7919).uniform(lo, hi, n)
+    ref = np.array([libm.pow(v, 2.0) for v in x])
+    assert np.array_equal(square(x), ref)
+
+
+def test_square_special_values():
+    x = np.array([0.0, -0.0, 1.0, -1.0, 2.0, 0.5, np.nextafter(1.0, 2), np.nextafter(1.0, 0), 1e-200, 1e200, 5e-324, np.inf, -np.inf, 1e-160, 1e154, 3.0, -8.0])
+    ref = np.array([libm.pow(v, 2.0) for v in x])
+    assert np.array_equal(square(x), ref)
+    assert np.isnan(square(np.array([np.nan]))[0])
+
+
+@pytest.mark.parametrize("lo,hi,n", [(-2.0, 2.0, 1_000_000), (-1e-3, 1e-3, 200_000), (-100.0, 100.0, 300_000)])
+def test_squaref_is_bit_identical_to_libm_powf(lo, hi, n):
+    x = np.random.default_rng(int(abs(hi) * 31) % 97).uniform(lo, hi, n).astype(np.float32)
+    ref = np.array([libm.powf(float(v), 2.0) for v in x], dtype=np.float32)
+    assert np.array_equal(squaref(x), ref)
+    assert np.array_equal(squaref(np.array([0.0, -0.0, 1.0, -2.0, 1e-30, 1e30], np.float32)), np.array([libm.powf(v, 2.0) for v in (0.0, -0.0, 1.0, -2.0, 1e-30, 1e30)], np.float32))
+
+
+def test_square_of_a_float32_value_is_exact():
+    """continuous_mountain_car.py:170 `math.pow(action[0], 2)`: a float32's square is a 48-bit double, and pow (error < 1 ulp before the final
+    rounding) returns it exactly -- so the kernels use a * a there."""
+    x = np.random.default_rng(3).uniform(-1.5, 1.5, 300000).astype(np.float32).astype(np.float64)
+    assert np.array_equal(square(x), x * x) and np.array_equal(np.array([libm.pow(v, 2.0) for v in x[:50000]]), (x * x)[:50000])

@@ -1,0 +1,121 @@
+"""gymnasium_amd/csrc/sincos_exact.h restates glibc's float64 sin / cos (s_sin.c, the FMA build) so that device results are bit-identical
+to the libm behind NumPy, which is what the reference's classic-control dynamics call.  Here the header is compiled for the HOST
+(tests/sincos_host/harness.cpp; same source, `__builtin_fma` = one hardware FMA) and compared with the RUNNING libm:
+
+  * 12 million arguments over the ranges the environments reach (|x| < 0.855 table path, < 2.43 quarter-wave path, up to 1e8 through the
+    three-term Cody-Waite reduction), every one bit for bit;
+  * the neighbourhoods of every branch threshold of the algorithm, tiny / subnormal arguments, +-0, inf, nan;
+  * NumPy's sin / cos (array and scalar paths) against the same libm: that is the assumption the whole exercise rests on.
+
+If the host CPU has no FMA, or a different libm is installed, the comparison is not meaningful: the test then skips (it checks that
+math.sin matches the reference values recorded in tests/golden first).
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        d = os.path.join(HERE, "sincos_host")
+        so, src = os.path.join(d, "libsincos_host.so"), os.path.join(d, "harness.cpp")
+        hdr = [os.path.join(HERE, "..", "gymnasium_amd", "csrc", f) for f in ("sincos_exact.h", "sincos_table.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in [src] + hdr):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-o", so, src], check=True, cwd=d)
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def run(fn, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    getattr(lib(), fn)(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_long(x.size))
+    return out
+
+
+def run_sincos(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().sincos_bf_batch(x.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), C.c_long(x.size))
+    return s, c
+
+
+def check_all_forms(x):
+    """the readable branchy statement, the branch-free form the kernels call, and the merged sin+cos: all equal libm bit for bit"""
+    with np.errstate(invalid="ignore"):
+        rs, rc = np.sin(x), np.cos(x)
+    assert same_bits(run("sin_exact_batch", x), rs), "sin"
+    assert same_bits(run("cos_exact_batch", x), rc), "cos"
+    assert same_bits(run("sin_bf_batch", x), rs), "branch-free sin"
+    assert same_bits(run("cos_bf_batch", x), rc), "branch-free cos"
+    inside = ~(np.abs(x) >= 105414336.0)  # high word 0x419921fb: beyond it the header defers to the platform's sin / cos, which the host compiler fuses into one sincos() call
+    s, c = run_sincos(x[inside])
+    assert same_bits(s, rs[inside]) and same_bits(c, rc[inside]), "merged sincos"
+
+
+def same_bits(a, b):
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64)) or bool(np.all((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))))
+
+
+def libm_is_the_expected_one():
+    """glibc's FMA build of sin: known answers taken from the reference-generated goldens' libm (sin(0.5), cos(0.5), sin(2), cos(100))."""
+    return (math.sin(0.5).hex(), math.cos(0.5).hex(), "fma" in open("/proc/cpuinfo").read()) == ("0x1.eaee8744b05f0p-2", "0x1.c1528065b7d50p-1", True)
+
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/proc/cpuinfo") or not libm_is_the_expected_one(),
+                                reason="host libm is not glibc's FMA sin / cos: nothing to compare against")
+
+
+def test_numpy_sin_cos_are_libm():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-3.2, 3.2, 100000), rng.uniform(-100, 100, 100000)])
+    assert np.array_equal(np.sin(x), np.array([math.sin(v) for v in x])) and np.array_equal(np.cos(x), np.array([math.cos(v) for v in x]))
+    assert all(float(np.sin(np.float64(v))) == math.sin(v) for v in x[:2000])
+
+
+@pytest.mark.parametrize("lo,hi,n", [(-0.86, 0.86, 3_000_000), (-2.45, 2.45, 3_000_000), (-3.1415926535897936, 3.1415926535897936, 2_000_000),
+                                     (-100.0, 100.0, 2_000_000), (-1.0e6, 1.0e6, 1_000_000), (-1.2e8, 1.2e8, 1_000_000)])
+def test_bit_identical_to_libm_on_random_arguments(lo, hi, n):
+    x = np.random.default_rng(int(abs(hi) * 1000) % 9973).uniform(lo, hi, n)
+    check_all_forms(x)
+
+
+def test_bit_identical_around_every_branch_point_and_special_values():
+    edges = [2.0 ** -27, 2.0 ** -26, 0.126, 0.855469, 0.8554688, 2.426265, 105414350.0, math.pi / 4, math.pi / 2, math.pi, 3 * math.pi / 2, 2 * math.pi,
+             1.0 / 128, 0.5 / 128, 109.5 / 128, 110.0 / 128, 1.5707963267948966 - 0.126, 1.5707963267948966 - 0.855469]
+    pts = []
+    for e in edges:
+        b = np.float64(e).view(np.uint64)
+        nb = (np.arange(-2000, 2001, dtype=np.int64) + np.int64(b)).astype(np.uint64).view(np.float64)
+        pts += [nb, -nb]
+    # every multiple of 1/256 (the table's rounding ties) up to 0.86, and their neighbours
+    ties = np.arange(0, 221) / 256.0
+    pts += [ties, np.nextafter(ties, 1), np.nextafter(ties, -1), -ties]
+    pts.append(np.array([0.0, -0.0, 5e-324, -5e-324, 2.2250738585072014e-308, 1e-300, 1e-30, np.inf, -np.inf, np.nan, 1e10, -1e10, 1e300]))
+    x = np.concatenate(pts)
+    check_all_forms(x)
+    tiny = np.random.default_rng(5).uniform(-1, 1, 200000) * 2.0 ** np.random.default_rng(6).integers(-1070, -20, 200000).astype(np.float64)
+    check_all_forms(tiny)
+
+
+def test_generated_table_is_the_one_inside_libm():
+    """scripts/gen_sincos_table.py computes the table (80-digit series + glibc's 18 low-part deviations); where the libm binary can be read,
+    its `__sincostab` (located by its first non-trivial entries) must equal it entry for entry."""
+    t = np.empty(440)
+    lib().table_copy(t.ctypes.data_as(C.c_void_p))
+    path = next((p for p in ("/lib/x86_64-linux-gnu/libm.so.6", "/usr/lib/x86_64-linux-gnu/libm.so.6", "/lib64/libm.so.6") if os.path.exists(p)), None)
+    if path is None:
+        pytest.skip("libm.so.6 not found at the usual places")
+    blob = open(path, "rb").read()
+    at = blob.find(t[:8].tobytes())
+    if at < 0:
+        pytest.skip("__sincostab not located in this libm build")
+    assert blob[at:at + 440 * 8] == t.tobytes()
