@@ -180,7 +180,9 @@ struct Board {
     // consecutive addresses), which is what keeps that kernel from spilling.
     static constexpr bool M_IN_LDS = NV > 16;
     double Mt[M_IN_LDS ? NV : 1][M_IN_LDS ? NV : 1];
-    int con_pair[MAXCON];
+    int con_pair[MAXCON];             // geom pair of the contact | body of its first geom << 16 | body of its second geom << 24
+    unsigned con_m1[MAXCON], con_m2[MAXCON];  // dofs on the paths to those two bodies: what a dof lane needs for its Jacobian column, kept
+                                              // here because pair -> geom -> body -> mask is three dependent table loads from global memory
     unsigned cmask[KS], anyrow;
     unsigned limmask[2];  // dofs whose lower / upper joint-limit row is active in this forward pass (PGS visits them in dof order)
     int ncon;
@@ -786,7 +788,10 @@ struct Sim {
                 if (idx < MAXCON) {
                     Cand c;
                     detect(bb, rd * G + lane, c);
-                    bb.con_pair[idx] = M::slot_pair[rd * G + lane];
+                    const int p = M::slot_pair[rd * G + lane];
+                    const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+                    bb.con_pair[idx] = p | (b1 << 16) | (b2 << 24);
+                    bb.con_m1[idx] = (unsigned)M::body_dofmask[b1], bb.con_m2[idx] = (unsigned)M::body_dofmask[b2];
                     bb.con_dist[idx] = c.dist;
 #pragma unroll
                     for (int k = 0; k < 3; k++) bb.con_r[idx][k] = c.pos[k] - bb.com[k];
@@ -898,9 +903,9 @@ struct Sim {
 #pragma unroll
             for (int k = 0; k < 8; k++) r.c_gw[kc][k] = 0;
             if (r.c_on[kc]) {
-                const int p = bb.con_pair[c];
+                const int packed = bb.con_pair[c], p = packed & 0xffff;
                 const int pp = uniform_pairs() ? 0 : p;  // constant index -> immediates
-                const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+                const int b1 = (packed >> 16) & 0xff, b2 = (packed >> 24) & 0xff;
                 const double tran = M::body_invweight0[b1][0] + M::body_invweight0[b2][0], mu = M::pair_friction[pp];
                 const bool pyramid = M::pair_condim[pp] > 1;
                 double k, b, imp, Rr;
@@ -965,9 +970,7 @@ struct Sim {
     }
     // dof role: column `lane` of the contact-frame Jacobian of contact c
     static MJX_DEV void jac_col(const B &bb, const R &r, int c, int lane, double *jcol) {
-        const int p = bb.con_pair[c];
-        const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
-        const int in1 = ((unsigned)M::body_dofmask[b1] >> lane) & 1u, in2 = ((unsigned)M::body_dofmask[b2] >> lane) & 1u;
+        const int in1 = (bb.con_m1[c] >> lane) & 1u, in2 = (bb.con_m2[c] >> lane) & 1u;
         const double sg = (double)(in2 - in1);
         double t[3];
         cross3(t, r.cdof, bb.con_r[c]);
@@ -1058,26 +1061,37 @@ struct Sim {
     //     updates then happen on the owner lane alone in the 3-dim contact frame against the block A = J_c M^-1 J_c^T (v += A E^T d),
     //     and a += (M^-1 J_c^T) (sum of E^T d) closes the contact: one exchange per contact and sweep, not one per row;
     //   * M^-1 J_c^T (3 x NV per contact) is computed once per pass; the first BCAP contacts keep it in the LDS storage of M (dead after
-    //     the factorisation), later ones in global memory (r.spill).
+    //     the factorisation), for later ones the sweeps apply M^-1 (register rows) to J_c^T dl directly (apply_b).
     // Warm start = mj's dual warmstart: the forces implied by qacc_warmstart (r.warm), dropped for zero if their dual cost is positive.
     static constexpr int BCAP = B::M_IN_LDS ? NV / 3 : 0;
-    static constexpr int SPILL_DOUBLES = (MAXCON > BCAP ? MAXCON - BCAP : 0) * 3 * NV;
-    static MJX_DEV void store_b(B &bb, const R &r, int c, int lane, const double *b) {
-        if (lane >= NV) return;
-        double *p = r.spill + (size_t)(c - BCAP) * 3 * NV;
+    static constexpr int SPILL_DOUBLES = 0;  // (a global-memory overflow store was tried for the contacts beyond BCAP: ~800 cycles per visit)
+    static MJX_DEV void store_b(B &bb, int c, int lane, const double *b) {
         if constexpr (B::M_IN_LDS) {
-            if (c < BCAP) p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+            if (lane < NV && c < BCAP) {
+                double *p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+                p[lane] = b[0], p[NV + lane] = b[1], p[2 * NV + lane] = b[2];
+            }
         }
-        p[lane] = b[0], p[NV + lane] = b[1], p[2 * NV + lane] = b[2];
     }
-    static MJX_DEV void load_b(const B &bb, const R &r, int c, int lane, double *b) {
-        b[0] = b[1] = b[2] = 0;
-        if (lane >= NV) return;
-        const double *p = r.spill + (size_t)(c - BCAP) * 3 * NV;
+    // (M^-1 J_c^T dl)_lane for the frame-space force step dl of contact c: from the stored block, or -- for the contacts beyond the LDS
+    // capacity -- as row `lane` of M^-1 (r.Hrow) times J_c^T dl, whose entries the dof lanes exchange through the blackboard.
+    static MJX_DEV double apply_b(B &bb, const R &r, int c, int lane, const double *jcol, const double *dl) {
         if constexpr (B::M_IN_LDS) {
-            if (c < BCAP) p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+            if (c < BCAP) {  // group-uniform
+                if (lane >= NV) return 0.0;
+                const double *p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+                return p[lane] * dl[0] + p[NV + lane] * dl[1] + p[2 * NV + lane] * dl[2];
+            }
         }
-        b[0] = p[lane], b[1] = p[NV + lane], b[2] = p[2 * NV + lane];
+        double (&q)[NV] = bb.A.sol.col[0];
+        if (lane < NV) q[lane] = jcol[0] * dl[0] + jcol[1] * dl[1] + jcol[2] * dl[2];
+        coop_sync();
+        double da = 0;
+        if (lane < NV) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) da += r.Hrow[j] * q[j];
+        }
+        return da;
     }
     // Row `lane` of M^-1 from the factor M = L L^T (packed copy on the blackboard, idiag = 1 / L[lane][lane]): L^-1 row by row through the
     // storage of M (dead), then L^-T L^-1.  OUT OF LINE on the device: inlined, this block alone drives the 32-lane kernel from 19 to 540
@@ -1286,7 +1300,7 @@ struct Sim {
 #pragma unroll
                     for (int j = 0; j < NV; j++) b[0] += r.Hrow[j] * J[0][j], b[1] += r.Hrow[j] * J[1][j], b[2] += r.Hrow[j] * J[2][j];
                 }
-                store_b(bb, r, c, lane, b);
+                store_b(bb, c, lane, b);
                 // A = J_c (M^-1 J_c^T): six reductions, kept by the owner together with the reciprocal row diagonals
                 const double a00 = group_sum<G>(jcol[0] * b[0], MJX_RED(bb), lane), a01 = group_sum<G>(jcol[0] * b[1], MJX_RED(bb), lane),
                              a02 = group_sum<G>(jcol[0] * b[2], MJX_RED(bb), lane), a11 = group_sum<G>(jcol[1] * b[1], MJX_RED(bb), lane),
@@ -1335,7 +1349,7 @@ struct Sim {
                 for (int owner = 0; owner < G; owner++) {
                     const int c = kc * G + owner;
                     if (c >= ncon) break;
-                    double jcol[3] = {0, 0, 0}, v[3], dl[3], b[3];
+                    double jcol[3] = {0, 0, 0}, v[3], dl[3];
                     if (isdof) jac_col(bb, r, c, lane, jcol);
                     v[0] = group_sum<G>(jcol[0] * a, MJX_RED(bb), lane), v[1] = group_sum<G>(jcol[1] * a, MJX_RED(bb), lane),
                     v[2] = group_sum<G>(jcol[2] * a, MJX_RED(bb), lane);
@@ -1344,9 +1358,9 @@ struct Sim {
                         pgs_contact(r, kc, v, dl, impr);
                         gw[0] = dl[0], gw[1] = dl[1], gw[2] = dl[2];
                     }
-                    load_b(bb, r, c, lane, b);
                     coop_sync();
-                    a += b[0] * gw[0] + b[1] * gw[1] + b[2] * gw[2];
+                    const double step[3] = {gw[0], gw[1], gw[2]};
+                    a += apply_b(bb, r, c, lane, jcol, step);
                 }
             }
             const double imp = group_sum<G>(impr, MJX_RED(bb), lane);
@@ -1712,8 +1726,7 @@ struct Sim {
         const int ncon = bb.ncon;
 #pragma unroll 1
         for (int c = 0; c < ncon; c++) {
-            const int p = bb.con_pair[c];
-            const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+            const int packed = bb.con_pair[c], b1 = (packed >> 16) & 0xff, b2 = (packed >> 24) & 0xff;
             if (b1 != b && b2 != b) continue;
             const double *Fw = bb.C.sol.con_F[c], *rr = bb.con_r[c];
             double tq[3];
