@@ -180,9 +180,9 @@ struct Board {
     // consecutive addresses), which is what keeps that kernel from spilling.
     static constexpr bool M_IN_LDS = NV > 16;
     double Mt[M_IN_LDS ? NV : 1][M_IN_LDS ? NV : 1];
-    int con_pair[MAXCON];             // geom pair of the contact | body of its first geom << 16 | body of its second geom << 24
-    unsigned con_m1[MAXCON], con_m2[MAXCON];  // dofs on the paths to those two bodies: what a dof lane needs for its Jacobian column, kept
-                                              // here because pair -> geom -> body -> mask is three dependent table loads from global memory
+    int con_pair[MAXCON];             // geom pair of the contact | body of its first geom << 16 | body of its second geom << 24 (the bodies
+                                      // ride along because pair -> geom -> body is two dependent table loads from global memory per use;
+                                      // no room for more: the 16-lane robots sit exactly at four workgroups' worth of LDS per CU)
     unsigned cmask[KS], anyrow;
     unsigned limmask[2];  // dofs whose lower / upper joint-limit row is active in this forward pass (PGS visits them in dof order)
     int ncon;
@@ -791,7 +791,6 @@ struct Sim {
                     const int p = M::slot_pair[rd * G + lane];
                     const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
                     bb.con_pair[idx] = p | (b1 << 16) | (b2 << 24);
-                    bb.con_m1[idx] = (unsigned)M::body_dofmask[b1], bb.con_m2[idx] = (unsigned)M::body_dofmask[b2];
                     bb.con_dist[idx] = c.dist;
 #pragma unroll
                     for (int k = 0; k < 3; k++) bb.con_r[idx][k] = c.pos[k] - bb.com[k];
@@ -970,7 +969,8 @@ struct Sim {
     }
     // dof role: column `lane` of the contact-frame Jacobian of contact c
     static MJX_DEV void jac_col(const B &bb, const R &r, int c, int lane, double *jcol) {
-        const int in1 = (bb.con_m1[c] >> lane) & 1u, in2 = (bb.con_m2[c] >> lane) & 1u;
+        const int packed = bb.con_pair[c], b1 = (packed >> 16) & 0xff, b2 = (packed >> 24) & 0xff;
+        const int in1 = ((unsigned)M::body_dofmask[b1] >> lane) & 1u, in2 = ((unsigned)M::body_dofmask[b2] >> lane) & 1u;
         const double sg = (double)(in2 - in1);
         double t[3];
         cross3(t, r.cdof, bb.con_r[c]);
