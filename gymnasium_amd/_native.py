@@ -37,7 +37,7 @@ SYMBOLS = [
 # (oracle/wrappers.py), so they are not part of the orc_-prefixed checker ABI.
 # Host stepping through the engine's pinned staging block (mi_step_async / mi_step_wait / mi_host_buffers): product library only.
 HOST_SYMBOLS = ["step_async", "step_wait", "host_buffers"]
-WRAPPER_SYMBOLS = ["rms_create", "rms_destroy", "rms_get", "rms_set", "normalize_observation", "normalize_reward", "clip_reward"]
+WRAPPER_SYMBOLS = ["rms_create", "rms_destroy", "rms_get", "rms_set", "normalize_observation", "normalize_reward", "clip_reward", "set_step_epilogue"]
 
 
 class MiConfig(C.Structure):
@@ -65,6 +65,14 @@ class MiTabularTable(C.Structure):
     _fields_ = [("num_states", C.c_int32), ("num_actions", C.c_int32), ("max_outcomes", C.c_int32), ("reserved", C.c_int32),
                 ("csprob", C.c_void_p), ("prob", C.c_void_p), ("next_state", C.c_void_p), ("reward", C.c_void_p),
                 ("terminated", C.c_void_p), ("count", C.c_void_p), ("isd_csprob", C.c_void_p)]
+
+
+class MiStepEpilogue(C.Structure):
+    """mi_step_epilogue: the stateful vector wrappers as the output stage of the step kernel (include/mi355env.h)."""
+    _fields_ = [("obs_rms", C.c_void_p), ("obs_epsilon", C.c_double), ("obs_update", C.c_int32), ("reward_update", C.c_int32),
+                ("return_rms", C.c_void_p), ("accumulated", C.c_void_p), ("prev_done", C.c_void_p), ("gamma", C.c_double),
+                ("reward_epsilon", C.c_double), ("clip_pre", C.c_int32), ("clip_post", C.c_int32), ("clip_pre_min", C.c_double),
+                ("clip_pre_max", C.c_double), ("clip_post_min", C.c_double), ("clip_post_max", C.c_double)]
 
 
 class MiStats(C.Structure):
@@ -125,6 +133,7 @@ class NativeLib:
             self.normalize_observation = f("normalize_observation", [vp, vp, vp, i32, i32, dbl, i32, vp], i32)
             self.normalize_reward = f("normalize_reward", [vp, vp, vp, vp, vp, vp, vp, i32, dbl, dbl, i32, i32, vp], i32)
             self.clip_reward = f("clip_reward", [i32, vp, vp, i32, vp, vp, vp], i32)
+            self.set_step_epilogue = f("set_step_epilogue", [vp, C.POINTER(MiStepEpilogue)], i32)
             self.step_async = f("step_async", [vp, C.POINTER(MiStepIO)], i32)
             self.step_wait = f("step_wait", [vp], i32)
             self.host_buffers = f("host_buffers", [vp, C.POINTER(MiStepIO)], i32)
@@ -222,6 +231,10 @@ class Engine:
 
     def set_stream(self, stream_ptr):
         self.lib.check(self.lib.set_stream(self.handle, stream_ptr))
+
+    def set_step_epilogue(self, epilogue: "MiStepEpilogue | None"):
+        """Attach (or, with None, detach) the wrappers' arithmetic as the output stage of the step kernel (mi_set_step_epilogue)."""
+        self.lib.check(self.lib.set_step_epilogue(self.handle, None if epilogue is None else C.byref(epilogue)))
 
     def synchronize(self):
         self.lib.check(self.lib.synchronize(self.handle))

@@ -28,6 +28,7 @@
 
 #include "../../include/mi355env.h"
 #include "envs_classic.h"
+#include "wrappers_internal.h"
 #include "pcg64_dev.h"
 #include "mjx_kernels.h"
 #include "mjx_coop.h"
@@ -287,6 +288,12 @@ MI_DEV void store_row(float *dst, const float *src) {
     }
 }
 
+template <int W>
+MI_DEV void load_row(const float *src, float *dst) {
+#pragma unroll
+    for (int k = 0; k < W; k++) dst[k] = src[k];
+}
+
 MI_DEV double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -332,6 +339,190 @@ MI_DEV void block_accumulate(const DevEnv &d, const LaneStats &st) {
 // kernels
 // ---------------------------------------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------------------------------------
+// Step epilogue: gymnasium.wrappers.vector.{NormalizeObservation, NormalizeReward, ClipReward} as the output stage of step_kernel
+// (mi_set_step_epilogue; the same arithmetic as the stand-alone passes of wrappers.hip, which cite the reference line by line).
+//   phase 1, inside step_kernel: ClipReward placed before the normalisation, the discounted-return update, and this workgroup's column sums
+//     of (obs - running mean), (return - running mean) and their squares: wavefront butterflies, four partials through LDS, one row of
+//     doubles per workgroup in global memory.  No cross-workgroup traffic inside the kernel: a "last workgroup folds the rows" scheme
+//     was measured first and cost 24 us per step -- a device-scope release on gfx950 writes back the whole XCD-local L2, which the step
+//     has just filled with dirty state and observation lines.
+//   phase 2, epilogue_finish: both normalisations need the UPDATED statistics of the whole batch (stateful_observation.py:146-152 updates
+//     before it normalises), i.e. a grid-wide dependency, so they are one small second launch: every workgroup folds the rows (the same
+//     sums in the same order -> the same bits everywhere), applies RunningMeanStd.update to a private copy and rewrites its obs / reward in
+//     place, before the single device-to-host copy of the NumPy path; workgroup 0 also stores the new statistics -- into the handle's
+//     SECOND buffer set, because the other workgroups are still reading the old one; the host swaps the two pointer sets after the launch.
+//     Beyond kEpiFoldMax step workgroups the fold is a one-workgroup launch of its own (epilogue_combine) and phase 2 reads its result.
+// Together: 2 launches per wrapped step (3 beyond 262144 sub-environments) instead of 1 + 4 + 5 + 1 with the stand-alone passes.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kEpiObsMax = 6, kEpiCols = 2 * kEpiObsMax + 3, kEpiFoldMax = 1024;
+struct EpiDev {
+    int obs_on, obs_update, ret_on, ret_update, same_step, clip_pre, clip_post, fold_in_finish;  // clip_*: bit 0 = has min, bit 1 = has max
+    int step_blocks;
+    float gamma;
+    double obs_eps, ret_eps, pre_lo, pre_hi, post_lo, post_hi;
+    double *obs_mean, *obs_var, *obs_count, *ret_mean, *ret_var, *ret_count;              // the statistics before this step (read only)
+    double *obs_mean2, *obs_var2, *obs_count2, *ret_mean2, *ret_var2, *ret_count2;        // where the updated ones go
+    float *acc;
+    uint8_t *prev_done;
+    double *partial;   // [step_blocks][kEpiCols]
+};
+MI_DEV double clip_to(double v, int flags, double lo, double hi) {  // np.clip(reward, min_reward, max_reward)
+    if (flags & 1) v = v < lo ? lo : v;
+    if (flags & 2) v = v > hi ? hi : v;
+    return v;
+}
+__host__ __device__ inline bool epi_reduces(const EpiDev &e) { return (e.obs_on && e.obs_update) || (e.ret_on && e.ret_update); }
+
+template <int NC>
+MI_DEV void block_sum_columns(double (&v)[NC], double (*sh)[kEpiCols]) {  // result on threads < NC of the workgroup: v[0] = their column's total
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    }
+    __syncthreads();  // sh may still be read from an earlier call
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) sh[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sh[w][threadIdx.x];
+        v[0] = t;
+    }
+}
+
+// every thread of the workgroup calls this (valid = it owns a sub-environment); reward is rewritten with what the finish pass / the caller reads
+template <class E>
+MI_DEV void epilogue_phase1(const EpiDev &e, int i, bool valid, const float *obs, double &reward, bool terminated) {
+    constexpr int OBS = E::OBS, NC = 2 * OBS + 3;
+    static_assert(OBS <= kEpiObsMax, "epilogue rows are sized for the classic-control observations");
+    double v[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) v[k] = 0;
+    if (valid) {
+        double r = clip_to(reward, e.clip_pre, e.pre_lo, e.pre_hi);
+        if (e.ret_on) {  // stateful_reward.py:150-176 (wrappers.hip accumulate_return / update_stats)
+            const bool pd = e.prev_done[i] != 0, active = e.same_step || !pd;
+            float a = e.acc[i];
+            if (active) {
+                const float g = a * e.gamma;
+                a = (float)((double)g * (terminated ? 0.0 : 1.0) + r);
+                e.acc[i] = a;
+            }
+            if (e.ret_update && active) {
+                const double d = (double)a - e.ret_mean[0];
+                v[2 * OBS] = d, v[2 * OBS + 1] = d * d, v[2 * OBS + 2] = 1.0;
+            }
+        } else {
+            r = clip_to(r, e.clip_post, e.post_lo, e.post_hi);  // no normalisation in between: both clips happen here
+        }
+        reward = r;
+        if (e.obs_on && e.obs_update) {
+#pragma unroll
+            for (int c = 0; c < OBS; c++) {
+                const double d = (double)obs[c] - e.obs_mean[c];
+                v[c] = d, v[OBS + c] = d * d;
+            }
+        }
+    }
+    if (!epi_reduces(e)) return;  // grid-uniform
+    __shared__ double sh[kBlock / 64][kEpiCols];
+    block_sum_columns<NC>(v, sh);
+    if (threadIdx.x < NC) e.partial[(size_t)blockIdx.x * kEpiCols + threadIdx.x] = v[0];
+}
+
+// The statistics after this step's update, for the whole workgroup: st[0..OBS) mean, st[OBS..2 OBS) var, st[2 OBS] return var, st[2 OBS + 1] return
+// mean, st[2 OBS + 2] obs count, st[2 OBS + 3] return count.  fold = sum the step workgroups' rows first (else: the statistics as they are).
+template <int OBS>
+MI_DEV void epilogue_statistics(const EpiDev &e, int N, bool fold, double (*sh)[kEpiCols], double *st) {
+    constexpr int NC = 2 * OBS + 3;
+    if (threadIdx.x < OBS && e.obs_on) st[threadIdx.x] = e.obs_mean[threadIdx.x], st[OBS + threadIdx.x] = e.obs_var[threadIdx.x];
+    if (threadIdx.x == 64) {
+        st[2 * OBS] = e.ret_on ? e.ret_var[0] : 1.0, st[2 * OBS + 1] = e.ret_on ? e.ret_mean[0] : 0.0;
+        st[2 * OBS + 2] = e.obs_on ? *e.obs_count : 0.0, st[2 * OBS + 3] = e.ret_on ? *e.ret_count : 0.0;
+    }
+    if (fold) {  // workgroup-uniform
+        double v[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) v[k] = 0;
+        for (int b = threadIdx.x; b < e.step_blocks; b += kBlock) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) v[k] += e.partial[(size_t)b * kEpiCols + k];
+        }
+        block_sum_columns<NC>(v, sh);
+        __syncthreads();
+        if (threadIdx.x < NC) sh[0][threadIdx.x] = v[0];
+        __syncthreads();
+        if (e.obs_on && e.obs_update && (int)threadIdx.x < OBS) {  // float32 observations, float32 statistics (RunningMeanStd(dtype=float32))
+            const int c = threadIdx.x;
+            mi_wrap::update_column<float, float>(st[c], st[OBS + c], *e.obs_count, sh[0][c], sh[0][OBS + c], (double)N);
+        }
+        if (threadIdx.x == 64) {
+            if (e.obs_on && e.obs_update) st[2 * OBS + 2] += (double)N;
+            const double rows = sh[0][2 * OBS + 2];
+            if (e.ret_on && e.ret_update && rows > 0) {  // float32 returns, float64 statistics; `if np.any(active)`
+                mi_wrap::update_column<double, float>(st[2 * OBS + 1], st[2 * OBS], *e.ret_count, sh[0][2 * OBS], sh[0][2 * OBS + 1], rows);
+                st[2 * OBS + 3] += rows;
+            }
+        }
+    }
+    __syncthreads();
+}
+template <int OBS>
+MI_DEV void epilogue_store_statistics(const EpiDev &e, const double *st) {  // one workgroup: the updated statistics into the second buffer set
+    if (e.obs_on && (int)threadIdx.x < OBS) e.obs_mean2[threadIdx.x] = st[threadIdx.x], e.obs_var2[threadIdx.x] = st[OBS + threadIdx.x];
+    if (threadIdx.x == 64) {
+        if (e.obs_on) *e.obs_count2 = st[2 * OBS + 2];
+        if (e.ret_on) e.ret_var2[0] = st[2 * OBS], e.ret_mean2[0] = st[2 * OBS + 1], *e.ret_count2 = st[2 * OBS + 3];
+    }
+}
+template <int OBS>
+__global__ __launch_bounds__(kBlock) void epilogue_combine(EpiDev e, int N) {
+    __shared__ double sh[kBlock / 64][kEpiCols];
+    __shared__ double st[2 * OBS + 4];
+    epilogue_statistics<OBS>(e, N, true, sh, st);
+    epilogue_store_statistics<OBS>(e, st);
+}
+
+template <int OBS>
+__global__ __launch_bounds__(kBlock) void epilogue_finish(EpiDev e, int N, float *obs, double *reward, const uint8_t *terminated, const uint8_t *truncated) {
+    __shared__ double sh[kBlock / 64][kEpiCols];
+    __shared__ double st[2 * OBS + 4];
+    if (e.fold_in_finish) {
+        epilogue_statistics<OBS>(e, N, epi_reduces(e), sh, st);
+        if (blockIdx.x == 0 && epi_reduces(e)) epilogue_store_statistics<OBS>(e, st);
+    } else {  // epilogue_combine ran: the second buffer set holds the updated statistics
+        if (threadIdx.x < OBS && e.obs_on) st[threadIdx.x] = e.obs_mean2[threadIdx.x], st[OBS + threadIdx.x] = e.obs_var2[threadIdx.x];
+        if (threadIdx.x == 64 && e.ret_on) st[2 * OBS] = e.ret_var2[0];
+        __syncthreads();
+    }
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    if (e.obs_on) {  // (obs - mean) / np.sqrt(var + epsilon), float32 throughout (wrappers.hip normalize_obs<float, float, float>)
+        float o[OBS];
+        load_row<OBS>(obs + (size_t)i * OBS, o);
+#pragma unroll
+        for (int c = 0; c < OBS; c++) {
+            const float num = o[c] - (float)st[c];
+            const float den = (float)sqrt((double)(float)((float)st[OBS + c] + (float)e.obs_eps));
+            o[c] = num / den;
+        }
+        store_row<OBS>(obs + (size_t)i * OBS, o);
+    }
+    if (e.ret_on) {  // wrappers.hip finish_reward
+        const uint8_t done = (terminated[i] || truncated[i]) ? 1 : 0;
+        e.prev_done[i] = done;
+        if (e.same_step && done) e.acc[i] = 0.0f;
+        const double r = reward[i] / sqrt(st[2 * OBS] + e.ret_eps);
+        reward[i] = clip_to(r, e.clip_post, e.post_lo, e.post_hi);
+    }
+}
+
 struct StepPtrs {
     const void *actions;
     float *obs;
@@ -342,26 +533,31 @@ struct StepPtrs {
     int32_t *ep_len;
 };
 
-template <class E, int MODE>
-__global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io) {
+template <class E, int MODE, bool EPI = false>
+__global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, EpiDev epi) {
     tables_init<E>();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    StepOut<E> o;
     if (i < d.N) {
         Lane<E> L;
         load_lane<E>(d, i, L);
         const typename E::Act a = static_cast<const typename E::Act *>(io.actions)[i];
-        StepOut<E> o;
         lane_step<E, MODE>(d, i, L, a, o, st);
         store_lane<E>(d, i, L);
         if (io.obs) store_row<E::OBS>(io.obs + (size_t)i * E::OBS, o.obs);
-        if (io.reward) io.reward[i] = o.reward;
+        if (!EPI && io.reward) io.reward[i] = o.reward;
         if (io.terminated) io.terminated[i] = o.terminated;
         if (io.truncated) io.truncated[i] = o.truncated;
         if (MODE == MI_AUTORESET_SAME_STEP && io.final_obs && o.has_final)
             store_row<E::OBS>(io.final_obs + (size_t)i * E::OBS, o.final_obs);
         if (io.ep_ret) io.ep_ret[i] = o.ep_ret;
         if (io.ep_len) io.ep_len[i] = o.ep_len;
+    }
+    if (EPI) {  // the wrappers' statistics see what the step wrote; episode statistics (above) keep the raw reward, like the reference's order
+        double r = i < d.N ? o.reward : 0.0;
+        epilogue_phase1<E>(epi, i, i < d.N, o.obs, r, i < d.N && o.terminated);
+        if (i < d.N && io.reward) io.reward[i] = r;
     }
     block_accumulate(d, st);
 }
@@ -1024,6 +1220,10 @@ struct mi_vecenv {
     DevEnv d;
     int grid;
     bool seeded, was_reset, act_seeded;
+    bool has_epi;           // mi_set_step_epilogue: the wrappers run as the output stage of step_kernel
+    EpiDev epi;
+    mi_step_epilogue epi_host;  // what the caller attached: the statistics handles swap their two buffer sets every step, so epi is rebuilt
+    double *d_epi_partial;      // [grid][kEpiCols] column sums of the step workgroups
     Pcg64 act_rng;          // host copy of the action-space generator
     PcgJump *d_pow2;        // [64] device jump table for act_rng.inc
     PcgJump jump_n;
@@ -1117,18 +1317,48 @@ int check_device_error(mi_vecenv *v) {
     return fail(MI_ERR_STATE, "DISABLED autoreset: a finished sub-environment was stepped without reset");
 }
 
+// the statistics handles' current buffer sets into the device view (they swap after every step that updated them)
+void epilogue_bind(mi_vecenv *v) {
+    EpiDev &d = v->epi;
+    if (const mi_running_stats *o = v->epi_host.obs_rms)
+        d.obs_mean = o->mean, d.obs_var = o->var, d.obs_count = o->count, d.obs_mean2 = o->mean2, d.obs_var2 = o->var2, d.obs_count2 = o->count2;
+    if (const mi_running_stats *r = v->epi_host.return_rms)
+        d.ret_mean = r->mean, d.ret_var = r->var, d.ret_count = r->count, d.ret_mean2 = r->mean2, d.ret_var2 = r->var2, d.ret_count2 = r->count2;
+}
+void epilogue_swap(mi_vecenv *v) {
+    auto swap = [](mi_running_stats *s) {
+        double *t;
+        t = s->mean, s->mean = s->mean2, s->mean2 = t;
+        t = s->var, s->var = s->var2, s->var2 = t;
+        t = s->count, s->count = s->count2, s->count2 = t;
+    };
+    if (v->epi.obs_on && v->epi.obs_update) swap(v->epi_host.obs_rms);
+    if (v->epi.ret_on && v->epi.ret_update) swap(v->epi_host.return_rms);
+}
+
+template <class E, bool EPI>
+void launch_step_mode(mi_vecenv *v, const StepPtrs &p) {
+    const dim3 g(v->grid), b(kBlock);
+    switch (v->cfg.autoreset_mode) {
+    case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_NEXT_STEP, EPI>), g, b, 0, v->stream, v->d, p, v->epi); break;
+    case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_SAME_STEP, EPI>), g, b, 0, v->stream, v->d, p, v->epi); break;
+    default: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_DISABLED, EPI>), g, b, 0, v->stream, v->d, p, v->epi); break;
+    }
+}
 template <class E>
 int launch_step(mi_vecenv *v, const StepPtrs &p) {
-    switch (v->cfg.autoreset_mode) {
-    case MI_AUTORESET_NEXT_STEP:
-        hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_NEXT_STEP>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p);
-        break;
-    case MI_AUTORESET_SAME_STEP:
-        hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_SAME_STEP>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p);
-        break;
-    default:
-        hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_DISABLED>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p);
-        break;
+    if (!v->has_epi) {
+        launch_step_mode<E, false>(v, p);
+    } else {
+        if (!p.obs || !p.reward || !p.terminated || !p.truncated) return fail(MI_ERR_INVALID_ARGUMENT, "a step with an epilogue needs obs, reward, terminated and truncated");
+        epilogue_bind(v);
+        launch_step_mode<E, true>(v, p);
+        const EpiDev &e = v->epi;
+        if (e.obs_on || e.ret_on) {
+            if (!e.fold_in_finish && epi_reduces(e)) hipLaunchKernelGGL((epilogue_combine<E::OBS>), dim3(1), dim3(kBlock), 0, v->stream, e, v->d.N);
+            hipLaunchKernelGGL((epilogue_finish<E::OBS>), dim3(v->grid), dim3(kBlock), 0, v->stream, e, v->d.N, p.obs, p.reward, p.terminated, p.truncated);
+            epilogue_swap(v);
+        }
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -1385,8 +1615,41 @@ void mi_destroy(mi_vecenv *v) {
     if (v->h_actions) (void)hipHostFree(v->h_actions);
     for (void *p : v->tab_bufs)
         if (p) (void)hipFree(p);
+    if (v->d_epi_partial) (void)hipFree(v->d_epi_partial);
     if (v->own_stream) (void)hipStreamDestroy(v->own_stream);
     delete v;
+}
+
+// The reference's stateful vector wrappers as the output stage of the classic-control step kernel (include/mi355env.h mi_step_epilogue).
+int mi_set_step_epilogue(mi_vecenv *v, const mi_step_epilogue *e) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (set_device(v)) return MI_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (!e) {
+        v->has_epi = false;
+        return MI_OK;
+    }
+    if (is_mj(v->cfg.kind) || is_tab(v->cfg.kind))
+        return fail(MI_ERR_INVALID_ARGUMENT, "mi_set_step_epilogue: only the classic-control kinds fuse the wrappers into their step kernel (use the mi_normalize_* passes)");
+    const mi_running_stats *o = e->obs_rms, *r = e->return_rms;
+    if (o && (o->dim != v->lay.obs_dim || o->dtype != MI_F32 || o->device != v->device))
+        return fail(MI_ERR_INVALID_ARGUMENT, "mi_set_step_epilogue: obs_rms must be float32 statistics of obs_dim columns on the env's device");
+    if (r && (r->dim != 1 || r->dtype != MI_F64 || r->device != v->device || !e->accumulated || !e->prev_done))
+        return fail(MI_ERR_INVALID_ARGUMENT, "mi_set_step_epilogue: return_rms must be scalar float64 statistics on the env's device, with accumulated and prev_done");
+    if ((o && !(e->obs_epsilon > 0)) || (r && (!(e->reward_epsilon > 0) || !(e->gamma >= 0 && e->gamma <= 1))))
+        return fail(MI_ERR_INVALID_ARGUMENT, "mi_set_step_epilogue: epsilon must be positive, gamma in [0, 1]");
+    if (!v->d_epi_partial) HIP_TRY(hipMalloc(&v->d_epi_partial, sizeof(double) * kEpiCols * (size_t)v->grid));
+    EpiDev d = {};
+    d.obs_on = o != nullptr, d.obs_update = e->obs_update != 0, d.ret_on = r != nullptr, d.ret_update = e->reward_update != 0;
+    d.same_step = v->cfg.autoreset_mode == MI_AUTORESET_SAME_STEP;
+    d.clip_pre = e->clip_pre & 3, d.clip_post = e->clip_post & 3;
+    d.gamma = (float)e->gamma, d.obs_eps = e->obs_epsilon, d.ret_eps = e->reward_epsilon;
+    d.pre_lo = e->clip_pre_min, d.pre_hi = e->clip_pre_max, d.post_lo = e->clip_post_min, d.post_hi = e->clip_post_max;
+    d.acc = e->accumulated, d.prev_done = e->prev_done;
+    d.partial = v->d_epi_partial, d.step_blocks = v->grid, d.fold_in_finish = v->grid <= kEpiFoldMax;
+    v->epi_host = *e;
+    v->epi = d, v->has_epi = d.obs_on || d.ret_on || d.clip_pre || d.clip_post;
+    return MI_OK;
 }
 
 int mi_get_layout(const mi_vecenv *v, mi_layout *out) {

@@ -18,21 +18,15 @@
 #include <new>
 
 #include "../../include/mi355env.h"
+#include "wrappers_internal.h"
 
 namespace mi_internal {
 int set_error(int code, const char *msg);
 }
 
-struct mi_running_stats {
-    int device, dim, dtype;  // dtype of the running mean / var: MI_F32 or MI_F64 (what NumPy's promotion gives in the reference)
-    double *mean, *var;      // [dim] device, values always representable in `dtype`
-    double *count;           // [1] device
-    double *partial;         // [2][kPartials] device scratch
-    int *flag;               // [1] device: number of rows of the last update (0 = the update was skipped)
-};
 
 namespace {
-constexpr int kBlock = 256, kMaxGrid = 1024;
+constexpr int kBlock = 256, kMaxGrid = 256;  // 64 Ki partial sums: the one-workgroup-per-column fold costs 85 us with 256 Ki of them
 
 #define W_TRY(expr)                                                                                             \
     do {                                                                                                        \
@@ -44,10 +38,7 @@ constexpr int kBlock = 256, kMaxGrid = 1024;
         }                                                                                                       \
     } while (0)
 
-template <class T>
-__device__ __forceinline__ double rd(double x) {  // round to the dtype NumPy holds the statistic in
-    return (double)(T)x;
-}
+using mi_wrap::rd;
 
 // Column sums of (x - shift_c) and (x - shift_c)^2 over the rows selected by `active` (nullptr = all), float64.
 // Thread t owns flattened elements t, t + S, t + 2S, ... with S a multiple of `dim`, so it always sees column t % dim and
@@ -90,15 +81,9 @@ __global__ __launch_bounds__(kBlock) void combine_update(const double *partial, 
     const double rows = sh[2][0];
     if (c == 0) *rows_out = (int)rows;
     if (rows == 0) return;  // `if self._update_running_mean and np.any(active)`
-    const double m1 = sh[0][0] / rows;
-    const double batch_mean = rd<X>(mean[c] + m1), batch_var = rd<X>(fmax(sh[1][0] / rows - m1 * m1, 0.0));
-    // wrappers/utils.py:57-71, every operation rounded to T where NumPy computes in T (count and batch_count are Python scalars)
-    const double cnt = *count, tot = cnt + rows;
-    const double delta = rd<T>(batch_mean - mean[c]);
-    const double new_mean = rd<T>(mean[c] + rd<T>(rd<T>(delta * rows) / tot));
-    const double m_a = rd<T>(var[c] * cnt), m_b = rd<T>(batch_var * rows);
-    const double M2 = rd<T>(rd<T>(m_a + m_b) + rd<T>(rd<T>(rd<T>(rd<T>(delta * delta) * cnt) * rows) / tot));
-    mean[c] = new_mean, var[c] = rd<T>(M2 / tot);
+    double m = mean[c], v = var[c];
+    mi_wrap::update_column<T, X>(m, v, *count, sh[0][0], sh[1][0], rows);
+    mean[c] = m, var[c] = v;
 }
 __global__ void bump_count(double *count, const int *rows) {
     if (*rows > 0) *count += (double)*rows;
@@ -185,6 +170,9 @@ int mi_rms_create(int device, int dim, int dtype, double epsilon, mi_running_sta
     W_TRY(hipMalloc(&s->mean, sizeof(double) * dim));
     W_TRY(hipMalloc(&s->var, sizeof(double) * dim));
     W_TRY(hipMalloc(&s->count, sizeof(double)));
+    W_TRY(hipMalloc(&s->mean2, sizeof(double) * dim));
+    W_TRY(hipMalloc(&s->var2, sizeof(double) * dim));
+    W_TRY(hipMalloc(&s->count2, sizeof(double)));
     W_TRY(hipMalloc(&s->flag, sizeof(int)));
     W_TRY(hipMalloc(&s->partial, sizeof(double) * 3 * ((size_t)kBlock * kMaxGrid + dim)));
     // RunningMeanStd.__init__ (wrappers/utils.py:37-41): mean = 0, var = 1, count = epsilon
@@ -204,6 +192,7 @@ void mi_rms_destroy(mi_running_stats *s) {
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(s->mean), (void)hipFree(s->var), (void)hipFree(s->count), (void)hipFree(s->partial), (void)hipFree(s->flag);
+    (void)hipFree(s->mean2), (void)hipFree(s->var2), (void)hipFree(s->count2);
     delete s;
 }
 

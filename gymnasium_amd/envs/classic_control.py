@@ -29,6 +29,8 @@ class _ClassicControlVectorEnv(HipVectorEnv):
     ``SyncVectorEnv``'s.  ``fast_math=True`` (MI_CFG_FAST_MATH) trades that for the device's own sin / cos and ``x * x``: results within
     1 ulp per call of the reference's, more env-steps/s."""
 
+    FUSES_WRAPPERS = True
+
     def __init__(self, *args, fast_math: bool = False, **kwargs):
         self.fast_math = bool(fast_math)
         super().__init__(*args, **kwargs)

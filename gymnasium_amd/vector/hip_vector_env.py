@@ -75,6 +75,38 @@ class HipVectorEnv(VectorEnv):
         """MI_CFG_* option bits of mi_config.reserved[0]."""
         return 0
 
+    # -- wrappers fused into the step kernel (gymnasium_amd/wrappers/vector.py, mi_set_step_epilogue) ----------------------------------
+    FUSES_WRAPPERS = False  # classic control: NormalizeObservation / NormalizeReward / ClipReward run as the step kernel's output stage
+
+    def _fusion_state(self):
+        st = self.__dict__.get("_fused")
+        if st is None:
+            st = self._fused = {"obs": None, "ret": None, "clip_pre": None, "clip_post": None, "closed": False}
+        return st
+
+    def _can_fuse(self) -> bool:
+        return (self.FUSES_WRAPPERS and self._engine_factory is None and hasattr(self._engine.lib, "set_step_epilogue")
+                and not self._fusion_state()["closed"])
+
+    def _refresh_epilogue(self):
+        """(Re)attach the epilogue from the wrappers that registered themselves; called when one of them is created or changes a setting."""
+        st = self._fusion_state()
+        e = _native.MiStepEpilogue()
+        o, r = st["obs"], st["ret"]
+        if o is not None:
+            e.obs_rms, e.obs_epsilon, e.obs_update = o.obs_rms._h, float(o.epsilon), int(o.update_running_mean)
+        if r is not None:
+            e.return_rms, e.accumulated, e.prev_done = r.return_rms._h, r._acc.data_ptr(), r._prev.data_ptr()
+            e.gamma, e.reward_epsilon, e.reward_update = float(r.gamma), float(r.epsilon), int(r.update_running_mean)
+        for key in ("clip_pre", "clip_post"):
+            c = st[key]
+            if c is not None:
+                lo, hi = c.min_reward, c.max_reward
+                setattr(e, key, (1 if lo is not None else 0) | (2 if hi is not None else 0))
+                setattr(e, key + "_min", 0.0 if lo is None else float(lo)), setattr(e, key + "_max", 0.0 if hi is None else float(hi))
+        self._epilogue_struct = e  # keep the ctypes object alive
+        self._engine.set_step_epilogue(e)
+
     def _parse_reset_options(self, options):
         """Return the env-specific (b0, b1) reset bounds or None for defaults; raise ValueError like the reference."""
         return None
@@ -105,6 +137,7 @@ class HipVectorEnv(VectorEnv):
         self.action_space = batch_space(self.single_action_space, self.num_envs)
 
         self._device_index = _resolve_device(device)
+        self._engine_factory = _engine_factory
         if _engine_factory is None:
             lib = _native.load_library()  # raises ImportError if the HIP library was not built
             self._engine = _native.Engine(lib, self.KIND, self.num_envs, self.max_episode_steps, self.autoreset_mode.value,

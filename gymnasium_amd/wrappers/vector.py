@@ -7,9 +7,16 @@ Same constructor arguments, attributes (`obs_rms`, `return_rms`, `epsilon`, `gam
   gymnasium/wrappers/vector/vectorize_reward.py:115-151      ClipReward
   gymnasium/wrappers/utils.py:33-71                          RunningMeanStd
 
-but the arithmetic runs in libmi355env.so (gymnasium_amd/csrc/wrappers.hip) on the arrays the engine produced: with
-``output="torch"`` nothing leaves the GPU; with NumPy output the batch is staged through the device (the wrappers have no CPU
-implementation -- the NumPy restatement in oracle/wrappers.py is test infrastructure).
+but the arithmetic runs in libmi355env.so on the GPU (the wrappers have no CPU implementation -- the NumPy restatement in
+oracle/wrappers.py is test infrastructure), in one of two forms:
+
+* FUSED (classic-control HipVectorEnv directly underneath, possibly through RecordEpisodeStatistics / NumpyToTorch): the wrapper registers
+  itself with the env and its arithmetic becomes the output stage of the step kernel (mi_set_step_epilogue, csrc/engine.hip): the batch
+  statistics are gathered by the step kernel's workgroups, one small second launch normalises in place, and ``env.step`` already returns
+  the wrapped observations / rewards -- NumPy callers get them with the step's one device-to-host copy.  The wrappers that fused form ONE
+  unit with the env: stepping an inner wrapper directly returns the same (fully wrapped) values.
+* STAND-ALONE (any other env of this package, or a wrapper order the epilogue cannot express): passes of csrc/wrappers.hip over the arrays
+  the engine produced; with ``output="torch"`` nothing leaves the GPU, NumPy batches are staged through the device.
 """
 from __future__ import annotations
 
@@ -81,8 +88,35 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _base_env(env):
+    while isinstance(env, VectorWrapper):
+        env = env.env
+    return env
+
+
+def _fusion_base(env):
+    """The HipVectorEnv under ``env`` if it fuses wrappers and everything in between passes observations and rewards through unchanged (or
+    is itself part of the fused unit); None otherwise."""
+    e = env
+    while isinstance(e, VectorWrapper):
+        if not (e._transparent or e._fused):
+            return None
+        e = e.env
+    return e if getattr(e, "_can_fuse", None) is not None and e._can_fuse() else None
+
+
+def _close_fusion(env):
+    """A stand-alone wrapper now sits on top of ``env``: nothing above it may join the fused unit underneath."""
+    base = _base_env(env)
+    if getattr(base, "_fusion_state", None) is not None and getattr(base, "FUSES_WRAPPERS", False):
+        base._fusion_state()["closed"] = True
+
+
 class VectorWrapper:
     """Minimal gymnasium.vector.VectorWrapper: forwards everything to the wrapped vector env (vector_env.py:341-470)."""
+
+    _transparent = False  # True: observations and rewards pass through unchanged (a fused unit may extend across this wrapper)
+    _fused = False        # True: this wrapper's arithmetic runs inside the step kernel of the HipVectorEnv underneath
 
     def __init__(self, env):
         self.env = env
@@ -127,6 +161,8 @@ class RecordEpisodeStatistics(VectorWrapper):
     every step counts) and hand out the rows of the episodes that just ended; this class adds the reference's bookkeeping around them --
     ``infos[stats_key] = {"r", "l", "t"}`` + ``infos["_" + stats_key]``, ``episode_count`` and the three bounded queues."""
 
+    _transparent = True
+
     def __init__(self, env, buffer_length: int = 100, stats_key: str = "episode"):
         from collections import deque
 
@@ -159,6 +195,8 @@ class NumpyToTorch(VectorWrapper):
     wrapper converts NumPy batches with ``torch.from_numpy`` / DLPack after the fact) and actions may be device tensors.  ``device``: where
     the caller wants the tensors -- None or the env's own GPU costs nothing, anything else (e.g. "cpu") is one ``.to(device)`` per array.
     The arrays inside ``infos`` become tensors as well, like the reference's recursive conversion."""
+
+    _transparent = True
 
     def __init__(self, env, device=None):
         super().__init__(env)
@@ -209,6 +247,13 @@ class NormalizeObservation(VectorWrapper):
         self._in_code = _native.MI_F32 if in_dtype == np.float32 else _native.MI_F64
         self.epsilon = epsilon
         self._update_running_mean = True
+        base = _fusion_base(self.env)
+        if base is not None and in_dtype == np.float32 and base._fusion_state()["obs"] is None:
+            base._fusion_state()["obs"] = self
+            self._fused, self._base = True, base
+            base._refresh_epilogue()
+        else:
+            _close_fusion(self.env)
 
     @property
     def update_running_mean(self) -> bool:
@@ -217,6 +262,8 @@ class NormalizeObservation(VectorWrapper):
     @update_running_mean.setter
     def update_running_mean(self, setting: bool):
         self._update_running_mean = setting
+        if self._fused:
+            self._base._refresh_epilogue()
 
     def observations(self, observations):
         torch = _torch()
@@ -234,6 +281,8 @@ class NormalizeObservation(VectorWrapper):
         return self.observations(obs), info
 
     def step(self, actions):
+        if self._fused:  # the step kernel's output stage already normalised (and updated obs_rms)
+            return self.env.step(actions)
         obs, reward, terminated, truncated, info = self.env.step(actions)
         return self.observations(obs), reward, terminated, truncated, info
 
@@ -255,6 +304,14 @@ class NormalizeReward(VectorWrapper):
         self.gamma, self.epsilon = gamma, epsilon
         self._update_running_mean = True
         self._autoreset_mode = self.env.metadata.get("autoreset_mode", AutoresetMode.NEXT_STEP)
+        base = _fusion_base(self.env)
+        st = None if base is None else base._fusion_state()
+        if st is not None and st["ret"] is None and st["clip_post"] is None:  # order inside the epilogue: clip_pre -> normalise -> clip_post
+            st["ret"] = self
+            self._fused, self._base = True, base
+            base._refresh_epilogue()
+        else:
+            _close_fusion(self.env)
 
     @property
     def accumulated_reward(self):
@@ -267,12 +324,16 @@ class NormalizeReward(VectorWrapper):
     @update_running_mean.setter
     def update_running_mean(self, setting: bool):
         self._update_running_mean = setting
+        if self._fused:
+            self._base._refresh_epilogue()
 
     def reset(self, *, seed=None, options=None):
         self._acc.zero_(), self._prev.zero_()
         return self.env.reset(seed=seed, options=options)
 
     def step(self, actions):
+        if self._fused:
+            return self.env.step(actions)
         torch = _torch()
         obs, reward, terminated, truncated, info = self.env.step(actions)
         r, was_tensor = self._to_device(reward, np.float64)
@@ -299,8 +360,25 @@ class ClipReward(VectorWrapper):
         super().__init__(env)
         self.min_reward, self.max_reward = min_reward, max_reward
         self._lib = _native.load_library()
+        base = _fusion_base(self.env)
+        st = None if base is None else base._fusion_state()
+        scalar = all(b is None or np.ndim(b) == 0 for b in (min_reward, max_reward))
+        slot = None
+        if st is not None and scalar:
+            if st["ret"] is None and st["clip_pre"] is None and st["clip_post"] is None:
+                slot = "clip_pre"
+            elif st["clip_post"] is None:
+                slot = "clip_post"
+        if slot is not None:
+            st[slot] = self
+            self._fused, self._base = True, base
+            base._refresh_epilogue()
+        else:
+            _close_fusion(self.env)
 
     def step(self, actions):
+        if self._fused:
+            return self.env.step(actions)
         torch = _torch()
         obs, reward, terminated, truncated, info = self.env.step(actions)
         r, was_tensor = self._to_device(reward, np.float64)

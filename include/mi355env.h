@@ -315,6 +315,26 @@ int mi_normalize_reward(mi_running_stats *return_rms, void *hip_stream, float *a
 int mi_clip_reward(int device, void *hip_stream, const double *reward, int num_envs, const double *min_reward, const double *max_reward,
                    double *out);
 
+/* The same three wrappers as the OUTPUT STAGE of the step kernel (classic-control kinds): mi_step / mi_step_async then return the wrapped
+ * observations and rewards in place of the raw ones -- one extra launch per step (the normalisations need the statistics of the WHOLE batch,
+ * stateful_observation.py:146-152) instead of the ten of the stand-alone passes, and no staging for host callers: the values are rewritten
+ * before the step's single device-to-host copy.  Reward order: ClipReward (clip_pre) -> NormalizeReward -> ClipReward (clip_post); each part
+ * optional.  The handles and arrays stay owned by the caller and must outlive the attachment; NULL detaches.  Fused rollouts (mi_rollout)
+ * and resets are not affected (normalise a reset observation with mi_normalize_observation). */
+typedef struct mi_step_epilogue {
+    mi_running_stats *obs_rms;     /* NormalizeObservation: float32 statistics of obs_dim columns, or NULL */
+    double obs_epsilon;
+    int32_t obs_update;            /* update_running_mean */
+    int32_t reward_update;
+    mi_running_stats *return_rms;  /* NormalizeReward: scalar float64 statistics, or NULL */
+    float *accumulated;            /* [N] device: discounted return per sub-environment */
+    uint8_t *prev_done;            /* [N] device */
+    double gamma, reward_epsilon;
+    int32_t clip_pre, clip_post;   /* bit 0: has min, bit 1: has max */
+    double clip_pre_min, clip_pre_max, clip_post_min, clip_post_max;
+} mi_step_epilogue;
+int mi_set_step_epilogue(mi_vecenv *env, const mi_step_epilogue *epilogue);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,103 @@ def test_numpy_to_torch_wrapper_hands_out_device_tensors():
     oc, _ = c.reset(seed=0)
     assert isinstance(oc, torch.Tensor) and not oc.is_cuda and oc.dtype == torch.float32
     a.close(), b.close(), c.close()
+
+
+# ---- the same wrappers FUSED into the step kernel (mi_set_step_epilogue) against the stand-alone passes on identical trajectories ----------
+def _pair(env_id, n, chain, output, **kw):
+    """(fused, stand-alone): the same env and the same wrapper chain twice; the second env is told not to fuse."""
+    out = []
+    for fuse in (True, False):
+        env = gymnasium_amd.make_vec(env_id, num_envs=n, output=output, **kw)
+        if not fuse:
+            env.FUSES_WRAPPERS = False
+        w = env
+        for make in chain:
+            w = make(w)
+        out.append((env, w))
+    return out
+
+
+def _np(x):
+    return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+
+
+@pytest.mark.parametrize("output", ["numpy", "torch"])
+@pytest.mark.parametrize("env_id,chain_name", [("CartPole-v1", "obs+rew"), ("Pendulum-v1", "clip+rew+clip"), ("Acrobot-v1", "obs"), ("MountainCarContinuous-v0", "rew+clip"),
+                                               ("CartPole-v1", "clip"), ("Pendulum-v1", "stats+obs+rew")])
+def test_fused_wrappers_equal_the_stand_alone_passes(env_id, chain_name, output):
+    chains = {
+        "obs+rew": [lambda e: gw.NormalizeObservation(e), lambda e: gw.NormalizeReward(e, gamma=0.97)],
+        "clip+rew+clip": [lambda e: gw.ClipReward(e, -6.0, -0.5), lambda e: gw.NormalizeReward(e), lambda e: gw.ClipReward(e, -3.0, None)],
+        "obs": [lambda e: gw.NormalizeObservation(e, epsilon=1e-6)],
+        "rew+clip": [lambda e: gw.NormalizeReward(e, gamma=0.9), lambda e: gw.ClipReward(e, None, 0.5)],
+        "clip": [lambda e: gw.ClipReward(e, 0.0, 0.5)],
+        "stats+obs+rew": [lambda e: gw.RecordEpisodeStatistics(e), lambda e: gw.NormalizeObservation(e), lambda e: gw.NormalizeReward(e)],
+    }
+    (ea, a), (eb, b) = _pair(env_id, 1536, chains[chain_name], output)
+    assert all(getattr(w, "_fused", False) for w in _chain(a) if isinstance(w, (gw.NormalizeObservation, gw.NormalizeReward, gw.ClipReward)))
+    assert not any(getattr(w, "_fused", False) for w in _chain(b))
+    oa, _ = a.reset(seed=11)
+    ob, _ = b.reset(seed=11)
+    np.testing.assert_allclose(_np(oa), _np(ob), rtol=1e-5, atol=1e-6)
+    ea.action_space.seed(5)
+    obs_w = [w for w in _chain(a) if isinstance(w, gw.NormalizeObservation)]
+    for t in range(120):
+        act = ea.action_space.sample()
+        if t == 80 and obs_w:  # freeze the statistics half-way, on both
+            for w in _chain(a) + _chain(b):
+                if isinstance(w, (gw.NormalizeObservation, gw.NormalizeReward)):
+                    w.update_running_mean = False
+        ra, rb = a.step(act), b.step(act)
+        np.testing.assert_allclose(_np(ra[0]), _np(rb[0]), rtol=2e-5, atol=2e-6, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(_np(ra[1]), _np(rb[1]), rtol=2e-6, atol=1e-12, err_msg=f"reward t={t}")
+        assert np.array_equal(_np(ra[2]), _np(rb[2])) and np.array_equal(_np(ra[3]), _np(rb[3]))
+        assert set(ra[4]) == set(rb[4])
+    for wa, wb in zip(_chain(a), _chain(b)):
+        if isinstance(wa, gw.NormalizeObservation):
+            np.testing.assert_allclose(wa.obs_rms.mean, wb.obs_rms.mean, rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(wa.obs_rms.var, wb.obs_rms.var, rtol=1e-5, atol=1e-9)
+            assert wa.obs_rms.count == wb.obs_rms.count
+        if isinstance(wa, gw.NormalizeReward):
+            assert np.array_equal(wa.accumulated_reward, wb.accumulated_reward), "the discounted returns are bit-exact"
+            np.testing.assert_allclose(wa.return_rms.var, wb.return_rms.var, rtol=1e-9)
+            assert wa.return_rms.count == wb.return_rms.count
+    a.close(), b.close()
+
+
+def _chain(w):
+    out = []
+    while isinstance(w, gw.VectorWrapper):
+        out.append(w)
+        w = w.env
+    return out[::-1]
+
+
+def test_fused_reward_normalisation_same_step_mode():
+    (ea, a), (eb, b) = _pair("CartPole-v1", 1024, [lambda e: gw.NormalizeReward(e, gamma=0.95)], "numpy", autoreset_mode="SameStep")
+    assert a._fused and not b._fused
+    a.reset(seed=2), b.reset(seed=2)
+    ea.action_space.seed(1)
+    for t in range(150):
+        act = ea.action_space.sample()
+        ra, rb = a.step(act), b.step(act)
+        np.testing.assert_allclose(ra[1], rb[1], rtol=2e-6, atol=1e-12, err_msg=f"t={t}")
+    assert np.array_equal(a.accumulated_reward, b.accumulated_reward)
+    a.close(), b.close()
+
+
+def test_wrapper_orders_the_epilogue_cannot_express_stay_stand_alone():
+    env = gymnasium_amd.make_vec("Pendulum-v1", num_envs=64)
+    w1 = gw.NormalizeReward(env)
+    w2 = gw.NormalizeReward(w1)  # a second normalisation: stand-alone, and it closes the fused unit
+    w3 = gw.ClipReward(w2, -1.0, 1.0)
+    assert w1._fused and not w2._fused and not w3._fused
+    w3.reset(seed=0)
+    env.action_space.seed(0)
+    for _ in range(5):
+        r = w3.step(env.action_space.sample())[1]
+        assert np.all(r >= -1.0) and np.all(r <= 1.0)
+    w3.close()
+    ant = gymnasium_amd.make_vec("Ant-v5", num_envs=16)
+    assert not gw.NormalizeObservation(ant)._fused, "the MuJoCo kinds keep the stand-alone passes"
+    ant.close()
