@@ -418,7 +418,38 @@ def main():
                                     "us_per_step_wall": dt_page * 1e6, "us_per_step_wall_actions_in_pinned_buffer": dt_pin * 1e6,
                                     "host_action_space_sample_us": sample_us}
         env_np.close()
+        # the reference's stateful wrappers on top (ClipReward(NormalizeReward(NormalizeObservation(env)))), device tensors in and out
+        if args.env in STEP_BYTES:
+            from gymnasium_amd import wrappers as gw
+
+            wrapped = {}
+            for mode in ("fused", "standalone"):
+                env_w = gymnasium_amd.make_vec(args.env, num_envs=N, device=local_rank, output="torch", copy=False)
+                if mode == "standalone":
+                    env_w.FUSES_WRAPPERS = False
+                w = gw.ClipReward(gw.NormalizeReward(gw.NormalizeObservation(env_w)), -5.0, 5.0)
+                w.reset(seed=0)
+                for _ in range(10):
+                    w.step(a_dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    w.step(a_dev)
+                torch.cuda.synchronize()
+                wrapped[mode] = (time.perf_counter() - t0) / 100 * 1e6
+                w.close()
+            result["api_step_wrapped"] = {"wrappers": "ClipReward(NormalizeReward(NormalizeObservation(env)))", "us_per_step_wall_fused": wrapped["fused"],
+                                          "us_per_step_wall_standalone_passes": wrapped["standalone"], "launches_per_step_fused": 2 if N <= 262144 else 3,
+                                          "launches_per_step_standalone": 11, "evidence": "profiles/r02_wrappers_fused.txt"}
     cfg.close()
+    if single and args.env in STEP_BYTES and not env_kwargs:  # the opt-in configuration next to the default (bit-exact libm) one
+        c_opt = Config(args.env, N, inner, local_rank, 0, {"fast_math": True})
+        for _ in range(2):
+            c_opt.launch()
+        el_o, _, st_o = c_opt.timed(K, sync_local)
+        result["opt_in"] = {"env_kwargs": {"fast_math": True}, "value": st_o["env_steps"] / el_o, "unit": "env-steps/s",
+                            "note": "device sin / cos and x * x instead of the bit-exact libm restatements (tolerance parity, tests/test_gpu_parity.py)"}
+        c_opt.close()
 
     # ---- secondary configurations (rank 0, one GPU) -------------------------------------------------------------------------------------
     if single and not args.no_secondary and args.env == "CartPole-v1":
@@ -438,6 +469,14 @@ def main():
             want = ("traffic", "sq") if args.pmc == "full" else (("sq",) if (args.pmc == "auto" and env_id in MJ_COOP) else ())
             line["roofline"] = c2.roofline(ks2, want)
             c2.close()
+            opt = {"fast_math": True} if env_id in STEP_BYTES else ({"solver": "Newton"} if env_id in ("Humanoid-v5", "HumanoidStandup-v5") else None)
+            if opt:  # the opt-in, faster configuration next to the default (reference-faithful) one
+                c3 = Config(env_id, n2, inner2, local_rank, 0, opt)
+                for _ in range(2):
+                    c3.launch()
+                el4, _, st4 = c3.timed(k2, sync_local)
+                line["opt_in"] = {"env_kwargs": opt, "value": st4["env_steps"] / el4, "unit": "env-steps/s"}
+                c3.close()
             if not args.no_cpu_baseline:  # MuJoCo: a 512-env sample (the oracle's per-env cost does not depend on the batch size)
                 line["cpu_baseline"] = cpu_baseline(env_id, 512 if env_id in MJ_COOP else n2, budget_s=3.0)
             result["secondary"].append(line)

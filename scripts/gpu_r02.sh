@@ -15,7 +15,7 @@ r = json.load(open("gpurun_out/${TAG}_bench.json"))
 print("value %.4g sustained %.4g frac %.3g kernel_ms %.4g traffic %s (%s)" % (r["value"], r.get("sustained_value", 0), r["roofline"]["frac"], r["roofline"]["avg_kernel_ms"], r["roofline"]["traffic"], (r["roofline"]["traffic_source"] or "")[:40]))
 for s in r.get("secondary", []):
     rf = s["roofline"]
-    print("  %-26s N=%-6d value %.4g sustained %.4g bound %s frac %s traffic/algo %s cpu %.4g" % (s["env"], s["num_envs"], s["value"], s.get("sustained_value", 0), rf["bound"], rf["frac"], rf.get("traffic_over_algorithmic"), (s.get("cpu_baseline") or {}).get("value", 0)))
-for k in ("api_step_device", "api_step_numpy", "cpu_baseline"):
+    print("  %-26s N=%-6d value %.4g sustained %.4g bound %s frac %s traffic/algo %s cpu %.4g opt-in %s" % (s["env"], s["num_envs"], s["value"], s.get("sustained_value", 0), rf["bound"], rf["frac"], rf.get("traffic_over_algorithmic"), (s.get("cpu_baseline") or {}).get("value", 0), json.dumps(s.get("opt_in"))))
+for k in ("opt_in", "api_step_device", "api_step_numpy", "api_step_wrapped", "cpu_baseline"):
     print(" ", k, json.dumps(r.get(k))[:260])
 PY
