@@ -1093,47 +1093,33 @@ struct Sim {
         }
         return da;
     }
-    // Row `lane` of M^-1 from the factor M = L L^T (packed copy on the blackboard, idiag = 1 / L[lane][lane]): L^-1 row by row through the
-    // storage of M (dead), then L^-T L^-1.  OUT OF LINE on the device: inlined, this block alone drives the 32-lane kernel from 19 to 540
-    // spilled registers (measured by compiling with and without it) and slows every other phase of the forward pass down with it; as a
-    // function it has its own register allocation and costs one save / restore of the caller's live registers per forward pass.
-#if defined(MJX_HOST_EMU)
-    static inline void invert(B &bb, double idiag, int lane, double *minv) {
-#else
-    static __device__ __attribute__((noinline)) void invert(B &bb, double idiag, int lane, double *minv) {
-#endif
-        static_assert(B::M_IN_LDS, "the explicit inverse goes through the blackboard storage of M");
-        double acc[NV];
+    // Row `lane` of M^-1 (= column `lane`: solve L L^T x = e_lane) from the packed factor on the blackboard.  Every lane runs its OWN forward
+    // and back substitution: the factor entries are read at the same LDS address by all lanes (broadcast reads), the iterate stays in
+    // registers, and there is no exchange and no fence between the rows -- 2 x NV (NV - 1) / 2 multiply-adds per lane.  (Round 2 first formed
+    // L^-1 cooperatively row by row through the storage of M and multiplied L^-T L^-1: 20 k cycles per forward pass, and inlined it drove the
+    // 32-lane kernel from 19 to 540 spilled registers.)
+    static MJX_DEV void invert(B &bb, double idiag, int lane, double *x) {
+        double (&dg)[NV] = bb.A.sol.col[0];
+        if (lane < NV) dg[lane] = idiag;
+        coop_sync();
+        const int me = lane < NV ? lane : 0;
 #pragma unroll
-        for (int j = 0; j < NV; j++) acc[j] = 0;
-        double (&S)[NV][NV] = bb.Mt;
+        for (int j = 0; j < NV; j++) {
+            double s = (j == me) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < NV; k++) {
-            if (lane == k) {
-#pragma unroll
-                for (int j = 0; j <= k; j++) S[k][j] = ((j == k ? 1.0 : 0.0) - acc[j]) * idiag;
-            }
-            coop_sync();
-            if (lane > k && lane < NV) {
-                const double lik = bb.A.sol.L[tri(lane < NV ? lane : 0, 0) + k];  // L[lane][k] from the packed copy: the register row is free for M^-1
-#pragma unroll
-                for (int j = 0; j <= k; j++) acc[j] += lik * S[k][j];
-            }
+            for (int k = 0; k < j; k++) s -= bb.A.sol.L[tri(j, 0) + k] * x[k];
+            x[j] = s * dg[j];
             MJX_SCHED_FENCE();  // keep the scheduler from hoisting the LDS reads of later rows (hundreds of live values -> spills)
         }
-        double row[NV];
 #pragma unroll
-        for (int j = 0; j < NV; j++) row[j] = 0;
+        for (int j = NV - 1; j >= 0; j--) {
+            double s = x[j];
 #pragma unroll
-        for (int k = 0; k < NV; k++) {
-            const double ski = (lane <= k) ? S[k][lane < NV ? lane : 0] : 0.0;
-#pragma unroll
-            for (int j = 0; j <= k; j++) row[j] += ski * S[k][j];
+            for (int k = j + 1; k < NV; k++) s -= bb.A.sol.L[tri(k, 0) + j] * x[k];
+            x[j] = s * dg[j];
             MJX_SCHED_FENCE();
         }
-#pragma unroll
-        for (int j = 0; j < NV; j++) minv[j] = row[j];
-        coop_sync();  // S is dead from here on: the storage becomes the M^-1 J_c^T store
+        coop_sync();  // dg (the solver's exchange column) is reused by the sweeps
     }
     // The rows of contact (kc, owner lane) against the contact-frame acceleration v = J_c a: relax them in order, keep v current, return the
     // frame-space force step dl = sum E^T delta and the cost improvement.  Runs on every lane (SIMD), meaningful on the owner.
