@@ -114,7 +114,7 @@ class HipVectorEnv(VectorEnv):
     # --------------------------------------------------------------------------------------------------
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, autoreset_mode=AutoresetMode.NEXT_STEP,
                  render_mode: str | None = None, device=None, output: str = "numpy", copy: bool = True,
-                 env_index_offset: int = 0, record_episode_statistics: bool = False, _engine_factory=None):
+                 env_index_offset: int = 0, record_episode_statistics: bool = False, strict_actions: bool = False, _engine_factory=None):
         if render_mode is not None:
             raise error.Error("gymnasium_amd sub-environments live on the GPU and cannot render; use render_mode=None")
         if output not in ("numpy", "torch"):
@@ -127,6 +127,12 @@ class HipVectorEnv(VectorEnv):
         self.metadata["autoreset_mode"] = self.autoreset_mode
         self.render_mode = None
         self.copy = bool(copy)
+        # output="torch": the engine runs asynchronously on torch's stream, so what the reference raises at once -- the AssertionError for an
+        # action outside the space (cartpole.py:165-167), stepping a finished sub-environment under DISABLED autoreset -- is DEFERRED: the
+        # kernel records a sticky error word (an invalid action is stepped as action 0) and the next synchronising call (`synchronize()`,
+        # `statistics()`, any NumPy-mode step) raises it.  strict_actions=True synchronises after every step and raises there, at the cost
+        # of the asynchrony (debugging aid).  NumPy input is always validated on the host before anything is mutated.
+        self.strict_actions = bool(strict_actions)
         self.output = output
         self.max_episode_steps = self.DEFAULT_MAX_EPISODE_STEPS if max_episode_steps is None else max_episode_steps
         self.env_index_offset = int(env_index_offset)
@@ -356,6 +362,8 @@ class HipVectorEnv(VectorEnv):
             self._engine.step(aptr, self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc),
                               self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc, self._p(self._info),
                               self._p(self._final_info))
+            if self.strict_actions and self.output == "torch":
+                self._engine.synchronize()  # raises the device error word of this very step
         except _native.NativeError as e:
             if e.code == -1:  # MI_ERR_INVALID_ARGUMENT: action outside the space (cartpole.py:165-167 asserts)
                 raise AssertionError(e.message) from e

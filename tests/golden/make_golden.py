@@ -384,7 +384,7 @@ def make_same_step_infos():
                 rec["final_action_mask_mask"].append(info["final_info"]["_action_mask"] if has else np.zeros(n, np.bool_))
         save(f"infos_same_step_{key}.npz", obs0=o0, **{k: np.stack(x) for k, x in rec.items() if x})
         v.close()
-    # NEXT_STEP + partial reset while sub-env 1 is pending its autoreset: CliffWalking with a 5-step TimeLimit makes every sub-env
+    # NEXT_STEP + partial reset while sub-env 1 is pending its autoreset: FrozenLake with a 5-step TimeLimit makes every sub-env
     # truncate at the same step; then only sub-envs {0, 2} are reset explicitly
     n = 4
     v = gym.make_vec("FrozenLake-v1", num_envs=n, vectorization_mode="sync", max_episode_steps=5)

@@ -144,6 +144,31 @@ def _episode_vs_oracle(key, T, tol, oracle_factory, resync_every, **gpu_kw):
     gpu.close(), cpu.close()
 
 
+def test_torch_mode_errors_are_deferred_unless_strict():
+    """output="torch": an action outside the space is reported by the next synchronising call; strict_actions=True raises at the step
+    (cartpole.py:165-167 asserts at once; NumPy input is validated on the host before anything is mutated)."""
+    import torch
+
+    bad = torch.full((64,), 7, dtype=torch.int64, device="cuda")
+    lazy = ps.make("cartpole", 64, None, output="torch")
+    lazy.reset(seed=0)
+    lazy.step(bad)  # enqueued; nothing raised yet
+    with pytest.raises(Exception):
+        lazy.synchronize()
+    lazy.close()
+    strict = ps.make("cartpole", 64, None, output="torch", strict_actions=True)
+    strict.reset(seed=0)
+    with pytest.raises(AssertionError):
+        strict.step(bad)
+    strict.step(torch.zeros(64, dtype=torch.int64, device="cuda"))  # the error word was cleared: the env is usable again
+    strict.close()
+    host = ps.make("cartpole", 64, None)
+    host.reset(seed=0)
+    with pytest.raises(AssertionError):
+        host.step(np.full(64, 7, dtype=np.int64))
+    host.close()
+
+
 def test_torch_output_matches_numpy_output():
     import torch
 
