@@ -413,7 +413,7 @@ def main():
         dt_page = timed_steps(False)
         env_np.action_buffer[...] = actions[0]
         dt_pin = timed_steps(True)
-        result["api_step_numpy"] = {"value": N / dt_page, "unit": "vector-env lanes/s (NumPy in / NumPy out over PCIe: pinned staging block, one H2D + one D2H per step; "
+        result["api_step_numpy"] = {"value": N / dt_page, "unit": "vector-env lanes/s (NumPy in / NumPy out over PCIe: the step kernel reads the actions from and writes its outputs to one page-locked block, no copy-engine hand-off; "
                                                                  "host action sampling excluded)",
                                     "us_per_step_wall": dt_page * 1e6, "us_per_step_wall_actions_in_pinned_buffer": dt_pin * 1e6,
                                     "host_action_space_sample_us": sample_us}
