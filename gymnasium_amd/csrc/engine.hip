@@ -1739,11 +1739,11 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
     void *dobs = obs;
     // classic kinds, host caller: the pinned block is where the last observations are (the step kernel writes it directly), so that is what
     // a partial reset must leave untouched for the sub-environments it does not reset
-    const bool pinned_obs = loc == MI_HOST && !is_mj(v->cfg.kind) && !is_tab(v->cfg.kind);
+    const bool pinned_obs = loc == MI_HOST && !is_mj(v->cfg.kind);
     if (loc == MI_HOST) {
         if (int rc = upload_mask(v, mask, &dm)) return rc;
         dobs = v->d_obs;  // persistent: rows of un-reset sub-envs keep their last observation (sync_vector_env.py:261)
-        if (pinned_obs) dobs = v->h_out_dev + ((char *)v->d_obs - v->d_out);
+        if (pinned_obs) dobs = v->h_out_dev + ((char *)v->d_obs - v->d_out);  // (pinned() is declared further down)
     }
     const int has_bounds = bounds != nullptr;
     const double b0 = has_bounds ? bounds[0] : 0.0, b1 = has_bounds ? bounds[1] : 0.0;
@@ -1753,8 +1753,8 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
         HIP_TRY(hipGetLastError());
         v->was_reset = true;
         if (loc == MI_HOST) {
-            if (obs) HIP_TRY(hipMemcpyAsync(obs, v->d_obs, v->obs_bytes, hipMemcpyDeviceToHost, v->stream));
             HIP_TRY(hipStreamSynchronize(v->stream));
+            if (obs && obs != v->h_io.obs) memcpy(obs, v->h_io.obs, v->obs_bytes);
         }
         return MI_OK;
     }
@@ -1779,6 +1779,9 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
     return MI_OK;
 }
 
+// the address, as the device sees it, of the place in the page-locked block that mirrors `device_ptr` of the device block
+static void *pinned(const mi_vecenv *v, const void *device_ptr) { return v->h_out_dev + ((const char *)device_ptr - v->d_out); }
+
 // Enqueue one vector step.  loc == MI_HOST: actions go through the pinned staging block (one H2D), the kernel writes the device output
 // block, and ONE D2H brings back the prefix of it that the caller asked for -- or, for the classic kinds, the kernel works on the pinned block
 // directly and there is no copy at all; nothing is synchronised here.
@@ -1800,23 +1803,21 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
                 if (a[i] < 0 || a[i] >= na) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
         }
         if (io->actions != v->h_actions) memcpy(v->h_actions, io->actions, v->act_bytes);  // callers that fill the pinned array skip this
-        // Classic control: the step kernel reads the actions from and writes its outputs to the PINNED block itself (coalesced rows of at most
+        // Classic control and ToyText: the step kernel reads the actions from and writes its outputs to the PINNED block itself (coalesced rows of at most
         // 24 bytes per lane stream over PCIe while the kernel runs): no copy-engine hand-offs, 97 -> 85 us per step at 65 536 sub-environments
         // (73 us when the caller's policy writes into the pinned action array).  MI355ENV_ZEROCOPY=0 restores the staged copies (A/B).  Not
         // with a finishing epilogue pass (it would re-read the batch over PCIe) and not for the wide float64 rows of the MuJoCo kinds.
         static const bool zero_copy = !(getenv("MI355ENV_ZEROCOPY") && getenv("MI355ENV_ZEROCOPY")[0] == '0');
-        zc = zero_copy && !is_mj(v->cfg.kind) && !is_tab(v->cfg.kind) && !(v->has_epi && (v->epi.obs_on || v->epi.ret_on));
+        zc = zero_copy && !is_mj(v->cfg.kind) && !(v->has_epi && (v->epi.obs_on || v->epi.ret_on));
         if (zc) {
             void *da = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&da, v->h_actions, 0));
-            char *H = v->h_out_dev;
-            const size_t o0 = (char *)v->d_obs - v->d_out, o1 = (char *)v->d_reward - v->d_out, o2 = (char *)v->d_term - v->d_out, o3 = (char *)v->d_trunc - v->d_out;
-            const size_t o5 = (char *)v->d_epret - v->d_out, o6 = (char *)v->d_eplen - v->d_out, o7 = (char *)v->d_final - v->d_out;
             p.actions = da;
-            p.obs = (float *)(H + o0), p.reward = (double *)(H + o1), p.terminated = (uint8_t *)(H + o2), p.truncated = (uint8_t *)(H + o3);
-            p.final_obs = io->final_obs ? (float *)(H + o7) : nullptr;
-            p.ep_ret = io->episode_return ? (double *)(H + o5) : nullptr;
-            p.ep_len = io->episode_length ? (int32_t *)(H + o6) : nullptr;
+            p.obs = (float *)pinned(v, v->d_obs), p.reward = (double *)pinned(v, v->d_reward);
+            p.terminated = (uint8_t *)pinned(v, v->d_term), p.truncated = (uint8_t *)pinned(v, v->d_trunc);
+            p.final_obs = io->final_obs ? (float *)pinned(v, v->d_final) : nullptr;
+            p.ep_ret = io->episode_return ? (double *)pinned(v, v->d_epret) : nullptr;
+            p.ep_len = io->episode_length ? (int32_t *)pinned(v, v->d_eplen) : nullptr;
         } else {
             HIP_TRY(hipMemcpyAsync(v->d_actions, v->h_actions, v->act_bytes, hipMemcpyHostToDevice, v->stream));
             p.actions = v->d_actions;
@@ -1832,6 +1833,7 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     }
     double *dinfo = loc == MI_HOST ? (io->info ? v->d_info : nullptr) : io->info;
     double *dfinfo = loc == MI_HOST ? (io->final_info ? v->d_final_info : nullptr) : io->final_info;
+    if (zc) dinfo = dinfo ? (double *)pinned(v, dinfo) : nullptr, dfinfo = dfinfo ? (double *)pinned(v, dfinfo) : nullptr;
     int rc;
     if (is_tab(v->cfg.kind)) {
         const TabStepPtrs tp = {(const int64_t *)p.actions, (int64_t *)p.obs, p.reward, p.terminated, p.truncated, (int64_t *)p.final_obs,
