@@ -1791,6 +1791,9 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     if (!io->actions) return fail(MI_ERR_INVALID_ARGUMENT, "actions is NULL");
     if (v->has_pending) return fail(MI_ERR_STATE, "mi_step_async: the previous asynchronous step has not been waited for (mi_step_wait)");
     if (set_device(v)) return MI_ERR_HIP;
+    // Device callers are asynchronous: an action outside the space (or a finished sub-environment stepped under DISABLED) is recorded by the
+    // kernel in the page-locked error word and raised HERE, by the first later step that finds it -- a plain host read, no synchronisation.
+    if (loc == MI_DEVICE && *v->h_err) return raise_device_error(v);
     const size_t N = (size_t)v->cfg.num_envs;
     StepPtrs p;
     bool zc = false;

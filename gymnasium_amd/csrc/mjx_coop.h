@@ -1728,6 +1728,10 @@ struct Sim {
     //   cfrc_ext[NB][6], cinert[NB][10], cvel[NB][6], qfrc_actuator[NV], ten_length[NTENDON], ten_velocity[NTENDON]
     static constexpr int EX_XY = 0, EX_CFRC = 4, EX_CINERT = EX_CFRC + 6 * NB, EX_CVEL = EX_CINERT + 10 * NB, EX_QFA = EX_CVEL + 6 * NB,
                          EX_TEN = EX_QFA + NV, EX_TOTAL = EX_TEN + 2 * M::NTENDON;
+    // WHAT: which parts the env glue of this robot reads -- bit 0: cfrc_ext (Ant's contact cost / observation, the Humanoids), bit 1: cinert,
+    // cvel, qfrc_actuator, tendons (the Humanoids' observation and infos).  HalfCheetah needs the tracked point only: writing the other
+    // 2.6 KB per env-step anyway was a third of the Ant kernel's HBM writes.
+    template <int WHAT = 3>
     static MJX_DEV void write_extras(const B &bb, const R &r, int lane, double *ex) {
         if (lane == 0) {
             ex[EX_XY] = bb.xpos[1][0], ex[EX_XY + 1] = bb.xpos[1][1];
@@ -1736,19 +1740,31 @@ struct Sim {
             for (int b = 0; b < NB; b++) nx += M::body_mass[b] * bb.xipos[b][0], ny += M::body_mass[b] * bb.xipos[b][1];
             ex[EX_XY + 2] = nx, ex[EX_XY + 3] = ny;
 #pragma unroll
-            for (int k = 0; k < 6; k++) ex[EX_CFRC + k] = 0, ex[EX_CVEL + k] = 0;
+            for (int k = 0; k < 6; k++) {
+                if (WHAT & 1) ex[EX_CFRC + k] = 0;
+                if (WHAT & 2) ex[EX_CVEL + k] = 0;
+            }
+            if (WHAT & 2) {
 #pragma unroll
-            for (int k = 0; k < 10; k++) ex[EX_CINERT + k] = 0;
+                for (int k = 0; k < 10; k++) ex[EX_CINERT + k] = 0;
+            }
         }
         const int b = lane + 1;
         if (b < NB) {
-            double f[6];
-            contact_force_of_body(bb, lane, f);
+            if (WHAT & 1) {
+                double f[6];
+                contact_force_of_body(bb, lane, f);
 #pragma unroll
-            for (int k = 0; k < 6; k++) ex[EX_CFRC + 6 * b + k] = f[k], ex[EX_CVEL + 6 * b + k] = bb.cvel[b][k];
+                for (int k = 0; k < 6; k++) ex[EX_CFRC + 6 * b + k] = f[k];
+            }
+            if (WHAT & 2) {
 #pragma unroll
-            for (int k = 0; k < 10; k++) ex[EX_CINERT + 10 * b + k] = r.cinert[k];
+                for (int k = 0; k < 6; k++) ex[EX_CVEL + 6 * b + k] = bb.cvel[b][k];
+#pragma unroll
+                for (int k = 0; k < 10; k++) ex[EX_CINERT + 10 * b + k] = r.cinert[k];
+            }
         }
+        if (!(WHAT & 2)) return;
         if (lane < NV) ex[EX_QFA + lane] = r.qfrc_actuator;
         if constexpr (M::NTENDON > 0)
             if (lane < 2 * M::NTENDON) ex[EX_TEN + lane] = bb.ten[lane];

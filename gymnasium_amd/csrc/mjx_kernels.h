@@ -77,6 +77,7 @@ struct ObsExtras {
 template <class M, int KIND>
 struct MjEnv {
     typedef M Model;
+    static constexpr int KIND_ID = KIND;
     static constexpr int NQ = M::NQ, NV = M::NV, NU = M::NU, NB = M::NBODY;
     static constexpr int S = NQ + 2 * NV + 2;  // state row: qpos, qvel, (warm-start slot, unused by the Newton solver), tracked xy
     static constexpr bool PLANAR_WALKER = KIND == kHopper || KIND == kWalker2d;

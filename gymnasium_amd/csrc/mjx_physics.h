@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *act
     for (int k = lane; k < M::NQ; k += G) d.state[(size_t)k * N + env] = bb.qpos[k];
     for (int k = lane; k < M::NV; k += G) d.state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
     if (lane < M::NV) d.state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
-    S::write_extras(bb, r, lane, extras + (size_t)env * S::EX_TOTAL);
+    constexpr int WHAT = E::HUMANOID_LIKE ? 3 : (E::KIND_ID == mjx::kAnt ? 1 : 0);  // what the glue of this robot reads (mjx_kernels.h)
+    S::template write_extras<WHAT>(bb, r, lane, extras + (size_t)env * S::EX_TOTAL);
 }
 
 template <class E>

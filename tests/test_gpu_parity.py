@@ -155,6 +155,12 @@ def test_torch_mode_errors_are_deferred_unless_strict():
     lazy.step(bad)  # enqueued; nothing raised yet
     with pytest.raises(Exception):
         lazy.synchronize()
+    good = torch.zeros(64, dtype=torch.int64, device="cuda")
+    lazy.step(bad)
+    torch.cuda.synchronize()  # (so that the test does not depend on timing: the kernel has written the error word)
+    with pytest.raises(AssertionError):
+        lazy.step(good)  # the NEXT step finds the error word, without synchronising
+    lazy.step(good)
     lazy.close()
     strict = ps.make("cartpole", 64, None, output="torch", strict_actions=True)
     strict.reset(seed=0)
