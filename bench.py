@@ -12,7 +12,8 @@ crosses PCIe inside it.
 value = env-steps/s counted like the reference's benchmark_vector_step (gymnasium/utils/performance.py:88-90: NEXT_STEP autoreset
 steps are not counted), whole job over all ranks.  The same JSON line also carries (rank 0, --gpus 1):
 
-  sustained_value   the same launch repeated for >= --sustained seconds (clock / thermal steady state; the K-step burst is ~2 ms)
+  sustained_value   the same launch repeated for >= --sustained seconds (clock / thermal steady state).  Without --steps the timed region
+                    itself is ~1 s (K chosen from a 5-launch pilot) and sustained_value repeats `value`
   secondary         BASELINE.json configs[2..4]: Pendulum / Acrobot / MountainCarContinuous @65536, Ant-v5 @32768 and @65536,
                     Humanoid-v5 @32768 (per GPU), each with its own roofline and cpu_baseline
   roofline          dominant kernel: HBM-bound classic kernels as algorithmic bytes / launch time vs 8 TB/s with `traffic` from
@@ -282,8 +283,8 @@ class Config:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed launches K (default: as many as fill ~1 s, so that clocks and thermals are in steady state)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed launches W before the timed region (default: K / 10, at least 5)")
     ap.add_argument("--env", default="CartPole-v1")
     ap.add_argument("--num-envs", type=int, default=65536, help="sub-environments PER GPU")
     ap.add_argument("--inner", type=int, default=128, help="vector steps fused into one launch (one bench step)")
@@ -323,6 +324,20 @@ def main():
 
     env_kwargs = json.loads(args.env_kwargs)
     cfg = Config(args.env, N, inner, local_rank, rank, env_kwargs)
+    if K is None:  # ~1 s of timed launches: a 50-launch burst is 5 ms, over before the clocks have ramped (round 1: the driver's sampler saw 0 % busy)
+        for _ in range(3):
+            cfg.launch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            cfg.launch()
+        torch.cuda.synchronize()
+        pilot = torch.tensor([(time.perf_counter() - t0) / 5], device=dev)
+        if world > 1:
+            dist.all_reduce(pilot, op=dist.ReduceOp.MAX)  # every rank must time the same K
+        K = int(min(20000, max(20, round(1.0 / max(float(pilot.item()), 1e-6)))))
+    if W is None:
+        W = max(5, K // 10)
     for _ in range(W):
         cfg.launch()
     if args.child:
@@ -356,7 +371,11 @@ def main():
         }
 
     # ---- sustained: the same launch back to back for >= args.sustained seconds (all ranks, same barrier discipline) ----------------
-    if args.sustained > 0:
+    if args.sustained > 0 and elapsed >= 0.8:  # (elapsed is the all-reduced maximum: every rank takes the same branch)
+        if rank == 0:
+            result["sustained_value"] = result["value"]
+            result["sustained"] = {"launches": K, "seconds": elapsed, "avg_kernel_ms": kernel_s * 1e3, "note": "the timed region itself is the sustained measurement"}
+    elif args.sustained > 0:
         Ks = max(K, int(args.sustained / max(kernel_s, 1e-7)) + 1)
         el_s, k_s, st_s = cfg.timed(Ks, sync_all)
         red_s = gd.reduce_statistics(st_s, elapsed_s=el_s, device=dev)
