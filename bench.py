@@ -473,17 +473,26 @@ def main():
     # ---- secondary configurations (rank 0, one GPU) -------------------------------------------------------------------------------------
     if single and not args.no_secondary and args.env == "CartPole-v1":
         result["secondary"] = []
+        def steady(c, seconds=0.7):
+            """~`seconds` of back-to-back launches after a tenth of that as warm-up: (env-steps/s, launches, avg kernel s)"""
+            for _ in range(2):
+                c.launch()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                c.launch()
+            torch.cuda.synchronize()
+            k = int(min(20000, max(3, round(seconds / max((time.perf_counter() - t0) / 3, 1e-6)))))
+            for _ in range(max(1, k // 10)):
+                c.launch()
+            el, ks, st = c.timed(k, sync_local)
+            return st["env_steps"] / el, k, ks, el
+
         for env_id, n2, inner2, k2 in SECONDARY:
             c2 = Config(env_id, n2, inner2, local_rank, 0)
-            for _ in range(2):
-                c2.launch()
-            el2, ks2, st2 = c2.timed(k2, sync_local)
-            line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": st2["env_steps"] / el2,
+            v2, k2, ks2, el2 = steady(c2)
+            line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "sustained_value": v2, "seconds": el2,
                     "unit": "env-steps/s", "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64"}
-            if args.sustained > 0:
-                ks_n = max(k2, int(min(args.sustained, 1.0) / max(ks2, 1e-7)) + 1)
-                el3, _, st3 = c2.timed(ks_n, sync_local)
-                line["sustained_value"] = st3["env_steps"] / el3
             # auto: one SQ-activity pass for the VALU-bound MuJoCo kernels (their traffic ratio from the recorded profile); full: everything live
             want = ("traffic", "sq") if args.pmc == "full" else (("sq",) if (args.pmc == "auto" and env_id in MJ_COOP) else ())
             line["roofline"] = c2.roofline(ks2, want)
@@ -491,10 +500,7 @@ def main():
             opt = {"fast_math": True} if env_id in STEP_BYTES else ({"solver": "Newton"} if env_id in ("Humanoid-v5", "HumanoidStandup-v5") else None)
             if opt:  # the opt-in, faster configuration next to the default (reference-faithful) one
                 c3 = Config(env_id, n2, inner2, local_rank, 0, opt)
-                for _ in range(2):
-                    c3.launch()
-                el4, _, st4 = c3.timed(k2, sync_local)
-                line["opt_in"] = {"env_kwargs": opt, "value": st4["env_steps"] / el4, "unit": "env-steps/s"}
+                line["opt_in"] = {"env_kwargs": opt, "value": steady(c3)[0], "unit": "env-steps/s"}
                 c3.close()
             if not args.no_cpu_baseline:  # MuJoCo: a 512-env sample (the oracle's per-env cost does not depend on the batch size)
                 line["cpu_baseline"] = cpu_baseline(env_id, 512 if env_id in MJ_COOP else n2, budget_s=3.0)

@@ -9,7 +9,9 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-3} --no-api --no-cpu-baseline $*"
+# PROF_STEPS=default: bench.py's own default timed region (~1 s), so that the kernel trace's average duration is the one of the bench line
+if [ "${PROF_STEPS:-20}" = default ]; then STEPS=""; else STEPS="--steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-3}"; fi
+CMD="python $ROOT/bench.py $STEPS --no-api --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -- $CMD > "$OUT/${TAG}_stats.log" 2>&1
 PMC=()
 for C in FETCH_SIZE WRITE_SIZE; do
