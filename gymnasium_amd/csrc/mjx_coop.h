@@ -523,6 +523,20 @@ struct Sim {
         return dpp_mov<0x150 + (K & 15)>(K < 16 ? a : b);
 #endif
     }
+    // the same with the source lane known only at run time (group-uniform): one ds_bpermute per 32-bit half -- the LDS crossbar without an
+    // LDS location, so no write / fence / read round trip
+    static MJX_DEV double bcast_from(double v, int src, B &bb, int lane) {
+#if defined(MJX_HOST_EMU)
+        bb.red[0][lane] = v;
+        coop_sync();
+        const double out = bb.red[0][src];
+        coop_sync();
+        return out;
+#else
+        (void)bb, (void)lane;
+        return __shfl(v, src, G);
+#endif
+    }
     // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.A.sol.L.
     // Right-looking, column by column: the pivot and the column below it come from the other lanes' registers by broadcast.
     template <int K, int J>
@@ -1159,6 +1173,7 @@ struct Sim {
     template <int I, bool WARM>
     static MJX_DEV void pgs_limits(B &bb, R &r, int lane, unsigned lm0, unsigned lm1, double &a, double &qf, double &impr) {
         if constexpr (M::jnt_limited[M::dof_jntid[I]] && (M::jnt_type[M::dof_jntid[I]] == HINGE || M::jnt_type[M::dof_jntid[I]] == SLIDE)) {
+            if (((lm0 | lm1) >> I) & 1u)  // (one scalar test per limited dof and sweep while neither side is active)
 #pragma unroll
             for (int sd = 0; sd < 2; sd++) {
                 if (((sd == 0 ? lm0 : lm1) >> I) & 1u) {  // group-uniform
@@ -1339,13 +1354,10 @@ struct Sim {
                     if (isdof) jac_col(bb, r, c, lane, jcol);
                     v[0] = group_sum<G>(jcol[0] * a, MJX_RED(bb), lane), v[1] = group_sum<G>(jcol[1] * a, MJX_RED(bb), lane),
                     v[2] = group_sum<G>(jcol[2] * a, MJX_RED(bb), lane);
-                    double (&gw)[8] = bb.C.sol.gw[c & 1];
-                    if (lane == owner) {
-                        pgs_contact(r, kc, v, dl, impr);
-                        gw[0] = dl[0], gw[1] = dl[1], gw[2] = dl[2];
-                    }
-                    coop_sync();
-                    const double step[3] = {gw[0], gw[1], gw[2]};
+                    dl[0] = dl[1] = dl[2] = 0;
+                    if (lane == owner) pgs_contact(r, kc, v, dl, impr);
+                    // the owner's frame-space force step to every lane of the group: a cross-lane read, not an LDS exchange
+                    const double step[3] = {bcast_from(dl[0], owner, bb, lane), bcast_from(dl[1], owner, bb, lane), bcast_from(dl[2], owner, bb, lane)};
                     a += apply_b(bb, r, c, lane, jcol, step);
                 }
             }
