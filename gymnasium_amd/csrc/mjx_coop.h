@@ -1008,6 +1008,11 @@ struct Sim {
                     if (jar < 0) {
                         grad += r.lim_sign[sd] * r.lim_D[sd] * jar;
                         if (hess) {
+                            // NOTE (round 2, open): LLVM turns this chain of tests into a switch over POINTERS into the row (`phi ptr addrspace(5)` in
+                            // the IR), which keeps nine elements of the row in scratch memory for the whole Newton solver: 336 scratch instructions in
+                            // the 32-lane kernel.  The select form `Hrow[j] += (j == lane) ? D : 0.0` brings that down to 71 -- but together with the
+                            // MachineLICM sinking flag of build.py the 32-lane Newton kernel then raised a GPU memory access fault
+                            // (scripts/coop_phase_bench.hip humanoid-newton), so the change is NOT in: it needs its own bisection first.
 #pragma unroll
                             for (int j = 0; j < NV; j++)
                                 if (j == lane) r.Hrow[j] += r.lim_D[sd];
