@@ -1,10 +1,11 @@
-"""-m gpu: the shipped cooperative physics kernels (physics16.hip / physics32.hip, compiled with LLVM's iterative GCN scheduler --
-gymnasium_amd/csrc/build.py TU_FLAGS) against the SAME sources under hipcc's default scheduler (libmi355env_ref.so, built next to the
-product by __graft_entry__.build()).
+"""-m gpu: the shipped cooperative physics kernels (physics16.hip / physics32.hip, compiled with LLVM's iterative GCN scheduler and the
+MachineLICM settings of gymnasium_amd/csrc/build.py TU_FLAGS) against the SAME sources under hipcc's defaults (libmi355env_ref.so, built next
+to the product by __graft_entry__.build()).
 
 Why this is a test: the iterative schedulers were measured to MISCOMPILE the 16-lane instantiation when the RK4 stage update is inlined
 (every environment differs after one sub-step); keeping `rk4_stage` out of line makes all instantiations
-bit-identical to the default scheduler's output.  A compiler update, a source change or a new flag can silently bring that back, and a
+bit-identical to the default scheduler's output; in round 2 the MachineLICM sinking flag turned the 16-lane library kernels wrong (Ant: NaNs) while
+the stand-alone harness stayed correct -- this test is what caught it.  A compiler update, a source change or a new flag can silently bring that back, and a
 tolerance-level parity test might not notice -- so the two builds must agree on EVERY BIT of the trajectory and of the final state after
 25 env-steps x 4096 sub-environments (Ant, HalfCheetah, Humanoid and HumanoidStandup with both of their solvers).
 
