@@ -778,41 +778,79 @@ struct Sim {
     }
     // pass 1: every lane tests its candidate slots and publishes a bit per hit; pass 2: the hits are recomputed and written at
     // their rank (slot order = the order in which the serial code emits contacts), truncated at MAXCON
+    // which lanes of this group see `pred` (bit i = lane i): the wavefront's ballot, cut down to the group -- no LDS word, no fence
+    static MJX_DEV unsigned group_ballot(bool pred, B &bb, int lane, int word) {
+#if defined(MJX_HOST_EMU)
+        if (pred) lds_or(&bb.cmask[word], 1u << lane);
+        coop_sync();
+        return bb.cmask[word];
+#else
+        (void)bb, (void)word;
+        const unsigned long long w = __ballot(pred);
+        const int first = (int)(threadIdx.x & 63u) - lane;  // wavefront lane of this group's lane 0
+        return (unsigned)(w >> first) & (G == 32 ? 0xffffffffu : ((1u << G) - 1u));
+#endif
+    }
+    // Contacts in MuJoCo's order (= slot order).  Two forms:
+    //   few candidate slots (Ant 25, HalfCheetah 16: one or two rounds): ONE pass -- a round's active lanes are ranked by the group ballot, the
+    //     rounds are sequential, so every contact can be written as soon as it is found (Ant: 5.8 k -> 4.4 k cycles per forward pass);
+    //   many slots, few contacts (Humanoid: 140 slots in five rounds): a cheap pass that only asks every slot whether it is active (the compiler
+    //     drops the contact point and frame from that call), then the full evaluation for the few active ones -- the one-pass form was measured
+    //     at 29 k cycles against 18 k this way.
+    static MJX_DEV void write_contact(B &bb, int idx, int slot, const Cand &c) {
+        const int p = M::slot_pair[slot];
+        const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+        bb.con_pair[idx] = p | (b1 << 16) | (b2 << 24);
+        bb.con_dist[idx] = c.dist;
+#pragma unroll
+        for (int k = 0; k < 3; k++) bb.con_r[idx][k] = c.pos[k] - bb.com[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) bb.con_frame[idx][k] = c.frame[k];
+    }
     static MJX_DEV void collision(B &bb, int lane) {
         if (lane < KS) bb.cmask[lane] = 0;
         if (lane == 0) bb.anyrow = 0, bb.limmask[0] = 0, bb.limmask[1] = 0;
         coop_sync();
-        unsigned mine = 0;
-#pragma unroll 1
-        for (int rd = 0; rd < KS; rd++) {
-            const int slot = rd * G + lane;
-            if (slot < M::NSLOT) {
-                Cand c;
-                detect(bb, slot, c);
-                if (c.on) lds_or(&bb.cmask[rd], 1u << lane), mine |= 1u << rd;
-            }
-        }
-        coop_sync();
         int base = 0;
+        if constexpr (M::NSLOT <= 2 * G) {
 #pragma unroll 1
-        for (int rd = 0; rd < KS; rd++) {
-            const unsigned m = bb.cmask[rd];
-            if ((mine >> rd) & 1u) {
-                const int idx = base + popc(m & ((1u << lane) - 1u));
-                if (idx < MAXCON) {
+            for (int rd = 0; rd < KS; rd++) {
+                const int slot = rd * G + lane;
+                Cand c;
+                c.on = false;
+                if (slot < M::NSLOT) detect(bb, slot, c);
+                const unsigned m = group_ballot(c.on, bb, lane, rd);
+                if (c.on) {
+                    const int idx = base + popc(m & ((1u << lane) - 1u));
+                    if (idx < MAXCON) write_contact(bb, idx, slot, c);
+                }
+                base += popc(m);
+            }
+        } else {
+            unsigned mine = 0;
+#pragma unroll 1
+            for (int rd = 0; rd < KS; rd++) {
+                const int slot = rd * G + lane;
+                if (slot < M::NSLOT) {
                     Cand c;
-                    detect(bb, rd * G + lane, c);
-                    const int p = M::slot_pair[rd * G + lane];
-                    const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
-                    bb.con_pair[idx] = p | (b1 << 16) | (b2 << 24);
-                    bb.con_dist[idx] = c.dist;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) bb.con_r[idx][k] = c.pos[k] - bb.com[k];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) bb.con_frame[idx][k] = c.frame[k];
+                    detect(bb, slot, c);
+                    if (c.on) lds_or(&bb.cmask[rd], 1u << lane), mine |= 1u << rd;
                 }
             }
-            base += popc(m);
+            coop_sync();
+#pragma unroll 1
+            for (int rd = 0; rd < KS; rd++) {
+                const unsigned m = bb.cmask[rd];
+                if ((mine >> rd) & 1u) {
+                    const int idx = base + popc(m & ((1u << lane) - 1u));
+                    if (idx < MAXCON) {
+                        Cand c;
+                        detect(bb, rd * G + lane, c);
+                        write_contact(bb, idx, rd * G + lane, c);
+                    }
+                }
+                base += popc(m);
+            }
         }
         if (lane == 0) bb.ncon = base < MAXCON ? base : MAXCON;
         coop_sync();
