@@ -197,8 +197,12 @@ MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, Ste
         return;
     } else {
         if (!E::valid(a)) {
+            // cartpole.py:165-167 asserts before it touches the state: report through the sticky error word, leave the lane untouched (host
+            // callers never get here -- their actions are validated before the launch)
             *d.error = kErrInvalidAction;
-            a = (typename E::Act)0;
+            E::obs(L.s, L.flags, o.obs);
+            o.reward = 0.0, o.terminated = false, o.truncated = false, o.ep_ret = 0.0, o.ep_len = 0;
+            return;
         }
         E::step(L.s, L.flags, a, d.P, rew, te);
         L.elapsed += 1;  // TimeLimit.step (wrappers/common.py:129-133)
@@ -1006,9 +1010,10 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
         obs = (int64_t)L.s, out_ret = 0.0, out_len = 0;
         return;
     } else {
-        if (a < 0 || a >= d.tab.nA) {
+        if (a < 0 || a >= d.tab.nA) {  // like the DISABLED case above: report, leave the lane untouched
             *d.error = kErrInvalidAction;
-            a = 0;
+            obs = (int64_t)L.s, out_ret = 0.0, out_len = 0;
+            return;
         }
         Pcg64 local;
         if (!held) local = load_rng(d, i);

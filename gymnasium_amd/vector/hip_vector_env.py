@@ -129,7 +129,7 @@ class HipVectorEnv(VectorEnv):
         self.copy = bool(copy)
         # output="torch": the engine runs asynchronously on torch's stream, so what the reference raises at once -- the AssertionError for an
         # action outside the space (cartpole.py:165-167), stepping a finished sub-environment under DISABLED autoreset -- is DEFERRED: the
-        # kernel records a sticky error word in page-locked memory (an invalid action is stepped as action 0) and a later `step()` -- the first
+        # kernel records a sticky error word in page-locked memory (the sub-environment with the invalid action is left untouched) and a later `step()` -- the first
         # one that finds the word set, usually the next -- or any synchronising call (`synchronize()`, `statistics()`) raises it.  strict_actions=True synchronises after every step and raises there, at the cost
         # of the asynchrony (debugging aid).  NumPy input is always validated on the host before anything is mutated.
         self.strict_actions = bool(strict_actions)

@@ -152,9 +152,12 @@ def test_torch_mode_errors_are_deferred_unless_strict():
     bad = torch.full((64,), 7, dtype=torch.int64, device="cuda")
     lazy = ps.make("cartpole", 64, None, output="torch")
     lazy.reset(seed=0)
+    before = lazy.get_state()
     lazy.step(bad)  # enqueued; nothing raised yet
     with pytest.raises(Exception):
         lazy.synchronize()
+    after = lazy.get_state()
+    assert all(np.array_equal(x, y) for x, y in zip(before, after)), "a sub-environment with an invalid action is left untouched (cartpole.py:165-167 asserts first)"
     good = torch.zeros(64, dtype=torch.int64, device="cuda")
     lazy.step(bad)
     torch.cuda.synchronize()  # (so that the test does not depend on timing: the kernel has written the error word)
