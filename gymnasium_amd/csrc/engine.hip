@@ -79,6 +79,7 @@ struct Lane {
     uint32_t elapsed, flags;
     double ep_ret;
     int32_t ep_len;
+    typename E::Trig trig;  // sin / cos of the state's angles from the last obs() (envs_classic.h), registers only
 };
 
 template <class E>
@@ -88,6 +89,7 @@ MI_DEV void load_lane(const DevEnv &d, int i, Lane<E> &L) {
     const uint32_t m = d.meta[i];
     L.elapsed = m & kElapsedMask, L.flags = m >> kFlagShift;
     L.ep_ret = d.ep_ret[i], L.ep_len = d.ep_len[i];
+    trig_invalidate(L.trig);
 }
 template <class E>
 MI_DEV void store_lane(const DevEnv &d, int i, const Lane<E> &L) {
@@ -192,7 +194,7 @@ MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, Ste
     } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
         // :295 `assert not self._autoreset_envs[i]`: report through the sticky error word, leave the lane untouched
         *d.error = kErrDisabledStepped;
-        E::obs(L.s, L.flags, o.obs);
+        E::obs(L.s, L.flags, o.obs, L.trig);
         o.reward = 0.0, o.terminated = false, o.truncated = false, o.ep_ret = 0.0, o.ep_len = 0;
         return;
     } else {
@@ -200,11 +202,11 @@ MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, Ste
             // cartpole.py:165-167 asserts before it touches the state: report through the sticky error word, leave the lane untouched (host
             // callers never get here -- their actions are validated before the launch)
             *d.error = kErrInvalidAction;
-            E::obs(L.s, L.flags, o.obs);
+            E::obs(L.s, L.flags, o.obs, L.trig);
             o.reward = 0.0, o.terminated = false, o.truncated = false, o.ep_ret = 0.0, o.ep_len = 0;
             return;
         }
-        E::step(L.s, L.flags, a, d.P, rew, te);
+        E::step(L.s, L.flags, a, d.P, rew, te, L.trig);
         L.elapsed += 1;  // TimeLimit.step (wrappers/common.py:129-133)
         tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;
         L.ep_ret += rew, L.ep_len += 1;
@@ -220,11 +222,11 @@ MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, Ste
     }
     if (MODE == MI_AUTORESET_SAME_STEP && done) {
         // :302-319 final_obs, then reset within the same step
-        E::obs(L.s, L.flags, o.final_obs);
+        E::obs(L.s, L.flags, o.final_obs, L.trig);
         o.has_final = true;
         lane_autoreset<E>(d, i, L, q);
     }
-    E::obs(L.s, L.flags, o.obs);
+    E::obs(L.s, L.flags, o.obs, L.trig);
     o.reward = rew, o.terminated = te, o.truncated = tr;
     if (done && MODE != MI_AUTORESET_SAME_STEP)
         L.flags |= kNeedsReset;  // _autoreset_envs (:329)
@@ -252,7 +254,7 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     double rew;
     bool te;
     uint32_t sflags = L.flags;
-    E::step(L.s, sflags, a, d.P, rew, te);
+    E::step(L.s, sflags, a, d.P, rew, te, L.trig);
     const uint32_t elapsed = L.elapsed + 1;  // TimeLimit.step (wrappers/common.py:129-133)
     const bool tr = d.max_steps > 0 && (int)elapsed >= d.max_steps;
     const double ep_ret = L.ep_ret + rew;
@@ -270,7 +272,7 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     st.episodes += done ? 1u : 0u;
     st.return_sum += done ? ep_ret : 0.0;
     st.length_sum += done ? (uint64_t)ep_len : 0ull;
-    E::obs(L.s, L.flags, o.obs);
+    E::obs(L.s, L.flags, o.obs, L.trig);
     o.reward = resetting ? 0.0 : rew;
     o.terminated = !resetting && te, o.truncated = !resetting && tr;
     o.ep_ret = done ? ep_ret : 0.0, o.ep_len = done ? ep_len : 0;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevEnv d, const uint8_t *
     store_lane<E>(d, i, L);
     if (obs) {
         float o[E::OBS];
-        E::obs(L.s, L.flags, o);
+        E::obs(L.s, L.flags, o, L.trig);
         store_row<E::OBS>(obs + (size_t)i * E::OBS, o);
     }
 }

@@ -121,6 +121,23 @@ struct EnvParams {
     double p[16];
 };
 
+// What an environment carries from obs() to the next step() while its state sits in registers (fused rollouts): obs() evaluates sin / cos of
+// the angles it reports, and the next step() starts from the very same angles -- with the exact libm routines an evaluation costs ~100
+// instructions, so Pendulum and Acrobot keep the values (same bits: the same function of the same argument).  obs() always recomputes and
+// refreshes; step() uses the values only if `ok` (false after a load from memory and after step() itself has moved the state).
+struct NoTrig {};
+struct PendulumTrig {
+    double sn, cs;
+    bool ok;
+};
+struct AcrobotTrig {
+    double s1, c1, s2, c2;
+    bool ok;
+};
+MI_DEV void trig_invalidate(NoTrig &) {}
+MI_DEV void trig_invalidate(PendulumTrig &t) { t.ok = false; }
+MI_DEV void trig_invalidate(AcrobotTrig &t) { t.ok = false; }
+
 // ---------------------------------------------------------------------------------------------------------
 // CartPole-v1: gymnasium/envs/classic_control/cartpole.py:119-247
 // ---------------------------------------------------------------------------------------------------------
@@ -146,7 +163,8 @@ struct CartPoleT {
         for (int k = 0; k < S; k++) s[k] = b0 + range * u[k];
         (void)flags;
     }
-    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
+    typedef NoTrig Trig;
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS], Trig &) {
 #pragma unroll
         for (int k = 0; k < OBS; k++) o[k] = (float)s[k];
     }
@@ -158,7 +176,7 @@ struct CartPoleT {
     static MI_DEV Act sample_bits(uint64_t bits) { return (Act)(bits >> 63); }
 
     // cartpole.py:164-226: explicit Euler with the OLD velocities, all float64.
-    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
+    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &) {
         const double gravity = 9.8, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
         const double polemass_length = masspole * length;
         const double theta_threshold = 12 * 2 * kPi / 360;
@@ -201,17 +219,18 @@ struct PendulumT {
         s[0] = -x_init + (x_init - (-x_init)) * u[0];
         s[1] = -y_init + (y_init - (-y_init)) * u[1];
     }
-    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
-        double cs, sn;
-        M::sincos(s[0], sn, cs);
-        o[0] = (float)cs, o[1] = (float)sn, o[2] = (float)s[1];
+    typedef PendulumTrig Trig;
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS], Trig &t) {
+        M::sincos(s[0], t.sn, t.cs);
+        t.ok = true;
+        o[0] = (float)t.cs, o[1] = (float)t.sn, o[2] = (float)s[1];
     }
     static MI_DEV bool valid(Act) { return true; }
     static MI_DEV Act sample(double u) { return (Act)(-2.0 + (2.0 - (-2.0)) * u); }  // Box.sample: uniform(low, high).astype(f32)
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
-    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
+    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &t) {
         const double max_speed = 8, max_torque = 2.0, dt = 0.05, m = 1.0, l = 1.0;
         const double g = P.p[0];
         const double th = s[0], thdot = s[1];
@@ -229,7 +248,9 @@ struct PendulumT {
         const float cu = 0.001f * M::sqf(u);  // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
         const double costs = M::sq(an) + 0.1 * M::sq(thdot) + (double)cu;
         const float tu = (float)(3.0 / (m * (l * l))) * u;  // float32: 3.0 / (m l^2) * u
-        double sn = M::sin(th);
+        if (!t.ok) t.sn = M::sin(th);  // (else: the observation of the previous step evaluated sin of this very angle)
+        const double sn = t.sn;
+        t.ok = false;
         double newthdot = thdot + (3 * g / (2 * l) * sn + (double)tu) * dt;
         newthdot = newthdot < -max_speed ? -max_speed : newthdot;
         newthdot = newthdot > max_speed ? max_speed : newthdot;
@@ -262,11 +283,12 @@ struct AcrobotT {
         flags |= kStateF32;
     }
     // acrobot.py:232-237 (after a reset NumPy evaluates these in float32; we return the correctly rounded value)
-    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) {
-        double c1, s1, c2, s2;
-        M::sincos_bounded(s[0], s1, c1);
-        M::sincos_bounded(s[1], s2, c2);
-        o[0] = (float)c1, o[1] = (float)s1, o[2] = (float)c2, o[3] = (float)s2, o[4] = (float)s[2], o[5] = (float)s[3];
+    typedef AcrobotTrig Trig;
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS], Trig &t) {
+        M::sincos_bounded(s[0], t.s1, t.c1);
+        M::sincos_bounded(s[1], t.s2, t.c2);
+        t.ok = true;
+        o[0] = (float)t.c1, o[1] = (float)t.s1, o[2] = (float)t.c2, o[3] = (float)t.s2, o[4] = (float)s[2], o[5] = (float)s[3];
     }
     static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
     static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }  // u * 3.0 rounds: not reducible to integer arithmetic
@@ -275,11 +297,12 @@ struct AcrobotT {
 
     // acrobot.py:244-279, "book" dynamics; y = (theta1, theta2, dtheta1, dtheta2), a = torque.  The `** 2` on Python floats (lc1**2 = 0.25, ...)
     // are exact; the ones on np.float64 state components go through libm pow (M::sq).
-    static MI_DEV void dsdt(const double y[4], double a, double d[4]) {
+    // known: sin / cos of y[1] if the caller already has them (the first RK4 stage starts at the state the last observation was taken of)
+    static MI_DEV void dsdt(const double y[4], double a, double d[4], bool known = false, double s2k = 0, double c2k = 0) {
         const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0, I2 = 1.0, g = 9.8;
         const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
-        double c2, s2;
-        M::sincos_bounded(theta2, s2, c2);
+        double c2 = c2k, s2 = s2k;
+        if (!known) M::sincos_bounded(theta2, s2, c2);
         const double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
         const double d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
         const double phi2 = m2 * lc2 * g * M::cos_bounded(theta1 + theta2 - kPi / 2.0);
@@ -301,11 +324,12 @@ struct AcrobotT {
         return (hi < t) ? hi : t;
     }
     // acrobot.py:202-230 with rk4 (:415-461) over t = [0, 0.2]; the torque component has derivative 0
-    static MI_DEV void step(double s[S], uint32_t &flags, Act action, const EnvParams &, double &reward, bool &terminated) {
+    static MI_DEV void step(double s[S], uint32_t &flags, Act action, const EnvParams &, double &reward, bool &terminated, Trig &tc) {
         const double dt = 0.2 - 0, dt2 = dt / 2.0, dt6 = dt / 6.0;
         const double a = action == 0 ? -1.0 : (action == 1 ? 0.0 : 1.0);
         double k1[4], k2[4], k3[4], k4[4], t[4];
-        dsdt(s, a, k1);
+        dsdt(s, a, k1, tc.ok, tc.s2, tc.c2);
+        tc.ok = false;
 #pragma unroll
         for (int i = 0; i < 4; i++) t[i] = s[i] + dt2 * k1[i];
         dsdt(t, a, k2);
@@ -348,13 +372,14 @@ struct MountainCarT {
         s[1] = 0.0;
         flags &= ~kStateF32;
     }
-    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) { o[0] = (float)s[0], o[1] = (float)s[1]; }
+    typedef NoTrig Trig;
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS], Trig &) { o[0] = (float)s[0], o[1] = (float)s[1]; }
     static MI_DEV bool valid(Act a) { return a >= 0 && a < N_ACTIONS; }
     static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }  // u * 3.0 rounds: not reducible to integer arithmetic
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
-    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated) {
+    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &) {
         const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5;
         const double force = 0.001, gravity = 0.0025;
         double position = s[0], velocity = s[1];
@@ -391,13 +416,14 @@ struct MountainCarContinuousT {
         s[1] = 0.0;
         flags &= ~kStateF32;
     }
-    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS]) { o[0] = (float)s[0], o[1] = (float)s[1]; }
+    typedef NoTrig Trig;
+    static MI_DEV void obs(const double s[S], uint32_t, float o[OBS], Trig &) { o[0] = (float)s[0], o[1] = (float)s[1]; }
     static MI_DEV bool valid(Act) { return true; }
     static MI_DEV Act sample(double u) { return (Act)(-1.0 + (1.0 - (-1.0)) * u); }
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
-    static MI_DEV void step(double s[S], uint32_t &flags, Act a0, const EnvParams &P, double &reward, bool &terminated) {
+    static MI_DEV void step(double s[S], uint32_t &flags, Act a0, const EnvParams &P, double &reward, bool &terminated, Trig &) {
         const double min_action = -1.0, max_action = 1.0, min_position = -1.2, max_position = 0.6, max_speed = 0.07;
         const double goal_position = 0.45, power = 0.0015, goal_velocity = P.p[0];
         // force = min(max(action[0], -1.0), 1.0): an np.float32 unless out of range, then the Python float bound
