@@ -94,7 +94,32 @@ def build(force: bool = False, verbose: bool = True, reference_scheduler: bool =
     return out
 
 
+def build_both(verbose: bool = True):
+    """libmi355env.so and libmi355env_ref.so with all translation units compiling side by side: the checker's own objects (the units that have
+    TU_FLAGS in the product) are started first, then the product is built, then the checker is linked from the shared and its own objects."""
+    generate_models()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    jobs = []
+    for src, headers in SOURCES.items():
+        if not TU_FLAGS.get(src):
+            continue
+        obj = os.path.join(HERE, os.path.splitext(src)[0] + "_ref.o")
+        if _stale(obj, [src, "build.py"] + headers):
+            cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *os.environ.get("MI355ENV_HIPCC_FLAGS", "").split(), "-c", "-o", obj, os.path.join(HERE, src)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=HERE)))
+    out = build(verbose=verbose)
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    return out, build(verbose=verbose, reference_scheduler=True)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
-    if "--ref" in sys.argv:
-        print(build(force="--force" in sys.argv, reference_scheduler=True))
+    if "--ref" in sys.argv and "--force" not in sys.argv:
+        print(*build_both())
+    else:
+        print(build(force="--force" in sys.argv))
+        if "--ref" in sys.argv:
+            print(build(force=True, reference_scheduler=True))
