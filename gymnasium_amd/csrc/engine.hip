@@ -1521,10 +1521,12 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         // one-lane kernel (16.4M vs 12.9M).  MI355ENV_MJ_SERIAL=1 / MI355ENV_MJ_COOP=1 force either one (cross-check tests).
         const char *serial = getenv("MI355ENV_MJ_SERIAL"), *coop = getenv("MI355ENV_MJ_COOP");
         // the faster kernel per robot: HalfCheetah 22.0 M (cooperative) vs 18.8 M (one-lane) env-steps/s at 65536 envs
-        v->mj_coop = cfg->kind == MI_ENV_HALF_CHEETAH || cfg->kind == MI_ENV_ANT || cfg->kind == MI_ENV_HUMANOID || cfg->kind == MI_ENV_HUMANOID_STANDUP;
+        const bool has_coop = cfg->kind == MI_ENV_HALF_CHEETAH || cfg->kind == MI_ENV_ANT || cfg->kind == MI_ENV_HUMANOID || cfg->kind == MI_ENV_HUMANOID_STANDUP ||
+                              cfg->kind == MI_ENV_HOPPER || cfg->kind == MI_ENV_WALKER2D;  // (round 2: the planar walkers joined -- Walker2d 6.6 M one-lane)
+        v->mj_coop = has_coop && cfg->kind != MI_ENV_HOPPER;  // measured @65536: Walker2d 8.4 M cooperative vs 6.6 M one-lane; Hopper 9.7 M vs 17.2 M
         if (serial && serial[0] == '1') v->mj_coop = false;
         if (coop && coop[0] == '1') v->mj_coop = true;
-        if (cfg->kind >= MI_ENV_HOPPER && cfg->kind != MI_ENV_HUMANOID_STANDUP) v->mj_coop = false;  // the small robots: one-lane kernel only
+        if (!has_coop) v->mj_coop = false;  // the other small robots: one-lane kernel only (cylinder geoms, fluid forces, two-dof arms)
     } else if (cfg->kind == MI_ENV_BLACKJACK) {
         const mi_layout l = {3, MI_I64, 1, MI_I64, 2, 0, {0, 0}};
         v->lay = l;

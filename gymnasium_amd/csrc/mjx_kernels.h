@@ -88,7 +88,7 @@ struct MjEnv {
     static constexpr int INFO_SCALARS =
         KIND == kHalfCheetah ? 4 : (PLANAR_WALKER ? 6 : (KIND == kInvertedPendulum ? 1 : (KIND == kInvertedDoublePendulum ? 3 : (KIND == kReacher ? 2 : (KIND == kHumanoidStandup ? 6 : (KIND == kSwimmer ? 7 : (KIND == kPusher ? 3 : 9)))))));
     static constexpr int INFO = INFO_SCALARS + 2 * M::NTENDON;
-    static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || HUMANOID_LIKE;  // small robots: one-lane kernel only
+    static constexpr bool HAS_COOP = KIND == kHalfCheetah || KIND == kAnt || HUMANOID_LIKE || PLANAR_WALKER;  // the other small robots: one-lane kernel only
     static constexpr int COOP_G = (NV > 16 || NB - 1 > 16) ? 32 : 16;  // lanes per sub-environment in the cooperative kernel (mjx_coop.h)
     static constexpr int SKIP = (KIND == kHalfCheetah || PLANAR_WALKER) ? 1 : ((PENDULUM || KIND == kReacher || KIND == kPusher) ? 0 : 2);
     static constexpr int MAX_OBS = NQ + NV + (KIND == kAnt ? 6 * (NB - 1) : 0) + (HUMANOID_LIKE ? 22 * (NB - 1) + NV - 6 : 0) +
@@ -335,11 +335,11 @@ struct MjEnv {
     }
 
     // The tracked point from the cooperative kernel's extras row (coop::Sim::write_extras): body-1 position for Ant, the
-    // mass-weighted sum of xipos over np.sum(body_mass) for Humanoid (humanoid_v5.py:17-21), the root slider for HalfCheetah.
+    // mass-weighted sum of xipos over np.sum(body_mass) for Humanoid (humanoid_v5.py:17-21), the root slider for HalfCheetah, Hopper and Walker2d.
     static MJX_DEV void after_from_extras(const double *s, const double *ex, double *after) {
         if (KIND == kHumanoidStandup) {
             after[0] = after[1] = 0.0;
-        } else if (KIND == kHalfCheetah) {
+        } else if (KIND == kHalfCheetah || PLANAR_WALKER) {
             after[0] = s[0], after[1] = 0.0;
         } else if (KIND == kAnt) {
             after[0] = ex[0], after[1] = ex[1];

@@ -8,6 +8,8 @@ bool launch16(int kind, const Args &a, bool skip_resetting, const float *actions
     switch (kind) {
     case MI_ENV_ANT: launch_kind<mjx::MjEnv<mjx::AntModel, mjx::kAnt>>(a, skip_resetting, actions, extras, stream); return true;
     case MI_ENV_HALF_CHEETAH: launch_kind<mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah>>(a, skip_resetting, actions, extras, stream); return true;
+    case MI_ENV_HOPPER: launch_kind<mjx::MjEnv<mjx::HopperModel, mjx::kHopper>>(a, skip_resetting, actions, extras, stream); return true;
+    case MI_ENV_WALKER2D: launch_kind<mjx::MjEnv<mjx::Walker2dModel, mjx::kWalker2d>>(a, skip_resetting, actions, extras, stream); return true;
     }
     return false;
 }

@@ -171,6 +171,8 @@ __attribute__((visibility("default"))) int coop_emu_step(int model, const double
     switch (model) {  // warm: in/out qacc_warmstart[nv] (NULL = start from zero)
         case 0: return emu_step<HalfCheetahModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
         case 1: return emu_step<AntModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
+        case 3: return emu_step<HopperModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
+        case 4: return emu_step<Walker2dModel, 16>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);
         case 2: return emu_step<HumanoidModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);  // the MJCF's solver: PGS / 50
         case 12: return emu_step<HumanoidModel, 32, false>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);  // opt-in Newton
         case 8: return emu_step<HumanoidStandupModel, 32>(qpos, qvel, ctrl, nsub, qpos_out, qvel_out, extras, debug, warm);  // lying on the floor: many contacts
@@ -190,6 +192,8 @@ __attribute__((visibility("default"))) int coop_emu_extras_dim(int model) {
     switch (model) {
         case 0: return coop::Sim<HalfCheetahModel, 16>::EX_TOTAL;
         case 1: return coop::Sim<AntModel, 16>::EX_TOTAL;
+        case 3: return coop::Sim<HopperModel, 16>::EX_TOTAL;
+        case 4: return coop::Sim<Walker2dModel, 16>::EX_TOTAL;
         case 2: return coop::Sim<HumanoidModel, 32>::EX_TOTAL;
         case 8: return coop::Sim<HumanoidStandupModel, 32>::EX_TOTAL;
     }
@@ -199,6 +203,8 @@ __attribute__((visibility("default"))) long coop_emu_board_bytes(int model) {
     switch (model) {
         case 0: return sizeof(coop::Board<HalfCheetahModel, 16>);
         case 1: return sizeof(coop::Board<AntModel, 16>);
+        case 3: return sizeof(coop::Board<HopperModel, 16>);
+        case 4: return sizeof(coop::Board<Walker2dModel, 16>);
         case 2: return sizeof(coop::Board<HumanoidModel, 32>);
     }
     return -1;

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(HERE, "coop_emu")
 NAMES = ["half_cheetah", "ant", "humanoid"]
 # emulator model id -> (robot, solver): the humanoid runs its MJCF's PGS / 50 (id 2) or the opt-in Newton solver (id 12)
-VARIANTS = {0: ("half_cheetah", None), 1: ("ant", None), 2: ("humanoid", "PGS"), 12: ("humanoid", "Newton"),
+VARIANTS = {0: ("half_cheetah", None), 1: ("ant", None), 3: ("hopper", None), 4: ("walker2d", None), 2: ("humanoid", "PGS"), 12: ("humanoid", "Newton"),
             8: ("humanoid_standup", "PGS"), 18: ("humanoid_standup", "Newton")}
 _LIB = None
 

@@ -123,16 +123,19 @@ def test_full_size_properties(env_id):
     a.close(), c.close()
 
 
-@pytest.mark.parametrize("name", list(IDS))
+COOP_ROBOTS = {**IDS, "hopper": "Hopper-v5", "walker2d": "Walker2d-v5"}  # (round 2: the planar walkers run on the cooperative kernel too)
+
+
+@pytest.mark.parametrize("name", list(COOP_ROBOTS))
 def test_cooperative_kernel_equals_one_lane_simulator(name, monkeypatch):
     """The two HIP implementations of the physics -- mjx_coop.h (G lanes per env, the default) and mjx_core.h (one lane per
     env, MI355ENV_MJ_SERIAL=1) -- agree over re-synchronised windows; flags and RNG consumption are identical."""
     n, T, window = (128, 30, 5) if name != "humanoid" else (64, 20, 5)
     monkeypatch.setenv("MI355ENV_MJ_SERIAL", "1")
-    ser = gymnasium_amd.make_vec(IDS[name], num_envs=n)
+    ser = gymnasium_amd.make_vec(COOP_ROBOTS[name], num_envs=n)
     monkeypatch.delenv("MI355ENV_MJ_SERIAL")
     monkeypatch.setenv("MI355ENV_MJ_COOP", "1")
-    coop = gymnasium_amd.make_vec(IDS[name], num_envs=n)
+    coop = gymnasium_amd.make_vec(COOP_ROBOTS[name], num_envs=n)
     monkeypatch.delenv("MI355ENV_MJ_COOP")
     o1, _ = ser.reset(seed=21)
     o2, _ = coop.reset(seed=21)

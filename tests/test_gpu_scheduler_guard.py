@@ -51,7 +51,7 @@ def run_build(lib, env_id, kw, path):
     return np.load(path)
 
 
-@pytest.mark.parametrize("env_id,solver", [("Ant-v5", None), ("HalfCheetah-v5", None), ("Humanoid-v5", "PGS"), ("HumanoidStandup-v5", "PGS"),
+@pytest.mark.parametrize("env_id,solver", [("Ant-v5", None), ("HalfCheetah-v5", None), ("Hopper-v5", None), ("Walker2d-v5", None), ("Humanoid-v5", "PGS"), ("HumanoidStandup-v5", "PGS"),
                                            ("Humanoid-v5", "Newton"), ("HumanoidStandup-v5", "Newton")])
 def test_iterative_scheduler_build_is_bit_identical_to_default_scheduler_build(env_id, solver, tmp_path):
     assert os.path.exists(REF), f"{REF} missing: run __graft_entry__.build() (python -m gymnasium_amd.csrc.build --ref)"
