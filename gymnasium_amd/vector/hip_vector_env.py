@@ -460,8 +460,9 @@ class HipVectorEnv(VectorEnv):
             # sync_vector_env.py:309-317 via VectorEnv._add_info: object array of per-env observations + nested final_info
             final = self._host(self._final)
             arr = np.full(N, None, dtype=object)
+            scalar_obs = final.ndim == 1  # Discrete observations: the scalar env returns a Python int (frozen_lake.py:343 `int(s)`)
             for i in np.flatnonzero(dones):
-                arr[i] = final[i].copy()
+                arr[i] = int(final[i]) if scalar_obs else final[i].copy()
             infos["final_obs"], infos["_final_obs"] = arr, dones.copy()
             finfo = {}
             if self.INFO_KEYS and self._final_info is not None:

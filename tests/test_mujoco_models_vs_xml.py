@@ -14,7 +14,7 @@ import pytest
 
 from gymnasium_amd.envs.mujoco import compiler, models
 
-from tests import mjcf
+import mjcf_parse as mjcf  # tests/ is on sys.path (rootdir conftest); a `tests` package would collide with the reference's own
 
 ASSETS = os.path.join(os.environ.get("GYM_REFERENCE", "/root/reference"), "gymnasium", "envs", "mujoco", "assets")
 pytestmark = pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference MJCF assets not present")
