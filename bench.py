@@ -20,7 +20,7 @@ steps are not counted), whole job over all ranks.  The same JSON line also carri
                     rocprofv3 PMC passes run BY THIS COMMAND on a short child invocation (FETCH_SIZE x2 + WRITE_SIZE, separate
                     passes); the cooperative MuJoCo kernels are VALU / latency bound: `bound: "valu"`, frac = SQ_ACTIVE_INST_VALU /
                     SQ_WAVE_CYCLES of the same kind of pass, plus the scratch-inclusive traffic ratio
-  cpu_baseline      the C oracle (kind "port", 1 thread) on the host cores, bounded sample
+  cpu_baseline      the C oracle (kind "port") on the host's cores: the batch sharded over one single-threaded process per core (count stated), bounded sample
   cpu_reference     Gymnasium's own AsyncVectorEnv (num_envs = os.cpu_count()) / SyncVectorEnv / NumPy CartPoleVectorEnv timed in
                     this run when `import gymnasium` works (GYM_REFERENCE or an installed package); the GPU box has neither, so there
                     the numbers measured in the build container are carried as cpu_reference_recorded (hardware stated)
@@ -70,14 +70,14 @@ CPU_REFERENCE_RECORDED = {
 
 
 # ---- CPU legs -----------------------------------------------------------------------------------------------------------------
-def cpu_baseline(env_id, num_envs, budget_s=12.0):
-    """The CPU oracle (C restatement of the reference's env + SyncVectorEnv semantics, 1 thread) on the same workload, bounded to
-    ~budget_s of CPU time.  kind="port": the Python reference itself is not present on the GPU box."""
+def _oracle_rollouts(env_id, num_envs, offset, budget_s, start_at=None):
+    """One process' share of the CPU baseline: `num_envs` sub-environments (global indices from `offset`) of the C oracle stepping the
+    same fused random-policy rollout for ~budget_s seconds.  Returns (env_steps, seconds, vector_steps)."""
     import gymnasium_amd
     from gymnasium_amd import _native
     from oracle import oracle
 
-    env = gymnasium_amd.make_vec(env_id, num_envs=num_envs, _engine_factory=oracle.engine_factory)
+    env = gymnasium_amd.make_vec(env_id, num_envs=num_envs, env_index_offset=offset, _engine_factory=oracle.engine_factory)
     env.reset(seed=0)
     env.action_space.seed(0)
     eng = env._engine
@@ -86,20 +86,59 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0):
     obs = np.zeros((T, num_envs) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (T, num_envs, eng.obs_dim), eng.obs_dtype)
     rew, te, tr = np.zeros((T, num_envs)), np.zeros((T, num_envs), np.bool_), np.zeros((T, num_envs), np.bool_)
     acts = np.zeros((T, num_envs) if eng.act_dtype is np.int64 else (T, num_envs, eng.act_dim), dtype=eng.act_dtype)
-    t0 = time.perf_counter()
-    eng.rollout(T, None, acts, obs, rew, te, tr)
-    per_call = time.perf_counter() - t0
-    reps = max(1, int(budget_s / per_call) - 1)
+    eng.rollout(T, None, acts, obs, rew, te, tr)  # warm-up (page faults, first-touch)
+    if start_at is not None:  # all workers of a multi-process sample start together
+        while time.time() < start_at:
+            time.sleep(0.001)
     eng.reset_stats()
+    reps = 0
     t0 = time.perf_counter()
-    for _ in range(reps):
+    while True:
         eng.rollout(T, None, acts, obs, rew, te, tr)
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
     dt = time.perf_counter() - t0
     steps = eng.stats()["env_steps"]
     env.close()
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{env_id} num_envs={num_envs}, {reps * T} vector steps ({steps} env-steps, {dt:.1f} s) of the C oracle's "
-                      "rollout (same random policy, same outputs materialised), 1 thread"}
+    return steps, dt, reps * T
+
+
+def cpu_baseline(env_id, num_envs, budget_s=12.0, workers=None):
+    """The CPU oracle (C restatement of the reference's env + SyncVectorEnv semantics) on the same workload ON THE HOST'S CORES: the batch
+    is sharded over `workers` processes (default: every core, MI355ENV_CPU_WORKERS overrides; each process runs the single-threaded C
+    rollout on its contiguous block of sub-environments, like one rank of the GPU job), all started together and run for ~budget_s.
+    value = env-steps of all processes / the longest process' time.  kind="port": the Python reference is not present on the GPU box."""
+    cores = os.cpu_count() or 1
+    if workers is None:
+        workers = int(os.environ.get("MI355ENV_CPU_WORKERS", min(cores, 64)))
+    workers = max(1, min(workers, num_envs))
+    if workers == 1:
+        steps, dt, vsteps = _oracle_rollouts(env_id, num_envs, 0, budget_s)
+        per = [(steps, dt, vsteps)]
+    else:
+        base, rem = divmod(num_envs, workers)
+        start_at = time.time() + 6.0 + 0.05 * workers  # interpreter start + imports + warm-up of every worker
+        procs, off = [], 0
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        for w in range(workers):
+            n = base + (1 if w < rem else 0)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", env_id, str(n), str(off), str(budget_s), str(start_at)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT, text=True))
+            off += n
+        per = []
+        for p in procs:
+            out, _ = p.communicate(timeout=budget_s + 180)
+            if p.returncode == 0 and out.strip():
+                per.append(tuple(json.loads(out.strip().splitlines()[-1])))
+        if len(per) != workers:  # a worker died: fall back to what one process measures
+            steps, dt, vsteps = _oracle_rollouts(env_id, num_envs, 0, budget_s)
+            per, workers = [(steps, dt, vsteps)], 1
+    steps, dt = sum(x[0] for x in per), max(x[1] for x in per)
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": workers, "host_cpu_count": cores, "kind": "port",
+            "per_core_value": steps / dt / workers,
+            "sample": f"{env_id} num_envs={num_envs} sharded over {workers} process(es) of the C oracle (one single-threaded rollout loop per core, "
+                      f"same random policy, same outputs materialised), {steps} env-steps in {dt:.1f} s"}
 
 
 def cpu_reference(budget_s=4.0):
@@ -188,13 +227,26 @@ def recorded_traffic(env_id, N, inner):
 
 # ---- one configuration on this rank's GPU --------------------------------------------------------------------------------------
 class Config:
-    def __init__(self, env_id, N, inner, local_rank, rank, env_kwargs=None):
+    def __init__(self, env_id, N, inner, local_rank, rank, env_kwargs=None, engine="hip"):
         import torch
 
         import gymnasium_amd
         from gymnasium_amd import _native
 
-        self.torch, self.env_id, self.N, self.inner, self.env_kwargs = torch, env_id, N, inner, env_kwargs
+        self.torch, self.env_id, self.N, self.inner, self.env_kwargs, self.engine = torch, env_id, N, inner, env_kwargs, engine
+        if engine == "oracle":  # dry-run seam (tests/test_bench_multirank.py): the same control flow on the CPU checker, NumPy buffers
+            from oracle import oracle
+
+            env = gymnasium_amd.make_vec(env_id, num_envs=N, env_index_offset=rank * N, _engine_factory=oracle.engine_factory, **(env_kwargs or {}))
+            env.reset(seed=0)
+            env.action_space.seed(rank)
+            eng = env._engine
+            self.env, self.eng = env, eng
+            self.acts = np.zeros((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=eng.act_dtype)
+            self.obs = np.zeros((inner, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (inner, N, eng.obs_dim), eng.obs_dtype)
+            self.rew, self.te, self.tr = np.zeros((inner, N)), np.zeros((inner, N), np.bool_), np.zeros((inner, N), np.bool_)
+            eng.action_seed(_native.pcg_words(env.action_space.np_random))
+            return
         dev = torch.device("cuda", local_rank)
         env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", env_index_offset=rank * N, **(env_kwargs or {}))
         env.reset(seed=0)
@@ -213,12 +265,25 @@ class Config:
         eng.action_seed(_native.pcg_words(env.action_space.np_random))
 
     def launch(self):
+        if self.engine == "oracle":
+            self.eng.rollout(self.inner, None, self.acts, self.obs, self.rew, self.te, self.tr)
+            return
         self.eng.rollout(self.inner, None, self.acts.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(), self.te.data_ptr(), self.tr.data_ptr())
 
     def timed(self, K, sync):
         """K launches between two HIP events on the engine's stream (env._bind_stream() = torch's current stream).  One event on either
         side: an event after every launch would put a marker packet between the kernels (+9 us per 96 us launch, measured)."""
         t = self.torch
+        if self.engine == "oracle":  # synchronous CPU launches: the wall clock is the kernel clock
+            sync()
+            self.eng.reset_stats()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                self.launch()
+            sync()
+            elapsed = time.perf_counter() - t0
+            return elapsed, elapsed / K, self.env.statistics()
         ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
         sync()
         self.eng.reset_stats()
@@ -297,10 +362,17 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (BASELINE.json configs[2..4])")
     ap.add_argument("--env-kwargs", default="{}", help='JSON constructor kwargs of the env, e.g. \'{"solver": "Newton"}\' (Humanoid: opt-in solver)')
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
+    # dry-run seam (tests/test_bench_multirank.py): the N > 1 control flow -- pilot MAX all-reduce, barriers, sustained branch, rank-0 CPU legs,
+    # the JSON line -- on gloo with the CPU checker as the engine.  Never a measurement: the line says engine = "oracle".
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--engine", choices=["hip", "oracle"], default="hip", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
+    ap.add_argument("--pilot-seconds", type=float, default=1.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
 
+    gpu = args.engine == "hip"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -308,34 +380,39 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if (gpu and args.backend == "nccl") else torch.device("cpu")
     N, K, W, inner = args.num_envs, args.steps, args.warmup, args.inner
+
+    def sync_local():
+        if gpu:
+            torch.cuda.synchronize()
 
     def sync_all():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    def sync_local():
-        torch.cuda.synchronize()
+        sync_local()
 
     env_kwargs = json.loads(args.env_kwargs)
-    cfg = Config(args.env, N, inner, local_rank, rank, env_kwargs)
+    cfg = Config(args.env, N, inner, local_rank, rank, env_kwargs, engine=args.engine)
     if K is None:  # ~1 s of timed launches: a 50-launch burst is 5 ms, over before the clocks have ramped (round 1: the driver's sampler saw 0 % busy)
         for _ in range(3):
             cfg.launch()
-        torch.cuda.synchronize()
+        sync_local()
         t0 = time.perf_counter()
         for _ in range(5):
             cfg.launch()
-        torch.cuda.synchronize()
+        sync_local()
         pilot = torch.tensor([(time.perf_counter() - t0) / 5], device=dev)
         if world > 1:
             dist.all_reduce(pilot, op=dist.ReduceOp.MAX)  # every rank must time the same K
-        K = int(min(20000, max(20, round(1.0 / max(float(pilot.item()), 1e-6)))))
+        K = int(min(20000, max(20, round(args.pilot_seconds / max(float(pilot.item()), 1e-6)))))
     if W is None:
         W = max(5, K // 10)
     for _ in range(W):
@@ -343,7 +420,7 @@ def main():
     if args.child:
         for _ in range(K):
             cfg.launch()
-        torch.cuda.synchronize()
+        sync_local()
         cfg.close()
         return
     elapsed, kernel_s, st = cfg.timed(K, sync_all)
@@ -352,7 +429,7 @@ def main():
     red = gd.reduce_statistics(st, elapsed_s=elapsed, device=dev)  # the only collective: a few dozen bytes over RCCL/xGMI
     elapsed = red["elapsed_s"]
     env_steps, episodes, return_sum = float(red["env_steps"]), float(red["episodes"]), float(red["return_sum"])
-    single = rank == 0 and world == 1
+    single = rank == 0 and world == 1 and gpu
     pmc_primary = ("traffic", "sq") if (single and args.pmc != "off") else ()
 
     result = None
@@ -361,7 +438,7 @@ def main():
             "metric": "env-steps/sec at num_envs=65536 (1/2/4/8 MI355X) vs CPU AsyncVectorEnv",
             "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", **({} if gpu else {"engine": "oracle (CPU checker: a dry run of the control flow, NOT a measurement)"}),
             "config": {"workload": f"{args.env} num_envs={N} per GPU, random policy (on-device action_space.sample()), "
                                    f"NEXT_STEP autoreset, TimeLimit, fused rollout of {inner} vector steps per launch, "
                                    "trajectory (actions, obs, rewards, terminated, truncated) written to HBM",
@@ -503,13 +580,16 @@ def main():
                 line["opt_in"] = {"env_kwargs": opt, "value": steady(c3)[0], "unit": "env-steps/s"}
                 c3.close()
             if not args.no_cpu_baseline:  # MuJoCo: a 512-env sample (the oracle's per-env cost does not depend on the batch size)
-                line["cpu_baseline"] = cpu_baseline(env_id, 512 if env_id in MJ_COOP else n2, budget_s=3.0)
+                line["cpu_baseline"] = cpu_baseline(env_id, min(n2, 64 * min(os.cpu_count() or 1, 64)) if env_id in MJ_COOP else n2, budget_s=3.0)
             result["secondary"].append(line)
 
     # ---- CPU legs: the oracle port on rank 0 (every N), the reference's own vectorisers where importable -------------------------------
     if rank == 0:
-        result["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.env, 512 if args.env in MJ_COOP else N)
-        if not args.no_cpu_baseline and world == 1:
+        # the whole batch of one GPU on every host core (MuJoCo: a bounded sample of 64 sub-environments per core -- the oracle's per-env cost
+        # does not depend on the batch size)
+        n_cpu = min(N, 64 * min(os.cpu_count() or 1, 64)) if args.env in MJ_COOP else N
+        result["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.env, n_cpu, budget_s=args.cpu_budget)
+        if not args.no_cpu_baseline and world == 1 and gpu:
             ref = cpu_reference()
             if ref is not None:
                 result["cpu_reference"] = ref
@@ -524,4 +604,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":  # one process of cpu_baseline's multi-core sample
+        _, _, w_env, w_n, w_off, w_budget, w_start = sys.argv
+        print(json.dumps(_oracle_rollouts(w_env, int(w_n), int(w_off), float(w_budget), float(w_start))))
+    else:
+        main()

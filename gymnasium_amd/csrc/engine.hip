@@ -24,6 +24,7 @@
 
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/mi355env.h"
@@ -243,9 +244,18 @@ template <class E, bool CHECK_ACTION>
 MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, StepOut<E> &o, LaneStats &st, ResetQueue<E> &q) {
     const bool resetting = (L.flags & kNeedsReset) != 0;
     if (__builtin_expect(resetting && !q.have, 0)) q.refill();  // rare: two episode ends within one refill period
-    if (CHECK_ACTION && !resetting && !E::valid(a)) {
-        *d.error = kErrInvalidAction;
-        a = (typename E::Act)0;
+    // cartpole.py:165-167 asserts before it touches the state: an action outside the space is reported through the sticky error word and
+    // the lane is left untouched (lane_step's rule) -- it integrates a stand-in action like a resetting lane does and SELECTS its old state.
+    bool invalid = false;
+    double s0[E::S];
+    if (CHECK_ACTION) {
+#pragma unroll
+        for (int k = 0; k < E::S; k++) s0[k] = L.s[k];
+        invalid = !resetting && !E::valid(a);
+        if (invalid) {
+            *d.error = kErrInvalidAction;
+            a = (typename E::Act)0;
+        }
     }
     // the reset candidate (sync_vector_env.py:279-284): the state was formed from the queued draws when they were drawn
     const double (&rs)[E::S] = q.rs;
@@ -255,10 +265,17 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     bool te;
     uint32_t sflags = L.flags;
     E::step(L.s, sflags, a, d.P, rew, te, L.trig);
-    const uint32_t elapsed = L.elapsed + 1;  // TimeLimit.step (wrappers/common.py:129-133)
-    const bool tr = d.max_steps > 0 && (int)elapsed >= d.max_steps;
+    if (CHECK_ACTION && invalid) {  // rare, divergent: undo
+#pragma unroll
+        for (int k = 0; k < E::S; k++) L.s[k] = s0[k];
+        sflags = L.flags, rew = 0.0, te = false;
+        trig_invalidate(L.trig);
+    }
+    const uint32_t moved = (CHECK_ACTION && invalid) ? 0u : 1u;
+    const uint32_t elapsed = L.elapsed + moved;  // TimeLimit.step (wrappers/common.py:129-133)
+    const bool tr = moved && d.max_steps > 0 && (int)elapsed >= d.max_steps;
     const double ep_ret = L.ep_ret + rew;
-    const int32_t ep_len = L.ep_len + 1;
+    const int32_t ep_len = L.ep_len + (int32_t)moved;
     const bool done = !resetting && (te || tr);
 #pragma unroll
     for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
@@ -268,7 +285,7 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     L.ep_len = resetting ? 0 : ep_len;
     q.have = q.have && !resetting;
     st.reset_steps += resetting ? 1u : 0u;
-    st.env_steps += resetting ? 0u : 1u;
+    st.env_steps += resetting ? 0u : moved;
     st.episodes += done ? 1u : 0u;
     st.return_sum += done ? ep_ret : 0.0;
     st.length_sum += done ? (uint64_t)ep_len : 0ull;
@@ -502,9 +519,13 @@ __global__ __launch_bounds__(kBlock) void epilogue_finish(EpiDev e, int N, float
     if (e.fold_in_finish) {
         epilogue_statistics<OBS>(e, N, epi_reduces(e), sh, st);
         if (blockIdx.x == 0 && epi_reduces(e)) epilogue_store_statistics<OBS>(e, st);
-    } else {  // epilogue_combine ran: the second buffer set holds the updated statistics
-        if (threadIdx.x < OBS && e.obs_on) st[threadIdx.x] = e.obs_mean2[threadIdx.x], st[OBS + threadIdx.x] = e.obs_var2[threadIdx.x];
-        if (threadIdx.x == 64 && e.ret_on) st[2 * OBS] = e.ret_var2[0];
+    } else {
+        // epilogue_combine ran iff some statistic is being updated: then the second buffer set holds the statistics after this step.  With
+        // frozen statistics (update_running_mean = False on both wrappers) nothing was folded or swapped: the primary set is the current one.
+        const bool upd = epi_reduces(e);
+        const double *om = upd ? e.obs_mean2 : e.obs_mean, *ov = upd ? e.obs_var2 : e.obs_var, *rv = upd ? e.ret_var2 : e.ret_var;
+        if (threadIdx.x < OBS && e.obs_on) st[threadIdx.x] = om[threadIdx.x], st[OBS + threadIdx.x] = ov[threadIdx.x];
+        if (threadIdx.x == 64 && e.ret_on) st[2 * OBS] = rv[0];
         __syncthreads();
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1317,10 +1338,10 @@ int dispatch_mj(int kind, F &&f) {
 
 // The sticky device error word lives in page-locked host memory (the kernels write it through its device address on the rare error): after
 // a stream synchronisation it is simply read, no copy.
-int raise_device_error(mi_vecenv *v) {
+int raise_device_error(mi_vecenv *v) {  // precondition: the stream is idle (a kernel in flight could set the word again right after the clear)
     const int err = *v->h_err;
     if (!err) return MI_OK;
-    *v->h_err = 0;  // the stream is idle: nobody else touches the word
+    *v->h_err = 0;
     if (err == kErrInvalidAction) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
     return fail(MI_ERR_STATE, "DISABLED autoreset: a finished sub-environment was stepped without reset");
 }
@@ -1492,6 +1513,8 @@ int mi_device_count(void) {
     return n;
 }
 
+static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device);
+
 int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(mi_config)) return fail(MI_ERR_INVALID_ARGUMENT, "bad mi_config");
     if (cfg->kind < 0 || cfg->kind >= MI_ENV_KIND_COUNT) return fail(MI_ERR_INVALID_ARGUMENT, "unknown env kind");
@@ -1506,6 +1529,17 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     if (!v) return fail(MI_ERR_HIP, "out of host memory");
     memset(v, 0, sizeof *v);
     v->cfg = *cfg, v->device = device;
+    const int rc = create_buffers(v, cfg, device);
+    if (rc != MI_OK) {  // a failing allocation half way: release what the earlier ones got (mi_destroy skips the null ones) and keep the message
+        const std::string msg = mi_last_error();
+        mi_destroy(v);
+        return fail(rc, "%s", msg.c_str());
+    }
+    *out = v;
+    return MI_OK;
+}
+
+static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
     if (is_mj(cfg->kind)) {
         mi::EnvParams P;
         for (int k = 0; k < 16; k++) P.p[k] = cfg->params[k];
@@ -1618,7 +1652,6 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
         if (spill) HIP_TRY(hipMalloc(&v->d_pgs_spill, sizeof(double) * spill * N));
     }
     HIP_TRY(hipStreamSynchronize(v->stream));
-    *out = v;
     return MI_OK;
 }
 
@@ -1802,7 +1835,8 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     if (set_device(v)) return MI_ERR_HIP;
     // Device callers are asynchronous: an action outside the space (or a finished sub-environment stepped under DISABLED) is recorded by the
     // kernel in the page-locked error word and raised HERE, by the first later step that finds it -- a plain host read, no synchronisation.
-    if (loc == MI_DEVICE && *v->h_err) return raise_device_error(v);
+    // The word is only CLEARED once the stream is idle (error path only: the common case stays a plain read).
+    if (loc == MI_DEVICE && *v->h_err) return check_device_error(v);
     const size_t N = (size_t)v->cfg.num_envs;
     StepPtrs p;
     bool zc = false;

@@ -81,31 +81,63 @@ class HipVectorEnv(VectorEnv):
     def _fusion_state(self):
         st = self.__dict__.get("_fused")
         if st is None:
-            st = self._fused = {"obs": None, "ret": None, "clip_pre": None, "clip_post": None, "closed": False}
+            # chain: the fused wrappers in wrapping order (innermost first); entry: the OUTERMOST fused wrapper the running step() call came
+            # through (None: the env is being stepped directly); attached: signature of the epilogue the engine currently holds
+            st = self._fused = {"obs": None, "ret": None, "clip_pre": None, "clip_post": None, "closed": False, "chain": [], "entry": None, "attached": None}
         return st
 
     def _can_fuse(self) -> bool:
         return (self.FUSES_WRAPPERS and self._engine_factory is None and hasattr(self._engine.lib, "set_step_epilogue")
                 and not self._fusion_state()["closed"])
 
-    def _refresh_epilogue(self):
-        """(Re)attach the epilogue from the wrappers that registered themselves; called when one of them is created or changes a setting."""
+    def _fuse(self, wrapper, slot: str) -> int:
+        """Register ``wrapper`` as the next member of the fused unit; returns its position in the chain."""
         st = self._fusion_state()
-        e = _native.MiStepEpilogue()
-        o, r = st["obs"], st["ret"]
-        if o is not None:
-            e.obs_rms, e.obs_epsilon, e.obs_update = o.obs_rms._h, float(o.epsilon), int(o.update_running_mean)
-        if r is not None:
-            e.return_rms, e.accumulated, e.prev_done = r.return_rms._h, r._acc.data_ptr(), r._prev.data_ptr()
-            e.gamma, e.reward_epsilon, e.reward_update = float(r.gamma), float(r.epsilon), int(r.update_running_mean)
-        for key in ("clip_pre", "clip_post"):
-            c = st[key]
-            if c is not None:
-                lo, hi = c.min_reward, c.max_reward
-                setattr(e, key, (1 if lo is not None else 0) | (2 if hi is not None else 0))
-                setattr(e, key + "_min", 0.0 if lo is None else float(lo)), setattr(e, key + "_max", 0.0 if hi is None else float(hi))
-        self._epilogue_struct = e  # keep the ctypes object alive
-        self._engine.set_step_epilogue(e)
+        st[slot] = wrapper
+        st["chain"].append((slot, wrapper))
+        return len(st["chain"]) - 1
+
+    def _sync_epilogue(self):
+        """Attach exactly the epilogue of the step() call in progress.  The wrapped values belong to the WRAPPER they come out of
+        (the reference's contract: the inner env returns raw values): a step entered through fused wrapper k runs the arithmetic of the
+        chain's members 0..k as the step kernel's output stage, a step of the env itself -- or of a wrapper below k -- runs none / fewer.
+        Settings are read from the wrappers at every step (a tuple compare), so a later ``w.gamma = ...`` / ``w.min_reward = ...`` /
+        ``w.update_running_mean = False`` takes effect like in the reference; the engine is only re-configured when something changed."""
+        st = self.__dict__.get("_fused")
+        if st is None or not st["chain"]:
+            return
+        entry = st["entry"]
+        level = -1 if entry is None else entry._fuse_index
+        members = st["chain"][:level + 1]
+        sig = [level]
+        for slot, w in members:
+            if slot == "obs":
+                sig += [float(w.epsilon), bool(w.update_running_mean)]
+            elif slot == "ret":
+                sig += [float(w.gamma), float(w.epsilon), bool(w.update_running_mean)]
+            else:
+                sig += [None if w.min_reward is None else float(w.min_reward), None if w.max_reward is None else float(w.max_reward)]
+        sig = tuple(sig)
+        if sig == st["attached"]:
+            return
+        if not members:
+            self._epilogue_struct = None
+            self._engine.set_step_epilogue(None)
+        else:
+            e = _native.MiStepEpilogue()
+            for slot, w in members:
+                if slot == "obs":
+                    e.obs_rms, e.obs_epsilon, e.obs_update = w.obs_rms._h, float(w.epsilon), int(w.update_running_mean)
+                elif slot == "ret":
+                    e.return_rms, e.accumulated, e.prev_done = w.return_rms._h, w._acc.data_ptr(), w._prev.data_ptr()
+                    e.gamma, e.reward_epsilon, e.reward_update = float(w.gamma), float(w.epsilon), int(w.update_running_mean)
+                else:
+                    lo, hi = w.min_reward, w.max_reward
+                    setattr(e, slot, (1 if lo is not None else 0) | (2 if hi is not None else 0))
+                    setattr(e, slot + "_min", 0.0 if lo is None else float(lo)), setattr(e, slot + "_max", 0.0 if hi is None else float(hi))
+            self._epilogue_struct = e  # keep the ctypes object alive
+            self._engine.set_step_epilogue(e)
+        st["attached"] = sig
 
     def _parse_reset_options(self, options):
         """Return the env-specific (b0, b1) reset bounds or None for defaults; raise ValueError like the reference."""
@@ -358,6 +390,7 @@ class HipVectorEnv(VectorEnv):
             raise AssertionError("Call reset before using step method.")
         keep, aptr = self._coerce_actions(actions)
         self._bind_stream()
+        self._sync_epilogue()
         try:
             self._engine.step(aptr, self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc),
                               self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc, self._p(self._info),
@@ -414,6 +447,7 @@ class HipVectorEnv(VectorEnv):
             return
         keep, aptr = self._coerce_actions(actions)
         self._bind_stream()
+        self._sync_epilogue()
         try:
             self._engine.step_async(aptr, self._obs, self._rew, self._term, self._trunc, self._final, self._ep_r, self._ep_l, self._info, self._final_info)
         except _native.NativeError as e:

@@ -12,9 +12,11 @@ oracle/wrappers.py is test infrastructure), in one of two forms:
 
 * FUSED (classic-control HipVectorEnv directly underneath, possibly through RecordEpisodeStatistics / NumpyToTorch): the wrapper registers
   itself with the env and its arithmetic becomes the output stage of the step kernel (mi_set_step_epilogue, csrc/engine.hip): the batch
-  statistics are gathered by the step kernel's workgroups, one small second launch normalises in place, and ``env.step`` already returns
-  the wrapped observations / rewards -- NumPy callers get them with the step's one device-to-host copy.  The wrappers that fused form ONE
-  unit with the env: stepping an inner wrapper directly returns the same (fully wrapped) values.
+  statistics are gathered by the step kernel's workgroups, one small second launch normalises in place -- NumPy callers get the wrapped
+  batch with the step's one device-to-host copy.  The fusion is SCOPED to the call: a ``step()`` entered through fused wrapper k runs the
+  arithmetic of the fused wrappers up to k; stepping the env itself (``w.env.step``, ``w.unwrapped.step``) or an inner wrapper returns that
+  object's own values -- raw for the env -- and leaves the outer wrappers' statistics alone, as in the reference.  Settings (``gamma``,
+  ``epsilon``, ``min_reward``, ``max_reward``, ``update_running_mean``) are read at every step.
 * STAND-ALONE (any other env of this package, or a wrapper order the epilogue cannot express): passes of csrc/wrappers.hip over the arrays
   the engine produced; with ``output="torch"`` nothing leaves the GPU, NumPy batches are staged through the device.
 """
@@ -136,6 +138,19 @@ class VectorWrapper:
     def step(self, actions):
         return self.env.step(actions)
 
+    def _step_fused(self, actions):
+        """step() of a fused wrapper: mark this call as entered through `self` (the outermost fused wrapper of a call wins) and run the
+        chain underneath -- the engine's step applies the epilogue of the members up to the entry (HipVectorEnv._sync_epilogue)."""
+        st = self._base._fusion_state()
+        outermost = st["entry"] is None
+        if outermost:
+            st["entry"] = self
+        try:
+            return self.env.step(actions)
+        finally:
+            if outermost:
+                st["entry"] = None
+
     def close(self, **kwargs):
         return self.env.close(**kwargs)
 
@@ -249,9 +264,8 @@ class NormalizeObservation(VectorWrapper):
         self._update_running_mean = True
         base = _fusion_base(self.env)
         if base is not None and in_dtype == np.float32 and base._fusion_state()["obs"] is None:
-            base._fusion_state()["obs"] = self
             self._fused, self._base = True, base
-            base._refresh_epilogue()
+            self._fuse_index = base._fuse(self, "obs")
         else:
             _close_fusion(self.env)
 
@@ -262,8 +276,6 @@ class NormalizeObservation(VectorWrapper):
     @update_running_mean.setter
     def update_running_mean(self, setting: bool):
         self._update_running_mean = setting
-        if self._fused:
-            self._base._refresh_epilogue()
 
     def observations(self, observations):
         torch = _torch()
@@ -281,8 +293,8 @@ class NormalizeObservation(VectorWrapper):
         return self.observations(obs), info
 
     def step(self, actions):
-        if self._fused:  # the step kernel's output stage already normalised (and updated obs_rms)
-            return self.env.step(actions)
+        if self._fused:  # the step kernel's output stage normalises (and updates obs_rms)
+            return self._step_fused(actions)
         obs, reward, terminated, truncated, info = self.env.step(actions)
         return self.observations(obs), reward, terminated, truncated, info
 
@@ -307,9 +319,8 @@ class NormalizeReward(VectorWrapper):
         base = _fusion_base(self.env)
         st = None if base is None else base._fusion_state()
         if st is not None and st["ret"] is None and st["clip_post"] is None:  # order inside the epilogue: clip_pre -> normalise -> clip_post
-            st["ret"] = self
             self._fused, self._base = True, base
-            base._refresh_epilogue()
+            self._fuse_index = base._fuse(self, "ret")
         else:
             _close_fusion(self.env)
 
@@ -324,8 +335,6 @@ class NormalizeReward(VectorWrapper):
     @update_running_mean.setter
     def update_running_mean(self, setting: bool):
         self._update_running_mean = setting
-        if self._fused:
-            self._base._refresh_epilogue()
 
     def reset(self, *, seed=None, options=None):
         self._acc.zero_(), self._prev.zero_()
@@ -333,7 +342,7 @@ class NormalizeReward(VectorWrapper):
 
     def step(self, actions):
         if self._fused:
-            return self.env.step(actions)
+            return self._step_fused(actions)
         torch = _torch()
         obs, reward, terminated, truncated, info = self.env.step(actions)
         r, was_tensor = self._to_device(reward, np.float64)
@@ -370,15 +379,14 @@ class ClipReward(VectorWrapper):
             elif st["clip_post"] is None:
                 slot = "clip_post"
         if slot is not None:
-            st[slot] = self
             self._fused, self._base = True, base
-            base._refresh_epilogue()
+            self._fuse_index = base._fuse(self, slot)
         else:
             _close_fusion(self.env)
 
     def step(self, actions):
         if self._fused:
-            return self.env.step(actions)
+            return self._step_fused(actions)
         torch = _torch()
         obs, reward, terminated, truncated, info = self.env.step(actions)
         r, was_tensor = self._to_device(reward, np.float64)

@@ -1,0 +1,58 @@
+"""bench.py's N > 1 control flow, executed end to end before the driver's first multi-GPU run.
+
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` exactly as the driver launches it, with two hidden flags that
+swap the transport and the engine: `--backend gloo --engine oracle` (the CPU checker behind the same host class; there is no GPU in the
+build container).  What runs is everything that had never executed anywhere: the pilot's MAX all-reduce that fixes K on every rank, the
+barrier + synchronise bracket, both `sustained` branches, the one statistics all-reduce, rank 0's CPU legs and the single JSON line with
+`n_gpus: N`.  The numbers are NOT measurements (the line says engine = oracle)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MI355ENV_CPU_WORKERS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--engine", "oracle",
+           "--num-envs", "256", "--inner", "8", "--cpu-budget", "0.5", *extra]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line from rank 0, got {len(lines)}: {p.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_default_flags_pilot_sets_k_on_every_rank(world):
+    """No --steps: K comes from the pilot, all-reduced MAX over the ranks; a timed region that is long enough IS the sustained figure."""
+    r = _run(world, ["--pilot-seconds", "0.9", "--sustained", "0.5"])
+    assert r["n_gpus"] == world and r["scaling"] == "weak" and r["higher_is_better"] is True and r["unit"] == "env-steps/s"
+    assert r["steps"] >= 20 and r["warmup"] >= 5
+    # every rank timed the same K launches of 8 vector steps over its own 256 sub-environments; autoreset steps are not counted
+    lanes = world * 256 * 8 * r["steps"]
+    assert 0.8 * lanes < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= lanes
+    assert r["config"]["parallelism"] == f"env-sharded x{world} (no data-path collective)" and "oracle" in r["engine"]
+    assert r["sustained_value"] == r["value"] or r["sustained"]["launches"] >= r["steps"]
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["algorithmic_bytes_per_launch"] == (34 * 8 + 96) * 256
+    assert r["cpu_baseline"]["cores"] == 2 and r["cpu_baseline"]["value"] > 0
+    assert "secondary" not in r and "api_step_device" not in r  # one-GPU extras stay out of the N > 1 line
+
+
+def test_driver_style_explicit_steps_takes_the_separate_sustained_loop():
+    """--steps K --warmup W as the driver passes them: EXACTLY K timed launches; a short timed region is followed by the separate sustained loop."""
+    r = _run(2, ["--steps", "6", "--warmup", "2", "--sustained", "0.3"])
+    assert r["steps"] == 6 and r["warmup"] == 2 and r["n_gpus"] == 2
+    assert r["sustained"]["launches"] > 6 and r["sustained"]["seconds"] >= 0.05
+    assert r["episodes"] > 0 and 9.0 < r["mean_episode_return"] < 60.0  # CartPole under the random policy: ~22 steps per episode

@@ -178,6 +178,48 @@ def test_torch_mode_errors_are_deferred_unless_strict():
     host.close()
 
 
+def test_fused_rollout_leaves_a_lane_with_an_invalid_action_untouched():
+    """mi_rollout with caller-supplied actions: a lane whose action is outside the space is NOT stepped with a stand-in action (round 2 did
+    that) -- it keeps its state for that step, like step() (cartpole.py:165-167 asserts before it touches the state); the other lanes and the
+    lane's later steps are unaffected, and the error is raised by the next synchronising call."""
+    import torch
+
+    n, T = 256, 12
+    acts = torch.randint(0, 2, (T, n), dtype=torch.int64, generator=torch.Generator().manual_seed(3)).cuda()
+    bad = acts.clone()
+    bad[4, 17] = 9
+    a = ps.make("cartpole", n, None, output="torch", max_episode_steps=10 ** 6)
+    b = ps.make("cartpole", n, None, output="torch", max_episode_steps=10 ** 6)
+    a.reset(seed=5), b.reset(seed=5)
+    ra = a.rollout(T, actions=bad)
+    with pytest.raises(Exception):
+        a.synchronize()
+    # the twin: the same actions, but lane 17 simply does not step at t = 4 -- emulated by stepping everything and restoring lane 17
+    outs = []
+    for t in range(T):
+        if t == 4:
+            st0 = b.get_state()
+        o, r, te, tr, _ = b.step(acts[t])
+        if t == 4:
+            st1 = b.get_state()
+            state, elapsed, flags = (x.copy() for x in st1)
+            state[17], elapsed[17], flags[17] = st0[0][17], st0[1][17], st0[2][17]
+            b.set_state(state, elapsed, flags)
+        outs.append((o.clone(), r.clone(), te.clone(), tr.clone()))
+    sa, sb = a.get_state(), b.get_state()
+    assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), "final states differ"
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[17] = False
+    for t in range(T):
+        o, r, te, tr = outs[t]
+        rows = keep if t == 4 else torch.ones(n, dtype=torch.bool)
+        assert torch.equal(ra["obs"][t].cpu()[rows], o.cpu()[rows]) and torch.equal(ra["rewards"][t].cpu()[rows], r.cpu()[rows]), t
+        assert torch.equal(ra["terminations"][t].cpu()[rows], te.cpu()[rows]), t
+    assert float(ra["rewards"][4, 17]) == 0.0 and not bool(ra["terminations"][4, 17])
+    assert torch.equal(ra["obs"][4, 17], ra["obs"][3, 17]), "the invalid step reports the unchanged observation"
+    a.close(), b.close()
+
+
 def test_torch_output_matches_numpy_output():
     import torch
 
