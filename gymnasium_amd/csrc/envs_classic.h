@@ -55,6 +55,7 @@ struct ExactMath {
     static MI_DEV double sin(double x) { return mi_sincos::sin_bf(g_trig6, x); }
     static MI_DEV double cos(double x) { return mi_sincos::cos_bf(g_trig6, x); }
     static MI_DEV void sincos(double x, double &s, double &c) { mi_sincos::sincos_bf(g_trig6, x, s, c); }
+    static MI_DEV void sincos_spread(double x, double &s, double &c) { mi_sincos::sincos_bf<false, false>(g_trig6, x, s, c); }  // any range, no small-angle short cut
     // for angles the environment wraps or clips (|x| far below 1e8): no hand-over to the platform's huge-argument routine, and lanes
     // spread over all ranges (no wavefront-uniform short cut)
     static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true>(g_trig6, x); }
@@ -92,6 +93,7 @@ struct FastMath {
         const double w = 1.0 - hz;
         cs = w + (((1.0 - w) - hz) + z * (z * rc));
     }
+    static MI_DEV void sincos_spread(double x, double &s, double &c) { ::sincos(x, &s, &c); }
     static MI_DEV double sin_bounded(double x) { return ::sin(x); }
     static MI_DEV double cos_bounded(double x) { return ::cos(x); }
     static MI_DEV void sincos_bounded(double x, double &s, double &c) { ::sincos(x, &s, &c); }
@@ -221,7 +223,10 @@ struct PendulumT {
     }
     typedef PendulumTrig Trig;
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS], Trig &t) {
-        M::sincos(s[0], t.sn, t.cs);
+        // theta is never wrapped in the state (pendulum.py:141): the lanes of a wavefront spread over all argument ranges, so the short cut
+        // for small angles (CartPole's) would only add its own instructions to the general path; the hand-over for huge angles stays
+        // (|theta| grows by up to 0.4 per step: 1e8 is reachable without a TimeLimit)
+        M::sincos_spread(s[0], t.sn, t.cs);
         t.ok = true;
         o[0] = (float)t.cs, o[1] = (float)t.sn, o[2] = (float)s[1];
     }

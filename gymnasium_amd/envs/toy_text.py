@@ -25,6 +25,7 @@ class TabularVectorEnv(HipVectorEnv):
     INFO_KEYS = ("prob",)
     N_RESET_INFO_KEYS = 1
     RESET_PROB_IS_INT = True  # FrozenLake / CliffWalking reset() returns {"prob": 1} (an int); Taxi returns 1.0
+    HOST_INFOS = True         # "prob" dtype quirk, Taxi's action_mask table: assembled on the host (one read-back per step with output="torch")
 
     def _build(self):
         """Return (P, initial_state_distrib): P[s][a] = list of (prob, next_state, reward, terminated)."""
@@ -267,6 +268,7 @@ class BlackjackVectorEnv(HipVectorEnv):
     Discrete(2)) batched by SyncVectorEnv: a tuple of three int64 arrays (player sum, dealer's showing card, usable ace)."""
 
     KIND = "blackjack"
+    HOST_INFOS = True  # SAME_STEP final_obs is an object array of tuples
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, natural: bool = False, sab: bool = False, **kwargs):
         self.natural, self.sab = bool(natural), bool(sab)

@@ -62,6 +62,7 @@ class HipVectorEnv(VectorEnv):
     INFO_KEYS: tuple = ()        # names of the engine's scalar info columns (MuJoCo envs); the first N_RESET_INFO_KEYS are also
     N_RESET_INFO_KEYS: int = 0   # what the scalar env's reset() reports (_get_reset_info), i.e. valid on autoreset steps
     INFO_VECTOR_KEYS: tuple = () # (name, width) array-valued info entries stored after the scalar columns; reported by step AND reset
+    HOST_INFOS = False           # True: the infos need host-side table look-ups (ToyText): built on the host also with output="torch"
     metadata: dict[str, Any] = {"render_modes": [], "autoreset_mode": AutoresetMode.NEXT_STEP}
 
     # -- to be provided by subclasses ------------------------------------------------------------------
@@ -191,9 +192,16 @@ class HipVectorEnv(VectorEnv):
         self._was_done = np.zeros(self.num_envs, dtype=np.bool_)  # mirror of the device's needs-reset flags (SyncVectorEnv._autoreset_envs)
         self._alloc_buffers()
         if self.record_episode_statistics:
-            self.episode_count = 0
+            self._episode_count = 0
             self._episode_start = np.zeros(self.num_envs)
             self._prev_dones = np.zeros(self.num_envs, dtype=np.bool_)
+
+    @property
+    def episode_count(self) -> int:
+        """Episodes finished so far (RecordEpisodeStatistics.episode_count); with device-resident infos the count lives on the device and
+        reading it synchronises."""
+        dev = self.__dict__.get("_episode_count_t")
+        return self._episode_count + (int(dev.item()) if dev is not None else 0)
 
     def set_output(self, output: str):
         """Switch between NumPy batches ("numpy": the engine's pinned host block, one H2D + one D2H per step) and device tensors ("torch": the engine writes
@@ -211,7 +219,7 @@ class HipVectorEnv(VectorEnv):
         the step kernels start writing the finished episodes' return / length rows.  Call before reset()."""
         if not self.record_episode_statistics:
             self.record_episode_statistics = True
-            self.episode_count = 0
+            self._episode_count = 0
             self._episode_start = np.zeros(self.num_envs)
             self._prev_dones = np.zeros(self.num_envs, dtype=np.bool_)
             self._alloc_buffers()
@@ -224,7 +232,8 @@ class HipVectorEnv(VectorEnv):
             import torch
 
             self._torch = torch
-            dev = torch.device("cuda", self._device_index)
+            # (the test seam's checker backend computes on the host: its "device" tensors are host tensors, same code path otherwise)
+            dev = torch.device("cuda", self._device_index) if self._engine_factory is None else torch.device("cpu")
             self._tdev = dev
             self._obs_tdtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
             self._obs_shape = (N,) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (N, eng.obs_dim)  # Discrete states batch to MultiDiscrete: (N,)
@@ -238,6 +247,14 @@ class HipVectorEnv(VectorEnv):
             self._ep_r = torch.zeros((N,), dtype=torch.float64, device=dev) if self.record_episode_statistics else None
             self._ep_l = torch.zeros((N,), dtype=torch.int32, device=dev) if self.record_episode_statistics else None
             self._loc = _native.MI_DEVICE
+            # device-resident infos (no read-back per step): the pending-autoreset set and the episode clocks live on the device too
+            self._device_infos = not self.HOST_INFOS
+            self._was_done_t = torch.zeros((N,), dtype=torch.bool, device=dev)
+            self._all_true_t = torch.ones((N,), dtype=torch.bool, device=dev)
+            if self.record_episode_statistics:
+                self._episode_start_t = torch.zeros((N,), dtype=torch.float64, device=dev)
+                self._prev_dones_t = torch.zeros((N,), dtype=torch.bool, device=dev)
+                self._episode_count_t = torch.zeros((), dtype=torch.int64, device=dev)
         else:
             self._obs_shape = (N,) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (N, eng.obs_dim)
             same = self.autoreset_mode == AutoresetMode.SAME_STEP
@@ -256,6 +273,8 @@ class HipVectorEnv(VectorEnv):
             self._ep_r = (hb["episode_return"] if hb else np.zeros((N,), dtype=np.float64)) if self.record_episode_statistics else None
             self._ep_l = (hb["episode_length"] if hb else np.zeros((N,), dtype=np.int32)) if self.record_episode_statistics else None
             self._loc = _native.MI_HOST
+            self._device_infos = False
+            self.__dict__.pop("_episode_count_t", None)
 
     def _p(self, buf):
         if buf is None:
@@ -268,7 +287,7 @@ class HipVectorEnv(VectorEnv):
         return buf.clone() if self.output == "torch" else buf.copy()
 
     def _bind_stream(self):
-        if self.output == "torch":
+        if self.output == "torch" and self._engine_factory is None:
             self._engine.set_stream(self._torch.cuda.current_stream(self._tdev).cuda_stream)
 
     # -- seeding ---------------------------------------------------------------------------------------
@@ -353,6 +372,15 @@ class HipVectorEnv(VectorEnv):
             else:
                 self._episode_start[mask.view(np.bool_)] = now
                 self._prev_dones[mask.view(np.bool_)] = False
+        if self._device_infos:
+            keep = None if mask is None else ~dmask.view(self._torch.bool)
+            self._was_done_t = self._was_done_t & keep if keep is not None else self._torch.zeros_like(self._was_done_t)
+            if self.record_episode_statistics:
+                if keep is None:
+                    self._episode_start_t.fill_(now), self._prev_dones_t.zero_()
+                else:
+                    self._episode_start_t = self._torch.where(keep, self._episode_start_t, now)
+                    self._prev_dones_t = self._prev_dones_t & keep
         return self._out(self._obs), self._reset_infos(mask)
 
     def _reset_infos(self, mask) -> dict:
@@ -472,12 +500,59 @@ class HipVectorEnv(VectorEnv):
         infos = self._build_infos()
         return self._out(self._obs), self._out(self._rew), self._out(self._term), self._out(self._trunc), infos
 
+    def _info_dict_device(self, rows, supplied, reset_rows) -> dict:
+        """_info_dict over a device info matrix without reading anything back.  supplied / reset_rows: device bool masks or None (= every
+        sub-env / none).  The KEY SET IS STATIC: a key no sub-env supplied in this step is still present (its `_key` mask is all False) --
+        deciding otherwise would need the masks on the host, i.e. a synchronisation per step."""
+        t, out = self._torch, {}
+        for name, start, width, in_reset in self._info_columns():
+            col = rows[:, start] if width == 0 else rows[:, start:start + width]
+            mask = supplied if (in_reset or reset_rows is None) else (~reset_rows if supplied is None else supplied & ~reset_rows)
+            if mask is None:
+                out[name], out["_" + name] = (col.clone() if self.copy else col), self._all_true_t
+            else:
+                out[name], out["_" + name] = t.where(mask if width == 0 else mask[:, None], col, 0.0), mask
+        return out
+
+    def _build_infos_device(self) -> dict:
+        """The infos of a step as DEVICE tensors (output="torch"): nothing is copied to the host and nothing synchronises -- the step stays
+        asynchronous for the MuJoCo kinds (whose infos carry x_position, reward terms, ...), under SAME_STEP autoreset and with episode
+        statistics.  Differences from the NumPy dict, all forced by not looking at the flags on the host: the key set is static (see
+        _info_dict_device); under SAME_STEP `final_obs` is the batched tensor of final observations (rows valid where `_final_obs`), not an
+        object array; `episode` is present every step with its `_episode` mask."""
+        t, N = self._torch, self.num_envs
+        infos: dict[str, Any] = {}
+        same_step = self.autoreset_mode == AutoresetMode.SAME_STEP
+        dones = self._term | self._trunc
+        if self.INFO_KEYS and self._info is not None:
+            reset_rows = self._was_done_t if self.autoreset_mode == AutoresetMode.NEXT_STEP else (dones if same_step else None)
+            infos.update(self._info_dict_device(self._info, None, reset_rows))
+        if same_step:
+            infos["final_obs"], infos["_final_obs"] = self._out(self._final), dones
+            finfo = self._info_dict_device(self._final_info, dones, None) if (self.INFO_KEYS and self._final_info is not None) else {}
+            infos["final_info"], infos["_final_info"] = finfo, dones
+        self._was_done_t = dones if not same_step else t.zeros_like(dones)
+        if self.record_episode_statistics:
+            now = time.perf_counter()
+            if not same_step:
+                self._episode_start_t = t.where(self._prev_dones_t, now, self._episode_start_t)
+            self._prev_dones_t = dones
+            infos["episode"] = {"r": self._out(self._ep_r), "l": self._ep_l.to(t.int64),
+                                "t": t.where(dones, t.round((now - self._episode_start_t) * 1e6) / 1e6, 0.0)}
+            infos["_episode"] = dones
+            self._episode_count_t = self._episode_count_t + dones.sum()
+            if same_step:
+                self._episode_start_t = t.where(dones, now, self._episode_start_t)
+        return infos
+
     def _build_infos(self) -> dict:
         infos: dict[str, Any] = {}
         N = self.num_envs
         same_step = self.autoreset_mode == AutoresetMode.SAME_STEP
         if not (self.INFO_KEYS or same_step or self.record_episode_statistics):
             return infos  # nothing to report: with device tensors the step stays asynchronous (no read-back of the flags)
+        if self._device_infos:
+            return self._build_infos_device()
         dones = np.logical_or(self._host(self._term), self._host(self._trunc))
         every = np.ones(N, dtype=np.bool_)
         if self.INFO_KEYS and self._info is not None:
@@ -515,7 +590,7 @@ class HipVectorEnv(VectorEnv):
                 infos["episode"] = {"r": r, "l": ln.astype(np.int64),
                                     "t": np.where(dones, np.round(now - self._episode_start, 6), 0.0)}
                 infos["_episode"] = dones.copy()
-                self.episode_count += int(dones.sum())
+                self._episode_count += int(dones.sum())
                 if self.autoreset_mode == AutoresetMode.SAME_STEP:
                     self._episode_start[dones] = now
         return infos
@@ -565,7 +640,10 @@ class HipVectorEnv(VectorEnv):
         # the vector env's "current" buffers follow the last step, as after T step() calls
         self._obs.copy_(obs[-1]); self._rew.copy_(rew[-1]); self._term.copy_(term[-1]); self._trunc.copy_(trunc[-1])
         if self.autoreset_mode == AutoresetMode.NEXT_STEP:  # the sub-envs that finished in the last step reset in the next one
-            self._was_done = (term[-1] | trunc[-1]).cpu().numpy()
+            if self._device_infos:
+                self._was_done_t = term[-1] | trunc[-1]
+            else:
+                self._was_done = (term[-1] | trunc[-1]).cpu().numpy()
         return out
 
     # -- bookkeeping -----------------------------------------------------------------------------------
@@ -585,6 +663,8 @@ class HipVectorEnv(VectorEnv):
         self._has_reset = True
         if flags is not None:  # keep the host mirror of the pending-autoreset set in step with the device flags
             self._was_done = (np.asarray(flags, dtype=np.uint8) & _native.FLAG_NEEDS_RESET) != 0
+            if self._device_infos:
+                self._was_done_t = self._torch.from_numpy(self._was_done.copy()).to(self._tdev)
 
     def get_rng_state(self) -> np.ndarray:
         """Per-env PCG64 words [N, 4] = {state_hi, state_lo, inc_hi, inc_lo}."""

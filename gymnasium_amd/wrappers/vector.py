@@ -199,8 +199,12 @@ class RecordEpisodeStatistics(VectorWrapper):
             if self._stats_key in infos or f"_{self._stats_key}" in infos:
                 raise ValueError(f"Attempted to add episode stats with key '{self._stats_key}' but this key already exists in info: {list(infos.keys())}")
             infos[self._stats_key], infos[f"_{self._stats_key}"] = stats, dones
-            idx = np.flatnonzero(dones)  # common.py:214-217: the queues take the finished episodes in sub-environment order
-            self.time_queue.extend(stats["t"][idx]), self.return_queue.extend(stats["r"][idx]), self.length_queue.extend(stats["l"][idx])
+            # common.py:214-217: the queues take the finished episodes in sub-environment order.  Device-resident infos (output="torch"): the
+            # queues live on the host, so this wrapper reads the done mask back every step (the env underneath does not synchronise by itself)
+            host = (lambda x: x.cpu().numpy()) if hasattr(dones, "cpu") else (lambda x: x)
+            idx = np.flatnonzero(host(dones))
+            if idx.size:
+                self.time_queue.extend(host(stats["t"])[idx]), self.return_queue.extend(host(stats["r"])[idx]), self.length_queue.extend(host(stats["l"])[idx])
         return obs, rewards, terminations, truncations, infos
 
 

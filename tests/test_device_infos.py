@@ -1,0 +1,81 @@
+"""output="torch": the infos of a step are DEVICE tensors assembled without reading anything back (HipVectorEnv._build_infos_device) --
+x_position / reward terms of the MuJoCo kinds, SAME_STEP final observations, episode statistics.  Checked here against the NumPy dict of
+the same env on the checker backend (whose "device" tensors are host tensors: same code path, no GPU needed); the GPU run of the same
+comparison is tests/test_gpu_mujoco.py::test_device_resident_infos_equal_the_numpy_infos."""
+import numpy as np
+import pytest
+
+import gymnasium_amd
+
+
+def compare_device_infos(env_id, factory, mode, steps=80, **kw):
+    import torch
+
+    common = dict(num_envs=6, autoreset_mode=mode, record_episode_statistics=True, max_episode_steps=30, **kw)
+    extra = {} if factory is None else {"_engine_factory": factory}
+    a = gymnasium_amd.make_vec(env_id, **common, **extra)
+    b = gymnasium_amd.make_vec(env_id, output="torch", **common, **extra)
+    host = lambda x: x.cpu().numpy()  # noqa: E731
+    oa, _ = a.reset(seed=1)
+    ob, _ = b.reset(seed=1)
+    assert np.array_equal(oa, host(ob))
+    a.action_space.seed(0)
+    seen_final = seen_episode = False
+    for t in range(steps):
+        act = a.action_space.sample()
+        ra, rb = a.step(act), b.step(torch.from_numpy(act).to(ob.device))
+        assert np.array_equal(ra[0], host(rb[0])), t
+        ia, ib = ra[4], rb[4]
+        assert all(isinstance(v, (torch.Tensor, dict)) for v in ib.values()), "every info entry is a device tensor"
+        for k, v in ia.items():
+            if k not in ("final_obs", "final_info", "episode"):
+                assert np.array_equal(v, host(ib[k])), (mode, t, k)
+        assert set(ia) <= set(ib), "the device dict has a static key set: a superset of the host dict's"
+        for k in set(ib) - set(ia):  # keys the host dict drops because no sub-env supplied them in this step
+            if k.startswith("_") and not isinstance(ib[k], dict):
+                assert not host(ib[k]).any(), (mode, t, k)
+        if "final_obs" in ia:
+            seen_final = True
+            m = ia["_final_obs"]
+            assert np.array_equal(m, host(ib["_final_obs"]))
+            for i in np.flatnonzero(m):
+                assert np.array_equal(ia["final_obs"][i], host(ib["final_obs"][i]))
+            for k, v in ia["final_info"].items():
+                assert np.array_equal(v, host(ib["final_info"][k])), k
+        if "episode" in ia:
+            seen_episode = True
+            m = ia["_episode"]
+            assert np.array_equal(m, host(ib["_episode"]))
+            assert np.array_equal(ia["episode"]["r"], np.where(m, host(ib["episode"]["r"]), 0.0))
+            assert np.array_equal(ia["episode"]["l"], np.where(m, host(ib["episode"]["l"]), 0))
+            assert (host(ib["episode"]["t"])[m] > 0).all() and (host(ib["episode"]["t"])[~m] == 0).all()
+        else:
+            assert not host(ib["_episode"]).any()
+        d = ra[2] | ra[3]
+        if mode == "Disabled" and d.any():
+            a.reset(options={"reset_mask": d}), b.reset(options={"reset_mask": d})
+    assert seen_episode and (seen_final or mode != "SameStep")
+    assert a.episode_count == b.episode_count > 0
+    a.close(), b.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
+@pytest.mark.parametrize("env_id", ["Hopper-v5", "Ant-v5"])
+def test_device_infos_equal_numpy_infos(env_id, mode, oracle_factory):
+    compare_device_infos(env_id, oracle_factory, mode, steps=80 if env_id == "Hopper-v5" else 45)
+
+
+def test_record_episode_statistics_wrapper_on_device_infos(oracle_factory):
+    import torch
+
+    from gymnasium_amd import wrappers as gw
+
+    a = gw.RecordEpisodeStatistics(gymnasium_amd.make_vec("CartPole-v1", num_envs=5, _engine_factory=oracle_factory))
+    b = gw.RecordEpisodeStatistics(gymnasium_amd.make_vec("CartPole-v1", num_envs=5, output="torch", _engine_factory=oracle_factory))
+    a.reset(seed=2), b.reset(seed=2)
+    a.action_space.seed(1)
+    for _ in range(150):
+        act = a.action_space.sample()
+        a.step(act), b.step(torch.from_numpy(act))
+    assert a.episode_count == b.episode_count > 10
+    assert list(a.return_queue) == list(b.return_queue) and list(a.length_queue) == list(b.length_queue)

@@ -219,3 +219,13 @@ def test_humanoid_solver_choice(env_id, oracle_factory):
         gymnasium_amd.make_vec(env_id, num_envs=1, solver="CG")
     for e in envs.values():
         e.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep"])
+def test_device_resident_infos_equal_the_numpy_infos(mode):
+    """output="torch": the MuJoCo kinds' infos are device tensors assembled without a read-back (no D2H, no synchronisation per step);
+    same values as the NumPy dict of a twin env (tests/test_device_infos.py runs the same comparison on the checker backend)."""
+    from test_device_infos import compare_device_infos
+
+    compare_device_infos("Ant-v5", None, mode, steps=45)
+    compare_device_infos("Hopper-v5", None, mode, steps=80)
