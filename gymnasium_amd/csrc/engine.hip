@@ -264,12 +264,29 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     double rew;
     bool te;
     uint32_t sflags = L.flags;
-    E::step(L.s, sflags, a, d.P, rew, te, L.trig);
-    if (CHECK_ACTION && invalid) {  // rare, divergent: undo
+    if constexpr (E::SPLIT_TERMINAL) {
+        // Acrobot: the terminal test needs cos(theta1) of the NEW state, which the observation evaluates anyway.  Integrate, select the reset
+        // lanes' state, take the observation, then test the terminal condition on it with the observation's trig values: for a stepping lane
+        // the selected state IS its new state (same argument, same function, same bits); a resetting lane's flag is discarded below.
+        E::integrate(L.s, sflags, a, L.trig);
+        if (CHECK_ACTION && invalid) {
 #pragma unroll
-        for (int k = 0; k < E::S; k++) L.s[k] = s0[k];
-        sflags = L.flags, rew = 0.0, te = false;
-        trig_invalidate(L.trig);
+            for (int k = 0; k < E::S; k++) L.s[k] = s0[k];
+            sflags = L.flags;
+        }
+#pragma unroll
+        for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
+        E::obs(L.s, sflags, o.obs, L.trig);
+        E::terminal_after_obs(L.s, L.trig, rew, te);
+        if (CHECK_ACTION && invalid) rew = 0.0, te = false;
+    } else {
+        E::step(L.s, sflags, a, d.P, rew, te, L.trig);
+        if (CHECK_ACTION && invalid) {  // rare, divergent: undo
+#pragma unroll
+            for (int k = 0; k < E::S; k++) L.s[k] = s0[k];
+            sflags = L.flags, rew = 0.0, te = false;
+            trig_invalidate(L.trig);
+        }
     }
     const uint32_t moved = (CHECK_ACTION && invalid) ? 0u : 1u;
     const uint32_t elapsed = L.elapsed + moved;  // TimeLimit.step (wrappers/common.py:129-133)
@@ -277,8 +294,10 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     const double ep_ret = L.ep_ret + rew;
     const int32_t ep_len = L.ep_len + (int32_t)moved;
     const bool done = !resetting && (te || tr);
+    if constexpr (!E::SPLIT_TERMINAL) {
 #pragma unroll
-    for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
+        for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
+    }
     L.flags = resetting ? rflags : (done ? (sflags | kNeedsReset) : sflags);
     L.elapsed = resetting ? 0u : elapsed;
     L.ep_ret = resetting ? 0.0 : ep_ret;
@@ -289,7 +308,7 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     st.episodes += done ? 1u : 0u;
     st.return_sum += done ? ep_ret : 0.0;
     st.length_sum += done ? (uint64_t)ep_len : 0ull;
-    E::obs(L.s, L.flags, o.obs, L.trig);
+    if constexpr (!E::SPLIT_TERMINAL) E::obs(L.s, L.flags, o.obs, L.trig);
     o.reward = resetting ? 0.0 : rew;
     o.terminated = !resetting && te, o.truncated = !resetting && tr;
     o.ep_ret = done ? ep_ret : 0.0, o.ep_len = done ? ep_len : 0;

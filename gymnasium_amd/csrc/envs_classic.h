@@ -149,6 +149,7 @@ struct CartPoleTotalMass {
 template <class M>
 struct CartPoleT {
     typedef M Math;
+    static constexpr bool SPLIT_TERMINAL = false;
     static constexpr bool USES_POW = false, USES_POWF = false;
     typedef CartPoleTotalMass TotalMass;
     static constexpr int S = 4, OBS = 4, N_ACTIONS = 2;
@@ -208,6 +209,7 @@ struct CartPoleT {
 template <class M>
 struct PendulumT {
     typedef M Math;
+    static constexpr bool SPLIT_TERMINAL = false;
     static constexpr bool USES_POW = true, USES_POWF = true;
     static constexpr int S = 2, OBS = 3;
     static constexpr bool DISCRETE = false;
@@ -272,6 +274,7 @@ struct PendulumT {
 template <class M>
 struct AcrobotT {
     typedef M Math;
+    static constexpr bool SPLIT_TERMINAL = true;  // fused rollouts: integrate(), obs(), terminal_after_obs() (engine.hip lane_step_fused)
     static constexpr bool USES_POW = true, USES_POWF = false;
     static constexpr int S = 4, OBS = 6, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
@@ -330,6 +333,16 @@ struct AcrobotT {
     }
     // acrobot.py:202-230 with rk4 (:415-461) over t = [0, 0.2]; the torque component has derivative 0
     static MI_DEV void step(double s[S], uint32_t &flags, Act action, const EnvParams &, double &reward, bool &terminated, Trig &tc) {
+        integrate(s, flags, action, tc);
+        terminated = (-M::cos_bounded(s[0]) - M::cos_bounded(s[1] + s[0])) > 1.0;
+        reward = terminated ? 0.0 : -1.0;
+    }
+    // acrobot.py:239-242 on a state whose observation has just been taken: t holds cos / sin of s[0] and s[1] (the same libm cos of the same argument)
+    static MI_DEV void terminal_after_obs(const double s[S], const Trig &t, double &reward, bool &terminated) {
+        terminated = (-t.c1 - M::cos_bounded(s[1] + s[0])) > 1.0;
+        reward = terminated ? 0.0 : -1.0;
+    }
+    static MI_DEV void integrate(double s[S], uint32_t &flags, Act action, Trig &tc) {
         const double dt = 0.2 - 0, dt2 = dt / 2.0, dt6 = dt / 6.0;
         const double a = action == 0 ? -1.0 : (action == 1 ? 0.0 : 1.0);
         double k1[4], k2[4], k3[4], k4[4], t[4];
@@ -354,8 +367,6 @@ struct AcrobotT {
 #pragma unroll
         for (int i = 0; i < 4; i++) s[i] = ns[i];
         flags &= ~kStateF32;
-        terminated = (-M::cos_bounded(ns[0]) - M::cos_bounded(ns[1] + ns[0])) > 1.0;
-        reward = terminated ? 0.0 : -1.0;
     }
 };
 
@@ -365,6 +376,7 @@ struct AcrobotT {
 template <class M>
 struct MountainCarT {
     typedef M Math;
+    static constexpr bool SPLIT_TERMINAL = false;
     static constexpr bool USES_POW = false, USES_POWF = false;
     static constexpr int S = 2, OBS = 2, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
@@ -409,6 +421,7 @@ struct MountainCarT {
 template <class M>
 struct MountainCarContinuousT {
     typedef M Math;
+    static constexpr bool SPLIT_TERMINAL = false;
     static constexpr bool USES_POW = false, USES_POWF = false;
     static constexpr int S = 2, OBS = 2;
     static constexpr bool DISCRETE = false;

@@ -36,6 +36,9 @@
 #ifndef MJX_CHOL_LDS_FOR_16
 #define MJX_CHOL_LDS_FOR_16 0  // diagnostic switch: 16-lane groups on the LDS-exchange Cholesky as well (costs LDS: 3 instead of 4 wavefronts per CU)
 #endif
+#ifndef MJX_PGS_QS_BY_INVERSE
+#define MJX_PGS_QS_BY_INVERSE 0  // 1: PGS forms qacc_smooth = M^-1 qfrc_smooth as a row product once M^-1 exists instead of by the triangular solves.  MEASURED (r03, profiles/r03_pgs_qs_by_inverse.txt): same results to 1e-15, but the changed control flow takes the 32-lane kernel from 4 to 999 spilled VGPRs and doubles its time -- off
+#endif
 #ifndef MJX_GROUP_SUM_SHFL
 #define MJX_GROUP_SUM_SHFL 0   // diagnostic switch: group reductions as __shfl_xor butterflies instead of DPP rotations
 #endif
@@ -1246,6 +1249,36 @@ struct Sim {
 #pragma unroll
         for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
         chol_factor(bb, r.Hrow, r.idiag, lane);
+#if MJX_PGS_QS_BY_INVERSE
+        // With constraint rows the sweeps need M^-1 explicitly anyway: the unconstrained acceleration is then one row-times-vector product
+        // (one exchange of qfrc_smooth through the blackboard) instead of the 2 NV dependent steps of the triangular solves.
+        double qs;
+        if (!anyrow) {
+            qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
+            r.qacc_smooth = qs, r.qfrc_constraint = 0, r.qacc = qs;
+            MJX_PHASE(r, 8);
+            return;
+        }
+        MJX_PHASE(r, 8);
+        {
+            double minv[NV];
+            invert(bb, r.idiag, lane, minv);
+#pragma unroll
+            for (int j = 0; j < NV; j++) r.Hrow[j] = minv[j];  // r.Hrow = row `lane` of M^-1
+        }
+        if (isdof) bb.A.sol.vdir[lane] = r.qfrc_smooth;
+        coop_sync();
+        qs = 0;
+        if (isdof) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) qs += r.Hrow[j] * bb.A.sol.vdir[j];
+        }
+        coop_sync();
+        if (isdof) bb.A.sol.vdir[lane] = qs;  // (what the solve used to leave there: qacc_smooth for the twist pass below)
+        coop_sync();
+        r.qacc_smooth = qs, r.qfrc_constraint = 0;
+        MJX_PHASE(r, 7);
+#else
         const double qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
         r.qacc_smooth = qs, r.qfrc_constraint = 0;
         MJX_PHASE(r, 8);
@@ -1253,6 +1286,7 @@ struct Sim {
             r.qacc = qs;
             return;
         }
+#endif
         // contact-frame images of qacc_smooth (vdir, left there by the solve) and of the warm start
         double jw[KC][3];
         twist(bb, bb.A.sol.vdir, lane);
@@ -1272,6 +1306,7 @@ struct Sim {
         }
         coop_sync();
         MJX_PHASE(r, 9);
+#if !MJX_PGS_QS_BY_INVERSE
         {
             double minv[NV];
             invert(bb, r.idiag, lane, minv);
@@ -1279,6 +1314,7 @@ struct Sim {
             for (int j = 0; j < NV; j++) r.Hrow[j] = minv[j];  // r.Hrow = row `lane` of M^-1
         }
         MJX_PHASE(r, 7);
+#endif
         const unsigned lm0 = bb.limmask[0], lm1 = bb.limmask[1];
         const int ncon = bb.ncon;
         // ---- rows: diagonal, warm-start force, dual cost pieces --------------------------------------------------------------------

@@ -72,9 +72,12 @@ MI_PW_DEV float from_bitsf(uint32_t u) {
 
 // pow(x, 2.0).  log_tab: kLogTab (or a copy), exp_tab: kExpTab (or a copy)
 MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x) {
+    // Written without data-dependent branches (a wavefront runs alone on its SIMD: every s_cbranch / exec-mask pair is issue slots, and
+    // the special cases below practically never occur): the main path is evaluated on whatever bits arrive -- the table indices are masked,
+    // nothing traps -- and the rare results are selected in at the end.
     const uint64_t ix = bits(x) & 0x7fffffffffffffffull;  // x < 0 with an even integer exponent: pow(|x|, 2), no sign
     const uint32_t topx = (uint32_t)(ix >> 52);
-    if (topx - 1u >= 0x7feu) return x * x;  // 0, subnormal, inf, nan
+    const bool special = topx - 1u >= 0x7feu;  // 0, subnormal, inf, nan: x * x
     // log_inline
     const uint64_t tmp = ix - 0x3fe6955500000000ull;
     const int i = (int)((tmp >> 45) & 127);
@@ -97,14 +100,14 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     const double lhi = hi + lo;
     const double ltail = (hi - lhi) + lo;
     // y log(x) with y = 2
+    // (e_pow.c: ehi = y * lhi, elo = y * ltail + fma(y, lhi, -ehi); with y = 2 the product is exact, the inner fma is +0 and adding it
+    //  changes no bit that survives the addition to rr below)
     const double ehi = 2.0 * lhi;
-    const double elo = fma_(2.0, ltail, fma_(lhi, 2.0, -ehi));
+    const double elo = 2.0 * ltail;
     // exp_inline
     const uint32_t abstop = (uint32_t)(bits(ehi) >> 52) & 0x7ffu;
-    if (abstop - 0x3c9u >= 0x3fu) {
-        if (abstop < 0x3c9u) return 1.0 + ehi;  // |2 log x| < 2^-54: x is 1 to working precision
-        return x * x;                           // |2 log x| >= 512: over / underflow range, never reached by the environments
-    }
+    const bool tiny = abstop < 0x3c9u;                                 // |2 log x| < 2^-54: x is 1 to working precision: 1.0 + ehi
+    const bool huge = abstop - 0x3c9u >= 0x3fu && !tiny;               // |2 log x| >= 512: over / underflow range (never reached by the environments): x * x
     const double zz = fma_k(ehi, MI_EXP_INVLN2N, MI_EXP_SHIFT);
     const uint64_t ki = bits(zz);
     const double kdd = zz - MI_EXP_SHIFT;
@@ -120,13 +123,15 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     const double s1 = fma_(q23, r2, rr + tail);
     const double tmp2 = fma_(q45, r2 * r2, s1);
     const double scale = from_bits(sbits);
-    return fma_(tmp2, scale, scale);
+    double res = fma_(tmp2, scale, scale);
+    res = tiny ? 1.0 + ehi : res;
+    return (special || huge) ? x * x : res;
 }
 
 // powf(x, 2.0f).  log2_tab: kLog2fTab (or a copy), exp2_tab: kExp2fTab (or a copy)
 MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float x) {
     const uint32_t ix = bitsf(x) & 0x7fffffffu;
-    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return x * x;  // 0, subnormal, inf, nan
+    const bool special = ix - 0x00800000u >= 0x7f800000u - 0x00800000u;  // 0, subnormal, inf, nan: x * x (selected at the end, see square())
     const uint32_t tmp = ix - 0x3f330000u;
     const int i = (int)((tmp >> 19) & 15);
     const uint32_t top = tmp & 0xff800000u;
@@ -140,7 +145,7 @@ MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float 
     q = fma_(r2, a23, q);
     const double logx = fma_(a01, r2 * r2, q);
     const double ylogx = 2.0 * logx;
-    if (((bits(ylogx) >> 47) & 0xffffu) > 0x80beu) return x * x;  // |y log2 x| >= 126: over / underflow range
+    const bool huge = ((bits(ylogx) >> 47) & 0xffffu) > 0x80beu;  // |y log2 x| >= 126: over / underflow range: x * x
     // exp2_inline
     const double kdd0 = ylogx + MI_EXP2F_SHIFT_SCALED;
     const uint64_t ki = bits(kdd0);
@@ -151,7 +156,8 @@ MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float 
     const double rr2 = rr * rr;
     const double y2 = fma_k(rr, kExp2fPoly[2], 1.0);
     const double y3 = fma_(zq, rr2, y2);
-    return (float)(y3 * from_bits(t));
+    const float res = (float)(y3 * from_bits(t));
+    return (special || huge) ? x * x : res;
 }
 
 }  // namespace mi_pow

@@ -294,6 +294,90 @@ MI_SC_DEV void sincos_main(const double *T6, double x, double &sn_out, double &c
     rs = ax < 0.126 ? rt : rs;
     sn_out = copysign_(rs, x);
 }
+// sin AND cos of one argument in any range (|x| < 105414350), branch-free, for lanes spread over all ranges (Pendulum's and Acrobot's angles).
+// Whatever the range, glibc evaluates exactly ONE do_sin and ONE do_cos between the two results:
+//   |x| < 0.855469:  sin = do_sin(x, 0),                         cos = do_cos(x, 0)
+//   |x| < 2.426265:  sin = +-do_cos(pi/2 - |x|, lo),             cos = do_sin(two-sum of the same)
+//   beyond:          x = n pi/2 + (b + db):  n even: sin = +-do_sin(b, db), cos = +-do_cos(b, db);  n odd: the two swap roles
+// so the pair costs one shared reduction, one dedicated do_sin stream (TAYLOR_SIN selected in) and one dedicated do_cos stream -- none of the
+// role selects the one-function core() above needs -- and two output selects.  Same operations on the same operands as sin_bf / cos_bf.
+MI_SC_DEV double do_sin_bf(const double *T6, double a, double da) {
+    const double ax = fabs(a);
+    const double u = kBig + ax;
+    const double x0 = ax - (u - kBig);
+    const int idx = (int)(uint32_t)bits(u) * 6;
+    const double sn = T6[idx], ssn = T6[idx + 1], cs = T6[idx + 2], ccs = T6[idx + 3];
+    const double dxs = (a <= 0) ? -da : da;
+    const double xx = x0 * x0;
+    const double q = fma_k(xx, kSn5, kSn3);
+    const double si = fma_(x0 * xx, q, dxs);
+    const double sv = x0 + si;
+    double c0 = fma_k(xx, kCs6, kCs4);
+    c0 = fma_k(xx, c0, kCs2);
+    const double c = fma_(x0, dxs, xx * c0);
+    double cor = fma_(sv, ccs, ssn);
+    cor = fma_(-c, sn, cor);
+    cor = fma_(sv, cs, cor);
+    double res = sn + cor;
+    const double axx = a * a;
+    double tp = fma_k(axx, kS5, kS4);
+    tp = fma_k(axx, tp, kS3), tp = fma_k(axx, tp, kS2), tp = fma_k(axx, tp, kS1);
+    const double t1 = fma_(a, tp, -(0.5 * da));
+    const double rt = a + fma_(t1, axx, da);
+    res = ax < 0.126 ? rt : res;
+    return copysign_(res, a);
+}
+MI_SC_DEV double do_cos_bf(const double *T6, double a, double da) {
+    const double ax = fabs(a);
+    const double u = kBig + ax;
+    const double dxs = (a < 0) ? -da : da;
+    const double xr = (ax - (u - kBig)) + dxs;
+    const int idx = (int)(uint32_t)bits(u) * 6;
+    const double sn = T6[idx], ssn = T6[idx + 1], cs = T6[idx + 2], ccs = T6[idx + 3];
+    const double xx = xr * xr;
+    const double q = fma_k(xx, kSn5, kSn3);
+    const double sv = fma_(xr * xx, q, xr);
+    double c0 = fma_k(xx, kCs6, kCs4);
+    c0 = fma_k(xx, c0, kCs2);
+    const double c = xx * c0;
+    double cor = fma_(-sv, ssn, ccs);
+    cor = fma_(-c, cs, cor);
+    cor = fma_(-sv, sn, cor);
+    return cs + cor;
+}
+template <bool BOUNDED = false>
+MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &cs_out) {
+    const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
+    if (!BOUNDED && __builtin_expect(k >= 0x419921fbu, 0)) {
+        sn_out = sin(x), cs_out = cos(x);
+        return;
+    }
+    const double ax = fabs(x);
+    // |x| >= 2.426265: n pi/2 + (b + db)
+    const double t = fma_k(x, kHpInv, kToInt);
+    const double xn = t - kToInt;
+    const uint32_t n = (uint32_t)bits(t);
+    double y = fma_(-xn, kMp1, x);
+    y = fma_(-xn, kMp2, y);
+    const double t2 = fma_(-xn, kPp3, y);
+    const double db = fma_(-kPp3, xn, y - t2);
+    const double b = fma_(-xn, kPp4, t2);
+    const double db2 = fma_(-xn, kPp4, t2 - b);
+    // 0.855469 <= |x| < 2.426265
+    const double ym = kHp0 - ax;
+    const double am = ym + kHp1;
+    const double dam = (ym - am) + kHp1;
+    const bool main = k < 0x3feb6000u, mid = k < 0x400368fdu;
+    const double as = main ? x : (mid ? am : b), das = main ? 0.0 : (mid ? dam : db + db2);
+    const double ac = main ? x : (mid ? ym : b), dac = main ? 0.0 : (mid ? kHp1 : db + db2);
+    const double S = do_sin_bf(T6, as, das), C = do_cos_bf(T6, ac, dac);
+    const bool swap = main ? false : (mid ? true : (n & 1u) != 0);
+    const bool neg_s = main ? false : (mid ? (x < 0) : (n & 2u) != 0);
+    const bool neg_c = (main || mid) ? false : ((n + 1u) & 2u) != 0;
+    const double sv = swap ? C : S, cv = swap ? S : C;
+    sn_out = neg_s ? -sv : sv, cs_out = neg_c ? -cv : cv;
+}
+
 // MAIN_FIRST: the arguments of all lanes are expected inside |x| < 0.855469 (CartPole), worth a wavefront-uniform test for the short routine
 template <bool BOUNDED = false, bool MAIN_FIRST = true>
 MI_SC_DEV void sincos_bf(const double *T6, double x, double &sn_out, double &cs_out) {
@@ -301,7 +385,7 @@ MI_SC_DEV void sincos_bf(const double *T6, double x, double &sn_out, double &cs_
     if (MAIN_FIRST && k < 0x3feb6000u) {
         sincos_main(T6, x, sn_out, cs_out);
     } else {
-        sn_out = sin_bf<BOUNDED>(T6, x), cs_out = cos_bf<BOUNDED>(T6, x);
+        sincos_pair<BOUNDED>(T6, x, sn_out, cs_out);
     }
 }
 

@@ -31,6 +31,11 @@ __attribute__((visibility("default"))) void sincos_bf_batch(const double *x, dou
     const double *t6 = table6();
     for (long i = 0; i < n; i++) mi_sincos::sincos_bf(t6, x[i], s[i], c[i]);
 }
+// the one-reduction sin + cos of any range (Pendulum / Acrobot observations and dynamics)
+__attribute__((visibility("default"))) void sincos_pair_batch(const double *x, double *s, double *c, long n) {
+    const double *t6 = table6();
+    for (long i = 0; i < n; i++) mi_sincos::sincos_pair<true>(t6, x[i], s[i], c[i]);
+}
 __attribute__((visibility("default"))) void table_copy(double *out) {
     for (int i = 0; i < 440; i++) out[i] = mi_sincos::kTable[i];
 }

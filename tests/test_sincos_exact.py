@@ -41,10 +41,10 @@ def run(fn, x):
     return out
 
 
-def run_sincos(x):
+def run_sincos(x, fn="sincos_bf_batch"):
     x = np.ascontiguousarray(x, dtype=np.float64)
     s, c = np.empty_like(x), np.empty_like(x)
-    lib().sincos_bf_batch(x.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), C.c_long(x.size))
+    getattr(lib(), fn)(x.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), C.c_long(x.size))
     return s, c
 
 
@@ -59,6 +59,8 @@ def check_all_forms(x):
     inside = ~(np.abs(x) >= 105414336.0)  # high word 0x419921fb: beyond it the header defers to the platform's sin / cos, which the host compiler fuses into one sincos() call
     s, c = run_sincos(x[inside])
     assert same_bits(s, rs[inside]) and same_bits(c, rc[inside]), "merged sincos"
+    s, c = run_sincos(x[inside], "sincos_pair_batch")
+    assert same_bits(s, rs[inside]) and same_bits(c, rc[inside]), "one-reduction sincos pair (every range)"
 
 
 def same_bits(a, b):
