@@ -218,11 +218,14 @@ def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150
 
 
 def recorded_traffic(env_id, N, inner):
+    """(bytes per launch, provenance) from profiles/pmc_traffic.json -- PMC passes of an earlier run of the same command; the file's
+    `_recorded_at` names the commit / round whose kernels were profiled (a later kernel change does not update it by itself)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(path)).get(f"{env_id}:{N}:{inner}")
+        rec = json.load(open(path))
+        return rec.get(f"{env_id}:{N}:{inner}"), rec.get("_recorded_at", "unstamped")
     except Exception:
-        return None
+        return None, None
 
 
 # ---- one configuration on this rank's GPU --------------------------------------------------------------------------------------
@@ -329,9 +332,8 @@ class Config:
         if traffic is not None:
             traffic *= per
         else:
-            traffic, src = recorded_traffic(self.env_id, self.N, self.inner), "profiles/pmc_traffic.json (recorded by an earlier rocprofv3 run of the same command; no live pass in this run)"
-            if traffic is None:
-                src = None
+            traffic, stamp = recorded_traffic(self.env_id, self.N, self.inner)
+            src = None if traffic is None else f"profiles/pmc_traffic.json, recorded at {stamp} by a rocprofv3 run of the same command (no live pass in this run)"
         base = {"kernel": kernel, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": kernel_s * 1e3,
                 "traffic_over_algorithmic": (traffic / algo) if traffic else None}
         if coop:
@@ -345,6 +347,9 @@ class Config:
         self.env.close()
 
 
+T_START = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,8 +360,10 @@ def main():
     ap.add_argument("--inner", type=int, default=128, help="vector steps fused into one launch (one bench step)")
     ap.add_argument("--sustained", type=float, default=1.5, help="seconds of back-to-back launches for sustained_value (0 = skip)")
     ap.add_argument("--pmc", choices=["auto", "full", "off"], default="auto",
-                    help="live rocprofv3 counter passes on a child invocation: auto = primary traffic + SQ activity of the MuJoCo secondaries, "
-                         "full = traffic for every line, off = recorded values only")
+                    help="live rocprofv3 counter passes on a child invocation: auto = primary traffic, then SQ activity of the MuJoCo secondaries and live "
+                         "traffic of every secondary while the run is younger than --pmc-budget seconds (recorded values, stamped with the profile's "
+                         "commit, after that); full = everything live; off = recorded values only")
+    ap.add_argument("--pmc-budget", type=float, default=150.0, help="auto: no further live traffic passes for the secondaries once the run is this old (s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the per-launch step() API measurements")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (BASELINE.json configs[2..4])")
@@ -570,8 +577,10 @@ def main():
             v2, k2, ks2, el2 = steady(c2)
             line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "sustained_value": v2, "seconds": el2,
                     "unit": "env-steps/s", "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64"}
-            # auto: one SQ-activity pass for the VALU-bound MuJoCo kernels (their traffic ratio from the recorded profile); full: everything live
-            want = ("traffic", "sq") if args.pmc == "full" else (("sq",) if (args.pmc == "auto" and env_id in MJ_COOP) else ())
+            # full: everything live.  auto: the SQ-activity pass for the VALU-bound MuJoCo kernels, and live FETCH / WRITE passes too while
+            # the run is young enough (each pass is a child process of ~5-10 s); after that the recorded profile's value, stamped as such
+            young = (time.perf_counter() - T_START) < args.pmc_budget
+            want = ("traffic", "sq") if args.pmc == "full" else ((("traffic",) if young else ()) + (("sq",) if env_id in MJ_COOP else ()) if args.pmc == "auto" else ())
             line["roofline"] = c2.roofline(ks2, want)
             c2.close()
             opt = {"fast_math": True} if env_id in STEP_BYTES else ({"solver": "Newton"} if env_id in ("Humanoid-v5", "HumanoidStandup-v5") else None)

@@ -11,11 +11,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {  # translation unit -> the headers it depends on
-    "engine.hip": ["envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", "ziggurat_tables.h",
+    "engine.hip": ["envs_classic.h", "sincos_exact.h", "sincos_table.h", "pow_exact.h", "pow_tables.h", "wrappers_internal.h", "mjx_physics.h", "pcg64_dev.h",
+                   "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", "ziggurat_tables.h",
                    os.path.join("generated", "mjx_models.h"), os.path.join("..", "..", "include", "mi355env.h")],
-    "physics16.hip": ["mjx_physics.h", "envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", os.path.join("generated", "mjx_models.h")],
-    "physics32.hip": ["mjx_physics.h", "envs_classic.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", os.path.join("generated", "mjx_models.h")],
-    "wrappers.hip": [os.path.join("..", "..", "include", "mi355env.h")],
+    "physics16.hip": ["mjx_physics.h", "envs_classic.h", "sincos_exact.h", "pow_exact.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", os.path.join("generated", "mjx_models.h")],
+    "physics32.hip": ["mjx_physics.h", "envs_classic.h", "sincos_exact.h", "pow_exact.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", os.path.join("generated", "mjx_models.h")],
+    "wrappers.hip": ["wrappers_internal.h", os.path.join("..", "..", "include", "mi355env.h")],
 }
 OUT = os.path.join(HERE, "libmi355env.so")
 ARCH = "gfx950"

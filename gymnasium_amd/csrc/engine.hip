@@ -1307,12 +1307,20 @@ struct mi_vecenv {
 
 namespace {
 
+template <class M>
+struct AcrobotMath {
+    typedef M type;
+};
+template <>
+struct AcrobotMath<ExactMath> {
+    typedef ExactMathBuiltinFma type;
+};
 template <class M, class F>
 int dispatch_kind_math(int kind, F &&f) {
     switch (kind) {
     case MI_ENV_CARTPOLE: return f(CartPoleT<M>());
     case MI_ENV_PENDULUM: return f(PendulumT<M>());
-    case MI_ENV_ACROBOT: return f(AcrobotT<M>());
+    case MI_ENV_ACROBOT: return f(AcrobotT<typename AcrobotMath<M>::type>());  // (exact math: without the inline-asm Horner steps, envs_classic.h)
     case MI_ENV_MOUNTAIN_CAR: return f(MountainCarT<M>());
     case MI_ENV_MOUNTAIN_CAR_CONTINUOUS: return f(MountainCarContinuousT<M>());
     }

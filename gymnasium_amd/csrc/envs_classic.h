@@ -38,7 +38,9 @@ static __shared__ uint64_t g_pow_exp[256];
 static __shared__ double g_powf_log2[32];
 static __shared__ uint64_t g_powf_exp2[32];
 
-struct ExactMath {
+// KASM: constant Horner steps as inline-asm v_fma_f64 (sincos_exact.h fma_k); false for kernels whose registers overflow into AGPRs
+template <bool KASM>
+struct ExactMathT {
     static constexpr bool EXACT = true;
     template <bool POW, bool POWF>
     static MI_DEV void init() {
@@ -52,18 +54,20 @@ struct ExactMath {
         }
         __syncthreads();
     }
-    static MI_DEV double sin(double x) { return mi_sincos::sin_bf(g_trig6, x); }
-    static MI_DEV double cos(double x) { return mi_sincos::cos_bf(g_trig6, x); }
-    static MI_DEV void sincos(double x, double &s, double &c) { mi_sincos::sincos_bf(g_trig6, x, s, c); }
-    static MI_DEV void sincos_spread(double x, double &s, double &c) { mi_sincos::sincos_bf<false, false>(g_trig6, x, s, c); }  // any range, no small-angle short cut
+    static MI_DEV double sin(double x) { return mi_sincos::sin_bf<false, KASM>(g_trig6, x); }
+    static MI_DEV double cos(double x) { return mi_sincos::cos_bf<false, KASM>(g_trig6, x); }
+    static MI_DEV void sincos(double x, double &s, double &c) { mi_sincos::sincos_bf<false, true, KASM>(g_trig6, x, s, c); }
+    static MI_DEV void sincos_spread(double x, double &s, double &c) { mi_sincos::sincos_bf<false, false, KASM>(g_trig6, x, s, c); }  // any range, no small-angle short cut
     // for angles the environment wraps or clips (|x| far below 1e8): no hand-over to the platform's huge-argument routine, and lanes
     // spread over all ranges (no wavefront-uniform short cut)
-    static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true>(g_trig6, x); }
-    static MI_DEV double cos_bounded(double x) { return mi_sincos::cos_bf<true>(g_trig6, x); }
-    static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false>(g_trig6, x, s, c); }
-    static MI_DEV double sq(double x) { return mi_pow::square(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
-    static MI_DEV float sqf(float x) { return mi_pow::squaref(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2
+    static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true, KASM>(g_trig6, x); }
+    static MI_DEV double cos_bounded(double x) { return mi_sincos::cos_bf<true, KASM>(g_trig6, x); }
+    static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false, KASM>(g_trig6, x, s, c); }
+    static MI_DEV double sq(double x) { return mi_pow::square<KASM>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
+    static MI_DEV float sqf(float x) { return mi_pow::squaref<KASM>(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2
 };
+typedef ExactMathT<true> ExactMath;
+typedef ExactMathT<false> ExactMathBuiltinFma;  // Acrobot: its kernels use AGPRs (see sincos_exact.h fma_k)
 struct FastMath {
     static constexpr bool EXACT = false;
     template <bool POW, bool POWF>
@@ -78,7 +82,7 @@ struct FastMath {
             ::sincos(x, &sn, &cs);
             return;
         }
-        using mi_sincos::fma_k;
+        auto fma_k = [](double a, double b, double c) { return mi_sincos::fma_k<true>(a, b, c); };
         const double z = x * x;
         const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                      S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
@@ -274,7 +278,12 @@ struct PendulumT {
 template <class M>
 struct AcrobotT {
     typedef M Math;
-    static constexpr bool SPLIT_TERMINAL = true;  // fused rollouts: integrate(), obs(), terminal_after_obs() (engine.hip lane_step_fused)
+    // This environment's kernels need ~290 live registers: the compiler parks the overflow in AGPRs (v_accvgpr_read / write in the loop).  They
+    // are instantiated with ExactMathBuiltinFma (engine.hip AcrobotMath): no inline-asm Horner steps next to AGPR traffic (sincos_exact.h fma_k).
+#ifndef MI_ACROBOT_SPLIT_TERMINAL
+#define MI_ACROBOT_SPLIT_TERMINAL 1
+#endif
+    static constexpr bool SPLIT_TERMINAL = MI_ACROBOT_SPLIT_TERMINAL != 0;  // fused rollouts: integrate(), obs(), terminal_after_obs() (engine.hip lane_step_fused)
     static constexpr bool USES_POW = true, USES_POWF = false;
     static constexpr int S = 4, OBS = 6, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
@@ -491,7 +500,7 @@ struct MountainCarContinuousT {
 
 typedef CartPoleT<ExactMath> CartPole;
 typedef PendulumT<ExactMath> Pendulum;
-typedef AcrobotT<ExactMath> Acrobot;
+typedef AcrobotT<ExactMathBuiltinFma> Acrobot;
 typedef MountainCarT<ExactMath> MountainCar;
 typedef MountainCarContinuousT<ExactMath> MountainCarContinuous;
 

@@ -39,14 +39,20 @@ MI_PW_TABLE const uint64_t kExp2fTab[32] = {MI_EXP2F_TAB_VALUES};
 MI_PW_TABLE const double kExp2fPoly[3] = {MI_EXP2F_POLY_VALUES};
 
 MI_PW_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// a Horner step with constant multiplier and addend as ONE v_fma_f64 with register operands (see sincos_exact.h fma_k)
-#if defined(__HIP_DEVICE_COMPILE__)
+// a Horner step with constant multiplier and addend as ONE v_fma_f64 with register operands; KASM = false: the builtin (see sincos_exact.h fma_k)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_NO_FMA_K)
+template <bool KASM = true>
 MI_PW_DEV double fma_k(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    if constexpr (KASM) {
+        double r;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    } else {
+        return __builtin_fma(a, b, c);
+    }
 }
 #else
+template <bool KASM = true>
 MI_PW_DEV double fma_k(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #endif
 MI_PW_DEV uint64_t bits(double x) {
@@ -71,6 +77,7 @@ MI_PW_DEV float from_bitsf(uint32_t u) {
 }
 
 // pow(x, 2.0).  log_tab: kLogTab (or a copy), exp_tab: kExpTab (or a copy)
+template <bool KASM = true>
 MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x) {
     // Written without data-dependent branches (a wavefront runs alone on its SIMD: every s_cbranch / exec-mask pair is issue slots, and
     // the special cases below practically never occur): the main path is evaluated on whatever bits arrive -- the table indices are masked,
@@ -94,7 +101,7 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     const double hi = t2 + ar2;
     const double lo3 = fma_(ar, r, -ar2);
     const double lo4 = (t2 - hi) + ar2;
-    const double pa = fma_k(r, kLogPoly[2], kLogPoly[1]), pb = fma_k(r, kLogPoly[4], kLogPoly[3]), pc = fma_k(r, kLogPoly[6], kLogPoly[5]);
+    const double pa = fma_k<KASM>(r, kLogPoly[2], kLogPoly[1]), pb = fma_k<KASM>(r, kLogPoly[4], kLogPoly[3]), pc = fma_k<KASM>(r, kLogPoly[6], kLogPoly[5]);
     const double p = fma_(ar2, fma_(pc, ar2, pb), pa);
     const double lo = fma_(ar3, p, ((lo1 + lo2) + lo3) + lo4);
     const double lhi = hi + lo;
@@ -108,7 +115,7 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     const uint32_t abstop = (uint32_t)(bits(ehi) >> 52) & 0x7ffu;
     const bool tiny = abstop < 0x3c9u;                                 // |2 log x| < 2^-54: x is 1 to working precision: 1.0 + ehi
     const bool huge = abstop - 0x3c9u >= 0x3fu && !tiny;               // |2 log x| >= 512: over / underflow range (never reached by the environments): x * x
-    const double zz = fma_k(ehi, MI_EXP_INVLN2N, MI_EXP_SHIFT);
+    const double zz = fma_k<KASM>(ehi, MI_EXP_INVLN2N, MI_EXP_SHIFT);
     const uint64_t ki = bits(zz);
     const double kdd = zz - MI_EXP_SHIFT;
     double rr = fma_(kdd, MI_EXP_NEGLN2HIN, ehi);
@@ -117,9 +124,9 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     const int idx = 2 * (int)(ki & 127);
     const uint64_t sbits = exp_tab[idx + 1] + (ki << 45);
     const double tail = from_bits(exp_tab[idx]);
-    const double q23 = fma_k(rr, kExpPoly[1], kExpPoly[0]);
+    const double q23 = fma_k<KASM>(rr, kExpPoly[1], kExpPoly[0]);
     const double r2 = rr * rr;
-    const double q45 = fma_k(rr, kExpPoly[3], kExpPoly[2]);
+    const double q45 = fma_k<KASM>(rr, kExpPoly[3], kExpPoly[2]);
     const double s1 = fma_(q23, r2, rr + tail);
     const double tmp2 = fma_(q45, r2 * r2, s1);
     const double scale = from_bits(sbits);
@@ -129,6 +136,7 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
 }
 
 // powf(x, 2.0f).  log2_tab: kLog2fTab (or a copy), exp2_tab: kExp2fTab (or a copy)
+template <bool KASM = true>
 MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float x) {
     const uint32_t ix = bitsf(x) & 0x7fffffffu;
     const bool special = ix - 0x00800000u >= 0x7f800000u - 0x00800000u;  // 0, subnormal, inf, nan: x * x (selected at the end, see square())
@@ -139,7 +147,7 @@ MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float 
     const double invc = log2_tab[2 * i], logc = log2_tab[2 * i + 1];
     const double r = fma_(z, invc, -1.0);
     const double y0 = logc + kd;
-    const double a01 = fma_k(r, kLog2fPoly[0], kLog2fPoly[1]), a23 = fma_k(r, kLog2fPoly[2], kLog2fPoly[3]);
+    const double a01 = fma_k<KASM>(r, kLog2fPoly[0], kLog2fPoly[1]), a23 = fma_k<KASM>(r, kLog2fPoly[2], kLog2fPoly[3]);
     const double r2 = r * r;
     double q = fma_(r, kLog2fPoly[4], y0);
     q = fma_(r2, a23, q);
@@ -152,9 +160,9 @@ MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float 
     const double kdd = kdd0 - MI_EXP2F_SHIFT_SCALED;
     const double rr = ylogx - kdd;
     const uint64_t t = exp2_tab[ki & 31] + (ki << 47);
-    const double zq = fma_k(rr, kExp2fPoly[0], kExp2fPoly[1]);
+    const double zq = fma_k<KASM>(rr, kExp2fPoly[0], kExp2fPoly[1]);
     const double rr2 = rr * rr;
-    const double y2 = fma_k(rr, kExp2fPoly[2], 1.0);
+    const double y2 = fma_k<KASM>(rr, kExp2fPoly[2], 1.0);
     const double y3 = fma_(zq, rr2, y2);
     const float res = (float)(y3 * from_bits(t));
     return (special || huge) ? x * x : res;

@@ -46,13 +46,24 @@ MI_SC_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b,
 // the same fused multiply-add for a Horner step whose multiplier AND addend are constants: on the device one v_fma_f64 with all three
 // operands in VGPRs.  Left to itself the compiler copies the constant addend into a fresh register pair and accumulates into the copy
 // (v_mov_b64 + v_fmac_f64, two issue slots in loops that are issue-bound); this way the coefficients stay in registers across a rollout loop.
-#if defined(__HIP_DEVICE_COMPILE__)
+// KASM = false: the plain builtin.  Inline asm is opaque to the compiler's hazard recognizer (GCNHazardRecognizer only protects the
+// instructions it emitted itself); round 3 met a kernel -- Acrobot's fused rollout, the only classic kernel whose live values overflow into
+// AGPRs (v_accvgpr_read / write around the asm) -- whose results with the asm form were NOT reproducible from launch to launch (1-ulp
+// float32 flips in 15 % of the lanes, one hang) and with the builtin were.  So the asm form is used only by kernels that stay inside the
+// VGPR file (tests/test_kernel_resources.py pins that), Acrobot takes the builtin.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_NO_FMA_K)
+template <bool KASM = true>
 MI_SC_DEV double fma_k(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    if constexpr (KASM) {
+        double r;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    } else {
+        return __builtin_fma(a, b, c);
+    }
 }
 #else
+template <bool KASM = true>
 MI_SC_DEV double fma_k(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #endif
 MI_SC_DEV uint64_t bits(double x) {
@@ -184,6 +195,7 @@ MI_SC_DEV void expand6(const double *T4, double *T6, int entry) {
 }
 MI_SC_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 
+template <bool KASM = true>
 MI_SC_DEV double core(const double *T6, double a, double da, bool cm) {
     const double ax = fabs(a);
     const double u = kBig + ax;
@@ -194,11 +206,11 @@ MI_SC_DEV double core(const double *T6, double a, double da, bool cm) {
     const double dxs = flip ? -da : da;
     const double xr = cm ? x0 + dxs : x0;
     const double xx = xr * xr;
-    const double poly_s = fma_k(xx, kSn5, kSn3);
+    const double poly_s = fma_k<KASM>(xx, kSn5, kSn3);
     const double tt = fma_(xr * xx, poly_s, sel(cm, xr, dxs));
     const double s = cm ? -tt : xr + tt;  // cos: -s with s = fma(xr^3, q, xr);  sin: s = xr + fma(xr^3, q, dx)
-    double c0 = fma_k(xx, kCs6, kCs4);
-    c0 = fma_k(xx, c0, kCs2);
+    double c0 = fma_k<KASM>(xx, kCs6, kCs4);
+    c0 = fma_k<KASM>(xx, c0, kCs2);
     const double xc = xx * c0;
     const double c = cm ? xc : fma_(xr, dxs, xc);
     double cor = fma_(s, qq, pp);
@@ -207,8 +219,8 @@ MI_SC_DEV double core(const double *T6, double a, double da, bool cm) {
     double res = p + cor;
     // TAYLOR_SIN for the sin of |a| < 0.126 (signed a, dx as given)
     const double axx = a * a;
-    double tp = fma_k(axx, kS5, kS4);
-    tp = fma_k(axx, tp, kS3), tp = fma_k(axx, tp, kS2), tp = fma_k(axx, tp, kS1);
+    double tp = fma_k<KASM>(axx, kS5, kS4);
+    tp = fma_k<KASM>(axx, tp, kS3), tp = fma_k<KASM>(axx, tp, kS2), tp = fma_k<KASM>(axx, tp, kS1);
     const double t1 = fma_(a, tp, -(0.5 * da));
     const double rt = a + fma_(t1, axx, da);
     res = (!cm && ax < 0.126) ? rt : res;
@@ -216,11 +228,12 @@ MI_SC_DEV double core(const double *T6, double a, double da, bool cm) {
 }
 
 // reduced argument of sin(x) (want_cos = false) or cos(x) (true) for |x| < 105414350
+template <bool KASM = true>
 MI_SC_DEV void prep(double x, bool want_cos, double &a, double &da, bool &cm, bool &neg) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     const double ax = fabs(x);
     // |x| >= 2.426265: n pi/2 + (b + db)
-    const double t = fma_k(x, kHpInv, kToInt);
+    const double t = fma_k<KASM>(x, kHpInv, kToInt);
     const double xn = t - kToInt;
     const uint32_t n = ((uint32_t)bits(t) + (want_cos ? 1u : 0u)) & 3u;
     double y = fma_(-xn, kMp1, x);
@@ -242,29 +255,30 @@ MI_SC_DEV void prep(double x, bool want_cos, double &a, double &da, bool &cm, bo
 
 // BOUNDED: the caller guarantees |x| < 105414336 (an angle that the environment wraps or clips), so the hand-over to the platform's sin / cos
 // for huge arguments -- a test, a branch and a page of never-executed code per call site -- is left out.
-template <bool BOUNDED = false>
+template <bool BOUNDED = false, bool KASM = true>
 MI_SC_DEV double sin_bf(const double *T6, double x) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (!BOUNDED && __builtin_expect(k >= 0x419921fbu, 0)) return sin(x);
     double a, da;
     bool cm, neg;
-    prep(x, false, a, da, cm, neg);
-    const double r = core(T6, a, da, cm);
+    prep<KASM>(x, false, a, da, cm, neg);
+    const double r = core<KASM>(T6, a, da, cm);
     return neg ? -r : r;
 }
-template <bool BOUNDED = false>
+template <bool BOUNDED = false, bool KASM = true>
 MI_SC_DEV double cos_bf(const double *T6, double x) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (!BOUNDED && __builtin_expect(k >= 0x419921fbu, 0)) return cos(x);
     double a, da;
     bool cm, neg;
-    prep(x, true, a, da, cm, neg);
-    const double r = core(T6, a, da, cm);
+    prep<KASM>(x, true, a, da, cm, neg);
+    const double r = core<KASM>(T6, a, da, cm);
     return neg ? -r : r;
 }
 
 // sin and cos of the same |x| < 0.855469 (CartPole's pole angle: the episode ends at 0.2095): one index, one table read, shared polynomials.
 // With dx = 0 the additions of +-0 in do_sin / do_cos drop out (they change at most the sign of a zero that is then added to a non-zero).
+template <bool KASM = true>
 MI_SC_DEV void sincos_main(const double *T6, double x, double &sn_out, double &cs_out) {
     const double ax = fabs(x);
     const double u = kBig + ax;
@@ -272,12 +286,12 @@ MI_SC_DEV void sincos_main(const double *T6, double x, double &sn_out, double &c
     const int idx = (int)(uint32_t)bits(u) * 6;
     const double sn = T6[idx], ssn = T6[idx + 1], cs = T6[idx + 2], ccs = T6[idx + 3];
     const double xx = xr * xr;
-    const double poly_s = fma_k(xx, kSn5, kSn3);
+    const double poly_s = fma_k<KASM>(xx, kSn5, kSn3);
     const double x3 = xr * xx;
     const double s_sin = xr + x3 * poly_s;
     const double s_cos = fma_(x3, poly_s, xr);
-    double c0 = fma_k(xx, kCs6, kCs4);
-    c0 = fma_k(xx, c0, kCs2);
+    double c0 = fma_k<KASM>(xx, kCs6, kCs4);
+    c0 = fma_k<KASM>(xx, c0, kCs2);
     const double c = xx * c0;
     double cor = fma_(s_sin, ccs, ssn);
     cor = fma_(-c, sn, cor);
@@ -288,8 +302,8 @@ MI_SC_DEV void sincos_main(const double *T6, double x, double &sn_out, double &c
     cc = fma_(-s_cos, sn, cc);
     cs_out = cs + cc;
     const double axx = x * x;
-    double tp = fma_k(axx, kS5, kS4);
-    tp = fma_k(axx, tp, kS3), tp = fma_k(axx, tp, kS2), tp = fma_k(axx, tp, kS1);
+    double tp = fma_k<KASM>(axx, kS5, kS4);
+    tp = fma_k<KASM>(axx, tp, kS3), tp = fma_k<KASM>(axx, tp, kS2), tp = fma_k<KASM>(axx, tp, kS1);
     const double rt = x + (x * tp) * axx;
     rs = ax < 0.126 ? rt : rs;
     sn_out = copysign_(rs, x);
@@ -301,6 +315,7 @@ MI_SC_DEV void sincos_main(const double *T6, double x, double &sn_out, double &c
 //   beyond:          x = n pi/2 + (b + db):  n even: sin = +-do_sin(b, db), cos = +-do_cos(b, db);  n odd: the two swap roles
 // so the pair costs one shared reduction, one dedicated do_sin stream (TAYLOR_SIN selected in) and one dedicated do_cos stream -- none of the
 // role selects the one-function core() above needs -- and two output selects.  Same operations on the same operands as sin_bf / cos_bf.
+template <bool KASM = true>
 MI_SC_DEV double do_sin_bf(const double *T6, double a, double da) {
     const double ax = fabs(a);
     const double u = kBig + ax;
@@ -309,24 +324,25 @@ MI_SC_DEV double do_sin_bf(const double *T6, double a, double da) {
     const double sn = T6[idx], ssn = T6[idx + 1], cs = T6[idx + 2], ccs = T6[idx + 3];
     const double dxs = (a <= 0) ? -da : da;
     const double xx = x0 * x0;
-    const double q = fma_k(xx, kSn5, kSn3);
+    const double q = fma_k<KASM>(xx, kSn5, kSn3);
     const double si = fma_(x0 * xx, q, dxs);
     const double sv = x0 + si;
-    double c0 = fma_k(xx, kCs6, kCs4);
-    c0 = fma_k(xx, c0, kCs2);
+    double c0 = fma_k<KASM>(xx, kCs6, kCs4);
+    c0 = fma_k<KASM>(xx, c0, kCs2);
     const double c = fma_(x0, dxs, xx * c0);
     double cor = fma_(sv, ccs, ssn);
     cor = fma_(-c, sn, cor);
     cor = fma_(sv, cs, cor);
     double res = sn + cor;
     const double axx = a * a;
-    double tp = fma_k(axx, kS5, kS4);
-    tp = fma_k(axx, tp, kS3), tp = fma_k(axx, tp, kS2), tp = fma_k(axx, tp, kS1);
+    double tp = fma_k<KASM>(axx, kS5, kS4);
+    tp = fma_k<KASM>(axx, tp, kS3), tp = fma_k<KASM>(axx, tp, kS2), tp = fma_k<KASM>(axx, tp, kS1);
     const double t1 = fma_(a, tp, -(0.5 * da));
     const double rt = a + fma_(t1, axx, da);
     res = ax < 0.126 ? rt : res;
     return copysign_(res, a);
 }
+template <bool KASM = true>
 MI_SC_DEV double do_cos_bf(const double *T6, double a, double da) {
     const double ax = fabs(a);
     const double u = kBig + ax;
@@ -335,17 +351,17 @@ MI_SC_DEV double do_cos_bf(const double *T6, double a, double da) {
     const int idx = (int)(uint32_t)bits(u) * 6;
     const double sn = T6[idx], ssn = T6[idx + 1], cs = T6[idx + 2], ccs = T6[idx + 3];
     const double xx = xr * xr;
-    const double q = fma_k(xx, kSn5, kSn3);
+    const double q = fma_k<KASM>(xx, kSn5, kSn3);
     const double sv = fma_(xr * xx, q, xr);
-    double c0 = fma_k(xx, kCs6, kCs4);
-    c0 = fma_k(xx, c0, kCs2);
+    double c0 = fma_k<KASM>(xx, kCs6, kCs4);
+    c0 = fma_k<KASM>(xx, c0, kCs2);
     const double c = xx * c0;
     double cor = fma_(-sv, ssn, ccs);
     cor = fma_(-c, cs, cor);
     cor = fma_(-sv, sn, cor);
     return cs + cor;
 }
-template <bool BOUNDED = false>
+template <bool BOUNDED = false, bool KASM = true>
 MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &cs_out) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (!BOUNDED && __builtin_expect(k >= 0x419921fbu, 0)) {
@@ -354,7 +370,7 @@ MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &c
     }
     const double ax = fabs(x);
     // |x| >= 2.426265: n pi/2 + (b + db)
-    const double t = fma_k(x, kHpInv, kToInt);
+    const double t = fma_k<KASM>(x, kHpInv, kToInt);
     const double xn = t - kToInt;
     const uint32_t n = (uint32_t)bits(t);
     double y = fma_(-xn, kMp1, x);
@@ -370,7 +386,7 @@ MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &c
     const bool main = k < 0x3feb6000u, mid = k < 0x400368fdu;
     const double as = main ? x : (mid ? am : b), das = main ? 0.0 : (mid ? dam : db + db2);
     const double ac = main ? x : (mid ? ym : b), dac = main ? 0.0 : (mid ? kHp1 : db + db2);
-    const double S = do_sin_bf(T6, as, das), C = do_cos_bf(T6, ac, dac);
+    const double S = do_sin_bf<KASM>(T6, as, das), C = do_cos_bf<KASM>(T6, ac, dac);
     const bool swap = main ? false : (mid ? true : (n & 1u) != 0);
     const bool neg_s = main ? false : (mid ? (x < 0) : (n & 2u) != 0);
     const bool neg_c = (main || mid) ? false : ((n + 1u) & 2u) != 0;
@@ -379,13 +395,13 @@ MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &c
 }
 
 // MAIN_FIRST: the arguments of all lanes are expected inside |x| < 0.855469 (CartPole), worth a wavefront-uniform test for the short routine
-template <bool BOUNDED = false, bool MAIN_FIRST = true>
+template <bool BOUNDED = false, bool MAIN_FIRST = true, bool KASM = true>
 MI_SC_DEV void sincos_bf(const double *T6, double x, double &sn_out, double &cs_out) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (MAIN_FIRST && k < 0x3feb6000u) {
-        sincos_main(T6, x, sn_out, cs_out);
+        sincos_main<KASM>(T6, x, sn_out, cs_out);
     } else {
-        sincos_pair<BOUNDED>(T6, x, sn_out, cs_out);
+        sincos_pair<BOUNDED, KASM>(T6, x, sn_out, cs_out);
     }
 }
 

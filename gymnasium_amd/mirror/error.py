@@ -43,3 +43,19 @@ class ClosedEnvironmentError(Error):
 
 class InvalidBound(Error):
     """Raised when the clipping an array with invalid upper and/or lower bound (gymnasium/error.py:62-63)."""
+
+
+class AlreadyPendingCallError(Exception):
+    """gymnasium/error.py:72-80: an asynchronous call (`step_async`) is outstanding and another call is made before its `step_wait`."""
+
+    def __init__(self, message: str, name: str):
+        super().__init__(message)
+        self.name = name
+
+
+class NoAsyncCallError(Exception):
+    """gymnasium/error.py:83-91: `step_wait` without a preceding `step_async`."""
+
+    def __init__(self, message: str, name: str):
+        super().__init__(message)
+        self.name = name

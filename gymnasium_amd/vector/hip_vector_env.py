@@ -334,6 +334,7 @@ class HipVectorEnv(VectorEnv):
     def reset(self, *, seed=None, options=None):
         """Reset the sub-environments (all, or options["reset_mask"]) and return (observations, infos)."""
         self._check_open()
+        self._check_not_pending("reset")
         if isinstance(seed, (int, np.integer)) and not isinstance(seed, bool):
             super().reset(seed=int(seed))
         mask = None
@@ -414,6 +415,7 @@ class HipVectorEnv(VectorEnv):
     def step(self, actions):
         """One lockstep step of every sub-environment: (obs, rewards, terminations, truncations, infos)."""
         self._check_open()
+        self._check_not_pending("step")
         if not self._has_reset:
             raise AssertionError("Call reset before using step method.")
         keep, aptr = self._coerce_actions(actions)
@@ -468,8 +470,7 @@ class HipVectorEnv(VectorEnv):
         self._check_open()
         if not self._has_reset:
             raise AssertionError("Call reset before using step method.")
-        if getattr(self, "_async_pending", None) is not None:
-            raise error.Error("Calling `step_async` while waiting for a pending call to `step_async` to complete.")  # AlreadyPendingCallError upstream
+        self._check_not_pending("step_async")
         if self.output == "torch" or not self._pinned:
             self._async_pending = ("done", self.step(actions))
             return
@@ -487,7 +488,7 @@ class HipVectorEnv(VectorEnv):
     def step_wait(self, timeout=None):
         pending = getattr(self, "_async_pending", None)
         if pending is None:
-            raise error.Error("Calling `step_wait` without any prior call to `step_async`.")  # NoAsyncCallError upstream
+            raise error.NoAsyncCallError("Calling `step_wait` without any prior call to `step_async`.", "step")  # async_vector_env.py:477-481
         self._async_pending = None
         if pending[0] == "done":
             return pending[1]
@@ -673,6 +674,11 @@ class HipVectorEnv(VectorEnv):
     def synchronize(self):
         self._engine.synchronize()
 
+    def _check_not_pending(self, what: str):
+        """AsyncVectorEnv's state machine (vector/async_vector_env.py:340-344, 440-452): one outstanding call at a time."""
+        if getattr(self, "_async_pending", None) is not None:
+            raise error.AlreadyPendingCallError(f"Calling `{what}` while waiting for a pending call to `step_async` to complete.", "step")
+
     def _check_open(self):
         if self.closed:
             raise error.ClosedEnvironmentError(f"Trying to operate on `{type(self).__name__}`, after a call to `close()`.")
@@ -680,6 +686,21 @@ class HipVectorEnv(VectorEnv):
     def close_extras(self, **kwargs):
         eng = getattr(self, "_engine", None)
         if eng is not None:
+            if getattr(self, "_async_pending", None) is not None and self._async_pending[0] == "engine":
+                try:  # a step is in flight on the pinned block: collect it before the block goes away
+                    eng.step_wait()
+                except Exception:
+                    pass
+                self._async_pending = None
+            if self.output == "numpy" and getattr(self, "_pinned", False):
+                # The NumPy arrays handed out with copy=False (and `action_buffer`) are VIEWS of the engine's page-locked block, which
+                # mi_destroy frees: replace this object's references by ordinary copies so that reading `env._obs` / the last returned
+                # batch's base after close() is not a use-after-free.  (Views a caller still holds are the caller's: documented in README.)
+                for name in ("_obs", "_rew", "_term", "_trunc", "_final", "_info", "_final_info", "_ep_r", "_ep_l", "action_buffer"):
+                    v = getattr(self, name, None)
+                    if isinstance(v, np.ndarray):
+                        setattr(self, name, v.copy())
+                self._pinned = False
             eng.close()
             self._engine = None
 

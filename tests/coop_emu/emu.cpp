@@ -23,6 +23,23 @@ bool g_done[kMaxLanes];
 int g_cur = 0, g_n = 0;
 long g_syncs = 0;
 std::function<void(int)> g_body;
+// RACE DETECTOR.  Between two coop_sync() calls the fibers run one after the other, in the order g_perm: ascending (mode 0, the default),
+// descending (1), or a fresh random permutation for every interval (2).  The kernel's discipline is that inside one interval no
+// blackboard word is written by one lane and read (or written) by another; on the GPU a violation reads old or new data depending on how
+// the compiler interleaved the two accesses -- the signature of "results change with the instruction scheduler".  Here a violation makes the
+// result depend on the fiber order, so tests/test_coop_emu.py::test_no_cross_lane_dependency_inside_a_sync_interval runs every robot under
+// all three orders and requires bit-identical states.
+int g_mode = 0, g_perm[kMaxLanes], g_pos = 0;
+unsigned long long g_rng = 0x9e3779b97f4a7c15ull;
+void make_perm(int n) {
+    for (int k = 0; k < n; k++) g_perm[k] = g_mode == 1 ? n - 1 - k : k;
+    if (g_mode == 2)
+        for (int k = n - 1; k > 0; k--) {
+            g_rng ^= g_rng << 13, g_rng ^= g_rng >> 7, g_rng ^= g_rng << 17;
+            const int j = (int)(g_rng % (unsigned long long)(k + 1)), t = g_perm[k];
+            g_perm[k] = g_perm[j], g_perm[j] = t;
+        }
+}
 
 void trampoline(int lane) {
     g_body(lane);
@@ -47,17 +64,23 @@ void run_group(int n, std::function<void(int)> body) {
         g_ctx[l].uc_stack.ss_sp = stacks.data() + kStack * l, g_ctx[l].uc_stack.ss_size = kStack, g_ctx[l].uc_link = nullptr;
         makecontext(&g_ctx[l], (void (*)())trampoline, 1, l);
     }
-    g_cur = 0;
-    swapcontext(&g_main, &g_ctx[0]);
+    make_perm(n);
+    g_pos = 0, g_cur = g_perm[0];
+    swapcontext(&g_main, &g_ctx[g_cur]);
 }
 }  // namespace
 
 long mjx::coop::g_stat[8] = {0};
 void mjx::coop::coop_sync() {
     g_syncs++;
-    const int me = g_cur, nxt = (me + 1) % g_n;
+    const int me = g_cur;
+    if (++g_pos == g_n) {  // every lane has run this interval: the next one starts, in a new order if the mode asks for it
+        g_pos = 0;
+        if (g_mode == 2) make_perm(g_n);
+    }
+    const int nxt = g_perm[g_pos];
     g_cur = nxt;
-    swapcontext(&g_ctx[me], &g_ctx[nxt]);
+    if (nxt != me) swapcontext(&g_ctx[me], &g_ctx[nxt]);
 }
 
 namespace {
@@ -210,6 +233,8 @@ __attribute__((visibility("default"))) long coop_emu_board_bytes(int model) {
     return -1;
 }
 __attribute__((visibility("default"))) long coop_emu_last_syncs() { return g_syncs; }
+// order in which the lanes of a group run inside one sync interval: 0 ascending, 1 descending, 2 a fresh random permutation per interval
+__attribute__((visibility("default"))) void coop_emu_set_order(int mode, unsigned long long seed) { g_mode = mode, g_rng = seed | 1ull; }
 __attribute__((visibility("default"))) void coop_emu_stats(long *out, int reset) {
     for (int k = 0; k < 8; k++) out[k] = mjx::coop::g_stat[k];
     if (reset)

@@ -192,3 +192,51 @@ def test_one_lane_simulator_matches_oracle(model):
             q, v = d.get("qpos"), d.get("qvel")
     if name not in ("swimmer", "reacher", "inverted_pendulum", "inverted_double_pendulum"):
         assert seen > 0, "these robots must have met their constraints (contacts / joint limits)"
+
+
+# ---- race detector: the result must not depend on the order in which the lanes of a group run between two coop_sync() calls -----------------
+@pytest.mark.parametrize("model", list(VARIANTS), ids=[f"{n}-{s}" if s else n for n, s in VARIANTS.values()])
+def test_no_cross_lane_dependency_inside_a_sync_interval(model):
+    """The cooperative kernel's synchronisation discipline (mjx_coop.h coop_sync): between two fences no blackboard word is written by one
+    lane and read or written by another.  On the GPU the lanes of a group run in lockstep, so a violation would read old or new data
+    depending on how the COMPILER interleaved the two accesses -- results that change with the instruction scheduler (build.py keeps three
+    such stories about the 16-lane unit).  The emulator runs the lanes of an interval one after the other; a violation makes the result
+    depend on that order.  So: ascending, descending and per-interval random lane orders must give bit-identical states, extras and
+    warm starts, over env steps with active contacts and joint limits."""
+    om_ = oracle_model(model)
+    m, d = om_.m, om_.make_data()
+    amp = 0.4 if model >= 2 else 1.0
+    rng = np.random.default_rng(7 + model)
+    qpos = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
+    if model > 0:
+        qpos[3:7] /= np.linalg.norm(qpos[3:7])
+    d.reset(), d.set_state(qpos, 0.1 * rng.normal(size=m.nv), np.zeros(m.nu))
+    states = []
+    for t in range(90 if model in (2, 12) else (24 if model in (8, 18) else 60)):
+        d.set_state(None, None, amp * rng.uniform(-1, 1, m.nu)), d.step(5)
+        if t % 12 == 11:
+            states.append((d.get("qpos").copy(), d.get("qvel").copy(), d.get("qacc_warmstart").copy()))
+            if model > 0:  # ... and the same state pushed into the floor: many active contact rows
+                q2 = states[-1][0].copy()
+                q2[2] -= 0.2
+                states.append((q2, states[-1][1], states[-1][2]))
+    set_order = lib().coop_emu_set_order
+    set_order.argtypes = [C.c_int, C.c_ulonglong]
+    contacts = 0
+    try:
+        for q, v, w in states:
+            ctrl = amp * rng.uniform(-1, 1, m.nu)
+            runs = []
+            for mode, seed in ((0, 1), (1, 1), (2, 12345), (2, 999), (2, 31337)):
+                set_order(mode, seed)
+                warm = w.copy()
+                qo, vo, ex, dbg, ncon = emu(model, m, q, v, ctrl, 5, warm)
+                runs.append((qo, vo, ex, warm, ncon))
+            contacts += runs[0][4]
+            for r in runs[1:]:
+                assert r[4] == runs[0][4]
+                for a, b, what in zip(r[:4], runs[0][:4], ("qpos", "qvel", "extras", "warm start")):
+                    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f"{what} depends on the lane order inside a sync interval: a blackboard race"
+    finally:
+        set_order(0, 1)
+    assert contacts > 0

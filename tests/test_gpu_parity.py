@@ -381,17 +381,26 @@ def test_step_async_wait_and_pinned_buffers():
         ra = a.step(act)
         b.action_buffer[:] = act
         b.step_async(b.action_buffer)
-        with pytest.raises(Exception):
+        with pytest.raises(gymnasium_amd.gym_api.error.AlreadyPendingCallError):
             b.step_async(act)  # one step may be pending
+        if t == 0:  # ... and neither step() nor reset() may cut in (AsyncVectorEnv's state machine, async_vector_env.py:340-344)
+            with pytest.raises(gymnasium_amd.gym_api.error.AlreadyPendingCallError):
+                b.step(act)
+            with pytest.raises(gymnasium_amd.gym_api.error.AlreadyPendingCallError):
+                b.reset()
         rb = b.step_wait()
         for x, y in zip(ra[:4], rb[:4]):
             assert np.array_equal(x, y), t
         assert np.shares_memory(rb[0], b._obs) and not np.shares_memory(ra[0], a._obs)
-    with pytest.raises(Exception):
+    with pytest.raises(gymnasium_amd.gym_api.error.NoAsyncCallError):
         b.step_wait()
     with pytest.raises(AssertionError):
         b.step_async(np.full(n, 7))
+    # close(): the env's own references to the page-locked block (which mi_destroy frees) become ordinary arrays with the last values
+    last = rb[0].copy()
+    b.step_async(b.action_buffer)  # closing with a step in flight collects it first
     a.close(), b.close()
+    assert b._obs.shape == last.shape and np.isfinite(b._obs).all() and b.action_buffer.shape == (n,)
 
 
 def test_step_async_mujoco_infos():

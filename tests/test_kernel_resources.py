@@ -1,0 +1,69 @@
+"""Static guards on the built library's ISA (llvm-objdump of libmi355env.so; no GPU needed).
+
+1. Inline-asm Horner steps (sincos_exact.h / pow_exact.h `fma_k<true>`) only in kernels that stay inside the VGPR file.  Inline asm is
+   opaque to the compiler's hazard recognizer; in round 3 the one classic kernel whose live values overflow into AGPRs -- Acrobot's fused
+   rollout -- gave results that were not reproducible from launch to launch with the asm form (and were with the builtin).  Acrobot is
+   therefore instantiated with ExactMathT<false>; every kernel instantiated with the asm-carrying policies must not touch AGPRs at all.
+2. The classic-control and ToyText kernels do not spill to scratch.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+LIB = os.path.join(ROOT, "gymnasium_amd", "csrc", "libmi355env.so")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(OBJDUMP) and os.path.exists(LIB)), reason="needs the ROCm llvm-objdump and the built library")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    """{demangled kernel name: [mnemonic, ...]} of every gfx950 kernel in the library's engine code object(s)."""
+    from kernel_resources import extract_all
+
+    out = {}
+    for co in extract_all(LIB):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co), f.flush()
+            text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        cur, per = None, {}
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                per[cur] = []
+                continue
+            m = re.match(r"^\s+(\S+)", line)
+            if m and cur:
+                per[cur].append(m.group(1))
+        names = subprocess.run(["c++filt"], input="\n".join(per), capture_output=True, text=True).stdout.splitlines()
+        for (_, ins), name in zip(per.items(), names):
+            if ins:
+                out[name] = ins
+    return out
+
+
+def test_inline_asm_fma_only_in_kernels_without_agpr_traffic(kernels):
+    asm_policies = ("ExactMathT<true>", "CartPoleT<mi::FastMath>")  # the instantiations whose trig / pow routines carry fma_k<true>
+    checked = 0
+    for name, ins in kernels.items():
+        if any(p in name for p in asm_policies):
+            checked += 1
+            n = sum(op.startswith("v_accvgpr") for op in ins)
+            assert n == 0, f"{name[:140]}: {n} AGPR moves in a kernel with inline-asm v_fma_f64 (instantiate it with ExactMathT<false>)"
+    assert checked >= 20, f"only {checked} kernels matched: the policy names changed?"
+    acro = [n for n in kernels if "AcrobotT<" in n and "FastMath" not in n]
+    assert acro and all("ExactMathT<false>" in n for n in acro), "Acrobot's exact kernels must use the builtin-fma policy"
+
+
+def test_classic_and_toytext_kernels_do_not_use_scratch(kernels):
+    for name, ins in kernels.items():
+        if ("mi::" in name and "T<mi::" in name) or "tab_" in name:
+            n = sum(op.startswith("scratch_") for op in ins)
+            assert n == 0, f"{name[:140]}: {n} scratch instructions"
