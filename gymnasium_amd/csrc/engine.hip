@@ -1300,7 +1300,6 @@ struct mi_vecenv {
     bool mj_coop;
     int extras_dim;
     double *d_extras;       // [N][EX_TOTAL]
-    double *d_pgs_spill;    // PGS kinds: [N][Sim::SPILL_DOUBLES] overflow store of the cooperative solver (mjx_coop.h pgs())
     float *d_act_scratch;   // [N][NU] actions of the current rollout step when the caller does not keep them
     void *d_obs_scratch;    // [N][obs_dim] observations of the current rollout step when the caller does not keep them
 };
@@ -1465,7 +1464,7 @@ int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
     if (v->mj_coop) {
         mi_phys::Args pa;
         pa.state = v->d.state, pa.meta = v->d.meta, pa.needs_reset_mask = kNeedsReset << kFlagShift, pa.N = v->d.N, pa.frame_skip = (int)v->d.P.p[4];
-        pa.pgs_spill = v->d_pgs_spill, pa.newton = v->d.solver_newton;
+        pa.newton = v->d.solver_newton;
         const bool skip_resetting = mode != MI_AUTORESET_SAME_STEP;  // SAME_STEP: every sub-environment steps
         const bool ok = E::COOP_G == 16 ? mi_phys::launch16(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream)
                                         : mi_phys::launch32(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream);
@@ -1675,8 +1674,6 @@ static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
         HIP_TRY(hipMalloc(&v->d_act_scratch, v->act_bytes));
         HIP_TRY(hipMalloc(&v->d_obs_scratch, v->obs_bytes));
         HIP_TRY(hipMemsetAsync(v->d_extras, 0, sizeof(double) * v->extras_dim * N, v->stream));
-        const size_t spill = v->mj_coop && !d.solver_newton ? mi_phys::pgs_spill_doubles(cfg->kind) : 0;
-        if (spill) HIP_TRY(hipMalloc(&v->d_pgs_spill, sizeof(double) * spill * N));
     }
     HIP_TRY(hipStreamSynchronize(v->stream));
     return MI_OK;
@@ -1687,7 +1684,7 @@ void mi_destroy(mi_vecenv *v) {
     (void)hipSetDevice(v->device);
     (void)hipStreamSynchronize(v->stream);
     void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d_out,
-                    v->d_pow2, v->d_actions, v->d_mask, v->d_words, v->d_pgs_spill, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
+                    v->d_pow2, v->d_actions, v->d_mask, v->d_words, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (v->h_out) (void)hipHostFree(v->h_out);

@@ -36,6 +36,13 @@
 #ifndef MJX_CHOL_LDS_FOR_16
 #define MJX_CHOL_LDS_FOR_16 0  // diagnostic switch: 16-lane groups on the LDS-exchange Cholesky as well (costs LDS: 3 instead of 4 wavefronts per CU)
 #endif
+#ifndef MJX_CHOL_MFMA
+#define MJX_CHOL_MFMA 0  // 1: 32-lane PGS kernels factor M in block-16 form with the Schur update on v_mfma_f64_16x16x4_f64 (chol_factor_blocked).
+                         // MEASURED in the product (round 3, profiles/r03_mfma_cholesky_in_product.txt): correct (GPU suite green, states equal to
+                         // 1e-15) but 1.9 % SLOWER end to end (Humanoid-v5 1.047 M vs 1.067 M env-steps/s, factor phase 24.9 k vs 24.5 k cycles) although
+                         // the isolated factorisation is 23 % faster (profiles/r03_mfma_humanoid.txt): two extra blackboard round trips and the
+                         // four dependent MFMAs sit on the critical path of a kernel that one wavefront per SIMD cannot overlap.  Off.
+#endif
 #ifndef MJX_PGS_QS_BY_INVERSE
 #define MJX_PGS_QS_BY_INVERSE 0  // 1: PGS forms qacc_smooth = M^-1 qfrc_smooth as a row product once M^-1 exists instead of by the triangular solves.  MEASURED (r03, profiles/r03_pgs_qs_by_inverse.txt): same results to 1e-15, but the changed control flow takes the 32-lane kernel from 4 to 999 spilled VGPRs and doubles its time -- off
 #endif
@@ -183,6 +190,9 @@ struct Board {
     // consecutive addresses), which is what keeps that kernel from spilling.
     static constexpr bool M_IN_LDS = NV > 16;
     double Mt[M_IN_LDS ? NV : 1][M_IN_LDS ? NV : 1];
+    // blocked Cholesky (Sim::chol_factor_blocked): this environment's block of the 16 x 16 MFMA tile L21 L21^T (rows / columns 16 .. NV - 1)
+    static constexpr bool CHOL_BLOCKED = G_ == 32 && NV > 16 && NV <= 24 && MJX_CHOL_MFMA;
+    double schur[CHOL_BLOCKED ? 8 : 1][CHOL_BLOCKED ? 8 : 1];
     int con_pair[MAXCON];             // geom pair of the contact | body of its first geom << 16 | body of its second geom << 24 (the bodies
                                       // ride along because pair -> geom -> body is two dependent table loads from global memory per use;
                                       // no room for more: the 16-lane robots sit exactly at four workgroups' worth of LDS per CU)
@@ -220,7 +230,7 @@ struct Lane {
     // (A00 A01 A02 A11 A12 A22), the reciprocals 1 / (E A E^T + R) of its rows, J_c qacc_smooth, and where contacts beyond the LDS
     // capacity keep their M^-1 J_c^T block (global memory, per environment)
     double p_lf[2], p_lari[2], p_f[KC][4], p_A[KC][6], p_ari[KC][4], p_js[KC][3];
-    double *spill;
+    int grp;  // which of the wavefront's sub-environments this lane belongs to (its blackboard is boards[grp]; the MFMA tile packs all of them)
 };
 
 template <class M, int G, bool PGS = (M::SOLVER == 1)>
@@ -620,6 +630,87 @@ struct Sim {
                 for (int j = k + 1; j < NV; j++) A[j] -= (j <= lane ? t : 0.0) * col[j];  // entries j > lane are never used
             }
         }
+        if (lane < NV) {
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+                if (j <= lane) bb.A.sol.L[tri(lane, 0) + j] = A[j];
+        }
+        coop_sync();
+    }
+    // Block-16 right-looking form of the same factorisation for the 32-lane PGS kernels (NV = 23): columns 0..15 by the row sweep WITHOUT touching
+    // A22 (rows / columns 16..NV-1), then A22 -= L21 L21^T as ONE 16 x 16 x 16 product on the matrix cores -- four v_mfma_f64_16x16x4_f64,
+    // the (NV - 16)-row blocks of the wavefront's two sub-environments packed block-diagonally into the tile (rows 0..7 / 8..15; the cross
+    // blocks are computed and dropped) -- and the last columns by the row sweep.  Measured (scripts/mfma/humanoid_bench.hip,
+    // profiles/r03_mfma_humanoid.txt): 16.8 k -> 13.0 k cycles per factorisation; the tile is bit-identical to fused multiply-add chains over
+    // k = 0..15 (the same benchmark), which is what the host emulation computes.
+    // Operand map (cdna_hip_programming.md section 3): A[i][k] on lane i + 16 k, B[k][j] on lane j + 16 k, D[row][col]: col = lane & 15,
+    // row = (lane >> 4) + 4 reg.  B = A^T here, so every lane supplies ONE value per instruction as both operands.
+    // REQUIRES the whole wavefront at this point: the kernel keeps a sub-environment that does not step this call alive on a dummy state
+    // (mjx_physics.h) instead of retiring its lanes.
+    template <int K0, int K1, int JMAX>
+    static MJX_DEV void chol_sweep(B &bb, double *A, double &idiag, int lane) {
+#pragma unroll
+        for (int k = K0; k < K1; k++) {
+            double (&col)[NV] = bb.A.sol.col[k & 1];
+            if (lane >= k && lane < NV) col[lane] = A[k];
+            coop_sync();
+            if (lane >= k && lane < NV) {
+                double piv = col[k];
+                piv = piv < kMinVal ? kMinVal : piv;
+                const double inv = rsq(piv);
+                const double lik = A[k] * inv;
+                A[k] = lik;
+                if (lane == k) idiag = inv;
+                const double t = lik * inv;
+#pragma unroll
+                for (int j = k + 1; j < JMAX; j++) A[j] -= (j <= lane ? t : 0.0) * col[j];
+            }
+        }
+    }
+    static MJX_DEV void chol_factor_blocked(B &bb, double *A, double &idiag, int lane, int grp) {
+        constexpr int KB = 16, NR = NV - KB;  // block size, rows of the trailing block
+        static_assert(NR >= 1 && NR <= 8, "the trailing blocks of two sub-environments share one 16 x 16 tile");
+        chol_sweep<0, KB, KB>(bb, A, idiag, lane);
+        if (lane >= KB && lane < NV) {  // L21 is final: into the packed factor (where the substitutions read it), from where the tile is gathered
+#pragma unroll
+            for (int k = 0; k < KB; k++) bb.A.sol.L[tri(lane, 0) + k] = A[k];
+        }
+        coop_sync();
+#if defined(MJX_HOST_EMU)
+        (void)grp;
+        if (lane >= KB && lane < NV) {
+#pragma unroll
+            for (int j = KB; j < NV; j++) {
+                double acc = 0;
+#pragma unroll
+                for (int k = 0; k < KB; k++) acc = fma(bb.A.sol.L[tri(lane, 0) + k], bb.A.sol.L[tri(j, 0) + k], acc);
+                bb.schur[lane - KB][j - KB] = acc;
+            }
+        }
+#else
+        {
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            B *wb = &bb - grp;  // the wavefront's blackboards
+            const int wl = (int)(threadIdx.x & 63u), i = wl & 15, kk = wl >> 4, e = i >> 3, p = i & 7;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < KB / 4; t++) {
+                const double a = p < NR ? wb[e].A.sol.L[tri(KB + (p < NR ? p : 0), 0) + 4 * t + kk] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int row = kk + 4 * rg;
+                if ((row >> 3) == e && (row & 7) < NR && p < NR) wb[e].schur[row & 7][p] = acc[rg];
+            }
+        }
+#endif
+        coop_sync();
+        if (lane >= KB && lane < NV) {
+#pragma unroll
+            for (int j = KB; j < NV; j++) A[j] -= (j <= lane) ? bb.schur[lane - KB][j - KB] : 0.0;
+        }
+        chol_sweep<KB, NV, NV>(bb, A, idiag, lane);
         if (lane < NV) {
 #pragma unroll
             for (int j = 0; j < NV; j++)
@@ -1124,7 +1215,7 @@ struct Sim {
     //     the factorisation), for later ones the sweeps apply M^-1 (register rows) to J_c^T dl directly (apply_b).
     // Warm start = mj's dual warmstart: the forces implied by qacc_warmstart (r.warm), dropped for zero if their dual cost is positive.
     static constexpr int BCAP = B::M_IN_LDS ? NV / 3 : 0;
-    static constexpr int SPILL_DOUBLES = 0;  // (a global-memory overflow store was tried for the contacts beyond BCAP: ~800 cycles per visit)
+    // (a global-memory overflow store was tried for the contacts beyond BCAP: ~800 cycles per visit; removed)
     static MJX_DEV void store_b(B &bb, int c, int lane, const double *b) {
         if constexpr (B::M_IN_LDS) {
             if (lane < NV && c < BCAP) {
@@ -1248,7 +1339,10 @@ struct Sim {
         const bool isdof = lane < NV;
 #pragma unroll
         for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
-        chol_factor(bb, r.Hrow, r.idiag, lane);
+        if constexpr (B::CHOL_BLOCKED)
+            chol_factor_blocked(bb, r.Hrow, r.idiag, lane, r.grp);
+        else
+            chol_factor(bb, r.Hrow, r.idiag, lane);
 #if MJX_PGS_QS_BY_INVERSE
         // With constraint rows the sweeps need M^-1 explicitly anyway: the unconstrained acceleration is then one row-times-vector product
         // (one exchange of qfrc_smooth through the blackboard) instead of the 2 NV dependent steps of the triangular solves.

@@ -43,6 +43,11 @@ MJX_DEV double standard_normal(mi::Pcg64 &rng) {
 }
 
 // np.sum of a contiguous array: NumPy's pairwise_sum (plain loop < 8 elements, 8 interleaved accumulators up to 128)
+// np.linalg.norm of a 2- / 3-vector of float64: sqrt(x.dot(x)) with the BLAS dot's accumulation -- x0 x0, then fused multiply-adds (oracle/mujoco_envs.c
+// orc_np_norm, pinned on NumPy by tests/test_mujoco_oracle.py); spelled with the builtin because this glue is compiled with contraction off
+MJX_DEV double np_norm(double a, double b) { return sqrt(__builtin_fma(b, b, a * a)); }
+MJX_DEV double np_norm(double a, double b, double c) { return sqrt(__builtin_fma(c, c, __builtin_fma(b, b, a * a))); }
+
 template <class T, int N>
 MJX_DEV T np_sum(const T *a) {
     static_assert(N <= 128, "block recursion not needed for these envs");
@@ -187,7 +192,7 @@ struct MjEnv {
             for (;;) {
                 const double c0 = -0.3 + (0.0 - (-0.3)) * rng.next_double(), c1 = -0.2 + (0.2 - (-0.2)) * rng.next_double();
                 s[NQ - 4] = c0, s[NQ - 3] = c1;
-                if (sqrt(c0 * c0 + c1 * c1) > 0.17) break;
+                if (np_norm(c0, c1) > 0.17) break;
             }
             s[NQ - 2] = 0.0, s[NQ - 1] = 0.0;
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * rng.next_double());
@@ -213,7 +218,7 @@ struct MjEnv {
             for (;;) {
                 const double g0 = -0.2 + (0.2 - (-0.2)) * rng.next_double(), g1 = -0.2 + (0.2 - (-0.2)) * rng.next_double();
                 s[2] = g0, s[3] = g1;
-                if (sqrt(g0 * g0 + g1 * g1) < 0.2) break;
+                if (np_norm(g0, g1) < 0.2) break;
             }
             for (int k = 0; k < NV; k++) s[NQ + k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * rng.next_double());
             s[NQ + 2] = 0.0, s[NQ + 3] = 0.0;
@@ -387,8 +392,8 @@ struct MjEnv {
             // pusher_v5.py:266-291: reward = -|object - goal| w_dist + (-sum(a^2) w_ctrl, float32) + (-|object - tips_arm| w_near); never terminates
             const double *tip = x.vec, *ob = x.vec + 3, *goal = x.vec + 6;
             const double v1[3] = {ob[0] - tip[0], ob[1] - tip[1], ob[2] - tip[2]}, v2[3] = {ob[0] - goal[0], ob[1] - goal[1], ob[2] - goal[2]};
-            const double reward_near = -sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) * P.p[0];
-            const double reward_dist = -sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]) * P.p[5];
+            const double reward_near = -np_norm(v1[0], v1[1], v1[2]) * P.p[0];
+            const double reward_dist = -np_norm(v2[0], v2[1], v2[2]) * P.p[5];
             const float reward_ctrl = -np_sum<float, NU>(sq) * (float)P.p[1];
             reward = (reward_dist + (double)reward_ctrl) + reward_near;
             terminated = false;
@@ -400,7 +405,7 @@ struct MjEnv {
         }
         if (KIND == kReacher) {
             // reacher_v5.py:188-207: reward = -|fingertip - target| w_dist - sum(a^2) w_ctrl (the control term in float32); never terminates
-            const double reward_dist = -sqrt(x.vec[0] * x.vec[0] + x.vec[1] * x.vec[1] + x.vec[2] * x.vec[2]) * P.p[0];
+            const double reward_dist = -np_norm(x.vec[0], x.vec[1], x.vec[2]) * P.p[0];
             const float reward_ctrl = -np_sum<float, NU>(sq) * (float)P.p[1];
             reward = reward_dist + (double)reward_ctrl;
             terminated = false;
@@ -461,7 +466,7 @@ struct MjEnv {
             const ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
             write_obs(s, ox, P, obs);
             if (info) {
-                info[0] = after[0], info[1] = after[1], info[2] = sqrt(after[0] * after[0] + after[1] * after[1]), info[3] = xv, info[4] = yv;
+                info[0] = after[0], info[1] = after[1], info[2] = np_norm(after[0], after[1]), info[3] = xv, info[4] = yv;
                 info[5] = forward_reward, info[6] = -(double)ctrl_cost_f;
             }
             return;
@@ -507,7 +512,7 @@ struct MjEnv {
         const ObsExtras ox = {cfrc, x.cinert, x.cvel, x.qfrc_actuator};
         write_obs(s, ox, P, obs);
         if (info) {
-            info[0] = s[0], info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]), info[3] = xv, info[4] = yv;
+            info[0] = s[0], info[1] = s[1], info[2] = np_norm(s[0], s[1]), info[3] = xv, info[4] = yv;
             info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
             if (HUMANOID_LIKE) write_tendon_info(x.ten, info);
         }
@@ -529,7 +534,7 @@ struct MjEnv {
             info[1] = s[1] - M::qpos0[1];  // z_distance_from_origin (hopper_v5.py:338-342)
             return;
         }
-        if (KIND != kHalfCheetah) info[1] = s[1], info[2] = sqrt(s[0] * s[0] + s[1] * s[1]);
+        if (KIND != kHalfCheetah) info[1] = s[1], info[2] = np_norm(s[0], s[1]);
     }
 };
 

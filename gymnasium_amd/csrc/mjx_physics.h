@@ -24,7 +24,6 @@ struct Args {
     const uint32_t *meta;
     uint32_t needs_reset_mask;
     int N, frame_skip;
-    double *pgs_spill;   // PGS: per-environment overflow store of M^-1 J_c^T for contacts beyond the LDS capacity (Sim::SPILL_DOUBLES each)
     int newton;          // MI_CFG_SOLVER_NEWTON: run the Newton instantiation although the model's MJCF asks for PGS
 };
 
@@ -41,20 +40,33 @@ __global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *act
     __shared__ typename S::B boards[EPW];
     const int grp = threadIdx.x / G, lane = threadIdx.x % G;
     const int env = blockIdx.x * EPW + grp;
-    if (env >= d.N) return;
-    if (SKIP_RESETTING && (d.meta[env] & d.needs_reset_mask)) return;
+    // A sub-environment that does not step in this call (past the end of the batch, or in its NEXT_STEP autoreset step) ...
+    const bool steps = env < d.N && !(SKIP_RESETTING && (d.meta[env < d.N ? env : 0] & d.needs_reset_mask));
+    // ... retires its lanes -- except in the kernels whose factorisation runs on the matrix cores (mjx_coop.h chol_factor_blocked): an MFMA
+    // instruction spans the whole wavefront, so there the idle group keeps running on a harmless dummy state (the model's initial pose, no
+    // controls) and simply stores nothing.  It costs nothing in time: the wavefront runs at the pace of its other sub-environment anyway.
+    constexpr bool KEEP_WAVE = S::B::CHOL_BLOCKED && PGS;
+    if (!KEEP_WAVE && !steps) return;
     typename S::B &bb = boards[grp];
     typename S::R r;
+    r.grp = grp;
     S::init(bb, lane);
     const size_t N = (size_t)d.N;
-    for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
-    for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
-    for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
-    r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
-    r.spill = PGS ? d.pgs_spill + (size_t)env * S::SPILL_DOUBLES : nullptr;
+    if (steps) {
+        for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
+        for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
+        for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
+        r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
+    } else {
+        for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = M::qpos0[k];
+        for (int k = lane; k < M::NV; k += G) bb.qvel[k] = 0.0;
+        for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = 0.0;
+        r.warm = 0.0;
+    }
     mjx::coop::coop_sync();
     for (int f = 0; f < d.frame_skip; f++) S::step(bb, r, lane);
     mjx::coop::coop_sync();
+    if (!steps) return;
     for (int k = lane; k < M::NQ; k += G) d.state[(size_t)k * N + env] = bb.qpos[k];
     for (int k = lane; k < M::NV; k += G) d.state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
     if (lane < M::NV) d.state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;
@@ -80,9 +92,6 @@ inline void launch_kind(const Args &a, bool skip_resetting, const float *actions
     else
         hipLaunchKernelGGL((mj_physics_kernel<E, false, false>), grid, block, 0, stream, a, actions, extras);
 }
-
-// doubles of pgs_spill one environment of `kind` needs (0: the kind does not use PGS)
-size_t pgs_spill_doubles(int kind);
 
 // defined in physics16.hip / physics32.hip; `kind` is an mi_env_kind; returns false for a kind the unit does not hold
 bool launch16(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream);

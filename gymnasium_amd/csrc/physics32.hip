@@ -13,11 +13,4 @@ bool launch32(int kind, const Args &a, bool skip_resetting, const float *actions
     }
     return false;
 }
-size_t pgs_spill_doubles(int kind) {
-    switch (kind) {
-    case MI_ENV_HUMANOID: return mjx::coop::Sim<mjx::HumanoidModel, 32, true>::SPILL_DOUBLES;
-    case MI_ENV_HUMANOID_STANDUP: return mjx::coop::Sim<mjx::HumanoidStandupModel, 32, true>::SPILL_DOUBLES;
-    }
-    return 0;
-}
 }  // namespace mi_phys

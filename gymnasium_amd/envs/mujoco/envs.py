@@ -23,6 +23,32 @@ from . import models as _models
 _WARNED_UNPINNED = False
 
 
+def _fma(a, b, c):
+    """fma(a, b, c) = RN(a b + c) elementwise without a hardware instruction: Dekker's exact product (Veltkamp splitting) + Knuth's exact sum; the
+    final addition rounds the three-term sum once (exact unless the sum sits within 2^-53 ulp of a rounding boundary)."""
+    p = a * b
+    ah = 134217729.0 * a
+    ah = ah - (ah - a)
+    al = a - ah
+    bh = 134217729.0 * b
+    bh = bh - (bh - b)
+    bl = b - bh
+    e = ((ah * bh - p) + ah * bl + al * bh) + al * bl
+    s = c + p
+    bb = s - c
+    t = (c - (s - bb)) + (p - bb)
+    return s + (t + e)
+
+
+def _np_norm(*cols):
+    """np.linalg.norm of the rows (x, y[, z]) the way the reference gets it for one row: sqrt(x.dot(x)) with the BLAS dot's accumulation -- x0 x0,
+    then fused multiply-adds (oracle/mujoco_envs.c orc_np_norm; ant_v5.py:427 `np.linalg.norm(self.data.qpos[0:2], ord=2)`)."""
+    acc = cols[0] * cols[0]
+    for c in cols[1:]:
+        acc = _fma(c, c, acc)
+    return np.sqrt(acc)
+
+
 class _MujocoVectorEnv(HipVectorEnv):
     STOCK_XML = ""
     NQ = NV = NU = NBODY = 0
@@ -70,7 +96,7 @@ class _MujocoVectorEnv(HipVectorEnv):
         if self.N_RESET_INFO_KEYS == 3:
             infos.update({"y_position": np.where(sel, qpos[:, 1], 0.0), "_y_position": sel.copy()})
             infos.update(self._reset_tendon_infos(qpos, sel))  # key order of humanoid_v5.py:534-541
-            infos.update({"distance_from_origin": np.where(sel, np.sqrt(qpos[:, 0] ** 2 + qpos[:, 1] ** 2), 0.0), "_distance_from_origin": sel.copy()})
+            infos.update({"distance_from_origin": np.where(sel, _np_norm(qpos[:, 0], qpos[:, 1]), 0.0), "_distance_from_origin": sel.copy()})
         return infos
 
     def _reset_tendon_infos(self, state, sel):
@@ -88,6 +114,7 @@ class HalfCheetahVectorEnv(_MujocoVectorEnv):
     NQ, NV, NU, NBODY = 9, 9, 6, 8
     CTRL_LOW, CTRL_HIGH = -1.0, 1.0
     INFO_KEYS = ("x_position", "x_velocity", "reward_forward", "reward_ctrl")
+    INFO_DTYPES = {"reward_ctrl": np.float32}  # -ctrl_cost_weight * np.sum(np.square(float32 action)): an np.float32 in the reference's info
     N_RESET_INFO_KEYS = 1
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "half_cheetah.xml", frame_skip: int = 5,
@@ -115,6 +142,7 @@ class AntVectorEnv(_MujocoVectorEnv):
     CTRL_LOW, CTRL_HIGH = -1.0, 1.0
     INFO_KEYS = ("x_position", "y_position", "distance_from_origin", "x_velocity", "y_velocity", "reward_forward", "reward_ctrl",
                  "reward_contact", "reward_survive")
+    INFO_DTYPES = {"reward_ctrl": np.float32}  # -ctrl_cost_weight * np.sum(np.square(float32 action)): an np.float32 in the reference's info
     N_RESET_INFO_KEYS = 3
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "ant.xml", frame_skip: int = 5,
@@ -147,6 +175,7 @@ class HumanoidVectorEnv(_MujocoVectorEnv):
     NQ, NV, NU, NBODY = 24, 23, 17, 14
     CTRL_LOW, CTRL_HIGH = -0.4, 0.4
     INFO_KEYS = AntVectorEnv.INFO_KEYS
+    INFO_DTYPES = {}  # (control cost from data.ctrl, float64: humanoid_v5.py:418)
     N_RESET_INFO_KEYS = 3
     INFO_VECTOR_KEYS = (("tendon_length", 2), ("tendon_velocity", 2))  # data.ten_length / data.ten_velocity (humanoid_v5.py:486-487)
     # <tendon><fixed name="left_hipknee"> -left_hip_y + left_knee, "right_hipknee" likewise (humanoid.xml:91-100): (qpos adr, dof adr, coef)
@@ -235,6 +264,7 @@ class _PlanarWalkerVectorEnv(_MujocoVectorEnv):
     DEFAULT_MAX_EPISODE_STEPS = 1000
     CTRL_LOW, CTRL_HIGH = -1.0, 1.0
     INFO_KEYS = ("x_position", "z_distance_from_origin", "x_velocity", "reward_forward", "reward_ctrl", "reward_survive")
+    INFO_DTYPES = {"reward_ctrl": np.float32}  # -ctrl_cost_weight * np.sum(np.square(float32 action)): an np.float32 in the reference's info
     N_RESET_INFO_KEYS = 2
 
     def _init_walker(self, num_envs, max_episode_steps, xml_file, frame_skip, forward_reward_weight, ctrl_cost_weight, healthy_reward,
@@ -309,6 +339,7 @@ class InvertedPendulumVectorEnv(_PendulumVectorEnv):
     NQ, NV, NU, NBODY = 2, 2, 1, 3
     CTRL_LOW, CTRL_HIGH = -3.0, 3.0
     INFO_KEYS = ("reward_survive",)
+    INFO_DTYPES = {"reward_survive": np.int64}  # inverted_pendulum_v5.py:188: `reward = int(not terminated)`
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "inverted_pendulum.xml", frame_skip: int = 2,
                  reset_noise_scale: float = 0.01, **kwargs):
@@ -351,6 +382,7 @@ class ReacherVectorEnv(_PendulumVectorEnv):
     NQ, NV, NU, NBODY = 4, 4, 2, 5
     CTRL_LOW, CTRL_HIGH = -1.0, 1.0
     INFO_KEYS = ("reward_dist", "reward_ctrl")
+    INFO_DTYPES = {"reward_ctrl": np.float32}  # -ctrl_cost_weight * np.sum(np.square(float32 action)): an np.float32 in the reference's info
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "reacher.xml", frame_skip: int = 2,
                  reward_dist_weight: float = 1, reward_control_weight: float = 1, **kwargs):
@@ -373,6 +405,7 @@ class PusherVectorEnv(_PendulumVectorEnv):
     NQ, NV, NU, NBODY = 11, 11, 7, 13
     CTRL_LOW, CTRL_HIGH = -2.0, 2.0
     INFO_KEYS = ("reward_dist", "reward_ctrl", "reward_near")
+    INFO_DTYPES = {"reward_ctrl": np.float32}  # -ctrl_cost_weight * np.sum(np.square(float32 action)): an np.float32 in the reference's info
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "pusher_v5.xml", frame_skip: int = 5,
                  reward_near_weight: float = 0.5, reward_dist_weight: float = 1, reward_control_weight: float = 0.1, **kwargs):
@@ -395,6 +428,7 @@ class SwimmerVectorEnv(_MujocoVectorEnv):
     NQ, NV, NU, NBODY = 5, 5, 2, 4
     CTRL_LOW, CTRL_HIGH = -1.0, 1.0
     INFO_KEYS = ("x_position", "y_position", "distance_from_origin", "x_velocity", "y_velocity", "reward_forward", "reward_ctrl")
+    INFO_DTYPES = {"reward_ctrl": np.float32}  # -ctrl_cost_weight * np.sum(np.square(float32 action)): an np.float32 in the reference's info
     N_RESET_INFO_KEYS = 3
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, xml_file: str = "swimmer.xml", frame_skip: int = 4,

@@ -62,6 +62,7 @@ class HipVectorEnv(VectorEnv):
     INFO_KEYS: tuple = ()        # names of the engine's scalar info columns (MuJoCo envs); the first N_RESET_INFO_KEYS are also
     N_RESET_INFO_KEYS: int = 0   # what the scalar env's reset() reports (_get_reset_info), i.e. valid on autoreset steps
     INFO_VECTOR_KEYS: tuple = () # (name, width) array-valued info entries stored after the scalar columns; reported by step AND reset
+    INFO_DTYPES: dict = {}       # info key -> dtype of the reference's entry where it is not float64 (e.g. reward_ctrl of a float32 action: np.float32)
     HOST_INFOS = False           # True: the infos need host-side table look-ups (ToyText): built on the host also with output="torch"
     metadata: dict[str, Any] = {"render_modes": [], "autoreset_mode": AutoresetMode.NEXT_STEP}
 
@@ -457,6 +458,8 @@ class HipVectorEnv(VectorEnv):
                 continue
             col = rows[:, start] if width == 0 else rows[:, start:start + width]
             val = np.where(mask if width == 0 else mask[:, None], col, 0.0)
+            if name in self.INFO_DTYPES:  # (the engine's info row is float64; such entries hold float32 values exactly)
+                val = val.astype(self.INFO_DTYPES[name])
             out[name], out["_" + name] = val, mask.copy()
         return out
 
@@ -510,9 +513,12 @@ class HipVectorEnv(VectorEnv):
             col = rows[:, start] if width == 0 else rows[:, start:start + width]
             mask = supplied if (in_reset or reset_rows is None) else (~reset_rows if supplied is None else supplied & ~reset_rows)
             if mask is None:
-                out[name], out["_" + name] = (col.clone() if self.copy else col), self._all_true_t
+                val, mask = (col.clone() if self.copy else col), self._all_true_t
             else:
-                out[name], out["_" + name] = t.where(mask if width == 0 else mask[:, None], col, 0.0), mask
+                val = t.where(mask if width == 0 else mask[:, None], col, 0.0)
+            if self.INFO_DTYPES.get(name) is np.float32:
+                val = val.to(t.float32)
+            out[name], out["_" + name] = val, mask
         return out
 
     def _build_infos_device(self) -> dict:

@@ -85,6 +85,7 @@ API int orc_mj_get(const mjo_model *m, const mjo_data *d, const char *name, doub
 /* test hooks for the glue arithmetic (pinned on NumPy by tests/test_mujoco_oracle.py) */
 #include "mujoco_envs.h"
 API double orc_test_np_sum_f64(const double *a, int n) { return orc_np_sum_f64(a, n); }
+API double orc_test_np_norm(const double *a, int n) { return orc_np_norm(a, n); }
 API float orc_test_np_sum_f32(const float *a, int n) { return orc_np_sum_f32(a, n); }
 API void orc_test_standard_normal(const uint64_t pcg[4], int n, double *out, uint64_t pcg_out[4]) {
     orc_pcg64 r;

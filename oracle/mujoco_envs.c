@@ -68,6 +68,15 @@ static double pairwise_f64(const double *a, int n) {
     }
 }
 double orc_np_sum_f64(const double *a, int n) { return pairwise_f64(a, n); }
+/* np.linalg.norm of a short 1-D float64 vector (ord None or 2): numpy/linalg/_linalg.py norm() takes sqrt(x.dot(x)), and the BLAS dot of the
+   reference environment (OpenBLAS, FMA kernels) accumulates x0 x0, then fma(x1, x1, acc), ... -- NOT the separately rounded sum of squares
+   (they differ in the last bit for ~8 % of 2-vectors).  Pinned on NumPy by tests/test_mujoco_oracle.py::test_norm_matches_numpy; found by
+   running the reference's own env classes against this glue (tests/test_mujoco_fixture_pipeline.py). */
+double orc_np_norm(const double *v, int n) {
+    double acc = v[0] * v[0];
+    for (int k = 1; k < n; k++) acc = fma(v[k], v[k], acc);
+    return sqrt(acc);
+}
 static float pairwise_f32(const float *a, int n) {
     if (n < 8) {
         float res = 0.f;
@@ -235,7 +244,8 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
         for (;;) { /* the object is re-drawn until it is farther than 0.17 from the goal at the origin of its sliders (y slider first) */
             const double c0 = -0.3 + (0.0 - (-0.3)) * orc_pcg64_double(rng), c1 = -0.2 + (0.2 - (-0.2)) * orc_pcg64_double(rng);
             qpos[m->nq - 4] = c0, qpos[m->nq - 3] = c1;
-            if (sqrt(c0 * c0 + c1 * c1) > 0.17) break;
+            const double cg[2] = {c0, c1};
+            if (orc_np_norm(cg, 2) > 0.17) break;
         }
         qpos[m->nq - 2] = 0.0, qpos[m->nq - 1] = 0.0;
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * orc_pcg64_double(rng));
@@ -250,7 +260,8 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
         for (;;) { /* the goal is re-drawn until it lies inside the 0.2 disc (np.linalg.norm of 2 elements = sqrt(g0 g0 + g1 g1)) */
             const double g0 = -0.2 + (0.2 - (-0.2)) * orc_pcg64_double(rng), g1 = -0.2 + (0.2 - (-0.2)) * orc_pcg64_double(rng);
             qpos[2] = g0, qpos[3] = g1;
-            if (sqrt(g0 * g0 + g1 * g1) < 0.2) break;
+            const double gg[2] = {g0, g1};
+            if (orc_np_norm(gg, 2) < 0.2) break;
         }
         for (int k = 0; k < m->nv; k++) qvel[k] = 0.0 + (-0.005 + (0.005 - (-0.005)) * orc_pcg64_double(rng));
         qvel[2] = 0.0, qvel[3] = 0.0;
@@ -306,8 +317,8 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     if (e->which == ORC_MJ_PUSHER) { /* pusher_v5.py:266-291 */
         const double *tip = d->xpos[m->nbody - 3], *ob = d->xpos[m->nbody - 2], *goal = d->xpos[m->nbody - 1];
         const double v1[3] = {ob[0] - tip[0], ob[1] - tip[1], ob[2] - tip[2]}, v2[3] = {ob[0] - goal[0], ob[1] - goal[1], ob[2] - goal[2]};
-        const double reward_near = -sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]) * P[0];
-        const double reward_dist = -sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]) * P[5];
+        const double reward_near = -orc_np_norm(v1, 3) * P[0];
+        const double reward_dist = -orc_np_norm(v2, 3) * P[5];
         float sq[MJO_MAXU];
         for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
         const float reward_ctrl = -orc_np_sum_f32(sq, nu) * (float)P[1]; /* float32 array sum times a Python float: float32 */
@@ -318,7 +329,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     }
     if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:188-207 */
         const double v[3] = {d->xpos[3][0] - d->xpos[4][0], d->xpos[3][1] - d->xpos[4][1], d->xpos[3][2] - d->xpos[4][2]};
-        const double reward_dist = -sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * P[0];
+        const double reward_dist = -orc_np_norm(v, 3) * P[0];
         float sq[MJO_MAXU];
         for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
         const float reward_ctrl = -orc_np_sum_f32(sq, nu) * (float)P[1]; /* float32 array sum times a Python float: float32 */
@@ -368,7 +379,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         float ctrl_cost = (float)P[1] * orc_np_sum_f32(sq, nu);
         *reward = forward_reward - (double)ctrl_cost;
         *terminated = 0;
-        info[0] = after[0], info[1] = after[1], info[2] = sqrt(after[0] * after[0] + after[1] * after[1]), info[3] = xv, info[4] = yv;
+        info[0] = after[0], info[1] = after[1], info[2] = orc_np_norm(after, 2), info[3] = xv, info[4] = yv;
         info[5] = forward_reward, info[6] = -(double)ctrl_cost;
         return;
     }
@@ -414,7 +425,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     const double rewards = forward_reward + healthy_reward, costs = ctrl_cost + contact_cost;
     *reward = rewards - costs;
     *terminated = !healthy && P[7] != 0.0;
-    info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = sqrt(d->qpos[0] * d->qpos[0] + d->qpos[1] * d->qpos[1]);
+    info[0] = d->qpos[0], info[1] = d->qpos[1], info[2] = orc_np_norm(d->qpos, 2);
     info[3] = xv, info[4] = yv, info[5] = forward_reward, info[6] = -ctrl_cost, info[7] = -contact_cost, info[8] = healthy_reward;
     if (e->which == ORC_MJ_HUMANOID) tendon_info(e, info + 9);
 }
@@ -429,7 +440,7 @@ void orc_mjenv_reset_info(const orc_mjenv *e, double *row) {
     else if (is_planar_walker(e->which))
         row[1] = e->d.qpos[1] - e->m->qpos0[1]; /* z_distance_from_origin, hopper_v5.py:338-342 */
     else if (e->which != ORC_MJ_HALF_CHEETAH)
-        row[1] = e->d.qpos[1], row[2] = sqrt(row[0] * row[0] + row[1] * row[1]);
+        row[1] = e->d.qpos[1], row[2] = orc_np_norm(row, 2);
 }
 
 /* checkpoint row: qpos, qvel, qacc_warmstart, tracked xy of the last forward pass */

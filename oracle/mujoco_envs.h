@@ -18,6 +18,7 @@ typedef struct orc_mjenv {
 
 double orc_standard_normal(orc_pcg64 *rng);
 double orc_np_sum_f64(const double *a, int n);
+double orc_np_norm(const double *v, int n);
 float orc_np_sum_f32(const float *a, int n);
 const mjo_model *orc_mj_model(int which);
 int orc_mjenv_obs_dim(int which, const double *params);

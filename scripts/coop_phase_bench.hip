@@ -21,7 +21,7 @@
 using namespace mjx;
 
 template <class M, int G, bool PGS>
-__global__ __launch_bounds__(64) void phys(double *state, const float *actions, int N, int nsub, unsigned long long *phase, double *spill) {
+__global__ __launch_bounds__(64) void phys(double *state, const float *actions, int N, int nsub, unsigned long long *phase) {
     typedef coop::Sim<M, G, PGS> S;
     constexpr int EPW = 64 / G;
     __shared__ typename S::B boards[EPW];
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = lane < M::NV ? state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;
-    r.spill = spill + (size_t)env * S::SPILL_DOUBLES;
+    r.grp = grp;
 #ifdef MJX_COUNT_WORK
     r.work = 0, r.work_wave = 0;
 #endif
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
 
 // COOP_DEBUG: ONE forward pass from the initial state; per env 4 NV + NV^2 doubles: qacc, qacc_smooth, bias, qfrc_constraint, mass-matrix rows
 template <class M, int G>
-__global__ __launch_bounds__(64) void fwd_debug(const double *state, const float *actions, int N, double *out, double *spill) {
+__global__ __launch_bounds__(64) void fwd_debug(const double *state, const float *actions, int N, double *out) {
     typedef coop::Sim<M, G> S;
     constexpr int EPW = 64 / G, NV = M::NV;
     __shared__ typename S::B boards[EPW];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void fwd_debug(const double *state, const float
     for (int k = lane; k < M::NV; k += G) bb.qvel[k] = state[(size_t)(M::NQ + k) * N + env];
     for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
     r.warm = 0.0;
-    r.spill = spill + (size_t)env * S::SPILL_DOUBLES;
+    r.grp = grp;
     coop::coop_sync();
     S::forward(bb, r, lane);
     coop::coop_sync();
@@ -104,8 +104,6 @@ int run(int N, int nsub, float amp) {
     unsigned long long *d_ph;
     hipMalloc(&d_st, sizeof(double) * st.size()), hipMalloc(&d_act, sizeof(float) * act.size()), hipMalloc(&d_ph, 12 * 8 + 256 + sizeof(int) * (size_t)N);
     hipMemcpy(d_st, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice);
-    double *d_spill;
-    hipMalloc(&d_spill, sizeof(double) * ((size_t)coop::Sim<M, G, PGS>::SPILL_DOUBLES * N + 1));
     const dim3 grid((N + 64 / G - 1) / (64 / G)), block(64);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
@@ -116,7 +114,7 @@ int run(int N, int nsub, float amp) {
         hipMemset(d_out, 0, sizeof(double) * W * N);
         for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
         hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL((fwd_debug<M, G>), grid, block, 0, 0, d_st, d_act, N, d_out, d_spill);
+        hipLaunchKernelGGL((fwd_debug<M, G>), grid, block, 0, 0, d_st, d_act, N, d_out);
         std::vector<double> out(W * N);
         hipMemcpy(out.data(), d_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost);
         FILE *f = fopen(getenv("COOP_DEBUG"), "wb");
@@ -131,7 +129,7 @@ int run(int N, int nsub, float amp) {
         for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
         hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
         if (t == warm) hipMemset(d_ph, 0, 16 * 8), hipEventRecord(e0);
-        hipLaunchKernelGGL((phys<M, G, PGS>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph, d_spill);
+        hipLaunchKernelGGL((phys<M, G, PGS>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph);
     }
     hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
     unsigned long long ph[12];

@@ -92,12 +92,11 @@ int emu_step(const double *qpos, const double *qvel, const double *ctrl, int nsu
     typedef coop::Sim<M, G, PGS> S;
     auto *bb = new typename S::B();
     std::memset((void *)bb, 0, sizeof(*bb));
-    std::vector<double> spill(S::SPILL_DOUBLES + 1);
     g_syncs = 0;
     run_group(G, [&](int lane) {
         typename S::R r;
         std::memset((void *)&r, 0, sizeof(r));
-        r.spill = spill.data();
+        r.grp = 0;
         if (warm && lane < M::NV) r.warm = warm[lane];
         S::init(*bb, lane);
         for (int k = lane; k < M::NQ; k += G) bb->qpos[k] = qpos[k];

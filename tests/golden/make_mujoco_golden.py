@@ -30,7 +30,7 @@ sys.dont_write_bytecode = True
 
 import numpy as np  # noqa: E402
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("MUJOCO_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))  # (the override is for tests/test_mujoco_fixture_pipeline.py)
 IDS = {"half_cheetah": "HalfCheetah-v5", "ant": "Ant-v5", "humanoid": "Humanoid-v5", "humanoid_standup": "HumanoidStandup-v5",
        "hopper": "Hopper-v5", "walker2d": "Walker2d-v5", "inverted_pendulum": "InvertedPendulum-v5",
        "inverted_double_pendulum": "InvertedDoublePendulum-v5", "reacher": "Reacher-v5", "swimmer": "Swimmer-v5", "pusher": "Pusher-v5"}
@@ -129,6 +129,9 @@ def main():
         return 2
     import gymnasium as gym
 
+    if getattr(mujoco, "IS_ORACLE_SHIM", False) and OUT == os.path.dirname(os.path.abspath(__file__)):
+        print("refusing to write oracle-shim fixtures into tests/golden/: they would look like a pin and are none (set MUJOCO_GOLDEN_OUT)")
+        return 3
     for name, env_id in IDS.items():
         fixtures_for(name, env_id, mujoco, gym)
     return 0

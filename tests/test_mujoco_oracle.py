@@ -148,6 +148,24 @@ def test_resting_contact_carries_the_weight_and_solver_kkt(name, models):
     assert (f >= 0).all()
 
 
+def test_norm_matches_numpy():
+    """np.linalg.norm of the 2- / 3-vectors the reference's glue takes (ant_v5.py:362 distance_from_origin, reacher_v5.py:190,
+    pusher_v5.py:268-271, the re-draw loops of their resets): sqrt(x.dot(x)) with the BLAS dot's fused accumulation -- NOT the separately
+    rounded sum of squares, which differs in the last bit for ~8 % of vectors (asserted, so that a NumPy / BLAS with another arithmetic shows up
+    here and not as a 1-ulp reward difference)."""
+    dll = omj.dll()
+    dll.orc_test_np_norm.restype, dll.orc_test_np_norm.argtypes = ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.default_rng(11)
+    plain_differs = 0
+    for n in (2, 3):
+        for _ in range(20000):
+            v = rng.normal(size=n) * 10.0 ** rng.integers(-3, 3)
+            ref = np.linalg.norm(v, ord=2)
+            assert dll.orc_test_np_norm(v.ctypes.data, n) == ref == np.linalg.norm(v), (n, v)
+            plain_differs += float(np.sqrt(np.sum(v * v))) != ref
+    assert plain_differs > 100
+
+
 def test_numpy_sum_order_and_standard_normal_bit_exact():
     dll = omj.dll()
     dll.orc_test_np_sum_f64.restype, dll.orc_test_np_sum_f64.argtypes = ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]
