@@ -358,6 +358,7 @@ def main():
     ap.add_argument("--env", default="CartPole-v1")
     ap.add_argument("--num-envs", type=int, default=65536, help="sub-environments PER GPU")
     ap.add_argument("--inner", type=int, default=128, help="vector steps fused into one launch (one bench step)")
+    ap.add_argument("--spinup", type=float, default=0.5, help="seconds of untimed launches before the warm-up, so that the timed region runs at sustained clocks (0 = off)")
     ap.add_argument("--sustained", type=float, default=1.5, help="seconds of back-to-back launches for sustained_value (0 = skip)")
     ap.add_argument("--pmc", choices=["auto", "full", "off"], default="auto",
                     help="live rocprofv3 counter passes on a child invocation: auto = primary traffic, then SQ activity of the MuJoCo secondaries and live "
@@ -422,6 +423,18 @@ def main():
         K = int(min(20000, max(20, round(args.pilot_seconds / max(float(pilot.item()), 1e-6)))))
     if W is None:
         W = max(5, K // 10)
+    # Clock spin-up (untimed, BEFORE the W warm-up launches, reported as `clock_spinup`): a GPU that has been idle starts in a low power state and
+    # takes a few hundred milliseconds of load to reach its sustained clocks -- round 2's 20-launch runs (2 ms) measured 99 us per launch where
+    # the steady state is 90.  With explicit --steps the timed region can be that short, so the device is brought to steady state first; with the
+    # default (~1 s) timed region the spin-up is the same load a few hundred milliseconds earlier.  --spinup 0 switches it off.
+    spin_launches = 0
+    if args.spinup > 0 and not args.child:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup:
+            for _ in range(8):
+                cfg.launch()
+            spin_launches += 8
+            sync_local()
     for _ in range(W):
         cfg.launch()
     if args.child:
@@ -445,7 +458,8 @@ def main():
             "metric": "env-steps/sec at num_envs=65536 (1/2/4/8 MI355X) vs CPU AsyncVectorEnv",
             "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", **({} if gpu else {"engine": "oracle (CPU checker: a dry run of the control flow, NOT a measurement)"}),
+            "dtype": "f64", "data": "synthetic", "clock_spinup": {"seconds": args.spinup, "launches": spin_launches, "note": "untimed, before the warmup launches"},
+            **({} if gpu else {"engine": "oracle (CPU checker: a dry run of the control flow, NOT a measurement)"}),
             "config": {"workload": f"{args.env} num_envs={N} per GPU, random policy (on-device action_space.sample()), "
                                    f"NEXT_STEP autoreset, TimeLimit, fused rollout of {inner} vector steps per launch, "
                                    "trajectory (actions, obs, rewards, terminated, truncated) written to HBM",

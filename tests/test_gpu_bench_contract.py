@@ -24,6 +24,7 @@ def test_bench_line_has_the_contract_fields():
     assert r["n_gpus"] == 1 and r["steps"] == 5 and r["warmup"] == 2 and r["higher_is_better"] is True and r["scaling"] == "weak"
     assert r["vs_baseline"] is None and r["data"] == "synthetic" and r["dtype"] == "f64" and "workload" in r["config"] and "model" not in r["config"]
     assert r["value"] > 1e9 and abs(r["ms_per_step"] - 65536 * 128 / r["value"] * 1e3) / r["ms_per_step"] < 0.2  # env-steps/s over 65536 x 128 steps per launch
+    assert r["clock_spinup"]["seconds"] == 0.5 and r["clock_spinup"]["launches"] > 0  # untimed, before the warm-up
     rf = r["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
