@@ -38,6 +38,9 @@ static __shared__ uint64_t g_pow_exp[256];
 static __shared__ double g_powf_log2[32];
 static __shared__ uint64_t g_powf_exp2[32];
 
+struct TwoPi {
+    static constexpr double value = 2 * kPi;
+};
 // KASM: constant Horner steps as inline-asm v_fma_f64 (sincos_exact.h fma_k); false for kernels whose registers overflow into AGPRs
 template <bool KASM>
 struct ExactMathT {
@@ -63,6 +66,7 @@ struct ExactMathT {
     static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true, KASM>(g_trig6, x); }
     static MI_DEV double cos_bounded(double x) { return mi_sincos::cos_bf<true, KASM>(g_trig6, x); }
     static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false, KASM>(g_trig6, x, s, c); }
+    static MI_DEV double fmod_2pi(double x) { return mi_sincos::fmod_const(x, TwoPi()); }  // fmod(x, 2 pi): exact, like the library's, in half the instructions
     static MI_DEV double sq(double x) { return mi_pow::square<KASM>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
     static MI_DEV float sqf(float x) { return mi_pow::squaref<KASM>(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2
 };
@@ -101,6 +105,7 @@ struct FastMath {
     static MI_DEV double sin_bounded(double x) { return ::sin(x); }
     static MI_DEV double cos_bounded(double x) { return ::cos(x); }
     static MI_DEV void sincos_bounded(double x, double &s, double &c) { ::sincos(x, &s, &c); }
+    static MI_DEV double fmod_2pi(double x) { return ::fmod(x, 2 * kPi); }
     static MI_DEV double sq(double x) { return x * x; }
     static MI_DEV float sqf(float x) { return x * x; }
 };
@@ -249,7 +254,7 @@ struct PendulumT {
         u = u < (float)-max_torque ? (float)-max_torque : u;
         u = u > (float)max_torque ? (float)max_torque : u;
         // angle_normalize: ((x + pi) % (2 pi)) - pi with Python floor-modulo
-        double md = fmod(th + kPi, 2 * kPi);
+        double md = M::fmod_2pi(th + kPi);
         if (md != 0.0) {
             if (md < 0.0) md += 2 * kPi;
         } else {

@@ -36,6 +36,12 @@ __attribute__((visibility("default"))) void sincos_pair_batch(const double *x, d
     const double *t6 = table6();
     for (long i = 0; i < n; i++) mi_sincos::sincos_pair<true>(t6, x[i], s[i], c[i]);
 }
+struct TwoPi {
+    static constexpr double value = 6.283185307179586;
+};
+__attribute__((visibility("default"))) void fmod_2pi_batch(const double *x, double *out, long n) {
+    for (long i = 0; i < n; i++) out[i] = mi_sincos::fmod_const(x[i], TwoPi());
+}
 __attribute__((visibility("default"))) void table_copy(double *out) {
     for (int i = 0; i < 440; i++) out[i] = mi_sincos::kTable[i];
 }

@@ -121,3 +121,16 @@ def test_generated_table_is_the_one_inside_libm():
     if at < 0:
         pytest.skip("__sincostab not located in this libm build")
     assert blob[at:at + 440 * 8] == t.tobytes()
+
+
+def test_fmod_by_a_constant_is_the_c_library_fmod():
+    """mi_sincos::fmod_const (Pendulum's angle_normalize): exact like fmod, for every sign, tiny and large arguments and the multiples of 2 pi."""
+    rng = np.random.default_rng(4)
+    two_pi = 6.283185307179586
+    k = np.arange(-5000, 5001, dtype=np.float64)
+    mult = k * two_pi
+    x = np.concatenate([rng.uniform(-50, 50, 2_000_000), rng.uniform(-1e6, 1e6, 1_000_000), rng.uniform(-1e12, 1e12, 500_000),
+                        rng.uniform(-1, 1, 200_000) * 2.0 ** rng.integers(-1070, 0, 200_000).astype(np.float64),
+                        mult, np.nextafter(mult, np.inf), np.nextafter(mult, -np.inf), np.array([0.0, -0.0, two_pi, -two_pi, 3.141592653589793, 1e15])])
+    got = run("fmod_2pi_batch", x)
+    assert same_bits(got, np.fmod(x, two_pi))
