@@ -196,7 +196,11 @@ def _rocprof_counters(args, counters, kernel_like, timeout_s):
 SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
 
 
-def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150, env_kwargs=None):
+ISSUE_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
+
+
+def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150, env_kwargs=None, want_issue=False):
     """HBM traffic per dispatch of `kernel` (WRITE_SIZE + 2 FETCH_SIZE, in KiB on gfx950; MI355X_MICROARCH.md HBM section: separate
     passes, FETCH_SIZE doubled) and, for the VALU-bound kernels, the SQ activity counters as shares of SQ_WAVE_CYCLES."""
     args = ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", "1", "--env-kwargs", json.dumps(env_kwargs or {})]
@@ -208,6 +212,17 @@ def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150
             out["traffic"] = 1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0])
             out["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, FETCH_SIZE doubled) on a child invocation in this run, "
                                      f"{f['FETCH_SIZE'][1]} dispatches of {kernel}")
+    if want_issue:
+        ic = _rocprof_counters(args, ISSUE_COUNTERS, kernel, timeout_s)
+        if ic and ic.get("SQ_WAVES", (0, 0))[0] > 0:
+            waves = ic["SQ_WAVES"][0]
+            valu, salu = ic["SQ_INSTS_VALU"][0] / waves / inner, ic["SQ_INSTS_SALU"][0] / waves / inner
+            out["issue"] = {"valu_per_env_step": valu, "salu_per_env_step": salu,
+                            # a SIMD issues at most one 64-lane fp64 VALU instruction per 4 cycles; with ONE wavefront per SIMD (num_envs = 65536)
+                            # scalar instructions are not hidden behind another wavefront's VALU work, so they take issue slots too
+                            "ceiling_env_steps_per_s": SIMDS * 64 * CLOCK_HZ / (4.0 * (valu + salu)),
+                            "assumptions": f"{SIMDS} SIMDs x 64 lanes, one instruction per 4 cycles at {CLOCK_HZ / 1e9:.1f} GHz, VALU + SALU of one wavefront per SIMD",
+                            "source": "rocprofv3 --pmc " + " ".join(ISSUE_COUNTERS) + " on a child invocation in this run"}
     if want_sq:
         sq = _rocprof_counters(args, SQ_COUNTERS, kernel, timeout_s)
         if sq and sq.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
@@ -327,7 +342,8 @@ class Config:
         kernel = self.dominant_kernel()
         coop = self.env_id in MJ_COOP
         per = self.inner if coop else 1  # dispatches of the dominant kernel per rollout launch
-        live = live_counters(self.env_id, self.N, self.inner, kernel, "traffic" in pmc, "sq" in pmc and coop, env_kwargs=self.env_kwargs) if pmc else {}
+        live = live_counters(self.env_id, self.N, self.inner, kernel, "traffic" in pmc, "sq" in pmc and coop, env_kwargs=self.env_kwargs,
+                             want_issue="issue" in pmc and not coop) if pmc else {}
         traffic, src = live.get("traffic"), live.get("traffic_source")
         if traffic is not None:
             traffic *= per
@@ -341,7 +357,16 @@ class Config:
             return {"bound": "valu", "achieved": (sq or {}).get("active_inst_valu_frac"), "peak": 1.0, "unit": "share of wave cycles issuing VALU instructions (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), one wavefront per SIMD",
                     "frac": (sq or {}).get("active_inst_valu_frac"), "sq": sq, "sq_source": live.get("sq_source"), "hbm_frac": achieved / HBM_PEAK_GBS,
                     "avg_vector_step_ms": kernel_s * 1e3 / self.inner, **base}
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **base}
+        out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **base}
+        if live.get("issue"):
+            # The OTHER ceiling of this kernel: at one wavefront per SIMD the instruction issue rate bounds it before HBM does.
+            iss = dict(live["issue"])
+            steps_per_s = self.N * self.inner / kernel_s  # lanes stepped per second by this kernel (autoreset lanes included: they execute too)
+            iss["achieved_lane_steps_per_s"] = steps_per_s
+            iss["frac_of_issue_ceiling"] = steps_per_s / iss["ceiling_env_steps_per_s"]
+            iss["hbm_ceiling_env_steps_per_s"] = HBM_PEAK_GBS * 1e9 / (algo / (self.N * self.inner))
+            out["issue_bound"] = iss
+        return out
 
     def close(self):
         self.env.close()
@@ -450,7 +475,7 @@ def main():
     elapsed = red["elapsed_s"]
     env_steps, episodes, return_sum = float(red["env_steps"]), float(red["episodes"]), float(red["return_sum"])
     single = rank == 0 and world == 1 and gpu
-    pmc_primary = ("traffic", "sq") if (single and args.pmc != "off") else ()
+    pmc_primary = ("traffic", "sq", "issue") if (single and args.pmc != "off") else ()
 
     result = None
     if rank == 0:
