@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 1: the whole GPU suite on the current build + the driver's bench command + the default bench (steady state)
 set -u
-cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/r03a_pytest.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/r03a_pytest.log
 tail -15 gpurun_out/r03a_pytest.log
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03a_bench_driver.json 2> gpurun_out/r03a_bench_driver.err; echo "bench(driver flags) exit $?"

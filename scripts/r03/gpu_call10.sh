@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 closing evidence: default bench line, CartPole / Ant / Humanoid rocprofv3 summaries, one steady-state line per env id
 set -u
-cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
 timeout 900 python bench.py > gpurun_out/r03_final_bench.json 2> gpurun_out/r03_final_bench.err; echo "bench exit $?"
 python - <<'PY'
 import json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 2: full GPU suite; MFMA A/B microbenchmark; PGS qacc_smooth-by-inverse A/B (phase harness + bench.py on two libraries)
 set -u
-cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r03b_pytest.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/r03b_pytest.log
 tail -25 gpurun_out/r03b_pytest.log
 echo "=== MFMA microbenchmark"; timeout 120 scripts/humanoid_mfma.bin | tee gpurun_out/r03b_mfma_humanoid.txt

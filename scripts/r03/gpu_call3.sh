@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 3: classic-control parity after the trig / pow trims + their bench lines and SQ instruction counters; MFMA microbench (tree fixed, fma-chain check)
 set -u
-cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_wrappers.py tests/test_gpu_bench_contract.py -m gpu -q > gpurun_out/r03c_pytest.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/r03c_pytest.log
 tail -12 gpurun_out/r03c_pytest.log
 echo "=== MFMA microbenchmark"; timeout 120 scripts/humanoid_mfma.bin | tee gpurun_out/r03c_mfma_humanoid.txt

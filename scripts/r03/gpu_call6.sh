@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 6: full GPU suite on the build with Acrobot on the builtin-fma policy; Acrobot determinism loop; classic bench lines + SQ counters
 set -u
-cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r03d_pytest.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/r03d_pytest.log
 tail -8 gpurun_out/r03d_pytest.log
 for rep in 1 2 3; do echo "=== determinism rep $rep"; timeout 120 python scripts/debug_acrobot3.py 2>&1 | grep "^T=" | grep -v "bad lanes \[\], given-actions t=0 bad \[\], sampled vs given per t: \[0\(, 0\)*\]$" ; done; echo "(lines above = launches that differed; none expected)"

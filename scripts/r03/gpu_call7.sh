@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 7: MFMA block Cholesky in the PGS kernels -- MuJoCo GPU tests, then A/B (phase harness + bench.py on two libraries)
 set -u
-cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_mujoco.py tests/test_gpu_scheduler_guard.py tests/test_gpu_parity.py -m gpu -q > gpurun_out/r03e_pytest.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/r03e_pytest.log
 tail -6 gpurun_out/r03e_pytest.log
 for W in 3 12; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 8: full GPU suite after the glue (np.linalg.norm) change; smoke; the driver's bench command
 set -u
-cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r03f_pytest.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/r03f_pytest.log
 tail -4 gpurun_out/r03f_pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
