@@ -36,6 +36,12 @@
 #ifndef MJX_CHOL_LDS_FOR_16
 #define MJX_CHOL_LDS_FOR_16 0  // diagnostic switch: 16-lane groups on the LDS-exchange Cholesky as well (costs LDS: 3 instead of 4 wavefronts per CU)
 #endif
+#ifndef MJX_KIN_LOCAL_JOINTS
+#define MJX_KIN_LOCAL_JOINTS 1  // kinematics: a body's joint chain is evaluated once, in the body's static frame, before the level loop (0: inside it, rounds 1-2)
+#endif
+#ifndef MJX_KIN_PREFIX
+#define MJX_KIN_PREFIX 1  // kinematics: world poses by pointer jumping over the body tree (ceil(log2(depth)) rounds) instead of one pass per tree level
+#endif
 #ifndef MJX_CHOL_MFMA
 #define MJX_CHOL_MFMA 0  // 1: 32-lane PGS kernels factor M in block-16 form with the Schur update on v_mfma_f64_16x16x4_f64 (chol_factor_blocked).
                          // MEASURED in the product (round 3, profiles/r03_mfma_cholesky_in_product.txt): correct (GPU suite green, states equal to
@@ -265,12 +271,197 @@ struct Sim {
         coop_sync();
     }
 
+    // ancestors at distance 1, 2, 4, ... of every body (0 = the world: nothing left to compose), for the pointer-jumping kinematics
+    struct AncTab {
+        static constexpr int MAXR = 4;
+        int ROUNDS;
+        int a[MAXR][NB];
+    };
+    static constexpr AncTab make_anc() {
+        AncTab t{};
+        t.ROUNDS = 0;
+        while ((1 << t.ROUNDS) < M::MAXDEPTH) t.ROUNDS++;
+        for (int b = 0; b < NB; b++) {
+            for (int rd = 0; rd < AncTab::MAXR; rd++) {
+                int x = b;
+                for (int s = 0; s < (1 << rd) && x > 0; s++) x = M::body_parentid[x];
+                t.a[rd][b] = x;
+            }
+        }
+        return t;
+    }
+    static constexpr AncTab kAnc = make_anc();
+    static_assert(kAnc.ROUNDS <= AncTab::MAXR, "body tree deeper than 16 levels");
+
     // ---- position stage ---------------------------------------------------------------------------------------------------
     static MJX_DEV void kinematics(B &bb, R &r, int lane) {
         const int b = lane + 1;
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
         const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+#if MJX_KIN_LOCAL_JOINTS
+        // (round 3) The joints of a body act in the body's own static frame F0 (parent pose o body_pos / body_quat): with pose = F0 o (pl, ql),
+        //   anchor_j = F0 (pl + R(ql) jnt_pos_j),  axis_j = F0 R(ql) jnt_axis_j,  hinge: ql <- ql o q(axis_j, theta_j), pl <- anchor_j^loc - R(ql) jnt_pos_j,
+        //   slide: pl += axis_j^loc theta_j
+        // -- the same recursion mj_kinematics runs in world coordinates, factored.  (pl, ql) and the local anchors / axes depend on this body's
+        // qpos only, so EVERY body evaluates its joint chain at once, before the level loop; a level then only composes the parent's pose with
+        // F0 and maps the locals to the world.  Before, the whole joint chain (a sincos, two quaternion products and three rotations per
+        // hinge, up to three hinges) sat inside the level loop, where a wavefront pays it once per LEVEL (six for the Humanoid) although each
+        // body uses it once.  Rounding differs from the world-frame order at the 1e-16 level (tests: HIP / emulation vs oracle tolerances).
+        const bool free_root = jn == 1 && M::jnt_type[ja] == FREE;
+        double ql[4] = {1, 0, 0, 0}, pl[3] = {0, 0, 0};
+        if (isbody && !free_root) {
+#pragma unroll
+            for (int jj = 0; jj < M::MAXJPB; jj++) {
+                if (jj < jn) {
+                    const int j = ja + jj;
+                    double Rm[9], qq[4], t[3];
+                    quat_to_mat(Rm, ql);
+                    rot_vec(t, Rm, M::jnt_pos[j]);
+                    r.anchor[jj][0] = pl[0] + t[0], r.anchor[jj][1] = pl[1] + t[1], r.anchor[jj][2] = pl[2] + t[2];
+                    rot_vec(r.axis[jj], Rm, M::jnt_axis[j]);
+                    const double q = bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]];
+                    if (M::jnt_type[j] == HINGE) {
+                        axis_angle_quat(qq, M::jnt_axis[j], q);
+                        quat_mul(ql, ql, qq);
+                        quat_to_mat(Rm, ql);
+                        rot_vec(t, Rm, M::jnt_pos[j]);
+                        pl[0] = r.anchor[jj][0] - t[0], pl[1] = r.anchor[jj][1] - t[1], pl[2] = r.anchor[jj][2] - t[2];
+                    } else {
+                        pl[0] += r.axis[jj][0] * q, pl[1] += r.axis[jj][1] * q, pl[2] += r.axis[jj][2] * q;
+                    }
+                }
+            }
+        }
+#if MJX_KIN_PREFIX
+        // World poses by pointer jumping.  T_b starts as the body's pose in its parent's frame (static frame o joint chain; the free root: its
+        // qpos) and a_b as the parent; a round replaces T_b by T_{a_b} o T_b and a_b by a_{a_b}, so after ceil(log2(MAXDEPTH)) rounds every T_b
+        // is a world pose -- 3 rounds of one pose product for the Humanoid's 6 levels (2 for Ant's 4) instead of one pass over the whole
+        // per-body work per LEVEL, which a lone wavefront pays in full each time however few bodies the level has.  The joints' anchors and
+        // axes need the body's static frame in world coordinates: F0 = T_b o (pl, ql)^-1.  The product order differs from mj_kinematics'
+        // (associativity): 1e-16-level rounding, and quaternions are normalised once at the end instead of per level.
+        double pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
+        if (isbody) {
+            if (free_root) {
+                const int qa = M::jnt_qposadr[ja];
+                pos[0] = bb.qpos[qa], pos[1] = bb.qpos[qa + 1], pos[2] = bb.qpos[qa + 2];
+                quat[0] = bb.qpos[qa + 3], quat[1] = bb.qpos[qa + 4], quat[2] = bb.qpos[qa + 5], quat[3] = bb.qpos[qa + 6];
+                quat_normalize(quat);
+            } else {
+                double RS[9], t[3];
+                quat_to_mat(RS, M::body_quat[bi]);
+                rot_vec(t, RS, pl);
+                pos[0] = M::body_pos[bi][0] + t[0], pos[1] = M::body_pos[bi][1] + t[1], pos[2] = M::body_pos[bi][2] + t[2];
+                quat_mul(quat, M::body_quat[bi], ql);
+            }
+        }
+#pragma unroll
+        for (int rd = 0; rd < kAnc.ROUNDS; rd++) {
+            if (isbody) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) bb.xpos[b][k] = pos[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) bb.A.kin.xquat[b][k] = quat[k];
+            }
+            coop_sync();
+            const int a = kAnc.a[rd][bi];
+            if (isbody && a != 0) {
+                double Ra[9], t[3], qa[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) qa[k] = bb.A.kin.xquat[a][k];
+                quat_to_mat(Ra, qa);
+                rot_vec(t, Ra, pos);
+                pos[0] = bb.xpos[a][0] + t[0], pos[1] = bb.xpos[a][1] + t[1], pos[2] = bb.xpos[a][2] + t[2];
+                quat_mul(quat, qa, quat);
+            }
+            coop_sync();  // every read of the old poses before the next round (or the final values) overwrites them
+        }
+        if (isbody) {
+            quat_normalize(quat);
+            double t[3];
+            if (free_root) {
+                r.anchor[0][0] = pos[0], r.anchor[0][1] = pos[1], r.anchor[0][2] = pos[2];
+                r.axis[0][0] = 0, r.axis[0][1] = 0, r.axis[0][2] = 1;
+            } else {
+                double posS[3], quatS[4], RS[9];
+                const double qc[4] = {ql[0], -ql[1], -ql[2], -ql[3]};
+                quat_mul(quatS, quat, qc);
+                quat_to_mat(RS, quatS);
+                rot_vec(t, RS, pl);
+                posS[0] = pos[0] - t[0], posS[1] = pos[1] - t[1], posS[2] = pos[2] - t[2];
+#pragma unroll
+                for (int jj = 0; jj < M::MAXJPB; jj++) {
+                    if (jj < jn) {
+                        rot_vec(t, RS, r.anchor[jj]);
+                        r.anchor[jj][0] = posS[0] + t[0], r.anchor[jj][1] = posS[1] + t[1], r.anchor[jj][2] = posS[2] + t[2];
+                        rot_vec(t, RS, r.axis[jj]);
+                        r.axis[jj][0] = t[0], r.axis[jj][1] = t[1], r.axis[jj][2] = t[2];
+                    }
+                }
+            }
+            quat_to_mat(r.xmat, quat);
+            rot_vec(t, r.xmat, M::body_ipos[bi]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) bb.xpos[b][k] = pos[k], bb.xipos[b][k] = pos[k] + t[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) bb.A.kin.xquat[b][k] = quat[k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) bb.A.kin.xmat[b][k] = r.xmat[k];
+        }
+        coop_sync();
+#else
+#pragma unroll 1
+        for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
+            if (isbody && depth == lev) {
+                double pos[3], quat[4];
+                if (free_root) {
+                    const int qa = M::jnt_qposadr[ja];
+                    pos[0] = bb.qpos[qa], pos[1] = bb.qpos[qa + 1], pos[2] = bb.qpos[qa + 2];
+                    quat[0] = bb.qpos[qa + 3], quat[1] = bb.qpos[qa + 4], quat[2] = bb.qpos[qa + 5], quat[3] = bb.qpos[qa + 6];
+                    quat_normalize(quat);
+                    r.anchor[0][0] = pos[0], r.anchor[0][1] = pos[1], r.anchor[0][2] = pos[2];
+                    r.axis[0][0] = 0, r.axis[0][1] = 0, r.axis[0][2] = 1;
+                } else {
+                    double t[3], posS[3], quatS[4], RS[9];
+                    if (p == 0) {  // the world frame is the identity (its rows of the blackboard are not kept)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) posS[k] = M::body_pos[bi][k];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) quatS[k] = M::body_quat[bi][k];
+                    } else {
+                        rot_vec(t, bb.A.kin.xmat[p], M::body_pos[bi]);
+                        posS[0] = bb.xpos[p][0] + t[0], posS[1] = bb.xpos[p][1] + t[1], posS[2] = bb.xpos[p][2] + t[2];
+                        quat_mul(quatS, bb.A.kin.xquat[p], M::body_quat[bi]);
+                    }
+                    quat_to_mat(RS, quatS);
+#pragma unroll
+                    for (int jj = 0; jj < M::MAXJPB; jj++) {
+                        if (jj < jn) {
+                            rot_vec(t, RS, r.anchor[jj]);
+                            r.anchor[jj][0] = posS[0] + t[0], r.anchor[jj][1] = posS[1] + t[1], r.anchor[jj][2] = posS[2] + t[2];
+                            rot_vec(t, RS, r.axis[jj]);
+                            r.axis[jj][0] = t[0], r.axis[jj][1] = t[1], r.axis[jj][2] = t[2];
+                        }
+                    }
+                    rot_vec(t, RS, pl);
+                    pos[0] = posS[0] + t[0], pos[1] = posS[1] + t[1], pos[2] = posS[2] + t[2];
+                    quat_mul(quat, quatS, ql);
+                }
+                quat_normalize(quat);
+                double t[3];
+                quat_to_mat(r.xmat, quat);
+                rot_vec(t, r.xmat, M::body_ipos[bi]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) bb.xpos[b][k] = pos[k], bb.xipos[b][k] = pos[k] + t[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) bb.A.kin.xquat[b][k] = quat[k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) bb.A.kin.xmat[b][k] = r.xmat[k];
+            }
+            coop_sync();
+        }
+#endif
+#else
 #pragma unroll 1
         for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
             if (isbody && depth == lev) {
@@ -329,6 +520,7 @@ struct Sim {
             }
             coop_sync();
         }
+    #endif
     }
 
     // subtree centre of mass of the tree (every lane computes it: same summation order as the one-lane code), the body's
