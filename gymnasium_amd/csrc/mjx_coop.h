@@ -39,6 +39,9 @@
 #ifndef MJX_KIN_LOCAL_JOINTS
 #define MJX_KIN_LOCAL_JOINTS 1  // kinematics: a body's joint chain is evaluated once, in the body's static frame, before the level loop (0: inside it, rounds 1-2)
 #endif
+#ifndef MJX_VEL_PREFIX
+#define MJX_VEL_PREFIX 1  // com velocities / RNE accelerations: prefix sums over the body tree by pointer jumping instead of one pass per tree level
+#endif
 #ifndef MJX_KIN_PREFIX
 #define MJX_KIN_PREFIX 1  // kinematics: world poses by pointer jumping over the body tree (ceil(log2(depth)) rounds) instead of one pass per tree level
 #endif
@@ -219,7 +222,7 @@ struct Lane {
     double cdof[6], Mrow[Board<M, G>::M_IN_LDS ? 1 : NV], Hrow[NV], idiag;
     double bias, qfrc_smooth, qfrc_actuator, qacc_smooth, qacc, qacc_int, qfrc_constraint;
 #if defined(MJX_PHASE_TIMING) && !defined(MJX_HOST_EMU)
-    unsigned long long tphase[12], tmark;
+    unsigned long long tphase[16], tmark;
 #endif
 #ifdef MJX_COUNT_WORK
     int work, work_wave;  // harness statistics: passes of the solver's state machine (factor / solve / assembly rounds) of this sub-environment
@@ -595,6 +598,103 @@ struct Sim {
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
         const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+#if MJX_VEL_PREFIX
+        // cvel and cacc live in ONE frame (the com-based world frame), so a body's value is its parent's plus the contributions of its own
+        // joints: two prefix sums over the tree, done by pointer jumping (see kinematics()) -- first the velocities (a joint's cdof_dot needs the
+        // velocity just before it), then the accelerations.  Each body walks its own joint chain ONCE instead of the wavefront walking the
+        // longest chain once per level.  The sums associate differently from the per-level recursion: rounding only.
+        double v[6] = {0, 0, 0, 0, 0, 0}, a[6] = {0, 0, 0, 0, 0, 0};
+        if (isbody) {
+#pragma unroll
+            for (int jj = 0; jj < M::MAXJPB; jj++) {
+                if (jj < jn) {
+                    const int j = ja + jj, da = M::jnt_dofadr[j];
+                    if (M::jnt_type[j] == FREE) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++) v[c] += bb.cdof[da + k][c] * bb.qvel[da + k];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) v[c] += bb.cdof[da][c] * bb.qvel[da];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rd = 0; rd < kAnc.ROUNDS; rd++) {
+            if (isbody) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) bb.cvel[b][k] = v[k];
+            }
+            coop_sync();
+            const int an = kAnc.a[rd][bi];
+            if (isbody && an != 0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] += bb.cvel[an][k];
+            }
+            coop_sync();
+        }
+        if (isbody) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb.cvel[b][k] = v[k];
+        }
+        coop_sync();
+        if (isbody) {
+            double vp[6] = {0, 0, 0, 0, 0, 0};  // the velocity the body's first joint sees: its parent's
+            if (p == 0) {
+                a[3] = -M::gravity[0], a[4] = -M::gravity[1], a[5] = -M::gravity[2];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) vp[k] = bb.cvel[p][k];
+            }
+#pragma unroll
+            for (int jj = 0; jj < M::MAXJPB; jj++) {
+                if (jj < jn) {
+                    const int j = ja + jj, da = M::jnt_dofadr[j];
+                    if (M::jnt_type[j] == FREE) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++) vp[c] += bb.cdof[da + k][c] * bb.qvel[da + k];
+                        double dd[3][6];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) cross_motion(dd[k], vp, bb.cdof[da + 3 + k]);
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++) a[c] += dd[k][c] * bb.qvel[da + 3 + k];
+                    } else {
+                        double dd[6];
+                        cross_motion(dd, vp, bb.cdof[da]);
+#pragma unroll
+                        for (int c = 0; c < 6; c++) vp[c] += bb.cdof[da][c] * bb.qvel[da], a[c] += dd[c] * bb.qvel[da];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rd = 0; rd < kAnc.ROUNDS; rd++) {
+            if (isbody) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) bb.Bu.rne.cacc[b][k] = a[k];
+            }
+            coop_sync();
+            const int an = kAnc.a[rd][bi];
+            if (isbody && an != 0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) a[k] += bb.Bu.rne.cacc[an][k];
+            }
+            coop_sync();
+        }
+        if (isbody) {
+            double Ia[6], Iv[6], x[6];
+            inert_mul(Ia, r.cinert, a), inert_mul(Iv, r.cinert, v), cross_force(x, v, Iv);
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb.Bu.rne.cacc[b][k] = a[k], bb.Bu.rne.cfrc[b][k] = Ia[k] + x[k];
+        }
+        coop_sync();
+#else
 #pragma unroll 1
         for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
             if (isbody && depth == lev) {
@@ -639,6 +739,7 @@ struct Sim {
             }
             coop_sync();
         }
+#endif
         // bias force of dof i: its motion subspace against the summed body forces of the subtree it moves
         if (lane < NV) {
             const unsigned desc = (unsigned)M::dof_descbodies[lane];
@@ -1531,10 +1632,12 @@ struct Sim {
         const bool isdof = lane < NV;
 #pragma unroll
         for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
+        MJX_PHASE(r, 12);
         if constexpr (B::CHOL_BLOCKED)
             chol_factor_blocked(bb, r.Hrow, r.idiag, lane, r.grp);
         else
             chol_factor(bb, r.Hrow, r.idiag, lane);
+        MJX_PHASE(r, 13);
 #if MJX_PGS_QS_BY_INVERSE
         // With constraint rows the sweeps need M^-1 explicitly anyway: the unconstrained acceleration is then one row-times-vector product
         // (one exchange of qfrc_smooth through the blackboard) instead of the 2 NV dependent steps of the triangular solves.

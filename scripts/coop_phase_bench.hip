@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
     typename S::B &bb = boards[grp];
     typename S::R r;
 #ifdef MJX_PHASE_TIMING
-    for (int k = 0; k < 12; k++) r.tphase[k] = 0;
+    for (int k = 0; k < 16; k++) r.tphase[k] = 0;
 #endif
     S::init(bb, lane);
     for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = state[(size_t)k * N + env];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void phys(double *state, const float *actions, 
 #endif
 #ifdef MJX_PHASE_TIMING
     if (threadIdx.x == 0)
-        for (int k = 0; k < 12; k++) atomicAdd(&phase[k], r.tphase[k]);
+        for (int k = 0; k < 16; k++) atomicAdd(&phase[k], r.tphase[k]);
 #endif
 }
 
@@ -132,7 +132,7 @@ int run(int N, int nsub, float amp) {
         hipLaunchKernelGGL((phys<M, G, PGS>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph);
     }
     hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
-    unsigned long long ph[12];
+    unsigned long long ph[16];
     hipMemcpy(ph, d_ph, sizeof ph, hipMemcpyDeviceToHost);
 #ifdef MJX_COUNT_WORK
     {  // how unevenly the solver's work is spread over the sub-environments that share a wavefront (they wait for the slowest)
@@ -169,16 +169,17 @@ int run(int N, int nsub, float amp) {
             fwrite(st.data(), sizeof(double), st.size(), f), fclose(f);
         }
     }
-    const char *newton_names[12] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "make_constraint",
-                                    "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other"};
-    const char *pgs_names[12] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "pgs: rows (M^-1 J^T, A, warm start) + make_constraint",
-                                 "pgs: M^-1", "pgs: factor M + qacc_smooth", "pgs: J qacc_smooth, J warm", "pgs: sweeps", "other"};
+    const char *newton_names[16] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "make_constraint",
+                                    "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other", "detail 12", "detail 13", "detail 14", "detail 15"};
+    const char *pgs_names[16] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "pgs: rows (M^-1 J^T, A, warm start) + make_constraint",
+                                 "pgs: M^-1", "pgs: factor M + qacc_smooth", "pgs: J qacc_smooth, J warm", "pgs: sweeps", "other", "pgs: actuation, passive, M row to registers", "pgs: Cholesky factor of M", "detail 14", "detail 15"};
     const char **names = PGS ? pgs_names : newton_names;
     double tot = 0;
-    for (int k = 0; k < 12; k++) tot += (double)ph[k];
+    for (int k = 0; k < 16; k++) tot += (double)ph[k];
     printf("%d envs, %d sub-steps per launch: %.3f ms per launch (incl. host action upload), %.4g env-steps/s\n", N, nsub, ms / timed, N / (ms / timed * 1e-3));
     const double waves = (double)((N + 64 / G - 1) / (64 / G)) * timed, forwards = waves * nsub * (M::INTEGRATOR ? 4 : 1);
-    for (int k = 0; k < 12; k++) printf("  %-26s %5.1f %%   %8.0f cycles per forward pass\n", names[k], 100.0 * ph[k] / tot, ph[k] / forwards);
+    for (int k = 0; k < 16; k++)
+        if (k < 12 || ph[k]) printf("  %-26s %5.1f %%   %8.0f cycles per forward pass\n", names[k], 100.0 * ph[k] / tot, ph[k] / forwards);
     printf("  total %.0f cycles per forward pass and wavefront (%d envs per wavefront)\n", tot / forwards, 64 / G);
     return 0;
 }
