@@ -39,6 +39,9 @@
 #ifndef MJX_KIN_LOCAL_JOINTS
 #define MJX_KIN_LOCAL_JOINTS 1  // kinematics: a body's joint chain is evaluated once, in the body's static frame, before the level loop (0: inside it, rounds 1-2)
 #endif
+#ifndef MJX_CHOL_PIPELINED
+#define MJX_CHOL_PIPELINED 1  // Cholesky sweeps: no selects for the unused upper entries; LDS variant: the next pivot column is published before the row update
+#endif
 #ifndef MJX_VEL_PREFIX
 #define MJX_VEL_PREFIX 1  // com velocities / RNE accelerations: prefix sums over the body tree by pointer jumping instead of one pass per tree level
 #endif
@@ -848,7 +851,11 @@ struct Sim {
     template <int K, int J>
     static MJX_DEV void chol_update(B &bb, double *A, double ak, double t, int lane) {
         const double cj = bcast<J>(ak, bb, lane);  // A'[J][K], held by lane J
+#if MJX_CHOL_PIPELINED
+        A[J] -= t * cj;  // entries J > lane are never used: unmasked, they carry a finite, meaningless mirror image of the elimination
+#else
         A[J] -= (J <= lane ? t : 0.0) * cj;        // entries J > lane are never used
+#endif
         if constexpr (J + 1 < NV) chol_update<K, J + 1>(bb, A, ak, t, lane);
     }
     template <int K>
@@ -906,6 +913,34 @@ struct Sim {
     // in flight per column and made the Humanoid kernel spill (335 VGPRs against 71 this way).
     // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.A.sol.L
     static MJX_DEV void chol_factor_lds(B &bb, double *A, double &idiag, int lane) {
+#if MJX_CHOL_PIPELINED
+        // The entry that becomes the NEXT pivot column is updated and published first, the rest of the row afterwards: the LDS round trip of
+        // the exchange overlaps the row update instead of following it.  Entries j > lane are never used, so nothing is masked: they carry
+        // the (finite, meaningless) mirror image of the elimination and cost no selects.
+        if (lane < NV) bb.A.sol.col[0][lane] = A[0];
+        coop_sync();
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            double (&col)[NV] = bb.A.sol.col[k & 1];
+            double (&nxt)[NV] = bb.A.sol.col[(k + 1) & 1];
+            if (lane >= k && lane < NV) {
+                double piv = col[k];
+                piv = piv < kMinVal ? kMinVal : piv;
+                const double inv = rsq(piv);
+                const double lik = A[k] * inv;
+                A[k] = lik;
+                if (lane == k) idiag = inv;
+                const double t = lik * inv;
+                if (k + 1 < NV) {
+                    A[k + 1] -= t * col[k + 1];
+                    nxt[lane] = A[k + 1];
+                }
+#pragma unroll
+                for (int j = k + 2; j < NV; j++) A[j] -= t * col[j];
+            }
+            coop_sync();
+        }
+#else
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             double (&col)[NV] = bb.A.sol.col[k & 1];
@@ -923,6 +958,7 @@ struct Sim {
                 for (int j = k + 1; j < NV; j++) A[j] -= (j <= lane ? t : 0.0) * col[j];  // entries j > lane are never used
             }
         }
+#endif
         if (lane < NV) {
 #pragma unroll
             for (int j = 0; j < NV; j++)
@@ -1041,8 +1077,11 @@ struct Sim {
         else
             chol_factor_lds(bb, A, idiag, lane);
     }
+#ifndef MJX_SOLVE_BCAST_FOR_32
+#define MJX_SOLVE_BCAST_FOR_32 1  // the triangular solves of a 32-lane group broadcast by v_permlane16_swap + DPP (a handful of live values: no spills) instead of LDS
+#endif
     static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
-        if constexpr ((G == 16 && !MJX_CHOL_LDS_FOR_16) || (G == 32 && !MJX_CHOL_LDS_FOR_32))
+        if constexpr ((G == 16 && !MJX_CHOL_LDS_FOR_16) || (G == 32 && (!MJX_CHOL_LDS_FOR_32 || MJX_SOLVE_BCAST_FOR_32)))
             return chol_solve_bcast(bb, Lrow, idiag, rhs, lane);
         else
             return chol_solve_lds(bb, Lrow, idiag, rhs, lane);
