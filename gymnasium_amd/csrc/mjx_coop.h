@@ -39,6 +39,12 @@
 #ifndef MJX_KIN_LOCAL_JOINTS
 #define MJX_KIN_LOCAL_JOINTS 1  // kinematics: a body's joint chain is evaluated once, in the body's static frame, before the level loop (0: inside it, rounds 1-2)
 #endif
+#ifndef MJX_CRB_BRANCHFREE
+#define MJX_CRB_BRANCHFREE 1  // mass-matrix rows: both candidate dot products and a select instead of two divergent branches per entry
+#endif
+#ifndef MJX_COLLIDE_TABLES
+#define MJX_COLLIDE_TABLES 1  // collision of the many-slot robots (Sim::COLLIDE_TABLES): geom poses once per pass on the blackboard + one flat descriptor per candidate slot
+#endif
 #ifndef MJX_CHOL_PIPELINED
 #define MJX_CHOL_PIPELINED 1  // Cholesky sweeps: no selects for the unused upper entries; LDS variant: the next pivot column is published before the row update
 #endif
@@ -182,6 +188,7 @@ struct Board {
             double cacc[NB][6], cfrc[NB][6];
         } rne;
         double cinert[NB][10];
+        double geo[(MJX_COLLIDE_TABLES && M::NSLOT > 2 * G_) ? M::NGEOM : 1][6];  // collision (Sim::COLLIDE_TABLES): world position and axis of every geom (dead before the RNE pass starts)
     } Bu;
     union {
         struct {
@@ -795,6 +802,16 @@ struct Sim {
             const unsigned anc = (unsigned)M::dof_ancmask[lane];
 #pragma unroll
             for (int j = 0; j < NV; j++) {
+#if MJX_CRB_BRANCHFREE
+                // both candidates, then a select: as two branches per entry (2 NV exec-mask regions, each waiting out its own LDS reads before a
+                // chain of six multiply-adds) this loop cost a lone wavefront ~9 k cycles for the Humanoid; the selected sum is the same, bit for bit
+                double s1 = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s1 += bb.cdof[j][k] * mybuf[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) s2 += r.cdof[k] * bb.C.crb.buf[j][k];
+                double s = ((anc >> j) & 1u) ? s1 : ((((unsigned)M::dof_ancmask[j] >> lane) & 1u) ? s2 : 0.0);
+#else
                 double s = 0;
                 if ((anc >> j) & 1u) {  // j is lane itself or one of its ancestors
 #pragma unroll
@@ -803,6 +820,7 @@ struct Sim {
 #pragma unroll
                     for (int k = 0; k < 6; k++) s += r.cdof[k] * bb.C.crb.buf[j][k];
                 }
+#endif
                 if (j == lane) s += M::dof_armature[j];
                 set_mrow(bb, r, lane, j, s);
             }
@@ -1135,18 +1153,69 @@ struct Sim {
         }
         return false;
     }
-    static MJX_DEV void detect(const B &bb, int slot, Cand &c) {
-        const int p = M::slot_pair[slot], sub = M::slot_sub[slot];
-        int g1 = M::pair_geom1[p], g2 = M::pair_geom2[p];
-        bool flip = false;
-        if (M::geom_type[g1] > M::geom_type[g2]) {
-            const int t = g1;
-            g1 = g2, g2 = t, flip = true;
+    // Everything static about a candidate slot in ONE record: slot -> pair -> geoms -> type / size / body were four levels of dependent
+    // per-lane table loads from global memory (a lone wavefront waits out each level), and every slot recomputed both geoms' world poses.
+    struct SlotTab {
+        static constexpr int NS = M::NSLOT > 0 ? M::NSLOT : 1;
+        int gi[NS][4];     // geom of the lower type, the other geom, type1 | type2 << 4 | flip << 8 | sub << 9, pair | body1 << 16 | body2 << 24
+        double sz[NS][4];  // r1, r2, h1, h2 (in the swapped order)
+    };
+    static constexpr SlotTab make_slots() {
+        SlotTab t{};
+        for (int s = 0; s < M::NSLOT; s++) {
+            const int p = M::slot_pair[s];
+            int g1 = M::pair_geom1[p], g2 = M::pair_geom2[p], flip = 0;
+            if (M::geom_type[g1] > M::geom_type[g2]) {
+                const int x = g1;
+                g1 = g2, g2 = x, flip = 1;
+            }
+            t.gi[s][0] = g1, t.gi[s][1] = g2;
+            t.gi[s][2] = M::geom_type[g1] | (M::geom_type[g2] << 4) | (flip << 8) | (M::slot_sub[s] << 9);
+            t.gi[s][3] = p | (M::geom_bodyid[M::pair_geom1[p]] << 16) | (M::geom_bodyid[M::pair_geom2[p]] << 24);
+            t.sz[s][0] = M::geom_size[g1][0], t.sz[s][1] = M::geom_size[g2][0], t.sz[s][2] = M::geom_size[g1][1], t.sz[s][3] = M::geom_size[g2][1];
         }
-        const int t1 = M::geom_type[g1], t2 = M::geom_type[g2];
-        double p1[3], z1[3], p2[3], z2[3];
-        geom_pose(bb, g1, p1, z1), geom_pose(bb, g2, p2, z2);
-        const double r1 = M::geom_size[g1][0], r2 = M::geom_size[g2][0], h1 = M::geom_size[g1][1], h2 = M::geom_size[g2][1];
+        return t;
+    }
+    static constexpr SlotTab kSlot = make_slots();
+    // world pose of every geom, once per forward pass (lane g, in rounds of G)
+    static MJX_DEV void geom_poses(B &bb, int lane) {
+#pragma unroll
+        for (int g0 = 0; g0 < M::NGEOM; g0 += G) {
+            const int g = g0 + lane;
+            if (g < M::NGEOM) {
+                double pos[3], az[3];
+                geom_pose(bb, g, pos, az);
+#pragma unroll
+                for (int k = 0; k < 3; k++) bb.Bu.geo[g][k] = pos[k], bb.Bu.geo[g][3 + k] = az[k];
+            }
+        }
+        coop_sync();
+    }
+    // Measured (profiles/r03_collision_tables.txt): Humanoid (140 slots, five rounds + the second pass) 18.6 k -> 11.8 k cycles per forward pass;
+    // the robots with one or two rounds lose 1 - 3 % to the extra pass and fence, so they keep the direct form.
+    static constexpr bool COLLIDE_TABLES = MJX_COLLIDE_TABLES && M::NSLOT > 2 * G;
+    static MJX_DEV void detect(const B &bb, int slot, Cand &c) {
+        int g1, g2, t1, t2, p, sub;
+        bool flip = false;
+        double r1, r2, h1, h2, p1[3], z1[3], p2[3], z2[3];
+        if constexpr (COLLIDE_TABLES) {
+            const int fl = kSlot.gi[slot][2];
+            g1 = kSlot.gi[slot][0], g2 = kSlot.gi[slot][1], p = kSlot.gi[slot][3] & 0xffff;
+            t1 = fl & 15, t2 = (fl >> 4) & 15, sub = (fl >> 9) & 1, flip = (fl >> 8) & 1;
+            r1 = kSlot.sz[slot][0], r2 = kSlot.sz[slot][1], h1 = kSlot.sz[slot][2], h2 = kSlot.sz[slot][3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) p1[k] = bb.Bu.geo[g1][k], z1[k] = bb.Bu.geo[g1][3 + k], p2[k] = bb.Bu.geo[g2][k], z2[k] = bb.Bu.geo[g2][3 + k];
+        } else {
+            p = M::slot_pair[slot], sub = M::slot_sub[slot];
+            g1 = M::pair_geom1[p], g2 = M::pair_geom2[p];
+            if (M::geom_type[g1] > M::geom_type[g2]) {
+                const int t = g1;
+                g1 = g2, g2 = t, flip = true;
+            }
+            t1 = M::geom_type[g1], t2 = M::geom_type[g2];
+            geom_pose(bb, g1, p1, z1), geom_pose(bb, g2, p2, z2);
+            r1 = M::geom_size[g1][0], r2 = M::geom_size[g2][0], h1 = M::geom_size[g1][1], h2 = M::geom_size[g2][1];
+        }
         c.on = false;
         if (t1 == PLANE) {
             if (has_pairs(PLANE, SPHERE) && (t2 == SPHERE || !has_pairs(PLANE, CAPSULE))) {
@@ -1224,9 +1293,13 @@ struct Sim {
     //     drops the contact point and frame from that call), then the full evaluation for the few active ones -- the one-pass form was measured
     //     at 29 k cycles against 18 k this way.
     static MJX_DEV void write_contact(B &bb, int idx, int slot, const Cand &c) {
-        const int p = M::slot_pair[slot];
-        const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
-        bb.con_pair[idx] = p | (b1 << 16) | (b2 << 24);
+        if constexpr (COLLIDE_TABLES) {
+            bb.con_pair[idx] = kSlot.gi[slot][3];
+        } else {
+            const int p = M::slot_pair[slot];
+            const int b1 = M::geom_bodyid[M::pair_geom1[p]], b2 = M::geom_bodyid[M::pair_geom2[p]];
+            bb.con_pair[idx] = p | (b1 << 16) | (b2 << 24);
+        }
         bb.con_dist[idx] = c.dist;
 #pragma unroll
         for (int k = 0; k < 3; k++) bb.con_r[idx][k] = c.pos[k] - bb.com[k];
@@ -1236,7 +1309,10 @@ struct Sim {
     static MJX_DEV void collision(B &bb, int lane) {
         if (lane < KS) bb.cmask[lane] = 0;
         if (lane == 0) bb.anyrow = 0, bb.limmask[0] = 0, bb.limmask[1] = 0;
-        coop_sync();
+        if constexpr (COLLIDE_TABLES)
+            geom_poses(bb, lane);  // (ends with the fence the two stores above need)
+        else
+            coop_sync();
         int base = 0;
         if constexpr (M::NSLOT <= 2 * G) {
 #pragma unroll 1
@@ -1681,12 +1757,14 @@ struct Sim {
         // With constraint rows the sweeps need M^-1 explicitly anyway: the unconstrained acceleration is then one row-times-vector product
         // (one exchange of qfrc_smooth through the blackboard) instead of the 2 NV dependent steps of the triangular solves.
         double qs;
+#if MJX_PGS_QS_BY_INVERSE == 1
         if (!anyrow) {
             qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
             r.qacc_smooth = qs, r.qfrc_constraint = 0, r.qacc = qs;
             MJX_PHASE(r, 8);
             return;
         }
+#endif
         MJX_PHASE(r, 8);
         {
             double minv[NV];
@@ -1706,6 +1784,12 @@ struct Sim {
         coop_sync();
         r.qacc_smooth = qs, r.qfrc_constraint = 0;
         MJX_PHASE(r, 7);
+#if MJX_PGS_QS_BY_INVERSE == 2  // no triangular solves in the kernel at all: environments without constraint rows pay the inversion instead
+        if (!anyrow) {
+            r.qacc = qs;
+            return;
+        }
+#endif
 #else
         const double qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
         r.qacc_smooth = qs, r.qfrc_constraint = 0;
