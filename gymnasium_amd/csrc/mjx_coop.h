@@ -160,6 +160,14 @@ MJX_DEV double group_sum(double v, decltype(nullptr), int) {
 #else
 #define MJX_PHASE(r, k) ((void)0)
 #endif
+// finer marks inside one phase, slots 12 .. 15: only the group selected by -DMJX_DETAIL=<tag> is compiled in (1: PGS factor, 2: crb, 3: RNE, 4: com_pos / kinematics)
+#ifndef MJX_DETAIL
+#define MJX_DETAIL 1
+#endif
+#define MJX_PHASE_X(r, tag, k)                \
+    do {                                      \
+        if (MJX_DETAIL == (tag)) MJX_PHASE(r, k); \
+    } while (0)
 
 template <class M, int G_>
 struct Board {
@@ -346,6 +354,7 @@ struct Sim {
                 }
             }
         }
+        MJX_PHASE_X(r, 4, 12);
 #if MJX_KIN_PREFIX
         // World poses by pointer jumping.  T_b starts as the body's pose in its parent's frame (static frame o joint chain; the free root: its
         // qpos) and a_b as the parent; a round replaces T_b by T_{a_b} o T_b and a_b by a_{a_b}, so after ceil(log2(MAXDEPTH)) rounds every T_b
@@ -389,6 +398,7 @@ struct Sim {
             }
             coop_sync();  // every read of the old poses before the next round (or the final values) overwrites them
         }
+        MJX_PHASE_X(r, 4, 13);
         if (isbody) {
             quat_normalize(quat);
             double t[3];
@@ -650,6 +660,7 @@ struct Sim {
             for (int k = 0; k < 6; k++) bb.cvel[b][k] = v[k];
         }
         coop_sync();
+        MJX_PHASE_X(r, 3, 12);
         if (isbody) {
             double vp[6] = {0, 0, 0, 0, 0, 0};  // the velocity the body's first joint sees: its parent's
             if (p == 0) {
@@ -704,6 +715,7 @@ struct Sim {
             for (int k = 0; k < 6; k++) bb.Bu.rne.cacc[b][k] = a[k], bb.Bu.rne.cfrc[b][k] = Ia[k] + x[k];
         }
         coop_sync();
+        MJX_PHASE_X(r, 3, 13);
 #else
 #pragma unroll 1
         for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
@@ -769,6 +781,10 @@ struct Sim {
     }
 
     // ---- composite rigid body: full row `lane` of the mass matrix in registers -----------------------------------------------
+    // The blended form of the row loop lets the scheduler overlap the entries (Humanoid rows 8.3 k -> 6.4 k cycles, +2.1 % end to end; HalfCheetah,
+    // Walker2d, Hopper +1 %) -- but the overlap costs registers, and the 14-dof Ant kernel, already at the register limit, went from 21 to 71
+    // spilled VGPRs and lost 2.8 % with it: that one keeps the select form (+1.4 % over the branches).  profiles/r03_collision_tables.txt
+    static constexpr bool CRB_BLEND = B::M_IN_LDS || NV <= 12;
     static MJX_DEV void crb(B &bb, R &r, int lane) {
         const int b = lane + 1;
         if (b < NB) {
@@ -791,6 +807,7 @@ struct Sim {
             for (int k = 0; k < 10; k++) bb.C.crb.cinertc[b][k] = c[k];
         }
         coop_sync();
+        MJX_PHASE_X(r, 2, 12);
         double mybuf[6] = {0, 0, 0, 0, 0, 0};
         if (lane < NV) {
             inert_mul(mybuf, bb.C.crb.cinertc[M::dof_bodyid[lane]], r.cdof);
@@ -798,6 +815,7 @@ struct Sim {
             for (int k = 0; k < 6; k++) bb.C.crb.buf[lane][k] = mybuf[k];
         }
         coop_sync();
+        MJX_PHASE_X(r, 2, 13);
         if (lane < NV) {
             const unsigned anc = (unsigned)M::dof_ancmask[lane];
 #pragma unroll
@@ -810,7 +828,16 @@ struct Sim {
                 for (int k = 0; k < 6; k++) s1 += bb.cdof[j][k] * mybuf[k];
 #pragma unroll
                 for (int k = 0; k < 6; k++) s2 += r.cdof[k] * bb.C.crb.buf[j][k];
-                double s = ((anc >> j) & 1u) ? s1 : ((((unsigned)M::dof_ancmask[j] >> lane) & 1u) ? s2 : 0.0);
+                // (blended arithmetically: written as selects, LLVM sinks the second dot product back into a conditional block, and a branch per
+                //  entry keeps the scheduler from overlapping one entry's LDS reads with the previous entry's multiply-adds; the dot products
+                //  are finite, so 1 * s + 0 * t is s)
+                double s;
+                if constexpr (CRB_BLEND) {
+                    const double w1 = ((anc >> j) & 1u) ? 1.0 : 0.0, w2 = ((((unsigned)M::dof_ancmask[j] >> lane) & 1u) && j != lane) ? 1.0 : 0.0;  // j == lane is in both masks
+                    s = w1 * s1 + w2 * s2;
+                } else {
+                    s = ((anc >> j) & 1u) ? s1 : ((((unsigned)M::dof_ancmask[j] >> lane) & 1u) ? s2 : 0.0);
+                }
 #else
                 double s = 0;
                 if ((anc >> j) & 1u) {  // j is lane itself or one of its ancestors
@@ -822,8 +849,21 @@ struct Sim {
                 }
 #endif
                 if (j == lane) s += M::dof_armature[j];
+#if MJX_CRB_BRANCHFREE
+                if (B::M_IN_LDS)
+                    r.Hrow[j] = s;  // stored below, all at once: a store into the blackboard between two entries pins the next entry's reads behind it
+                else
+                    set_mrow(bb, r, lane, j, s);
+#else
                 set_mrow(bb, r, lane, j, s);
+#endif
             }
+#if MJX_CRB_BRANCHFREE
+            if (B::M_IN_LDS) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) set_mrow(bb, r, lane, j, r.Hrow[j]);
+            }
+#endif
         } else if (!B::M_IN_LDS) {
 #pragma unroll
             for (int j = 0; j < NV; j++) set_mrow(bb, r, lane, j, 0.0);
@@ -1747,12 +1787,12 @@ struct Sim {
         const bool isdof = lane < NV;
 #pragma unroll
         for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
-        MJX_PHASE(r, 12);
+        MJX_PHASE_X(r, 1, 12);
         if constexpr (B::CHOL_BLOCKED)
             chol_factor_blocked(bb, r.Hrow, r.idiag, lane, r.grp);
         else
             chol_factor(bb, r.Hrow, r.idiag, lane);
-        MJX_PHASE(r, 13);
+        MJX_PHASE_X(r, 1, 13);
 #if MJX_PGS_QS_BY_INVERSE
         // With constraint rows the sweeps need M^-1 explicitly anyway: the unconstrained acceleration is then one row-times-vector product
         // (one exchange of qfrc_smooth through the blackboard) instead of the 2 NV dependent steps of the triangular solves.

@@ -20,6 +20,24 @@
 
 using namespace mjx;
 
+// the finer marks of the phase selected with -DMJX_DETAIL=<tag> (mjx_coop.h MJX_PHASE_X); the rest of that phase stays in its own slot
+#if MJX_DETAIL == 1
+#define DETAIL12 "pgs: actuation, passive, M row to registers"
+#define DETAIL13 "pgs: Cholesky factor of M"
+#elif MJX_DETAIL == 2
+#define DETAIL12 "crb: composite inertias"
+#define DETAIL13 "crb: I * cdof"
+#elif MJX_DETAIL == 3
+#define DETAIL12 "RNE: velocity prefix"
+#define DETAIL13 "RNE: joint chain, acceleration prefix, body forces"
+#elif MJX_DETAIL == 4
+#define DETAIL12 "kinematics: joint chains"
+#define DETAIL13 "kinematics: pointer-jumping rounds"
+#else
+#define DETAIL12 "detail 12"
+#define DETAIL13 "detail 13"
+#endif
+
 template <class M, int G, bool PGS>
 __global__ __launch_bounds__(64) void phys(double *state, const float *actions, int N, int nsub, unsigned long long *phase) {
     typedef coop::Sim<M, G, PGS> S;
@@ -170,9 +188,9 @@ int run(int N, int nsub, float amp) {
         }
     }
     const char *newton_names[16] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "make_constraint",
-                                    "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other", "detail 12", "detail 13", "detail 14", "detail 15"};
+                                    "solver: assemble", "solver: factor + solve", "solver: twist / J dir", "solver: line search", "solver: other", DETAIL12, DETAIL13, "detail 14", "detail 15"};
     const char *pgs_names[16] = {"integrator / glue", "kinematics", "com_pos", "collision", "com_vel_and_bias (RNE)", "crb", "pgs: rows (M^-1 J^T, A, warm start) + make_constraint",
-                                 "pgs: M^-1", "pgs: factor M + qacc_smooth", "pgs: J qacc_smooth, J warm", "pgs: sweeps", "other", "pgs: actuation, passive, M row to registers", "pgs: Cholesky factor of M", "detail 14", "detail 15"};
+                                 "pgs: M^-1", "pgs: factor M + qacc_smooth", "pgs: J qacc_smooth, J warm", "pgs: sweeps", "other", DETAIL12, DETAIL13, "detail 14", "detail 15"};
     const char **names = PGS ? pgs_names : newton_names;
     double tot = 0;
     for (int k = 0; k < 16; k++) tot += (double)ph[k];
