@@ -39,6 +39,9 @@
 #ifndef MJX_KIN_LOCAL_JOINTS
 #define MJX_KIN_LOCAL_JOINTS 1  // kinematics: a body's joint chain is evaluated once, in the body's static frame, before the level loop (0: inside it, rounds 1-2)
 #endif
+#ifndef MJX_FLAT_JOINTS
+#define MJX_FLAT_JOINTS 1  // the phases that walk a body's joints read one flat static record per body instead of chained model tables
+#endif
 #ifndef MJX_CRB_BRANCHFREE
 #define MJX_CRB_BRANCHFREE 1  // mass-matrix rows: both candidate dot products and a select instead of two divergent branches per entry
 #endif
@@ -292,6 +295,58 @@ struct Sim {
         coop_sync();
     }
 
+    // Everything static about a body's joints in ONE record (see SlotTab: body -> jntadr -> type / qposadr / dofadr -> qpos0 is a chain of
+    // dependent per-lane loads from global memory in every phase that walks the joints; this is one level)
+    struct BodyTab {
+        struct Rec {
+            int jn, jtype[M::MAXJPB], qadr[M::MAXJPB], dadr[M::MAXJPB];
+            double jpos[M::MAXJPB][3], jaxis[M::MAXJPB][3], q0[M::MAXJPB];
+        } b[NB];
+    };
+    static constexpr BodyTab make_bodies() {
+        BodyTab t{};
+        for (int b = 0; b < NB; b++) {
+            const int ja = M::body_jntadr[b], jn = M::body_jntnum[b];
+            t.b[b].jn = jn;
+            for (int jj = 0; jj < M::MAXJPB; jj++) {
+                const int j = jj < jn ? ja + jj : 0;
+                t.b[b].jtype[jj] = jj < jn ? M::jnt_type[j] : -1;
+                t.b[b].qadr[jj] = M::jnt_qposadr[j], t.b[b].dadr[jj] = M::jnt_dofadr[j], t.b[b].q0[jj] = M::qpos0[M::jnt_qposadr[j]];
+                for (int k = 0; k < 3; k++) t.b[b].jpos[jj][k] = M::jnt_pos[j][k], t.b[b].jaxis[jj][k] = M::jnt_axis[j][k];
+            }
+        }
+        return t;
+    }
+    static constexpr BodyTab kBody = make_bodies();
+    // ... and about a dof: its actuator, passive terms, joint limit
+    struct DofTab {
+        struct Rec {
+            int act, scalar_joint, limited, qadr, jnt;  // actuator (-1: none), hinge / slide, limited hinge / slide, qpos address, joint
+            double gear, clo, chi, damping, stiffness, q0, range[2], invweight0;
+        } d[NV];
+    };
+    static constexpr DofTab make_dofs() {
+        DofTab t{};
+        for (int i = 0; i < NV; i++) {
+            const int u = M::dof_actuator[i], j = M::dof_jntid[i];
+            const bool sc = M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE;
+            t.d[i].act = u, t.d[i].scalar_joint = sc, t.d[i].limited = sc && M::jnt_limited[j], t.d[i].qadr = M::jnt_qposadr[j], t.d[i].jnt = j;
+            t.d[i].gear = u >= 0 ? M::actuator_gear[u] : 0.0, t.d[i].clo = u >= 0 ? M::actuator_ctrlrange[u][0] : 0.0, t.d[i].chi = u >= 0 ? M::actuator_ctrlrange[u][1] : 0.0;
+            t.d[i].damping = M::dof_damping[i], t.d[i].stiffness = M::jnt_stiffness[j], t.d[i].q0 = M::qpos0[M::jnt_qposadr[j]];
+            t.d[i].range[0] = M::jnt_range[j][0], t.d[i].range[1] = M::jnt_range[j][1], t.d[i].invweight0 = M::dof_invweight0[i];
+        }
+        return t;
+    }
+    static constexpr DofTab kDof = make_dofs();
+    // joint jj of body b (MJX_FLAT_JOINTS = 0: through the model tables, for A/B runs)
+    static MJX_DEV int jnum(int b) { return MJX_FLAT_JOINTS ? kBody.b[b].jn : M::body_jntnum[b]; }
+    static MJX_DEV int jtype(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].jtype[jj] : M::jnt_type[M::body_jntadr[b] + jj]; }
+    static MJX_DEV int jqadr(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].qadr[jj] : M::jnt_qposadr[M::body_jntadr[b] + jj]; }
+    static MJX_DEV int jdadr(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].dadr[jj] : M::jnt_dofadr[M::body_jntadr[b] + jj]; }
+    static MJX_DEV double jq0(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].q0[jj] : M::qpos0[M::jnt_qposadr[M::body_jntadr[b] + jj]]; }
+    static MJX_DEV const double *jpos(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].jpos[jj] : M::jnt_pos[M::body_jntadr[b] + jj]; }
+    static MJX_DEV const double *jaxis(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].jaxis[jj] : M::jnt_axis[M::body_jntadr[b] + jj]; }
+
     // ancestors at distance 1, 2, 4, ... of every body (0 = the world: nothing left to compose), for the pointer-jumping kinematics
     struct AncTab {
         static constexpr int MAXR = 4;
@@ -319,7 +374,7 @@ struct Sim {
         const int b = lane + 1;
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
-        const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+        const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = jnum(bi);
 #if MJX_KIN_LOCAL_JOINTS
         // (round 3) The joints of a body act in the body's own static frame F0 (parent pose o body_pos / body_quat): with pose = F0 o (pl, ql),
         //   anchor_j = F0 (pl + R(ql) jnt_pos_j),  axis_j = F0 R(ql) jnt_axis_j,  hinge: ql <- ql o q(axis_j, theta_j), pl <- anchor_j^loc - R(ql) jnt_pos_j,
@@ -329,7 +384,7 @@ struct Sim {
         // F0 and maps the locals to the world.  Before, the whole joint chain (a sincos, two quaternion products and three rotations per
         // hinge, up to three hinges) sat inside the level loop, where a wavefront pays it once per LEVEL (six for the Humanoid) although each
         // body uses it once.  Rounding differs from the world-frame order at the 1e-16 level (tests: HIP / emulation vs oracle tolerances).
-        const bool free_root = jn == 1 && M::jnt_type[ja] == FREE;
+        const bool free_root = jn == 1 && jtype(bi, 0) == FREE;
         double ql[4] = {1, 0, 0, 0}, pl[3] = {0, 0, 0};
         if (isbody && !free_root) {
 #pragma unroll
@@ -338,15 +393,15 @@ struct Sim {
                     const int j = ja + jj;
                     double Rm[9], qq[4], t[3];
                     quat_to_mat(Rm, ql);
-                    rot_vec(t, Rm, M::jnt_pos[j]);
+                    rot_vec(t, Rm, jpos(bi, jj));
                     r.anchor[jj][0] = pl[0] + t[0], r.anchor[jj][1] = pl[1] + t[1], r.anchor[jj][2] = pl[2] + t[2];
-                    rot_vec(r.axis[jj], Rm, M::jnt_axis[j]);
-                    const double q = bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]];
-                    if (M::jnt_type[j] == HINGE) {
-                        axis_angle_quat(qq, M::jnt_axis[j], q);
+                    rot_vec(r.axis[jj], Rm, jaxis(bi, jj));
+                    const double q = bb.qpos[jqadr(bi, jj)] - jq0(bi, jj);
+                    if (jtype(bi, jj) == HINGE) {
+                        axis_angle_quat(qq, jaxis(bi, jj), q);
                         quat_mul(ql, ql, qq);
                         quat_to_mat(Rm, ql);
-                        rot_vec(t, Rm, M::jnt_pos[j]);
+                        rot_vec(t, Rm, jpos(bi, jj));
                         pl[0] = r.anchor[jj][0] - t[0], pl[1] = r.anchor[jj][1] - t[1], pl[2] = r.anchor[jj][2] - t[2];
                     } else {
                         pl[0] += r.axis[jj][0] * q, pl[1] += r.axis[jj][1] * q, pl[2] += r.axis[jj][2] * q;
@@ -365,7 +420,7 @@ struct Sim {
         double pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
         if (isbody) {
             if (free_root) {
-                const int qa = M::jnt_qposadr[ja];
+                const int qa = jqadr(bi, 0);
                 pos[0] = bb.qpos[qa], pos[1] = bb.qpos[qa + 1], pos[2] = bb.qpos[qa + 2];
                 quat[0] = bb.qpos[qa + 3], quat[1] = bb.qpos[qa + 4], quat[2] = bb.qpos[qa + 5], quat[3] = bb.qpos[qa + 6];
                 quat_normalize(quat);
@@ -575,13 +630,13 @@ struct Sim {
             ci[0] = W[0] + mm * (dd - off[0] * off[0]), ci[1] = W[4] + mm * (dd - off[1] * off[1]), ci[2] = W[8] + mm * (dd - off[2] * off[2]);
             ci[3] = W[1] - mm * off[0] * off[1], ci[4] = W[2] - mm * off[0] * off[2], ci[5] = W[5] - mm * off[1] * off[2];
             ci[6] = mm * off[0], ci[7] = mm * off[1], ci[8] = mm * off[2], ci[9] = mm;
-            const int ja = M::body_jntadr[b], jn = M::body_jntnum[b];
+            const int jn = jnum(b);
 #pragma unroll
             for (int jj = 0; jj < M::MAXJPB; jj++) {
                 if (jj < jn) {
-                    const int j = ja + jj, a = M::jnt_dofadr[j];
+                    const int a = jdadr(b, jj), jt = jtype(b, jj);
                     const double o[3] = {com[0] - r.anchor[jj][0], com[1] - r.anchor[jj][1], com[2] - r.anchor[jj][2]};
-                    if (M::jnt_type[j] == FREE) {
+                    if (jt == FREE) {
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
 #pragma unroll
@@ -593,7 +648,7 @@ struct Sim {
                             bb.cdof[a + 3 + k][0] = ax[0], bb.cdof[a + 3 + k][1] = ax[1], bb.cdof[a + 3 + k][2] = ax[2];
                             bb.cdof[a + 3 + k][3] = cr[0], bb.cdof[a + 3 + k][4] = cr[1], bb.cdof[a + 3 + k][5] = cr[2];
                         }
-                    } else if (M::jnt_type[j] == HINGE) {
+                    } else if (jt == HINGE) {
                         double cr[3];
                         cross3(cr, r.axis[jj], o);
                         bb.cdof[a][0] = r.axis[jj][0], bb.cdof[a][1] = r.axis[jj][1], bb.cdof[a][2] = r.axis[jj][2];
@@ -617,7 +672,7 @@ struct Sim {
         const int b = lane + 1;
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
-        const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = M::body_jntnum[bi];
+        const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = jnum(bi);
 #if MJX_VEL_PREFIX
         // cvel and cacc live in ONE frame (the com-based world frame), so a body's value is its parent's plus the contributions of its own
         // joints: two prefix sums over the tree, done by pointer jumping (see kinematics()) -- first the velocities (a joint's cdof_dot needs the
@@ -628,8 +683,8 @@ struct Sim {
 #pragma unroll
             for (int jj = 0; jj < M::MAXJPB; jj++) {
                 if (jj < jn) {
-                    const int j = ja + jj, da = M::jnt_dofadr[j];
-                    if (M::jnt_type[j] == FREE) {
+                    const int da = jdadr(bi, jj);
+                    if (jtype(bi, jj) == FREE) {
 #pragma unroll
                         for (int k = 0; k < 6; k++)
 #pragma unroll
@@ -672,8 +727,8 @@ struct Sim {
 #pragma unroll
             for (int jj = 0; jj < M::MAXJPB; jj++) {
                 if (jj < jn) {
-                    const int j = ja + jj, da = M::jnt_dofadr[j];
-                    if (M::jnt_type[j] == FREE) {
+                    const int da = jdadr(bi, jj);
+                    if (jtype(bi, jj) == FREE) {
 #pragma unroll
                         for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -1464,19 +1519,27 @@ struct Sim {
         bool any = false;
         r.lim_on[0] = r.lim_on[1] = false;
         if (lane < NV) {
+#if MJX_FLAT_JOINTS
+            const typename DofTab::Rec &dr = kDof.d[lane];
+            const int j = dr.jnt;
+            const bool limited = dr.limited;
+            const double value = bb.qpos[dr.qadr], rng[2] = {dr.range[0], dr.range[1]}, invw = dr.invweight0;
+#else
             const int j = M::dof_jntid[lane];
-            if (M::jnt_limited[j] && (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)) {
-                const double value = bb.qpos[M::jnt_qposadr[j]];
+            const bool limited = M::jnt_limited[j] && (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE);
+            const double value = bb.qpos[M::jnt_qposadr[j]], rng[2] = {M::jnt_range[j][0], M::jnt_range[j][1]}, invw = M::dof_invweight0[lane];
+#endif
+            if (limited) {
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
                     const double side = sd == 0 ? -1.0 : 1.0;
-                    const double dist = side * (M::jnt_range[j][sd] - value);
+                    const double dist = side * (rng[sd] - value);
                     constexpr int JF = first_limited_joint();
                     const int jp = uniform_limits() ? JF : j;  // constant index -> the table reads below fold into immediates
                     const double margin = M::jnt_margin[jp];
                     if (dist < margin) {
                         double k, b, imp, Rr;
-                        row_params<M>(M::jnt_solref[jp], M::jnt_solimp[jp], dist, margin, M::dof_invweight0[lane], k, b, imp, Rr);
+                        row_params<M>(M::jnt_solref[jp], M::jnt_solimp[jp], dist, margin, invw, k, b, imp, Rr);
                         r.lim_on[sd] = true, r.lim_sign[sd] = -side, r.lim_D[sd] = 1.0 / Rr;
                         r.lim_aref[sd] = -b * (-side * bb.qvel[lane]) - k * imp * (dist - margin);
                         if (PGS) lds_or(&bb.limmask[sd], 1u << lane);
@@ -2052,18 +2115,29 @@ struct Sim {
         make_constraint(bb, r, lane);
         MJX_PHASE(r, 6);
         if (isdof) {
-            double act = 0.0;
+            double act = 0.0, passive;
+#if MJX_FLAT_JOINTS
+            const typename DofTab::Rec &dr = kDof.d[lane];
+            if (dr.act >= 0) {
+                double c = bb.ctrl[dr.act];
+                c = c < dr.clo ? dr.clo : (c > dr.chi ? dr.chi : c);
+                act = dr.gear * c;
+            }
+            passive = -dr.damping * bb.qvel[lane];
+            if (dr.scalar_joint) passive -= dr.stiffness * (bb.qpos[dr.qadr] - dr.q0);
+#else
             const int u = M::dof_actuator[lane];
             if (u >= 0) {
                 double c = bb.ctrl[u];
                 c = c < M::actuator_ctrlrange[u][0] ? M::actuator_ctrlrange[u][0] : (c > M::actuator_ctrlrange[u][1] ? M::actuator_ctrlrange[u][1] : c);
                 act = M::actuator_gear[u] * c;
             }
-            r.qfrc_actuator = act;
-            double passive = -M::dof_damping[lane] * bb.qvel[lane];
+            passive = -M::dof_damping[lane] * bb.qvel[lane];
             const int j = M::dof_jntid[lane];
             if (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)
                 passive -= M::jnt_stiffness[j] * (bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]]);
+#endif
+            r.qfrc_actuator = act;
             r.qfrc_smooth = passive - r.bias + act;
         } else {
             r.qfrc_smooth = 0, r.qfrc_actuator = 0;
@@ -2273,12 +2347,12 @@ struct Sim {
     static MJX_DEV void integrate_pos(B &bb, const double *vel, double h, int lane) {
         const int b = lane + 1;
         if (b < NB) {
-            const int ja = M::body_jntadr[b], jn = M::body_jntnum[b];
+            const int jn = jnum(b);
 #pragma unroll
             for (int jj = 0; jj < M::MAXJPB; jj++) {
                 if (jj < jn) {
-                    const int j = ja + jj, qa = M::jnt_qposadr[j], va = M::jnt_dofadr[j];
-                    if (M::jnt_type[j] == FREE) {
+                    const int qa = jqadr(b, jj), va = jdadr(b, jj);
+                    if (jtype(b, jj) == FREE) {
                         bb.qpos[qa] += h * vel[va], bb.qpos[qa + 1] += h * vel[va + 1], bb.qpos[qa + 2] += h * vel[va + 2];
                         double w[3] = {vel[va + 3], vel[va + 4], vel[va + 5]}, qr[4], q[4] = {bb.qpos[qa + 3], bb.qpos[qa + 4], bb.qpos[qa + 5], bb.qpos[qa + 6]};
                         const double ang = h * normalize3(w);
