@@ -2169,7 +2169,7 @@ struct Sim {
             coop_sync();
         }
 #ifdef MJX_COUNT_WORK
-        int passes = 0;
+        int passes = 0, lsn = 0;
 #endif
 #pragma unroll 1
         for (;;) {
@@ -2265,6 +2265,9 @@ struct Sim {
 #endif
 #pragma unroll 1
             for (int ls = 0; ls < 40; ls++) {
+#ifdef MJX_COUNT_WORK
+                lsn++;
+#endif
 #if defined(MJX_HOST_EMU)
                 if (lane == 0) g_stat[3]++;
 #endif
@@ -2332,9 +2335,10 @@ struct Sim {
         }
 #if defined(MJX_COUNT_WORK) && !defined(MJX_HOST_EMU)
         {
-            int m = passes;
+            const int cost = 5 * passes + lsn;  // ~ cycles / 850: a pass of the state machine (assembly, factor / solve, twist) ~ 4 - 5 k cycles, a line-search iteration ~ 0.85 k
+            int m = cost;
             m = max(m, __shfl_xor(m, 16, 64)), m = max(m, __shfl_xor(m, 32, 64));  // the other sub-environments of this wavefront
-            r.work += passes, r.work_wave += m;
+            r.work += cost, r.work_wave += m;
         }
 #endif
         if (!damped_euler()) r.qacc_int = r.qacc;

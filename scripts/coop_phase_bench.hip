@@ -123,8 +123,9 @@ int run(int N, int nsub, float amp) {
     hipMalloc(&d_st, sizeof(double) * st.size()), hipMalloc(&d_act, sizeof(float) * act.size()), hipMalloc(&d_ph, 12 * 8 + 256 + sizeof(int) * (size_t)N);
     hipMemcpy(d_st, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice);
     const dim3 grid((N + 64 / G - 1) / (64 / G)), block(64);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0), hipEventCreate(&e1);
+    hipEvent_t e0, e1, k0, k1;
+    hipEventCreate(&e0), hipEventCreate(&e1), hipEventCreate(&k0), hipEventCreate(&k1);
+    float kernel_ms = 0;
     if (getenv("COOP_DEBUG")) {
         const size_t W = 4 * M::NV + M::NV * M::NV;
         double *d_out;
@@ -147,7 +148,28 @@ int run(int N, int nsub, float amp) {
         for (auto &a : act) a = amp * (float)(2 * rnd() - 1);
         hipMemcpy(d_act, act.data(), sizeof(float) * act.size(), hipMemcpyHostToDevice);
         if (t == warm) hipMemset(d_ph, 0, 16 * 8), hipEventRecord(e0);
+        hipEventRecord(k0);
         hipLaunchKernelGGL((phys<M, G, PGS>), grid, block, 0, 0, d_st, d_act, N, nsub, d_ph);
+        hipEventRecord(k1);
+#ifdef MJX_COUNT_WORK
+        {  // COOP_SORT=1: regroup the environments between launches by the solver work of the launch just finished (experiment: how much of the
+           // waiting inside a wavefront is predictable from one launch to the next).  Environments are independent: permuting the columns is exact.
+            float el = 0;
+            hipEventSynchronize(k1), hipEventElapsedTime(&el, k0, k1);
+            if (t >= warm) kernel_ms += el;
+            if (getenv("COOP_SORT")) {
+                std::vector<int> w(N), order(N);
+                hipMemcpy(w.data(), (const char *)d_ph + 128, sizeof(int) * N, hipMemcpyDeviceToHost);
+                hipMemcpy(st.data(), d_st, sizeof(double) * st.size(), hipMemcpyDeviceToHost);
+                for (int i = 0; i < N; i++) order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a] < w[b]; });
+                std::vector<double> st2(st.size());
+                for (int k = 0; k < S; k++)
+                    for (int i = 0; i < N; i++) st2[(size_t)k * N + i] = st[(size_t)k * N + order[i]];
+                hipMemcpy(d_st, st2.data(), sizeof(double) * st2.size(), hipMemcpyHostToDevice);
+            }
+        }
+#endif
     }
     hipEventRecord(e1), hipEventSynchronize(e1), hipEventElapsedTime(&ms, e0, e1);
     unsigned long long ph[16];
@@ -171,8 +193,9 @@ int run(int N, int nsub, float amp) {
                waves / sum, sorted_waves / sum);
         unsigned long long tot[2];
         hipMemcpy(tot, (const char *)d_ph + 14 * 8, sizeof tot, hipMemcpyDeviceToHost);
-        printf("per forward pass: the slowest sub-environment of a wavefront does x%.3f the passes of the average one (all launches)\n",
+        printf("per forward pass: the slowest sub-environment of a wavefront has x%.3f the solver cost (5 x passes + line-search iterations) of the average one (all launches)\n",
                (double)tot[1] / (double)tot[0]);
+        printf("kernel time of the timed launches: %.3f ms per launch%s\n", kernel_ms / timed, getenv("COOP_SORT") ? " (COOP_SORT: regrouped by the previous launch's work)" : "");
     }
 #endif
     {  // fingerprint of the final state: lets two builds of this harness (compiler flags, code variants) be compared bit for bit
