@@ -27,16 +27,18 @@ ARCH = "gfx950"
 # engine.hip stays on the default scheduler: built with iterative-maxocc its one-lane Humanoid kernel diverged.
 ITERATIVE = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
 # ... and MachineLICM told to sink loop invariants back next to their uses when that avoids a spill: these 9 - 21 k-instruction kernels hoist
-# hundreds of literal / address materialisations out of the sub-step loop, whose live ranges then cost more than they save (Ant: 51 -> 4
+# hundreds of literal / address materialisations out of the sub-step loop, whose live ranges then cost more than they save (round 2, Ant: 51 -> 4
 # spilled VGPRs, 72 -> 11 scratch instructions, +5.7 % in the stand-alone harness; Humanoid Newton +4 %, PGS +2 %, bit-identical results, A/B on
-# one box).  ONLY for the 32-lane unit: the 16-lane kernels of the LIBRARY (not of the harness) come out wrong with it -- Ant-v5 produces NaNs,
-# caught by tests/test_gpu_scheduler_guard.py and tests/test_gpu_mujoco.py -- another code-generation problem of the 16-lane instantiation, like the
-# inlined RK4 stage above.
-# The 16-lane unit gets MachineLICM switched off instead (Ant: 51 -> 19 spilled VGPRs, +2.7 % in the library; every test and the bit comparison
-# with the default-scheduler build green).
+# one box).
+# History of the 16-lane unit: in round 2 its LIBRARY kernels (not the harness's) came out WRONG with this flag -- Ant-v5 produced NaNs, caught by
+# tests/test_gpu_scheduler_guard.py and tests/test_gpu_mujoco.py -- so it shipped with MachineLICM switched off instead (NO_MLICM).  The cause was never
+# isolated.  After the round-3 rewrites of the forward pass the same flag set builds a physics16.hip that is bit-identical to the
+# default-scheduler build on all four 16-lane robots, NaN-free, with 0 spilled VGPRs for the Ant (was 13 - 25) and +1.1 % (scripts/r03/gpu_call25.sh,
+# gpu_call26.sh, scripts/r03/guard_variant.py): both units now use ONE flag set.  The guard test stays what decides: if it ever fails again,
+# NO_MLICM for physics16.hip is the known-good fallback.
 SINK = ["-mllvm", "-sink-insts-to-avoid-spills=true"]
 NO_MLICM = ["-mllvm", "-disable-machine-licm"]
-TU_FLAGS = {"physics16.hip": ITERATIVE + NO_MLICM, "physics32.hip": ITERATIVE + SINK}
+TU_FLAGS = {"physics16.hip": ITERATIVE + SINK, "physics32.hip": ITERATIVE + SINK}
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
 
 

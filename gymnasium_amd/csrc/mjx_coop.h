@@ -42,6 +42,9 @@
 #ifndef MJX_FLAT_JOINTS
 #define MJX_FLAT_JOINTS 1  // the phases that walk a body's joints read one flat static record per body instead of chained model tables
 #endif
+#ifndef MJX_CRB_BLEND_ALL
+#define MJX_CRB_BLEND_ALL 1  // the blended mass-matrix rows for every robot (see Sim::CRB_BLEND)
+#endif
 #ifndef MJX_CRB_BRANCHFREE
 #define MJX_CRB_BRANCHFREE 1  // mass-matrix rows: both candidate dot products and a select instead of two divergent branches per entry
 #endif
@@ -837,9 +840,9 @@ struct Sim {
 
     // ---- composite rigid body: full row `lane` of the mass matrix in registers -----------------------------------------------
     // The blended form of the row loop lets the scheduler overlap the entries (Humanoid rows 8.3 k -> 6.4 k cycles, +2.1 % end to end; HalfCheetah,
-    // Walker2d, Hopper +1 %) -- but the overlap costs registers, and the 14-dof Ant kernel, already at the register limit, went from 21 to 71
-    // spilled VGPRs and lost 2.8 % with it: that one keeps the select form (+1.4 % over the branches).  profiles/r03_collision_tables.txt
-    static constexpr bool CRB_BLEND = B::M_IN_LDS || NV <= 12;
+    // Walker2d, Hopper +1 %).  The overlap costs registers: while physics16.hip was built with MachineLICM off, the 14-dof Ant kernel went from 21 to
+    // 71 spilled VGPRs with it and lost 2.8 %; on the sink flag set (build.py) it has no spills either way and gains 0.6 %.  profiles/r03_collision_tables.txt
+    static constexpr bool CRB_BLEND = MJX_CRB_BLEND_ALL || B::M_IN_LDS || NV <= 12;  // (MJX_CRB_BLEND_ALL = 0: the select form for the Ant, for A/B runs)
     static MJX_DEV void crb(B &bb, R &r, int lane) {
         const int b = lane + 1;
         if (b < NB) {
