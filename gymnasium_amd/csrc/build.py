@@ -23,7 +23,9 @@ ARCH = "gfx950"
 # Per translation unit, on top of FLAGS: LLVM's iterative GCN scheduler for the cooperative physics kernels.  With ONE wavefront per SIMD it
 # hides LDS / VALU latency better than the default max-occupancy scheduler (which trades ILP for an occupancy these kernels cannot have):
 # Humanoid-v5 +33 %, Ant-v5 +19 %, results bit-identical to the default scheduler's (scripts/coop_phase_bench.hip: 65536 / 32768 envs x 25
-# env-steps, every bit of the state) -- PROVIDED the RK4 stage update stays out of line (mjx_coop.h rk4_stage), inlined it is miscompiled.
+# env-steps, every bit of the state) -- PROVIDED the RK4 stage update stays out of line (mjx_coop.h rk4_stage): inlined, the 16-lane Ant instantiation is
+# miscompiled (round 2: wrong results under the iterative scheduler; round 3: a memory fault under the DEFAULT scheduler; stand-alone reproducer and the
+# mechanism -- SGPR spills into VGPR lanes -- in scripts/repro/README.md, profiles/r03_rk4_inline.txt).
 # engine.hip stays on the default scheduler: built with iterative-maxocc its one-lane Humanoid kernel diverged.
 ITERATIVE = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
 # ... and MachineLICM told to sink loop invariants back next to their uses when that avoids a spill: these 9 - 21 k-instruction kernels hoist

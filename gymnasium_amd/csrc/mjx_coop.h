@@ -42,6 +42,9 @@
 #ifndef MJX_FLAT_JOINTS
 #define MJX_FLAT_JOINTS 1  // the phases that walk a body's joints read one flat static record per body instead of chained model tables
 #endif
+#ifndef MJX_RK4_INLINE
+#define MJX_RK4_INLINE 0  // 1: the RK4 stage update inlined into the stage loop -- DO NOT: see rk4_stage
+#endif
 #ifndef MJX_CRB_BLEND_ALL
 #define MJX_CRB_BLEND_ALL 1  // the blended mass-matrix rows for every robot (see Sim::CRB_BLEND)
 #endif
@@ -2377,12 +2380,19 @@ struct Sim {
     }
 
     // One stage of the RK4 tableau, as selects on the stage index: sub-diagonal (0.5, 0.5, 1) and weights (1/6, 1/3, 1/3, 1/6).
-    // Deliberately OUT OF LINE on the device: inlined into the stage loop, LLVM's iterative schedulers (build.py TU_FLAGS) produce wrong code
-    // for exactly this block in the 16-lane instantiation (every environment differs after one sub-step); as a function of its own the
-    // kernel is bit-identical to the default scheduler's and 18 % faster (scripts/coop_phase_bench.hip).  Four calls
-    // per sub-step cost nothing next to four forward passes.
+    // Deliberately OUT OF LINE on the device.  Round 2: inlined into the stage loop, LLVM's iterative schedulers (build.py TU_FLAGS) produced wrong
+    // code for exactly this block in the 16-lane instantiation (every environment differed after one sub-step).  Round 3 re-tested it on the
+    // rewritten sources (-DMJX_RK4_INLINE=1, scripts/r03/gpu_call28.sh, gpu_call29.sh): the iterative-scheduler build is now bit-identical to the
+    // out-of-line default-scheduler build on all four 16-lane robots and 1 - 2 % faster -- but the DEFAULT-scheduler build of the inlined form
+    // (libmi355env_ref.so) makes the Ant kernel die with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  So the failure follows the inlining, not the
+    // scheduler flag: some address computation of the 16-lane Ant instantiation goes wrong when this block is merged into the stage loop, under either
+    // scheduler, and which build shows it changes with the surrounding code.  Stand-alone reproducer with default flags: scripts/repro/README.md -- it goes
+    // away with -mllvm -amdgpu-spill-sgpr-to-vgpr=false or -disable-machine-licm: an SGPR spilled into a VGPR lane comes back wrong (profiles/r03_rk4_inline.txt).
+    // As a function of its own the kernel is bit-identical across schedulers; four calls per sub-step cost ~1 % next to four forward passes.
 #if defined(MJX_HOST_EMU)
     static inline void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {
+#elif MJX_RK4_INLINE
+    static MJX_DEV void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {
 #else
     static __device__ __attribute__((noinline)) void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {
 #endif
