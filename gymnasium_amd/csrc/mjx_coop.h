@@ -45,6 +45,9 @@
 #ifndef MJX_RK4_INLINE
 #define MJX_RK4_INLINE 0  // 1: the RK4 stage update inlined into the stage loop -- DO NOT: see rk4_stage
 #endif
+#ifndef MJX_PGS_MORE_BLOCKS
+#define MJX_PGS_MORE_BLOCKS 1  // PGS: M^-1 J_c^T of up to 15 contacts (not 7) stays on the blackboard (Sim::bblock)
+#endif
 #ifndef MJX_CRB_BLEND_ALL
 #define MJX_CRB_BLEND_ALL 1  // the blended mass-matrix rows for every robot (see Sim::CRB_BLEND)
 #endif
@@ -229,6 +232,10 @@ struct Board {
     // blocked Cholesky (Sim::chol_factor_blocked): this environment's block of the 16 x 16 MFMA tile L21 L21^T (rows / columns 16 .. NV - 1)
     static constexpr bool CHOL_BLOCKED = G_ == 32 && NV > 16 && NV <= 24 && MJX_CHOL_MFMA;
     double schur[CHOL_BLOCKED ? 8 : 1][CHOL_BLOCKED ? 8 : 1];
+    // PGS (Sim::bblock): M^-1 J_c^T blocks beyond the ones that fit the dead storage of M, of the Cholesky factor and of union Bu -- as many as keep
+    // the 32-lane robots at four wavefronts' worth of LDS per CU (2 x 20 064 B per wavefront for the Humanoid)
+    static constexpr int NBX = (M_IN_LDS && MJX_PGS_MORE_BLOCKS) ? 2 : 0;
+    double bx[NBX ? NBX : 1][NBX ? 3 * NV : 1];
     int con_pair[MAXCON];             // geom pair of the contact | body of its first geom << 16 | body of its second geom << 24 (the bodies
                                       // ride along because pair -> geom -> body is two dependent table loads from global memory per use;
                                       // no room for more: the 16-lane robots sit exactly at four workgroups' worth of LDS per CU)
@@ -1731,12 +1738,25 @@ struct Sim {
     //   * M^-1 J_c^T (3 x NV per contact) is computed once per pass; the first BCAP contacts keep it in the LDS storage of M (dead after
     //     the factorisation), for later ones the sweeps apply M^-1 (register rows) to J_c^T dl directly (apply_b).
     // Warm start = mj's dual warmstart: the forces implied by qacc_warmstart (r.warm), dropped for zero if their dual cost is positive.
-    static constexpr int BCAP = B::M_IN_LDS ? NV / 3 : 0;
+    // Where the blocks live (all of it storage that is dead while the sweeps run): the NV x NV words of M (NV / 3 blocks), then -- MJX_PGS_MORE_BLOCKS --
+    // the packed Cholesky factor (dead once M^-1 is formed: NTRI / (3 NV) blocks), the RNE / CRB scratch of union Bu, and B::NBX blocks of their own.
+    typedef decltype(B::Bu) bb_union_b_t;
+    static constexpr int BCAP0 = B::M_IN_LDS ? NV / 3 : 0;
+    static constexpr bool MORE_BLOCKS = MJX_PGS_MORE_BLOCKS && B::M_IN_LDS && PGS;
+    static constexpr int BCAP1 = BCAP0 + (MORE_BLOCKS ? B::NTRI / (3 * NV) : 0);
+    static constexpr int BCAP2 = BCAP1 + (MORE_BLOCKS ? (int)(sizeof(bb_union_b_t) / sizeof(double)) / (3 * NV) : 0);
+    static constexpr int BCAP = BCAP2 + (MORE_BLOCKS ? B::NBX : 0);
+    static MJX_DEV double *bblock(B &bb, int c) {  // c < BCAP, group-uniform
+        if (c < BCAP0) return &bb.Mt[0][0] + (size_t)c * 3 * NV;
+        if (c < BCAP1) return bb.A.sol.L + (size_t)(c - BCAP0) * 3 * NV;
+        if (c < BCAP2) return reinterpret_cast<double *>(&bb.Bu) + (size_t)(c - BCAP1) * 3 * NV;
+        return bb.bx[c - BCAP2 < B::NBX ? c - BCAP2 : 0];
+    }
     // (a global-memory overflow store was tried for the contacts beyond BCAP: ~800 cycles per visit; removed)
     static MJX_DEV void store_b(B &bb, int c, int lane, const double *b) {
         if constexpr (B::M_IN_LDS) {
             if (lane < NV && c < BCAP) {
-                double *p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+                double *p = bblock(bb, c);
                 p[lane] = b[0], p[NV + lane] = b[1], p[2 * NV + lane] = b[2];
             }
         }
@@ -1747,7 +1767,7 @@ struct Sim {
         if constexpr (B::M_IN_LDS) {
             if (c < BCAP) {  // group-uniform
                 if (lane >= NV) return 0.0;
-                const double *p = &bb.Mt[0][0] + (size_t)c * 3 * NV;
+                const double *p = bblock(bb, c);
                 return p[lane] * dl[0] + p[NV + lane] * dl[1] + p[2 * NV + lane] * dl[2];
             }
         }

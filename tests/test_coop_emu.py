@@ -32,7 +32,7 @@ def oracle_model(model):
 
 # the round-3 rewrites of the forward pass keep their predecessors behind these switches (A/B runs on the GPU, scripts/build_variant.py)
 LEGACY_FLAGS = ["-DMJX_KIN_LOCAL_JOINTS=0", "-DMJX_KIN_PREFIX=0", "-DMJX_VEL_PREFIX=0", "-DMJX_CHOL_PIPELINED=0", "-DMJX_COLLIDE_TABLES=0",
-                "-DMJX_CRB_BRANCHFREE=0", "-DMJX_FLAT_JOINTS=0"]
+                "-DMJX_CRB_BRANCHFREE=0", "-DMJX_FLAT_JOINTS=0", "-DMJX_PGS_MORE_BLOCKS=0"]
 _LIBS = {}
 
 
@@ -160,9 +160,11 @@ def test_env_steps_match_oracle_with_contacts(model):
     assert seen_contacts > 0 and most_contacts > 0
 
 
-def test_pgs_more_contacts_than_the_lds_store_holds():
-    """The cooperative PGS keeps M^-1 J_c^T of the first 7 contacts in LDS and spills the rest to global memory: a humanoid pressed flat
-    into the floor (>= 10 contacts) must still equal the oracle, forward pass and sub-steps."""
+@pytest.mark.parametrize("legacy", [False, True], ids=["15-block store", "7-block store"])
+def test_pgs_more_contacts_than_the_lds_store_holds(legacy):
+    """The cooperative PGS keeps M^-1 J_c^T of the first contacts on the blackboard (15 blocks: the storage of M, of the Cholesky factor, of the RNE
+    pass and two of their own; 7 in the build with the switches off) and applies M^-1 directly for the rest: a humanoid pressed flat into the floor
+    (>= 10 contacts: beyond the 7-block store, inside the 15-block one) must equal the oracle either way, forward pass and sub-steps."""
     om_ = oracle_model(8)
     m, d = om_.m, om_.make_data()
     rng = np.random.default_rng(5)
@@ -173,11 +175,11 @@ def test_pgs_more_contacts_than_the_lds_store_holds():
         qvel, ctrl = 0.3 * rng.normal(size=m.nv), 0.4 * rng.uniform(-1, 1, m.nu)
         d.reset(), d.set_state(qpos, qvel, ctrl), d.forward()
         assert d.get("ncon") >= 10, d.get("ncon")
-        _, _, _, dbg, ncon = emu(8, m, qpos, qvel, ctrl, 0)
+        _, _, _, dbg, ncon = emu(8, m, qpos, qvel, ctrl, 0, legacy=legacy)
         assert ncon == d.get("ncon")
         np.testing.assert_allclose(dbg[:m.nv], d.get("qacc"), rtol=0, atol=1e-10 * max(1.0, np.abs(d.get("qacc")).max()))
         d.reset(), d.set_state(qpos, qvel, ctrl), d.step(2), d.rne_post_constraint()
-        qo, vo, ex, _, _ = emu(8, m, qpos, qvel, ctrl, 2, np.zeros(m.nv))
+        qo, vo, ex, _, _ = emu(8, m, qpos, qvel, ctrl, 2, np.zeros(m.nv), legacy=legacy)
         np.testing.assert_allclose(qo, d.get("qpos"), rtol=0, atol=1e-10)
         np.testing.assert_allclose(vo, d.get("qvel"), rtol=0, atol=1e-8 * max(1.0, np.abs(vo).max()))
         cf = ex[4:4 + 6 * m.nbody].reshape(m.nbody, 6)
