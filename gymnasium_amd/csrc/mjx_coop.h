@@ -231,11 +231,14 @@ struct Board {
     double Mt[M_IN_LDS ? NV : 1][M_IN_LDS ? NV : 1];
     // blocked Cholesky (Sim::chol_factor_blocked): this environment's block of the 16 x 16 MFMA tile L21 L21^T (rows / columns 16 .. NV - 1)
     static constexpr bool CHOL_BLOCKED = G_ == 32 && NV > 16 && NV <= 24 && MJX_CHOL_MFMA;
-    double schur[CHOL_BLOCKED ? 8 : 1][CHOL_BLOCKED ? 8 : 1];
     // PGS (Sim::bblock): M^-1 J_c^T blocks beyond the ones that fit the dead storage of M, of the Cholesky factor and of union Bu -- as many as keep
     // the 32-lane robots at four wavefronts' worth of LDS per CU (2 x 20 064 B per wavefront for the Humanoid)
     static constexpr int NBX = (M_IN_LDS && MJX_PGS_MORE_BLOCKS) ? 2 : 0;
-    double bx[NBX ? NBX : 1][NBX ? 3 * NV : 1];
+    double schur[CHOL_BLOCKED ? 8 : 1][CHOL_BLOCKED ? 8 : 1];
+    // (zero-length -- a GNU / clang extension -- for the robots without it: a Board that grows by a single double re-lays every LDS offset, and these
+    //  kernels' code generation is sensitive to that: measured Ant 5.02 -> 4.83 M env-steps/s for one unused word, and the Humanoid 1.26 -> 1.23 M when
+    //  the word was folded into a union with `schur` instead; scripts/r03/gpu_call37.sh, gpu_call38.sh)
+    double bx[NBX][NBX ? 3 * NV : 1];  // live from the row assembly to the end of the sweeps
     int con_pair[MAXCON];             // geom pair of the contact | body of its first geom << 16 | body of its second geom << 24 (the bodies
                                       // ride along because pair -> geom -> body is two dependent table loads from global memory per use;
                                       // no room for more: the 16-lane robots sit exactly at four workgroups' worth of LDS per CU)
@@ -1750,7 +1753,8 @@ struct Sim {
         if (c < BCAP0) return &bb.Mt[0][0] + (size_t)c * 3 * NV;
         if (c < BCAP1) return bb.A.sol.L + (size_t)(c - BCAP0) * 3 * NV;
         if (c < BCAP2) return reinterpret_cast<double *>(&bb.Bu) + (size_t)(c - BCAP1) * 3 * NV;
-        return bb.bx[c - BCAP2 < B::NBX ? c - BCAP2 : 0];
+        if constexpr (B::NBX > 0) return bb.bx[c - BCAP2 < B::NBX ? c - BCAP2 : 0];
+        return nullptr;
     }
     // (a global-memory overflow store was tried for the contacts beyond BCAP: ~800 cycles per visit; removed)
     static MJX_DEV void store_b(B &bb, int c, int lane, const double *b) {

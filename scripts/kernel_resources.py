@@ -34,6 +34,37 @@ def extract(path):
     return extract_all(path)[0]
 
 
+def resources(so):
+    """[{name (demangled), vgpr_count, vgpr_spill_count, sgpr_count, group_segment_fixed_size, private_segment_fixed_size}, ...] of every gfx950 kernel"""
+    notes = ""
+    for co in extract_all(so):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co), f.flush()
+            notes += subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True).stdout
+    rows, cur = [], {}
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(name|vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size|vgpr_spill_count):\s*(\S+)", line)
+        if not m:
+            continue
+        k, v = m.groups()
+        if k == "group_segment_fixed_size":  # first of these keys in a kernel's (alphabetically sorted) metadata block
+            if "vgpr_count" in cur:
+                rows.append(cur)
+            cur = {}
+        if k == "name" and "name" in cur:  # argument names inside .args
+            continue
+        cur[k] = v
+    if "vgpr_count" in cur:
+        rows.append(cur)
+    names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
+    out = []
+    for r, nm in zip(rows, names):
+        d = {k: int(v) for k, v in r.items() if k != "name"}
+        d["name"] = re.sub(r"\(.*", "", nm.replace("(anonymous namespace)::", ""))
+        out.append(d)
+    return out
+
+
 def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gymnasium_amd", "csrc", "libmi355env.so")
     pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None

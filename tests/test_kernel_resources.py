@@ -5,6 +5,8 @@
    rollout -- gave results that were not reproducible from launch to launch with the asm form (and were with the builtin).  Acrobot is
    therefore instantiated with ExactMathT<false>; every kernel instantiated with the asm-carrying policies must not touch AGPRs at all.
 2. The classic-control and ToyText kernels do not spill to scratch.
+3. The cooperative MuJoCo kernels keep the resources their throughput rests on: at most a quarter of a CU's LDS per workgroup (four wavefronts per CU,
+   one per SIMD -- one byte more and it is three), and no spilled vector registers in the shipped Ant / Humanoid instantiations.
 """
 import os
 import re
@@ -67,3 +69,18 @@ def test_classic_and_toytext_kernels_do_not_use_scratch(kernels):
         if ("mi::" in name and "T<mi::" in name) or "tab_" in name:
             n = sum(op.startswith("scratch_") for op in ins)
             assert n == 0, f"{name[:140]}: {n} scratch instructions"
+
+
+def test_cooperative_mujoco_kernels_keep_their_lds_and_register_budget():
+    from kernel_resources import resources
+
+    rows = [r for r in resources(LIB) if "mj_physics_kernel" in r["name"]]
+    assert len(rows) >= 16, [r["name"] for r in rows]
+    for r in rows:
+        # 160 KB of LDS per CU (MI355X_MICROARCH.md): four workgroups of one wavefront each must fit, or a SIMD stays empty
+        assert r["group_segment_fixed_size"] * 4 <= 160 * 1024, f"{r['name']}: {r['group_segment_fixed_size']} B of LDS per workgroup: only three workgroups per CU"
+        assert r["vgpr_count"] <= 512
+    for robot in ("AntModel", "HumanoidModel", "HumanoidStandupModel"):
+        for r in rows:
+            if robot + "," in r["name"]:
+                assert r.get("vgpr_spill_count", 0) == 0, f"{r['name']}: {r['vgpr_spill_count']} spilled VGPRs (build.py TU_FLAGS, DESIGN.md section 7)"
