@@ -14,10 +14,11 @@ import numpy as np
 MI_OK = 0
 MI_HOST, MI_DEVICE = 0, 1
 MI_F32, MI_F64, MI_I64 = 0, 1, 2
+MI_F64_WEAK = 3  # action rows only: float64 values that were Python floats on the caller's side (weak under NEP 50)
 FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
 CFG_SOLVER_NEWTON = 1  # MI_CFG_SOLVER_NEWTON
 CFG_FAST_MATH = 2  # MI_CFG_FAST_MATH (classic control: device sin / cos and x * x instead of the libm restatements)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
              "half_cheetah": 5, "ant": 6, "humanoid": 7, "tabular": 8,
@@ -53,12 +54,13 @@ class MiLayout(C.Structure):
 class MiStepIO(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
                 ("truncated", C.c_void_p), ("final_obs", C.c_void_p), ("episode_return", C.c_void_p),
-                ("episode_length", C.c_void_p), ("info", C.c_void_p), ("final_info", C.c_void_p)]
+                ("episode_length", C.c_void_p), ("info", C.c_void_p), ("final_info", C.c_void_p),
+                ("actions_dtype", C.c_int32), ("reserved", C.c_int32)]  # actions_dtype: MI_F32 (default) / MI_F64 rows of a Box action space
 
 
 class MiRolloutIO(C.Structure):
     _fields_ = [("actions_in", C.c_void_p), ("actions_out", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p),
-                ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
+                ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("actions_in_dtype", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MiTabularTable(C.Structure):
@@ -252,25 +254,26 @@ class Engine:
         self.lib.check(self.lib.reset(self.handle, _ptr(mask), _ptr(b), _ptr(obs), loc))
 
     def step(self, actions, obs, reward, terminated, truncated, final_obs=None, episode_return=None,
-             episode_length=None, loc=MI_HOST, info=None, final_info=None):
+             episode_length=None, loc=MI_HOST, info=None, final_info=None, actions_dtype=MI_F32):
         io = self._step_io
-        io.final_info = _ptr(final_info)
+        io.final_info, io.actions_dtype = _ptr(final_info), int(actions_dtype)
         io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
         io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
         io.episode_return, io.episode_length, io.info = _ptr(episode_return), _ptr(episode_length), _ptr(info)
         self.lib.check(self.lib.step(self.handle, C.byref(io), loc))
 
-    def _fill_io(self, actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info):
+    def _fill_io(self, actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info, actions_dtype=MI_F32):
         io = self._step_io
+        io.actions_dtype = int(actions_dtype)
         io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
         io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
         io.episode_return, io.episode_length, io.info, io.final_info = _ptr(episode_return), _ptr(episode_length), _ptr(info), _ptr(final_info)
         return io
 
     def step_async(self, actions, obs, reward, terminated, truncated, final_obs=None, episode_return=None, episode_length=None, info=None,
-                   final_info=None):
+                   final_info=None, actions_dtype=MI_F32):
         """Enqueue a host step (H2D, kernel, one D2H) without waiting; the arrays are filled by step_wait()."""
-        io = self._fill_io(actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info)
+        io = self._fill_io(actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info, actions_dtype)
         self.lib.check(self.lib.step_async(self.handle, C.byref(io)))
 
     def step_wait(self):
@@ -305,8 +308,9 @@ class Engine:
         w = np.ascontiguousarray(words, dtype=np.uint64)
         self.lib.check(self.lib.action_seed(self.handle, _ptr(w)))
 
-    def rollout(self, T, actions_in=None, actions_out=None, obs=None, reward=None, terminated=None, truncated=None):
+    def rollout(self, T, actions_in=None, actions_out=None, obs=None, reward=None, terminated=None, truncated=None, actions_in_dtype=MI_F32):
         io = self._rollout_io
+        io.actions_in_dtype = int(actions_in_dtype)
         io.actions_in, io.actions_out, io.obs = _ptr(actions_in), _ptr(actions_out), _ptr(obs)
         io.reward, io.terminated, io.truncated = _ptr(reward), _ptr(terminated), _ptr(truncated)
         self.lib.check(self.lib.rollout(self.handle, int(T), C.byref(io)))

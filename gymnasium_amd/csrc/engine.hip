@@ -710,7 +710,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
 // MuJoCo-family kernels (mjx_kernels.h): same vectoriser state machine, float64 observations, float32 action rows
 // ---------------------------------------------------------------------------------------------------------
 struct MjStepPtrs {
-    const float *actions;
+    const void *actions;  // [N][NU] float32 rows, or float64 rows taken un-rounded (act_f64; mujoco_env.py:148 data.ctrl[:] = ctrl)
     double *obs, *reward;
     uint8_t *terminated, *truncated;
     double *final_obs, *ep_ret;
@@ -718,6 +718,7 @@ struct MjStepPtrs {
     double *info, *final_info;
     int obs_dim;
     const double *extras;  // [N][EX_TOTAL] rows written by mj_physics_kernel, or nullptr (one-lane simulator inside the step kernel)
+    int act_f64;
 };
 
 template <class E>
@@ -752,7 +753,7 @@ MI_DEV void mj_autoreset(const DevEnv &d, int i, MjLane<E> &L, double *obs) {
 // `extras` != nullptr: the physics of this step was already advanced by mj_physics_kernel (L.s holds the new qpos / qvel
 // and the old tracked point); nullptr: the one-lane simulator runs here.
 template <class E, int MODE, bool COOP = false>
-MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const float *action, double *obs, double *final_obs, double *info,
+MI_DEV void mj_lane_step(const DevEnv &d, int i, MjLane<E> &L, const mjx::ActRow action, double *obs, double *final_obs, double *info,
                          double &reward, bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st,
                          const double *extras = nullptr, double *final_info = nullptr) {
     te = tr = false, reward = 0.0;
@@ -812,7 +813,8 @@ __global__ __launch_bounds__(kBlock) void mj_step_kernel(DevEnv d, MjStepPtrs io
         double reward, out_ret;
         int32_t out_len;
         bool te, tr;
-        mj_lane_step<E, MODE, COOP>(d, i, L, io.actions + (size_t)i * E::NU, io.obs + (size_t)i * io.obs_dim,
+        const mjx::ActRow a = {static_cast<const char *>(io.actions) + (size_t)i * E::NU * (io.act_f64 ? 8 : 4), io.act_f64 != 0};
+        mj_lane_step<E, MODE, COOP>(d, i, L, a, io.obs + (size_t)i * io.obs_dim,
                               io.final_obs ? io.final_obs + (size_t)i * io.obs_dim : nullptr,
                               io.info ? io.info + (size_t)i * E::INFO : nullptr, reward, te, tr, out_ret, out_len, st,
                               COOP ? io.extras + (size_t)i * mjx::coop::Sim<typename E::Model, E::COOP_G>::EX_TOTAL : nullptr,
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void mj_reset_kernel(DevEnv d, const uint8_
 // fused rollout: T steps per launch, Box action space sampled on device from the batched space's single PCG64 stream
 // (draw number (t*N + i)*NU + u belongs to lane i, component u, step t)
 template <class E, int MODE, bool SAMPLE>
-__global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int obs_dim) {
+__global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int obs_dim, int in_f64) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     if (i < d.N) {
@@ -859,6 +861,7 @@ __global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtr
         double scratch_obs[E::MAX_OBS];
         for (int t = 0; t < T; t++) {
             float a[E::NU];
+            mjx::ActRow row = {a, false};
             if (SAMPLE) {
                 for (int u = 0; u < E::NU; u++) {
                     const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate, x = hi ^ lo;
@@ -871,14 +874,14 @@ __global__ __launch_bounds__(kBlock) void mj_rollout_kernel(DevEnv d, RolloutPtr
                 astate = as.jump_n.mult * astate + as.jump_n.plus;
                 if (io.actions_out)
                     for (int u = 0; u < E::NU; u++) static_cast<float *>(io.actions_out)[(t * N + i) * E::NU + u] = a[u];
-            } else {
-                for (int u = 0; u < E::NU; u++) a[u] = static_cast<const float *>(io.actions_in)[(t * N + i) * E::NU + u];
+            } else {  // the caller's rows, read in place
+                row.p = static_cast<const char *>(io.actions_in) + (t * N + i) * E::NU * (in_f64 ? 8 : 4), row.f64 = in_f64 != 0;
             }
             double reward, out_ret;
             int32_t out_len;
             bool te, tr;
             double *obs = io.obs ? static_cast<double *>(io.obs) + (t * N + i) * obs_dim : scratch_obs;
-            mj_lane_step<E, MODE>(d, i, L, a, obs, nullptr, nullptr, reward, te, tr, out_ret, out_len, st);
+            mj_lane_step<E, MODE>(d, i, L, row, obs, nullptr, nullptr, reward, te, tr, out_ret, out_len, st);
             if (io.reward) io.reward[t * N + i] = reward;
             if (io.terminated) io.terminated[t * N + i] = te;
             if (io.truncated) io.truncated[t * N + i] = tr;
@@ -1287,7 +1290,7 @@ struct mi_vecenv {
     uint8_t *d_term, *d_trunc, *d_mask;
     int32_t *d_eplen;
     uint64_t *d_words;
-    size_t act_bytes, obs_bytes;
+    size_t act_bytes, act_bytes_max, obs_bytes;
     double *d_info, *d_final_info;
     size_t info_bytes;
     mi_step_io h_io;        // the pinned host arrays (mi_host_buffers)
@@ -1329,6 +1332,19 @@ int dispatch_kind_math(int kind, F &&f) {
 template <class F>
 int dispatch_kind(int kind, bool fast_math, F &&f) {
     return fast_math ? dispatch_kind_math<FastMath>(kind, f) : dispatch_kind_math<ExactMath>(kind, f);
+}
+// ... and the kind of the action rows (mi_step_io.actions_dtype): the two Box kinds have float64 instantiations (envs_classic.h ActF64 / ActF64Weak)
+template <class M, class F>
+int dispatch_kind_act_math(int kind, int act_kind, F &&f) {
+    if (act_kind != MI_F32) {
+        if (kind == MI_ENV_PENDULUM) return f(PendulumT<M, ActF64>());  // (a Python float and an np.float64 behave alike there)
+        if (kind == MI_ENV_MOUNTAIN_CAR_CONTINUOUS) return act_kind == MI_F64_WEAK ? f(MountainCarContinuousT<M, ActF64Weak>()) : f(MountainCarContinuousT<M, ActF64>());
+    }
+    return dispatch_kind_math<M>(kind, f);
+}
+template <class F>
+int dispatch_kind_act(int kind, bool fast_math, int act_kind, F &&f) {
+    return fast_math ? dispatch_kind_act_math<FastMath>(kind, act_kind, f) : dispatch_kind_act_math<ExactMath>(kind, act_kind, f);
 }
 
 typedef mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah> HalfCheetahEnv;
@@ -1432,7 +1448,13 @@ template <class E>
 int launch_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample) {
     const bool next_step = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
     const bool full = p.obs && p.reward && p.terminated && p.truncated && (!sample || p.actions_out);
-    if (next_step && sample && full)  // the collector's configuration (bench.py)
+    if constexpr (E::ACT_KIND == MI_F64 || E::ACT_KIND == MI_F64_WEAK) {  // float64 action rows are always the caller's (the sampler draws float32)
+        if (sample) return fail(MI_ERR_INVALID_ARGUMENT, "the on-device policy samples float32 actions");
+        if (next_step)
+            launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, false, false>(v, p, as, T);
+        else
+            launch_rollout_variant<E, MI_AUTORESET_SAME_STEP, false, false>(v, p, as, T);
+    } else if (next_step && sample && full)  // the collector's configuration (bench.py)
         launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, true>(v, p, as, T);
     else if (next_step && sample)
         launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, false>(v, p, as, T);
@@ -1464,7 +1486,7 @@ int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
     if (v->mj_coop) {
         mi_phys::Args pa;
         pa.state = v->d.state, pa.meta = v->d.meta, pa.needs_reset_mask = kNeedsReset << kFlagShift, pa.N = v->d.N, pa.frame_skip = (int)v->d.P.p[4];
-        pa.newton = v->d.solver_newton;
+        pa.newton = v->d.solver_newton, pa.act_f64 = mp.act_f64;
         const bool skip_resetting = mode != MI_AUTORESET_SAME_STEP;  // SAME_STEP: every sub-environment steps
         const bool ok = E::COOP_G == 16 ? mi_phys::launch16(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream)
                                         : mi_phys::launch32(v->cfg.kind, pa, skip_resetting, mp.actions, v->d_extras, v->stream);
@@ -1491,21 +1513,23 @@ int launch_mj_step(mi_vecenv *v, MjStepPtrs mp) {
 
 // T vector steps with the cooperative physics: per step [sample actions ->] physics -> glue, all on the env's stream
 template <class E>
-int launch_mj_rollout_coop(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample) {
+int launch_mj_rollout_coop(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample, int in_f64) {
     const size_t N = (size_t)v->cfg.num_envs;
     const dim3 g(v->grid), b(kBlock);
     for (int t = 0; t < T; t++) {
-        const float *act;
+        const void *act;
         if (sample) {
             float *dst = p.actions_out ? static_cast<float *>(p.actions_out) + (size_t)t * N * E::NU : v->d_act_scratch;
             hipLaunchKernelGGL((mj_sample_kernel<E>), g, b, 0, v->stream, v->d, as, t, dst);
             act = dst;
+        } else if (in_f64) {
+            act = static_cast<const double *>(p.actions_in) + (size_t)t * N * E::NU;
         } else {
             act = static_cast<const float *>(p.actions_in) + (size_t)t * N * E::NU;
         }
         MjStepPtrs mp;
         memset(&mp, 0, sizeof mp);
-        mp.actions = act;
+        mp.actions = act, mp.act_f64 = !sample && in_f64;
         mp.obs = p.obs ? static_cast<double *>(p.obs) + (size_t)t * N * v->lay.obs_dim : static_cast<double *>(v->d_obs_scratch);
         mp.reward = p.reward ? p.reward + (size_t)t * N : nullptr;
         mp.terminated = p.terminated ? p.terminated + (size_t)t * N : nullptr;
@@ -1638,6 +1662,7 @@ static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
     HIP_TRY(hipMemsetAsync(d.blk_count, 0, sizeof(uint64_t) * 4 * v->grid, v->stream));
     HIP_TRY(hipMemsetAsync(d.blk_ret, 0, sizeof(double) * v->grid, v->stream));
     v->act_bytes = N * (v->lay.act_dtype == MI_I64 ? 8 : 4) * v->lay.act_dim;
+    v->act_bytes_max = N * 8 * v->lay.act_dim;  // a Box kind may be handed float64 rows (mi_step_io.actions_dtype)
     v->obs_bytes = N * (v->lay.obs_dtype == MI_F32 ? sizeof(float) : sizeof(double)) * v->lay.obs_dim;
     v->info_bytes = N * sizeof(double) * (v->lay.info_dim > 0 ? v->lay.info_dim : 1);
     {
@@ -1659,9 +1684,9 @@ static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
         v->d_obs = D + start[0], v->d_reward = (double *)(D + start[1]), v->d_term = (uint8_t *)(D + start[2]), v->d_trunc = (uint8_t *)(D + start[3]);
         v->d_info = (double *)(D + start[4]), v->d_epret = (double *)(D + start[5]), v->d_eplen = (int32_t *)(D + start[6]);
         v->d_final = D + start[7], v->d_final_info = (double *)(D + start[8]);
-        HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes));
-        HIP_TRY(hipHostMalloc(&v->h_actions, v->act_bytes, hipHostMallocDefault));
-        memset(v->h_actions, 0, v->act_bytes);
+        HIP_TRY(hipMalloc(&v->d_actions, v->act_bytes_max));
+        HIP_TRY(hipHostMalloc(&v->h_actions, v->act_bytes_max, hipHostMallocDefault));
+        memset(v->h_actions, 0, v->act_bytes_max);
         v->h_io.actions = v->h_actions, v->h_io.obs = H + start[0], v->h_io.reward = (double *)(H + start[1]);
         v->h_io.terminated = (uint8_t *)(H + start[2]), v->h_io.truncated = (uint8_t *)(H + start[3]), v->h_io.info = (double *)(H + start[4]);
         v->h_io.episode_return = (double *)(H + start[5]), v->h_io.episode_length = (int32_t *)(H + start[6]);
@@ -1862,6 +1887,12 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     // The word is only CLEARED once the stream is idle (error path only: the common case stays a plain read).
     if (loc == MI_DEVICE && *v->h_err) return check_device_error(v);
     const size_t N = (size_t)v->cfg.num_envs;
+    // element type of the action rows: Box kinds take float32 rows or un-rounded float64 rows (include/mi355env.h mi_step_io.actions_dtype)
+    const bool box = v->lay.act_dtype == MI_F32;
+    if (box && io->actions_dtype != MI_F32 && io->actions_dtype != MI_F64 && io->actions_dtype != MI_F64_WEAK)
+        return fail(MI_ERR_INVALID_ARGUMENT, "actions_dtype must be MI_F32, MI_F64 or MI_F64_WEAK");
+    const int act_kind = box ? io->actions_dtype : (int)MI_F32;
+    const size_t act_bytes = act_kind == MI_F32 ? v->act_bytes : v->act_bytes_max;
     StepPtrs p;
     bool zc = false;
     if (loc == MI_HOST) {
@@ -1872,7 +1903,7 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
             for (size_t i = 0; i < N; i++)
                 if (a[i] < 0 || a[i] >= na) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
         }
-        if (io->actions != v->h_actions) memcpy(v->h_actions, io->actions, v->act_bytes);  // callers that fill the pinned array skip this
+        if (io->actions != v->h_actions) memcpy(v->h_actions, io->actions, act_bytes);  // callers that fill the pinned array skip this
         // Classic control and ToyText: the step kernel reads the actions from and writes its outputs to the PINNED block itself (coalesced rows of at most
         // 24 bytes per lane stream over PCIe while the kernel runs): no copy-engine hand-offs, 97 -> 85 us per step at 65 536 sub-environments
         // (73 us when the caller's policy writes into the pinned action array).  MI355ENV_ZEROCOPY=0 restores the staged copies (A/B).  Not
@@ -1889,7 +1920,7 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
             p.ep_ret = io->episode_return ? (double *)pinned(v, v->d_epret) : nullptr;
             p.ep_len = io->episode_length ? (int32_t *)pinned(v, v->d_eplen) : nullptr;
         } else {
-            HIP_TRY(hipMemcpyAsync(v->d_actions, v->h_actions, v->act_bytes, hipMemcpyHostToDevice, v->stream));
+            HIP_TRY(hipMemcpyAsync(v->d_actions, v->h_actions, act_bytes, hipMemcpyHostToDevice, v->stream));
             p.actions = v->d_actions;
             p.obs = (float *)v->d_obs, p.reward = v->d_reward, p.terminated = v->d_term, p.truncated = v->d_trunc;
             p.final_obs = io->final_obs ? (float *)v->d_final : nullptr;
@@ -1917,12 +1948,12 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
         HIP_TRY(hipGetLastError());
         rc = MI_OK;
     } else if (is_mj(v->cfg.kind)) {
-        const MjStepPtrs mp = {(const float *)p.actions, (double *)p.obs, p.reward, p.terminated, p.truncated, (double *)p.final_obs,
-                               p.ep_ret, p.ep_len, dinfo, dfinfo, v->lay.obs_dim, nullptr};
+        const MjStepPtrs mp = {p.actions, (double *)p.obs, p.reward, p.terminated, p.truncated, (double *)p.final_obs,
+                               p.ep_ret, p.ep_len, dinfo, dfinfo, v->lay.obs_dim, nullptr, act_kind != MI_F32};
         if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int { return launch_mj_step<decltype(env)>(v, mp); });
     } else {
-        rc = dispatch_kind(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
+        rc = dispatch_kind_act(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, act_kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
     }
     if (rc) return rc;
     if (loc == MI_HOST) {
@@ -2029,6 +2060,11 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
     if (T == 0) return MI_OK;
     if (set_device(v)) return MI_ERR_HIP;
     RolloutPtrs p = {io->actions_in, io->actions_out, io->obs, io->reward, io->terminated, io->truncated};
+    const bool box = v->lay.act_dtype == MI_F32;
+    if (box && !sample && io->actions_in_dtype != MI_F32 && io->actions_in_dtype != MI_F64 && io->actions_in_dtype != MI_F64_WEAK)
+        return fail(MI_ERR_INVALID_ARGUMENT, "actions_in_dtype must be MI_F32, MI_F64 or MI_F64_WEAK");
+    const int in_kind = (box && !sample) ? io->actions_in_dtype : (int)MI_F32, in_f64 = in_kind != MI_F32;
+    if (in_f64 && io->actions_out) return fail(MI_ERR_INVALID_ARGUMENT, "actions_out echoes float32 rows: not with float64 actions_in");
     ActionStream as;
     memset(&as, 0, sizeof as);
     if (sample) {
@@ -2062,22 +2098,22 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
     } else if (is_mj(v->cfg.kind)) {
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int {
             using E = decltype(env);
-            if (v->mj_coop) return launch_mj_rollout_coop<E>(v, p, as, T, sample);
+            if (v->mj_coop) return launch_mj_rollout_coop<E>(v, p, as, T, sample, in_f64);
             const dim3 g(v->grid), b(kBlock);
             const bool next = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
             if (next && sample)
-                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim, in_f64);
             else if (next)
-                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_NEXT_STEP, false>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim, in_f64);
             else if (sample)
-                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim, in_f64);
             else
-                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim);
+                hipLaunchKernelGGL((mj_rollout_kernel<E, MI_AUTORESET_SAME_STEP, false>), g, b, 0, v->stream, v->d, p, as, T, v->lay.obs_dim, in_f64);
             HIP_TRY(hipGetLastError());
             return (int)MI_OK;
         });
     } else {
-        rc = dispatch_kind(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
+        rc = dispatch_kind_act(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, in_kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
     }
     if (rc) return rc;
     if (sample) {  // the host copy of the generator moves past the T*N draws the kernel consumes

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/mi355env.h"
 #include "pcg64_dev.h"
 #include "pow_exact.h"
 #include "sincos_exact.h"
@@ -149,6 +150,23 @@ MI_DEV void trig_invalidate(NoTrig &) {}
 MI_DEV void trig_invalidate(PendulumTrig &t) { t.ok = false; }
 MI_DEV void trig_invalidate(AcrobotTrig &t) { t.ok = false; }
 
+// What an action row of a Box space holds (mi_step_io.actions_dtype).  The reference hands the caller's rows to the scalar env as they are
+// (vector/sync_vector_env.py:274), and NumPy 2's promotion then depends on what `action[0]` is: an np.float32 (rows of a float32 array: the
+// space's dtype, what Box.sample() draws), an np.float64 (rows of a float64 array), or a Python float (rows of a list of lists), which is
+// WEAK: np.float32 + float stays float32.
+struct ActF32 {
+    typedef float T;
+    static constexpr int KIND = MI_F32;
+};
+struct ActF64 {
+    typedef double T;
+    static constexpr int KIND = MI_F64;
+};
+struct ActF64Weak {
+    typedef double T;
+    static constexpr int KIND = MI_F64_WEAK;
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // CartPole-v1: gymnasium/envs/classic_control/cartpole.py:119-247
 // ---------------------------------------------------------------------------------------------------------
@@ -163,6 +181,7 @@ struct CartPoleT {
     typedef CartPoleTotalMass TotalMass;
     static constexpr int S = 4, OBS = 4, N_ACTIONS = 2;
     static constexpr bool DISCRETE = true;
+    static constexpr int ACT_KIND = MI_I64;
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.05, b1 = 0.05; }
@@ -215,14 +234,15 @@ struct CartPoleT {
 // ---------------------------------------------------------------------------------------------------------
 // Pendulum-v1: gymnasium/envs/classic_control/pendulum.py:102-171,281-282
 // ---------------------------------------------------------------------------------------------------------
-template <class M>
+template <class M, class AK = ActF32>
 struct PendulumT {
     typedef M Math;
     static constexpr bool SPLIT_TERMINAL = false;
-    static constexpr bool USES_POW = true, USES_POWF = true;
+    static constexpr int ACT_KIND = AK::KIND;
+    static constexpr bool USES_POW = true, USES_POWF = ACT_KIND == MI_F32;
     static constexpr int S = 2, OBS = 3;
     static constexpr bool DISCRETE = false;
-    typedef float Act;
+    typedef typename AK::T Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
 
@@ -250,9 +270,9 @@ struct PendulumT {
         const double max_speed = 8, max_torque = 2.0, dt = 0.05, m = 1.0, l = 1.0;
         const double g = P.p[0];
         const double th = s[0], thdot = s[1];
-        float u = action;  // np.clip(u, -2, 2)[0] stays np.float32
-        u = u < (float)-max_torque ? (float)-max_torque : u;
-        u = u > (float)max_torque ? (float)max_torque : u;
+        Act u = action;  // np.clip(u, -2, 2)[0] stays np.float32 for a float32 row; a float64 row (or a list's) makes it an np.float64
+        u = u < (Act)-max_torque ? (Act)-max_torque : u;
+        u = u > (Act)max_torque ? (Act)max_torque : u;
         // angle_normalize: ((x + pi) % (2 pi)) - pi with Python floor-modulo
         double md = M::fmod_2pi(th + kPi);
         if (md != 0.0) {
@@ -261,13 +281,18 @@ struct PendulumT {
             md = 0.0;
         }
         const double an = md - kPi;
-        const float cu = 0.001f * M::sqf(u);  // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
-        const double costs = M::sq(an) + 0.1 * M::sq(thdot) + (double)cu;
-        const float tu = (float)(3.0 / (m * (l * l))) * u;  // float32: 3.0 / (m l^2) * u
+        double cu, tu;
+        if constexpr (ACT_KIND == MI_F32) {
+            cu = (double)(0.001f * M::sqf(u));                 // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
+            tu = (double)((float)(3.0 / (m * (l * l))) * u);  // float32: 3.0 / (m l^2) * u
+        } else {
+            cu = 0.001 * M::sq(u), tu = 3.0 / (m * (l * l)) * u;  // all float64
+        }
+        const double costs = M::sq(an) + 0.1 * M::sq(thdot) + cu;
         if (!t.ok) t.sn = M::sin(th);  // (else: the observation of the previous step evaluated sin of this very angle)
         const double sn = t.sn;
         t.ok = false;
-        double newthdot = thdot + (3 * g / (2 * l) * sn + (double)tu) * dt;
+        double newthdot = thdot + (3 * g / (2 * l) * sn + tu) * dt;
         newthdot = newthdot < -max_speed ? -max_speed : newthdot;
         newthdot = newthdot > max_speed ? max_speed : newthdot;
         const double newth = th + newthdot * dt;
@@ -292,6 +317,7 @@ struct AcrobotT {
     static constexpr bool USES_POW = true, USES_POWF = false;
     static constexpr int S = 4, OBS = 6, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
+    static constexpr int ACT_KIND = MI_I64;
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.1, b1 = 0.1; }
@@ -394,6 +420,7 @@ struct MountainCarT {
     static constexpr bool USES_POW = false, USES_POWF = false;
     static constexpr int S = 2, OBS = 2, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
+    static constexpr int ACT_KIND = MI_I64;
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
@@ -432,14 +459,15 @@ struct MountainCarT {
 // The state is a float64 array right after reset and a float32 array from the first step on (":178"); NumPy-2
 // promotion then makes most of the update float32 arithmetic.
 // ---------------------------------------------------------------------------------------------------------
-template <class M>
+template <class M, class AK = ActF32>
 struct MountainCarContinuousT {
     typedef M Math;
     static constexpr bool SPLIT_TERMINAL = false;
-    static constexpr bool USES_POW = false, USES_POWF = false;
+    static constexpr int ACT_KIND = AK::KIND;
+    static constexpr bool USES_POW = ACT_KIND != MI_F32, USES_POWF = false;  // math.pow(action[0], 2): exact for a float32 value, libm's rounding for a float64 one
     static constexpr int S = 2, OBS = 2;
     static constexpr bool DISCRETE = false;
-    typedef float Act;
+    typedef typename AK::T Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
     static constexpr int NDRAWS = 1;
@@ -451,11 +479,17 @@ struct MountainCarContinuousT {
     typedef NoTrig Trig;
     static MI_DEV void obs(const double s[S], uint32_t, float o[OBS], Trig &) { o[0] = (float)s[0], o[1] = (float)s[1]; }
     static MI_DEV bool valid(Act) { return true; }
-    static MI_DEV Act sample(double u) { return (Act)(-1.0 + (1.0 - (-1.0)) * u); }
+    static MI_DEV Act sample(double u) { return (Act)(float)(-1.0 + (1.0 - (-1.0)) * u); }
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
-    static MI_DEV void step(double s[S], uint32_t &flags, Act a0, const EnvParams &P, double &reward, bool &terminated, Trig &) {
+    static MI_DEV void step(double s[S], uint32_t &flags, Act a0, const EnvParams &P, double &reward, bool &terminated, Trig &t) {
+        if constexpr (ACT_KIND == MI_F32)
+            step_f32(s, flags, a0, P, reward, terminated, t);
+        else
+            step_f64(s, flags, a0, P, reward, terminated, t);
+    }
+    static MI_DEV void step_f32(double s[S], uint32_t &flags, float a0, const EnvParams &P, double &reward, bool &terminated, Trig &) {
         const double min_action = -1.0, max_action = 1.0, min_position = -1.2, max_position = 0.6, max_speed = 0.07;
         const double goal_position = 0.45, power = 0.0015, goal_velocity = P.p[0];
         // force = min(max(action[0], -1.0), 1.0): an np.float32 unless out of range, then the Python float bound
@@ -499,6 +533,47 @@ struct MountainCarContinuousT {
         const double a_d = (double)a0;
         reward = (terminated ? 100.0 : 0.0) - (a_d * a_d) * 0.1;  // math.pow(action[0], 2) * 0.1 (exact in double)
         s[0] = position, s[1] = velocity;
+        flags |= kStateF32;
+    }
+    // A float64 action row (continuous_mountain_car.py:150-178 again): `force` is an np.float64 -- or, out of range and for the rows of a list
+    // batch (ActF64Weak), a Python float.  `force * power - 0.0025 * math.cos(3 * position)` is then an np.float64 and `velocity += ...`
+    // promotes the np.float32 velocity of a float32 state to float64 for the rest of the step; a Python float leaves it float32.  Each clamp
+    // REPLACES the scalar by a Python float (weak again: `position += velocity` with an np.float32 position stays float32), and comparisons
+    // with Python floats happen in the array scalar's own type.  vk / pk: 0 = np.float32, 1 = np.float64, 2 = Python float.
+    static MI_DEV void step_f64(double s[S], uint32_t &flags, double a0, const EnvParams &P, double &reward, bool &terminated, Trig &) {
+        const double min_action = -1.0, max_action = 1.0, min_position = -1.2, max_position = 0.6, max_speed = 0.07;
+        const double goal_position = 0.45, power = 0.0015, goal_velocity = P.p[0];
+        bool force_is_py = ACT_KIND == MI_F64_WEAK;
+        double force = a0;
+        if (min_action > a0) force_is_py = true, force = min_action;
+        if (force == a0 && max_action < a0) force_is_py = true, force = max_action;
+        const bool state_f32 = (flags & kStateF32) != 0;
+        double p = s[0], v = s[1];
+        const double g = state_f32 ? 0.0025 * M::cos_bounded((double)(3.0f * (float)p)) : 0.0025 * M::cos_bounded(3 * p);
+        int vk = state_f32 ? 0 : 1, pk = vk;
+        if (force_is_py) {
+            if (vk == 0)
+                v = (double)((float)v + (float)(force * power - g));
+            else
+                v = v + (force * power - g);
+        } else {
+            v = v + (force * power - g), vk = 1;
+        }
+        if (vk == 0 ? ((float)v > (float)max_speed) : (v > max_speed)) v = max_speed, vk = 2;
+        if (vk == 0 ? ((float)v < (float)-max_speed) : (v < -max_speed)) v = -max_speed, vk = 2;
+        if (pk == 0 && (vk == 0 || vk == 2))
+            p = (double)((float)p + (float)v);
+        else
+            p = p + v, pk = 1;
+        if (pk == 0 ? ((float)p > (float)max_position) : (p > max_position)) p = max_position, pk = 2;
+        if (pk == 0 ? ((float)p < (float)min_position) : (p < min_position)) p = min_position, pk = 2;
+        const bool at_wall = pk == 0 ? ((float)p == (float)min_position) : (p == min_position);
+        if (at_wall && v < 0) v = 0, vk = 2;
+        const bool p_ge = pk == 0 ? ((float)p >= (float)goal_position) : (p >= goal_position);
+        const bool v_ge = vk == 0 ? ((float)v >= (float)goal_velocity) : (v >= goal_velocity);
+        terminated = p_ge && v_ge;
+        reward = (terminated ? 100.0 : 0.0) - M::sq(a0) * 0.1;  // math.pow(action[0], 2) * 0.1: libm pow, not the correctly rounded a0 * a0
+        s[0] = (double)(float)p, s[1] = (double)(float)v;       // np.array([position, velocity], dtype=np.float32)
         flags |= kStateF32;
     }
 };

@@ -12,6 +12,7 @@
 #pragma once
 #include "mjx_core.h"
 #include "ziggurat_tables.h"
+#include "pow_exact.h"
 
 namespace mjx {
 
@@ -65,6 +66,14 @@ MJX_DEV T np_sum(const T *a) {
     for (; i < N; i++) res += a[i];
     return res;
 }
+
+// One action row as the caller gave it: float32 values, or float64 values taken un-rounded (mi_step_io.actions_dtype; mujoco_env.py:148
+// `data.ctrl[:] = ctrl`).  Read where it is used -- no per-lane copy: the glue kernels are register-bound.
+struct ActRow {
+    const void *p;
+    bool f64;
+    MJX_DEV double operator[](int u) const { return f64 ? static_cast<const double *>(p)[u] : (double)static_cast<const float *>(p)[u]; }
+};
 
 enum MjKind { kHalfCheetah = 0, kAnt = 1, kHumanoid = 2, kHopper = 3, kWalker2d = 4, kInvertedPendulum = 5, kInvertedDoublePendulum = 6, kReacher = 7, kHumanoidStandup = 8, kSwimmer = 9, kPusher = 10 };
 
@@ -285,12 +294,12 @@ struct MjEnv {
     }
 
     // One env.step() with the one-lane simulator (mjx_core.h): physics, then finish().
-    static MJX_DEV void step(double *s, const float *action, const mi::EnvParams &P, double *obs, double &reward, bool &terminated,
+    static MJX_DEV void step(double *s, const ActRow action, const mi::EnvParams &P, double *obs, double &reward, bool &terminated,
                              double *info, bool newton = false) {
         Data<M> d;
         for (int k = 0; k < NQ; k++) d.qpos[k] = s[k];
         for (int k = 0; k < NV; k++) d.qvel[k] = s[NQ + k];
-        for (int u = 0; u < NU; u++) d.ctrl[u] = (double)action[u];
+        for (int u = 0; u < NU; u++) d.ctrl[u] = action[u];
         for (int k = 0; k < NV; k++) d.qacc_warm[k] = s[NQ + NV + k];  // the qacc_warmstart slot of the state row
         const double before[2] = {s[NQ + 2 * NV], s[NQ + 2 * NV + 1]};
         const int frame_skip = (int)P.p[4];
@@ -357,22 +366,33 @@ struct MjEnv {
     }
 
     // Everything of env.step() after do_simulation: s holds the NEW qpos / qvel, `before` the tracked point before the step.
-    static MJX_DEV void finish(double *s, const double *before, const StepExtras &x, const float *action, const mi::EnvParams &P, double *obs,
+    // weight * np.sum(np.square(action)) in the action row's OWN dtype (half_cheetah_v5.py:216-218 control_cost and its siblings): NEP 50 keeps a
+    // float32 row's reduction and its product with the Python-float weight in float32; a float64 row makes all of it float64.  Returned widened to
+    // double (exact).  -np.square(action).sum() * w (reacher_v5.py:201, pusher_v5.py:281) is its negation bit for bit.
+    static MJX_DEV double control_cost(const ActRow action, double weight) {
+        if (!action.f64) {
+            float sq[NU];
+            for (int u = 0; u < NU; u++) sq[u] = static_cast<const float *>(action.p)[u] * static_cast<const float *>(action.p)[u];
+            return (double)((float)weight * np_sum<float, NU>(sq));
+        }
+        double sq[NU];
+        for (int u = 0; u < NU; u++) sq[u] = action[u] * action[u];
+        return weight * np_sum<double, NU>(sq);
+    }
+    static MJX_DEV void finish(double *s, const double *before, const StepExtras &x, const ActRow action, const mi::EnvParams &P, double *obs,
                                double &reward, bool &terminated, double *info) {
         const int frame_skip = (int)P.p[4];
         const double *after = x.after;
         s[NQ + 2 * NV] = after[0], s[NQ + 2 * NV + 1] = after[1];
         const double dt = M::TIMESTEP * frame_skip;
         const double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
-        float sq[NU];
-        for (int u = 0; u < NU; u++) sq[u] = action[u] * action[u];
-        const float ctrl_cost_f = (float)P.p[1] * np_sum<float, NU>(sq);  // weight * np.sum(np.square(float32 action)): float32
+        const double ctrl_cost_f = control_cost(action, P.p[1]);  // weight * np.sum(np.square(action)): float32 arithmetic for a float32 row
         if (KIND == kHumanoidStandup) {
             // humanoidstandup_v5.py:423-462: reward = z / opt.timestep - w_ctrl sum(ctrl^2) - clip(w_impact sum(cfrc_ext^2)) + 1 (the
             // `uph_cost_weight` argument is stored but never applied there); never terminates
             const double uph_cost = (s[2] - 0) / M::TIMESTEP;
             double sqd[NU], c2s[6 * NB];
-            for (int u = 0; u < NU; u++) sqd[u] = (double)action[u] * (double)action[u];
+            for (int u = 0; u < NU; u++) sqd[u] = action[u] * action[u];
             const double quad_ctrl_cost = P.p[1] * np_sum<double, NU>(sqd);
             for (int b = 0; b < NB; b++)
                 for (int k = 0; k < 6; k++) c2s[6 * b + k] = x.cfrc[b][k] * x.cfrc[b][k];
@@ -394,7 +414,7 @@ struct MjEnv {
             const double v1[3] = {ob[0] - tip[0], ob[1] - tip[1], ob[2] - tip[2]}, v2[3] = {ob[0] - goal[0], ob[1] - goal[1], ob[2] - goal[2]};
             const double reward_near = -np_norm(v1[0], v1[1], v1[2]) * P.p[0];
             const double reward_dist = -np_norm(v2[0], v2[1], v2[2]) * P.p[5];
-            const float reward_ctrl = -np_sum<float, NU>(sq) * (float)P.p[1];
+            const double reward_ctrl = -ctrl_cost_f;
             reward = (reward_dist + (double)reward_ctrl) + reward_near;
             terminated = false;
             ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
@@ -406,7 +426,7 @@ struct MjEnv {
         if (KIND == kReacher) {
             // reacher_v5.py:188-207: reward = -|fingertip - target| w_dist - sum(a^2) w_ctrl (the control term in float32); never terminates
             const double reward_dist = -np_norm(x.vec[0], x.vec[1], x.vec[2]) * P.p[0];
-            const float reward_ctrl = -np_sum<float, NU>(sq) * (float)P.p[1];
+            const double reward_ctrl = -ctrl_cost_f;
             reward = reward_dist + (double)reward_ctrl;
             terminated = false;
             ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
@@ -431,8 +451,10 @@ struct MjEnv {
             const double tx = after[0], ty = after[1];
             terminated = ty <= 1.0;
             const double v1 = s[NQ + 1], v2 = s[NQ + 2];
-            const double dist_penalty = 0.01 * (tx * tx) + (ty - 2) * (ty - 2);
-            const double vel_penalty = 1e-3 * (v1 * v1) + 5e-3 * (v2 * v2);
+            // np.float64 scalars `** 2`: libm pow(x, 2.0), restated bit for bit (pow_exact.h; its tables read from global memory here: four squares a step)
+            auto sq = [](double v) { return mi_pow::square<false>(mi_pow::kLogTab, mi_pow::kExpTab, v); };
+            const double dist_penalty = 0.01 * sq(tx) + sq(ty - 2);
+            const double vel_penalty = 1e-3 * sq(v1) + 5e-3 * sq(v2);
             const double alive_bonus = P.p[6] * (terminated ? 0.0 : 1.0);
             reward = alive_bonus - dist_penalty - vel_penalty;
             ObsExtras ox = {nullptr, nullptr, nullptr, nullptr};
@@ -498,7 +520,7 @@ struct MjEnv {
         } else {
             healthy = P.p[8] < s[2] && s[2] < P.p[9];
             double sqd[NU];
-            for (int u = 0; u < NU; u++) sqd[u] = (double)action[u] * (double)action[u];  // np.square(self.data.ctrl): float64
+            for (int u = 0; u < NU; u++) sqd[u] = action[u] * action[u];  // np.square(self.data.ctrl): float64
             ctrl_cost = P.p[1] * np_sum<double, NU>(sqd);
             for (int b = 0; b < NB; b++)
                 for (int k = 0; k < 6; k++) c2[6 * b + k] = cfrc[b][k] * cfrc[b][k];

@@ -25,6 +25,7 @@ struct Args {
     uint32_t needs_reset_mask;
     int N, frame_skip;
     int newton;          // MI_CFG_SOLVER_NEWTON: run the Newton instantiation although the model's MJCF asks for PGS
+    int act_f64;         // the action rows are float64 (taken un-rounded: mujoco_env.py:148 data.ctrl[:] = ctrl), not float32
 };
 
 // Advances qpos / qvel of every sub-environment that takes a real step this call by frame_skip sub-steps, in place, and leaves what
@@ -33,7 +34,7 @@ struct Args {
 // PGS: the constraint solver of the model's MJCF (M::SOLVER == 1: humanoid.xml:8 `solver="PGS" iterations="50"`) or, false, the converged
 // primal Newton solver (every other robot's MJCF default; opt-in for the humanoids, MI_CFG_SOLVER_NEWTON).
 template <class E, bool SKIP_RESETTING, bool PGS>
-__global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *actions, double *extras) {
+__global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const void *actions, double *extras) {
     typedef typename E::Model M;
     constexpr int G = E::COOP_G, EPW = 64 / G;
     typedef mjx::coop::Sim<M, G, PGS> S;
@@ -55,7 +56,11 @@ __global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *act
     if (steps) {
         for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
         for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
-        for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)actions[(size_t)env * M::NU + k];
+        if (d.act_f64) {  // (grid-uniform)
+            for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = static_cast<const double *>(actions)[(size_t)env * M::NU + k];
+        } else {
+            for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)static_cast<const float *>(actions)[(size_t)env * M::NU + k];
+        }
         r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
     } else {
         for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = M::qpos0[k];
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const float *act
 }
 
 template <class E>
-inline void launch_kind(const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream) {
+inline void launch_kind(const Args &a, bool skip_resetting, const void *actions, double *extras, hipStream_t stream) {
     constexpr int EPW = 64 / E::COOP_G;
     const dim3 grid((a.N + EPW - 1) / EPW), block(64);
     if constexpr (E::Model::SOLVER == 1) {
@@ -94,7 +99,7 @@ inline void launch_kind(const Args &a, bool skip_resetting, const float *actions
 }
 
 // defined in physics16.hip / physics32.hip; `kind` is an mi_env_kind; returns false for a kind the unit does not hold
-bool launch16(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream);
-bool launch32(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream);
+bool launch16(int kind, const Args &a, bool skip_resetting, const void *actions, double *extras, hipStream_t stream);
+bool launch32(int kind, const Args &a, bool skip_resetting, const void *actions, double *extras, hipStream_t stream);
 
 }  // namespace mi_phys

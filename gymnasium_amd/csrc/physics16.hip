@@ -4,7 +4,7 @@
 #include "mjx_physics.h"
 
 namespace mi_phys {
-bool launch16(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream) {
+bool launch16(int kind, const Args &a, bool skip_resetting, const void *actions, double *extras, hipStream_t stream) {
     switch (kind) {
     case MI_ENV_ANT: launch_kind<mjx::MjEnv<mjx::AntModel, mjx::kAnt>>(a, skip_resetting, actions, extras, stream); return true;
     case MI_ENV_HALF_CHEETAH: launch_kind<mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah>>(a, skip_resetting, actions, extras, stream); return true;

@@ -4,7 +4,7 @@
 #include "mjx_physics.h"
 
 namespace mi_phys {
-bool launch32(int kind, const Args &a, bool skip_resetting, const float *actions, double *extras, hipStream_t stream) {
+bool launch32(int kind, const Args &a, bool skip_resetting, const void *actions, double *extras, hipStream_t stream) {
     switch (kind) {
     case MI_ENV_HUMANOID: launch_kind<mjx::MjEnv<mjx::HumanoidModel, mjx::kHumanoid>>(a, skip_resetting, actions, extras, stream); return true;
     case MI_ENV_HUMANOID_STANDUP:

@@ -64,9 +64,12 @@ class _MujocoVectorEnv(HipVectorEnv):
         self.frame_skip = int(frame_skip)
         if not _WARNED_UNPINNED:  # once per process
             _WARNED_UNPINNED = True
-            logger.warn("gymnasium_amd MuJoCo-family environments run a from-scratch restatement of MuJoCo's published pipeline; no fixture "
-                        "from a real `mujoco` build pins it yet (DESIGN.md section 7), so trajectories and rewards are NOT guaranteed to equal "
-                        "the reference's within a tolerance.")
+            logger.warn("gymnasium_amd MuJoCo-family environments run a from-scratch restatement of MuJoCo's published pipeline.  It reproduces "
+                        "the two `mujoco`-produced known answers the reference holds to every printed digit (HalfCheetah-v5: Euler + frictional "
+                        "contact + Newton solver, gymnasium/wrappers/vector/dict_info_to_list.py:49-56; Reacher-v5: RK4 + joint limits, "
+                        "gymnasium/wrappers/transform_action.py:223-257); free-joint RK4 contact (Ant), PGS (Humanoid), capsule-capsule collisions, "
+                        "tendons and fluid forces have no `mujoco` fixture yet (DESIGN.md section 7), so those trajectories are NOT guaranteed to "
+                        "equal the reference's within a tolerance.")
 
     @property
     def dt(self) -> float:

@@ -113,10 +113,13 @@ class HipVectorEnv(VectorEnv):
         members = st["chain"][:level + 1]
         sig = [level]
         for slot, w in members:
+            # (the statistics HANDLES and accumulator addresses are part of the signature: replacing `w.obs_rms` / `w.return_rms`, e.g. when a
+            # checkpoint is restored, must re-attach the epilogue to the new object)
             if slot == "obs":
-                sig += [float(w.epsilon), bool(w.update_running_mean)]
+                sig += [float(w.epsilon), bool(w.update_running_mean), w.obs_rms._h.value]
             elif slot == "ret":
-                sig += [float(w.gamma), float(w.epsilon), bool(w.update_running_mean)]
+                sig += [float(w.gamma), float(w.epsilon), bool(w.update_running_mean),
+                        w.return_rms._h.value, w._acc.data_ptr(), w._prev.data_ptr()]
             else:
                 sig += [None if w.min_reward is None else float(w.min_reward), None if w.max_reward is None else float(w.max_reward)]
         sig = tuple(sig)
@@ -229,6 +232,9 @@ class HipVectorEnv(VectorEnv):
     # -- buffers ---------------------------------------------------------------------------------------
     def _alloc_buffers(self):
         N, eng = self.num_envs, self._engine
+        old_count = self.__dict__.pop("_episode_count_t", None)
+        if old_count is not None:  # episodes counted on the device so far survive a re-allocation / a switch of the output mode
+            self._episode_count = getattr(self, "_episode_count", 0) + int(old_count.item())
         if self.output == "torch":
             import torch
 
@@ -275,7 +281,6 @@ class HipVectorEnv(VectorEnv):
             self._ep_l = (hb["episode_length"] if hb else np.zeros((N,), dtype=np.int32)) if self.record_episode_statistics else None
             self._loc = _native.MI_HOST
             self._device_infos = False
-            self.__dict__.pop("_episode_count_t", None)
 
     def _p(self, buf):
         if buf is None:
@@ -390,28 +395,43 @@ class HipVectorEnv(VectorEnv):
         return {}
 
     def _coerce_actions(self, actions):
+        """The action batch as the engine reads it: (object to keep alive, pointer, mi_dtype of a Box row).
+
+        Box action spaces: the reference hands every sub-environment its row of the caller's array AS IT IS (sync_vector_env.py:274 iterate();
+        pendulum.py:127-134, continuous_mountain_car.py:153, mujoco_env.py:148 `data.ctrl[:] = ctrl`) -- a float64 array is not rounded to the
+        space's float32, and NumPy's promotion rules then make parts of the step float64 arithmetic.  So float64 rows (and integer arrays:
+        exact in float64) go to the engine un-rounded with actions_dtype = MI_F64; float32 and float16 rows take the float32 path, which is
+        also the on-device sampler's type.  A list of Python lists reaches the scalar envs as Python lists: `action[0]` is then a Python
+        float, which NumPy 2 treats as WEAK (np.float32 + float stays float32) -- MI_F64_WEAK; only MountainCarContinuous tells it from MI_F64."""
         eng = self._engine
         if self.output == "torch" and hasattr(actions, "data_ptr"):
             t = self._torch
-            want = t.int64 if self._discrete else t.float32
+            if self._discrete:
+                want = t.int64
+            else:
+                want = t.float32 if actions.dtype in (t.float32, t.float16, t.bfloat16) else t.float64
             if actions.device != self._tdev or actions.dtype != want or not actions.is_contiguous():
                 actions = actions.to(device=self._tdev, dtype=want).contiguous()
             if actions.numel() != self.num_envs * eng.act_dim:
                 raise ValueError(f"actions must have {self.num_envs * eng.act_dim} elements, got shape {tuple(actions.shape)}")
-            return actions, actions.data_ptr()
+            return actions, actions.data_ptr(), (_native.MI_F64 if want is t.float64 else _native.MI_F32)
         a = np.asarray(actions)
+        dtype = _native.MI_F32
         if self._discrete:
             if not np.issubdtype(a.dtype, np.integer):
                 raise AssertionError(f"{actions!r} ({type(actions)}) invalid")
             a = np.ascontiguousarray(a, dtype=np.int64)
-        else:
+        elif a.dtype in (np.float32, np.float16):
             a = np.ascontiguousarray(a, dtype=np.float32)
+        else:
+            weak = isinstance(actions, (list, tuple)) and len(actions) > 0 and all(isinstance(r, (list, tuple)) for r in actions)
+            a, dtype = np.ascontiguousarray(a, dtype=np.float64), (_native.MI_F64_WEAK if weak else _native.MI_F64)
         if a.size != self.num_envs * eng.act_dim:
             raise ValueError(f"actions must have shape {self._act_shape}, got {a.shape}")
         if self.output == "torch":
             ta = self._torch.from_numpy(a).to(self._tdev)
-            return ta, ta.data_ptr()
-        return a, a
+            return ta, ta.data_ptr(), dtype
+        return a, a, dtype
 
     def step(self, actions):
         """One lockstep step of every sub-environment: (obs, rewards, terminations, truncations, infos)."""
@@ -419,13 +439,14 @@ class HipVectorEnv(VectorEnv):
         self._check_not_pending("step")
         if not self._has_reset:
             raise AssertionError("Call reset before using step method.")
-        keep, aptr = self._coerce_actions(actions)
+        keep, aptr, adt = self._coerce_actions(actions)
+        self._act_f64 = adt != _native.MI_F32
         self._bind_stream()
         self._sync_epilogue()
         try:
             self._engine.step(aptr, self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc),
                               self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc, self._p(self._info),
-                              self._p(self._final_info))
+                              self._p(self._final_info), actions_dtype=adt)
             if self.strict_actions and self.output == "torch":
                 self._engine.synchronize()  # raises the device error word of this very step
         except _native.NativeError as e:
@@ -458,10 +479,19 @@ class HipVectorEnv(VectorEnv):
                 continue
             col = rows[:, start] if width == 0 else rows[:, start:start + width]
             val = np.where(mask if width == 0 else mask[:, None], col, 0.0)
-            if name in self.INFO_DTYPES:  # (the engine's info row is float64; such entries hold float32 values exactly)
-                val = val.astype(self.INFO_DTYPES[name])
+            dt = self._info_dtype(name)
+            if dt is not None:  # (the engine's info row is float64; such entries hold float32 / integer values exactly)
+                val = val.astype(dt)
             out[name], out["_" + name] = val, mask.copy()
         return out
+
+    def _info_dtype(self, name):
+        """dtype of the reference's info entry where it is not float64.  An np.float32 entry is one computed from the action row
+        (`reward_ctrl`): float32 for a float32 row, float64 for a float64 row (see _coerce_actions)."""
+        dt = self.INFO_DTYPES.get(name)
+        if dt is np.float32 and getattr(self, "_act_f64", False):
+            return None
+        return dt
 
     def _host(self, buf):
         return buf.cpu().numpy() if self.output == "torch" else buf
@@ -477,11 +507,13 @@ class HipVectorEnv(VectorEnv):
         if self.output == "torch" or not self._pinned:
             self._async_pending = ("done", self.step(actions))
             return
-        keep, aptr = self._coerce_actions(actions)
+        keep, aptr, adt = self._coerce_actions(actions)
+        self._act_f64 = adt != _native.MI_F32
         self._bind_stream()
         self._sync_epilogue()
         try:
-            self._engine.step_async(aptr, self._obs, self._rew, self._term, self._trunc, self._final, self._ep_r, self._ep_l, self._info, self._final_info)
+            self._engine.step_async(aptr, self._obs, self._rew, self._term, self._trunc, self._final, self._ep_r, self._ep_l, self._info, self._final_info,
+                                    actions_dtype=adt)
         except _native.NativeError as e:
             if e.code in (-1, -5):
                 raise AssertionError(e.message) from e
@@ -516,9 +548,10 @@ class HipVectorEnv(VectorEnv):
                 val, mask = (col.clone() if self.copy else col), self._all_true_t
             else:
                 val = t.where(mask if width == 0 else mask[:, None], col, 0.0)
-            if self.INFO_DTYPES.get(name) is np.float32:
-                val = val.to(t.float32)
-            out[name], out["_" + name] = val, mask
+            dt = self._info_dtype(name)
+            if dt is not None:  # same dtypes as the NumPy infos (_info_dict)
+                val = val.to({np.float32: t.float32, np.int64: t.int64, np.int32: t.int32, np.bool_: t.bool}[dt])
+            out[name], out["_" + name] = val, (mask.clone() if (self.copy and mask is self._all_true_t) else mask)
         return out
 
     def _build_infos_device(self) -> dict:
@@ -538,12 +571,14 @@ class HipVectorEnv(VectorEnv):
             infos["final_obs"], infos["_final_obs"] = self._out(self._final), dones
             finfo = self._info_dict_device(self._final_info, dones, None) if (self.INFO_KEYS and self._final_info is not None) else {}
             infos["final_info"], infos["_final_info"] = finfo, dones
-        self._was_done_t = dones if not same_step else t.zeros_like(dones)
+        # (private copies: `dones` itself is handed to the caller as the `_episode` / `_final_obs` / `_final_info` masks, and an in-place edit of
+        # those must not reach the next step's autoreset bookkeeping -- the NumPy path returns copies as well)
+        self._was_done_t = dones.clone() if not same_step else t.zeros_like(dones)
         if self.record_episode_statistics:
             now = time.perf_counter()
             if not same_step:
                 self._episode_start_t = t.where(self._prev_dones_t, now, self._episode_start_t)
-            self._prev_dones_t = dones
+            self._prev_dones_t = dones.clone()
             infos["episode"] = {"r": self._out(self._ep_r), "l": self._ep_l.to(t.int64),
                                 "t": t.where(dones, t.round((now - self._episode_start_t) * 1e6) / 1e6, 0.0)}
             infos["_episode"] = dones
@@ -623,8 +658,12 @@ class HipVectorEnv(VectorEnv):
         act_dtype = t.int64 if self._discrete else t.float32
         act_shape = (T, N) if self._discrete else (T, N, eng.act_dim)
         a_in = a_out = None
+        in_dtype = _native.MI_F32
         if actions is not None:
-            a_in = actions.to(device=dev, dtype=act_dtype).contiguous()
+            if not self._discrete and actions.dtype == t.float64:  # float64 rows are taken un-rounded, like step() does (_coerce_actions)
+                a_in, in_dtype = actions.to(device=dev).contiguous(), _native.MI_F64
+            else:
+                a_in = actions.to(device=dev, dtype=act_dtype).contiguous()
             if tuple(a_in.shape) != act_shape:
                 raise ValueError(f"actions must have shape {act_shape}, got {tuple(a_in.shape)}")
         else:
@@ -636,7 +675,8 @@ class HipVectorEnv(VectorEnv):
         term = t.empty((T, N), dtype=t.bool, device=dev)
         trunc = t.empty((T, N), dtype=t.bool, device=dev)
         eng.rollout(T, None if a_in is None else a_in.data_ptr(), None if a_out is None else a_out.data_ptr(),
-                    obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr())
+                    obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), actions_in_dtype=in_dtype)
+        self._act_f64 = in_dtype == _native.MI_F64
         if actions is None:
             self.action_space.np_random.bit_generator.advance(T * N * eng.act_dim)
         out = {"obs": obs, "rewards": rew, "terminations": term, "truncations": trunc}

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355ENV_ABI_VERSION 4
+#define MI355ENV_ABI_VERSION 5
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -80,7 +80,17 @@ typedef enum mi_autoreset_mode {
 typedef enum mi_mem_location { MI_HOST = 0, MI_DEVICE = 1 } mi_mem_location;
 
 /* Element types of the action / observation rows (mi_layout). */
-typedef enum mi_dtype { MI_F32 = 0, MI_F64 = 1, MI_I64 = 2 } mi_dtype;
+typedef enum mi_dtype {
+    MI_F32 = 0,
+    MI_F64 = 1,
+    MI_I64 = 2,
+    /* action rows only (mi_step_io.actions_dtype): float64 values that were PYTHON floats on the caller's side -- the rows of a list-of-lists
+     * batch, which sync_vector_env.py:274 iterate() hands to the scalar env as Python lists.  Python scalars are weak under NumPy 2's
+     * promotion (NEP 50): np.float32 + float stays float32 where np.float32 + np.float64 becomes float64.  Only
+     * MountainCarContinuous tells the two apart (continuous_mountain_car.py:153-155, its np.float32 state); every other kind treats the
+     * value as MI_F64. */
+    MI_F64_WEAK = 3
+} mi_dtype;
 
 /*
  * Construction parameters = the kwargs the reference passes to the scalar env constructor through
@@ -138,7 +148,9 @@ typedef struct mi_layout {
 /*
  * Buffers of one step() call, all row-major [num_envs][dim].  Pointers are all host or all device
  * (mi_mem_location).  Nullable members are skipped.
- *   actions          in   [N][act_dim] act_dtype     (i64 for Discrete -- what iterate(MultiDiscrete) yields)
+ *   actions          in   [N][act_dim] act_dtype     (i64 for Discrete -- what iterate(MultiDiscrete) yields); Box kinds: float32
+ *                                               rows (layout.act_dtype, the dtype of the space and of its sampler) or, with
+ *                                               actions_dtype = MI_F64, float64 rows taken UN-ROUNDED
  *   obs              out  [N][obs_dim] obs_dtype
  *   reward           out  [N] f64                     (sync_vector_env.py:171)
  *   terminated       out  [N] u8 0/1                  (np.bool_ compatible)
@@ -163,17 +175,27 @@ typedef struct mi_step_io {
     int32_t *episode_length;
     double *info;
     double *final_info;
+    /* Element type of `actions` for the Box kinds: MI_F32 (0, the default: layout.act_dtype), MI_F64 or MI_F64_WEAK.  The reference hands the caller's rows
+     * to the scalar env as they are (vector/sync_vector_env.py:274 iterate(); envs/classic_control/pendulum.py:127-134 np.clip(u)[0],
+     * continuous_mountain_car.py:153 action[0], envs/mujoco/mujoco_env.py:148 data.ctrl[:] = ctrl), so a float64 action array is NOT
+     * rounded to float32 on the way in, and NumPy's promotion rules then make parts of the step float64 arithmetic that are float32 for a
+     * float32 row (the control cost of the MuJoCo kinds, Pendulum's torque terms, MountainCarContinuous' velocity update).  MI_F64
+     * reproduces that; the pinned action array of mi_host_buffers is sized for either type.  Ignored by the Discrete kinds (MI_I64). */
+    int32_t actions_dtype;
+    int32_t reserved;
 } mi_step_io;
 
 /* Buffers of one fused rollout() call: T consecutive step()s in one launch, time-major [T][N][dim].
  * Any output pointer may be NULL (not materialised).  Device pointers only. */
 typedef struct mi_rollout_io {
-    const void *actions_in;   /* [T][N][act_dim] or NULL => sample on device from the action stream */
+    const void *actions_in;   /* [T][N][act_dim] or NULL => sample on device from the action stream; element type: actions_in_dtype */
     void *actions_out;        /* [T][N][act_dim] the sampled actions (NULL to skip)                    */
     void *obs;                /* [T][N][obs_dim] */
     double *reward;           /* [T][N] */
     uint8_t *terminated;      /* [T][N] */
     uint8_t *truncated;       /* [T][N] */
+    int32_t actions_in_dtype; /* Box kinds: MI_F32 (0, default) or MI_F64 rows in actions_in (see mi_step_io.actions_dtype); actions_out is always layout.act_dtype */
+    int32_t reserved;
 } mi_rollout_io;
 
 /* Running totals kept on device (the multi-GPU metric all-reduce operates on these three numbers). */

@@ -282,7 +282,23 @@ void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *P) {
     /* cfrc_ext stays zero after mj_resetData until the first mj_rnePostConstraint (the reset observation shows zeros) */
 }
 
-void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *reward, int *terminated, double *info) {
+/* weight * np.sum(np.square(action)) in the action's OWN dtype (half_cheetah_v5.py:216-218 control_cost and its siblings): NEP 50 keeps a
+ * float32 array's reduction and its product with the Python-float weight in float32; a float64 action row makes all of it float64.  The
+ * value is returned widened to double (exact).  -np.square(action).sum() * w (reacher_v5.py:201, pusher_v5.py:281) is its negation bit for bit. */
+static double control_cost(const double *a, int nu, int act_f64, double weight) {
+    if (act_f64) {
+        double sq[MJO_MAXU];
+        for (int u = 0; u < nu; u++) sq[u] = a[u] * a[u];
+        return weight * orc_np_sum_f64(sq, nu);
+    }
+    float sq[MJO_MAXU];
+    for (int u = 0; u < nu; u++) sq[u] = (float)a[u] * (float)a[u];
+    return (double)((float)weight * orc_np_sum_f32(sq, nu));
+}
+
+void orc_mjenv_step(orc_mjenv *e, const void *action_row, int act_f64, const double *P, double *reward, int *terminated, double *info) {
+    double action[MJO_MAXU]; /* the row widened to double: exact for float32 values */
+    for (int u = 0; u < e->m->nu; u++) action[u] = act_f64 ? ((const double *)action_row)[u] : (double)((const float *)action_row)[u];
     const mjo_model *m = e->m;
     mjo_data *d = &e->d;
     const int nu = m->nu, frame_skip = (int)P[4];
@@ -291,7 +307,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         before[0] = e->track_override[0], before[1] = e->track_override[1], e->has_override = 0;
     else
         tracked_xy(e, before);
-    for (int u = 0; u < nu; u++) d->ctrl[u] = (double)action[u];
+    for (int u = 0; u < nu; u++) d->ctrl[u] = action[u];
     mjo_step(m, d, frame_skip);
     mjo_rne_post_constraint(m, d);
     tracked_xy(e, after);
@@ -319,9 +335,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         const double v1[3] = {ob[0] - tip[0], ob[1] - tip[1], ob[2] - tip[2]}, v2[3] = {ob[0] - goal[0], ob[1] - goal[1], ob[2] - goal[2]};
         const double reward_near = -orc_np_norm(v1, 3) * P[0];
         const double reward_dist = -orc_np_norm(v2, 3) * P[5];
-        float sq[MJO_MAXU];
-        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
-        const float reward_ctrl = -orc_np_sum_f32(sq, nu) * (float)P[1]; /* float32 array sum times a Python float: float32 */
+        const double reward_ctrl = -control_cost(action, nu, act_f64, P[1]); /* a float32 row: float32 sum times a Python float -> float32 */
         *reward = (reward_dist + (double)reward_ctrl) + reward_near;
         *terminated = 0;
         info[0] = reward_dist, info[1] = (double)reward_ctrl, info[2] = reward_near;
@@ -330,9 +344,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     if (e->which == ORC_MJ_REACHER) { /* reacher_v5.py:188-207 */
         const double v[3] = {d->xpos[3][0] - d->xpos[4][0], d->xpos[3][1] - d->xpos[4][1], d->xpos[3][2] - d->xpos[4][2]};
         const double reward_dist = -orc_np_norm(v, 3) * P[0];
-        float sq[MJO_MAXU];
-        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
-        const float reward_ctrl = -orc_np_sum_f32(sq, nu) * (float)P[1]; /* float32 array sum times a Python float: float32 */
+        const double reward_ctrl = -control_cost(action, nu, act_f64, P[1]); /* a float32 row: float32 sum times a Python float -> float32 */
         *reward = reward_dist + (double)reward_ctrl;
         *terminated = 0;
         info[0] = reward_dist, info[1] = (double)reward_ctrl;
@@ -350,16 +362,16 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     if (e->which == ORC_MJ_INVERTED_DOUBLE_PENDULUM) { /* inverted_double_pendulum_v5.py:186-215 */
         const double x = after[0], y = after[1], v1 = d->qvel[1], v2 = d->qvel[2];
         *terminated = y <= 1.0;
-        const double dist_penalty = 0.01 * (x * x) + (y - 2) * (y - 2), vel_penalty = 1e-3 * (v1 * v1) + 5e-3 * (v2 * v2);
+        /* x, y, v1, v2 are np.float64 SCALARS there: `** 2` is NumPy's scalar power = libm pow(x, 2.0), which is not the correctly rounded x * x for
+         * ~0.09 % of arguments (the same fact as pendulum.py:131, oracle/classic_control.c pendulum_step) */
+        const double dist_penalty = 0.01 * pow(x, 2.0) + pow(y - 2, 2.0), vel_penalty = 1e-3 * pow(v1, 2.0) + 5e-3 * pow(v2, 2.0);
         const double alive_bonus = P[6] * (*terminated ? 0.0 : 1.0);
         *reward = alive_bonus - dist_penalty - vel_penalty;
         info[0] = alive_bonus, info[1] = -dist_penalty, info[2] = -vel_penalty;
         return;
     }
     if (is_planar_walker(e->which)) { /* hopper_v5.py:240-309, walker2d_v5.py:245-311 */
-        float sq[MJO_MAXU];
-        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
-        const float ctrl_cost = (float)P[1] * orc_np_sum_f32(sq, nu);
+        const double ctrl_cost = control_cost(action, nu, act_f64, P[1]);
         const double z = d->qpos[1], angle = d->qpos[2];
         int healthy = P[8] < z && z < P[9] && P[10] < angle && angle < P[11];
         if (e->which == ORC_MJ_HOPPER) { /* healthy_state_range on state_vector()[2:] */
@@ -374,9 +386,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         return;
     }
     if (e->which == ORC_MJ_SWIMMER) { /* swimmer_v5.py:225-263: never terminates; the control cost is float32 like HalfCheetah's */
-        float sq[MJO_MAXU];
-        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
-        float ctrl_cost = (float)P[1] * orc_np_sum_f32(sq, nu);
+        const double ctrl_cost = control_cost(action, nu, act_f64, P[1]);
         *reward = forward_reward - (double)ctrl_cost;
         *terminated = 0;
         info[0] = after[0], info[1] = after[1], info[2] = orc_np_norm(after, 2), info[3] = xv, info[4] = yv;
@@ -385,9 +395,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
     }
     if (e->which == ORC_MJ_HALF_CHEETAH) {
         /* control_cost: weight * np.sum(np.square(action)) with a float32 action -> float32 (NEP 50) */
-        float sq[MJO_MAXU];
-        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
-        float ctrl_cost = (float)P[1] * orc_np_sum_f32(sq, nu);
+        const double ctrl_cost = control_cost(action, nu, act_f64, P[1]);
         *reward = forward_reward - (double)ctrl_cost;
         *terminated = 0;
         info[0] = d->qpos[0], info[1] = xv, info[2] = forward_reward, info[3] = -(double)ctrl_cost;
@@ -400,9 +408,7 @@ void orc_mjenv_step(orc_mjenv *e, const float *action, const double *P, double *
         for (int k = 0; k < m->nq; k++) finite &= isfinite(d->qpos[k]) != 0;
         for (int k = 0; k < m->nv; k++) finite &= isfinite(d->qvel[k]) != 0;
         healthy = finite && P[8] <= d->qpos[2] && d->qpos[2] <= P[9];
-        float sq[MJO_MAXU];
-        for (int u = 0; u < nu; u++) sq[u] = action[u] * action[u];
-        ctrl_cost = (double)((float)P[1] * orc_np_sum_f32(sq, nu));
+        ctrl_cost = control_cost(action, nu, act_f64, P[1]);
         double c2[6 * MJO_MAXB];
         for (int b = 0; b < m->nbody; b++)
             for (int k = 0; k < 6; k++) {

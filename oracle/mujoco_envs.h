@@ -27,7 +27,8 @@ int orc_mjenv_state_dim(int which);
 orc_mjenv *orc_mjenv_create(int which, int force_newton);
 void orc_mjenv_obs(const orc_mjenv *e, const double *params, double *obs);
 void orc_mjenv_reset(orc_mjenv *e, orc_pcg64 *rng, const double *params);
-void orc_mjenv_step(orc_mjenv *e, const float *action, const double *params, double *reward, int *terminated, double *info);
+/* action: nu float32 values, or (act_f64) nu float64 values taken un-rounded (mujoco_env.py:148 data.ctrl[:] = ctrl) */
+void orc_mjenv_step(orc_mjenv *e, const void *action, int act_f64, const double *params, double *reward, int *terminated, double *info);
 void orc_mjenv_reset_info(const orc_mjenv *e, double *row);
 void orc_mjenv_get_state(const orc_mjenv *e, double *s);
 void orc_mjenv_set_state(orc_mjenv *e, const double *s);

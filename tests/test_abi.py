@@ -36,14 +36,38 @@ def test_oracle_exports_the_same_abi(oracle_factory):
         assert hasattr(lib.dll, "orc_" + s)
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors == what a C compiler makes of include/mi355env.h: sizes, and the offset of every field (gcc is in the image)."""
+    import shutil
+    import subprocess
+
     from gymnasium_amd import _native as n
 
     assert ctypes.sizeof(n.MiConfig) == 8 * 4 + 16 * 8
     assert ctypes.sizeof(n.MiLayout) == 8 * 4
-    assert ctypes.sizeof(n.MiStepIO) == 10 * 8
-    assert ctypes.sizeof(n.MiRolloutIO) == 6 * 8
+    assert ctypes.sizeof(n.MiStepIO) == 10 * 8 + 2 * 4  # ten pointers, actions_dtype, reserved
+    assert ctypes.sizeof(n.MiRolloutIO) == 6 * 8 + 2 * 4
     assert ctypes.sizeof(n.MiStats) == 5 * 8
+    assert (n.MI_F32, n.MI_F64, n.MI_I64, n.MI_F64_WEAK) == (0, 1, 2, 3)
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler to cross-check the offsets with")
+    pairs = {"mi_config": n.MiConfig, "mi_layout": n.MiLayout, "mi_step_io": n.MiStepIO, "mi_rollout_io": n.MiRolloutIO, "mi_stats": n.MiStats,
+             "mi_tabular_table": n.MiTabularTable, "mi_step_epilogue": n.MiStepEpilogue}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "mi355env.h")}"', "int main(void) {"]
+    for cname, ct in pairs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append(f'printf("abi %d\\n", MI355ENV_ABI_VERSION); return 0; }}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-o", str(tmp_path / "layout"), str(src)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(tmp_path / "layout")], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ct in pairs.items():
+        assert int(out[cname]) == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+    assert int(out["abi"]) == n.ABI_VERSION
 
 
 def test_no_cpu_fallback():

@@ -109,6 +109,8 @@ for env_id in ["HalfCheetah-v5", "Ant-v5", "Humanoid-v5", "HumanoidStandup-v5", 
         dones = 0
         for t in range(70):
             a = ref.action_space.sample()
+            if t % 3 == 2:  # a float64 action batch: handed to the sub-environments un-rounded (sync_vector_env.py:274), float64 control cost / info dtypes
+                a = a.astype(np.float64) * 0.7
             s1, s2 = ours.step(a), ref.step(a)
             for k, what in enumerate(("obs", "reward", "terminated", "truncated")):
                 assert data_equivalence(s1[k], s2[k], exact=True), (env_id, mode, t, what)
@@ -137,3 +139,32 @@ def test_reference_env_classes_equal_our_glue_on_the_same_physics():
     p = subprocess.run([sys.executable, "-c", GLUE_CHECK], env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0 and "GLUE_OK" in p.stdout, p.stdout[-2500:] + p.stderr[-3500:]
     assert p.stdout.count(" ok:") == 11
+
+
+DOCTEST_CHECK = r'''
+import doctest
+import mujoco, gymnasium as gym
+import gymnasium.wrappers.transform_action as ta
+import gymnasium.wrappers.vector.dict_info_to_list as di
+assert getattr(mujoco, "IS_ORACLE_SHIM", False)
+for mod, name in ((ta, "DiscretizeAction"), (di, "DictInfoToList")):
+    obj = getattr(mod, name)
+    finder, runner = doctest.DocTestFinder(recurse=False), doctest.DocTestRunner(optionflags=doctest.ELLIPSIS | doctest.NORMALIZE_WHITESPACE)
+    globs = {"gym": gym, name: obj}
+    tests = [t for t in finder.find(obj, name, globs=globs) if t.examples]
+    assert len(tests) == 1, (name, len(tests))
+    res = runner.run(tests[0])
+    assert res.failed == 0 and res.attempted >= 15, (name, res)
+    print(name, "doctest ok:", res.attempted, "examples")
+print("DOCTEST_OK")
+'''
+
+
+def test_the_reference_doctests_that_print_mujoco_numbers_pass_on_the_oracle():
+    """The two docstrings of the reference that print numbers a real `mujoco` produced -- DiscretizeAction (Reacher-v5: three 10-value
+    observations, gymnasium/wrappers/transform_action.py:223-257) and DictInfoToList (HalfCheetah-v5 infos of a 2-env SyncVectorEnv,
+    gymnasium/wrappers/vector/dict_info_to_list.py:49-62) -- run by `doctest` itself, with the reference's own env classes and wrappers on top
+    of the oracle's physics: every printed digit matches.  (tests/test_mujoco_reference_pins.py holds the same numbers as constants for
+    the boxes without the reference tree, and checks the HIP engine against them.)"""
+    p = subprocess.run([sys.executable, "-c", DOCTEST_CHECK], env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "DOCTEST_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]

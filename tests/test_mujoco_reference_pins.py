@@ -1,5 +1,23 @@
-"""The few NUMERIC facts about the MuJoCo-family envs that the reference's own test-suite pins (tests/envs/mujoco/test_mujoco_v5.py),
-restated against the oracle (CPU) and the HIP engine (-m gpu):
+"""The NUMERIC facts about the MuJoCo-family envs that the reference tree itself holds, restated against the oracle (CPU) and the HIP
+engine (-m gpu).
+
+(1) KNOWN ANSWERS PRODUCED BY A REAL `mujoco` -- the only ones in the tree (searched: every docstring under gymnasium/ and every file under
+docs/ and tests/ that names a MuJoCo env id; the Hopper-v4 examples of gymnasium/wrappers/transform_action.py:90,144 and
+gymnasium/wrappers/__init__.py:12-32 print no number; docs/environments/mujoco.md, docs/tutorials/** print none either):
+
+  gymnasium/wrappers/vector/dict_info_to_list.py:49-56   make_vec("HalfCheetah-v5", 2), reset(seed=123), action_space.seed(123), one step:
+                                                         x_position, x_velocity, reward_forward (float64) and reward_ctrl (float32) of both envs
+  gymnasium/wrappers/transform_action.py:223-231         make("Reacher-v5"), reset(seed=42), step([-0.3, -0.5]): the 10 observation values
+  gymnasium/wrappers/transform_action.py:232-239,250-257 the same through DiscretizeAction(bins=10): step(32) / step([3, 2]) (float32 bin centres)
+
+What they pin: HalfCheetah -- reset noise (uniform + ziggurat normal), the implicit-in-velocity-damping Euler integrator, 5 sub-steps, the
+frictional (pyramidal) contact model with the Newton solver (env 0 is in 4-row contact for 4 of the 5 sub-steps), the float32 control cost.
+Reacher -- RK4 (2 sub-steps), joint limits, armature / damping, the hinge-chain kinematics behind the fingertip-target vector, and the
+un-rounded float64 action row (mujoco_env.py:148): the float32-rounded [-0.3, -0.5] gives qvel[0] = -1.18958130, not the doctest's -1.18958125.
+What stays UNPINNED (no number from `mujoco` obtainable here): free-joint RK4 with contact (Ant), PGS / 50 (Humanoid), capsule-capsule
+collisions, tendons, fluid forces (Swimmer), cylinder geoms (Pusher).
+
+(2) What the reference's own test-suite pins (tests/envs/mujoco/test_mujoco_v5.py):
 
   :480-488  test_inverted_double_pendulum_max_height   site "tip" z == 1.2 at the zero-noise reset
   :353-372  test_ant_com                               qpos[0] == body("torso").xpos[0] after mj_kinematics
@@ -8,12 +26,138 @@ restated against the oracle (CPU) and the HIP engine (-m gpu):
 and the info entries humanoid_v5.py:486-487 / humanoidstandup_v5.py:433-434 add (tendon_length / tendon_velocity: fixed tendons are
 linear in qpos / qvel, evaluated at the LAST forward pass like every other mjData field the env reads after mj_step).
 """
+import os
+
 import numpy as np
 import pytest
 
 import gymnasium_amd
 from gymnasium_amd.envs.mujoco import compiler as cp
 from oracle import mujoco as omj
+
+# ---- (1) the `mujoco`-produced known answers ----------------------------------------------------------------------------------------
+# gymnasium/wrappers/vector/dict_info_to_list.py:56 (the printed infos dict; array repr = 8 decimals, float32 repr = shortest round-trip)
+HALFCHEETAH_PIN = {
+    "x_position": np.array([0.03332211, 0.10172355]), "x_velocity": np.array([-0.06296527, 0.89345848]),
+    "reward_forward": np.array([-0.06296527, 0.89345848]), "reward_ctrl": np.array([-0.24503504, -0.21944423], dtype=np.float32)}
+# gymnasium/wrappers/transform_action.py:229-231 (= :247-249)
+REACHER_PIN = np.array([0.99908342, 0.99948506, 0.04280567, -0.03208766, 0.10445588, 0.11442572, -1.18958125, -1.97979484, 0.1054461, -0.10896341])
+# gymnasium/wrappers/transform_action.py:237-239 (= :255-257): the float32 bin centres move qvel[0] by 7e-8
+REACHER_DISCRETIZED_PIN = np.array([0.99908342, 0.99948506, 0.04280567, -0.03208766, 0.10445588, 0.11442572, -1.18958118, -1.97979484, 0.1054461, -0.10896341])
+PRINTED = 5e-9  # half a unit of the 8th decimal: everything the doctest prints
+
+
+def discretize_action_bin_centres(low, high, bins):
+    """DiscretizeAction.__init__'s bin centres (gymnasium/wrappers/transform_action.py:303-310) -- pure NumPy on the space's float32 bounds
+    (NumPy 2: linspace of float32 scalars is float32)."""
+    return [0.5 * (np.linspace(low[i], high[i], bins + 1)[:-1] + np.linspace(low[i], high[i], bins + 1)[1:]) for i in range(len(low))]
+
+
+def discretized_reacher_action(index_pair, dtype=np.float32):
+    """DiscretizeAction(env, bins=10).action(...) for Reacher-v5's Box(-1, 1, (2,), float32): step(32) unflattens to (3, 2) (:346-351)."""
+    centres = discretize_action_bin_centres(np.array([-1, -1], np.float32), np.array([1, 1], np.float32), 10)
+    return np.array([centres[i][k] for i, k in enumerate(index_pair)], dtype=dtype)  # :340 np.array(centers, dtype=action_space.dtype)
+
+
+def check_halfcheetah_pin(make):
+    env = make("HalfCheetah-v5", 2)
+    env.reset(seed=123)
+    env.action_space.seed(123)
+    infos = env.step(env.action_space.sample())[4]
+    assert [k for k in infos] == ["x_position", "_x_position", "x_velocity", "_x_velocity", "reward_forward", "_reward_forward", "reward_ctrl", "_reward_ctrl"]
+    for k, want in HALFCHEETAH_PIN.items():
+        assert infos[k].dtype == want.dtype and infos["_" + k].all(), k
+        if want.dtype == np.float32:
+            np.testing.assert_array_equal(infos[k], want, err_msg=k)  # the float32 control cost: every bit
+        else:
+            np.testing.assert_allclose(infos[k], want, rtol=0, atol=PRINTED, err_msg=k)
+    env.close()
+
+
+def check_reacher_pin(make):
+    env = make("Reacher-v5", 1)
+    assert env.single_action_space.shape == (2,) and env.single_action_space.dtype == np.float32
+    env.reset(seed=42)
+    obs = env.step([[-0.3, -0.5]])[0]  # a Python list, as in the doctest: float64 values, NOT rounded to the space's float32
+    assert obs.dtype == np.float64
+    np.testing.assert_allclose(obs[0], REACHER_PIN, rtol=0, atol=PRINTED)
+    env.reset(seed=42)
+    a32 = discretized_reacher_action((3, 2))
+    assert a32.dtype == np.float32 and a32[0] == np.float32(-0.29999998) and a32[1] == np.float32(-0.5)
+    obs = env.step(a32[None])[0]
+    np.testing.assert_allclose(obs[0], REACHER_DISCRETIZED_PIN, rtol=0, atol=PRINTED)
+    assert abs(obs[0, 6] - REACHER_PIN[6]) > 4 * PRINTED  # the two doctest outputs really are different numbers
+    env.close()
+
+
+def test_halfcheetah_doctest_known_answer_oracle(oracle_factory):
+    check_halfcheetah_pin(lambda env_id, n: gymnasium_amd.make_vec(env_id, num_envs=n, _engine_factory=oracle_factory))
+
+
+def test_reacher_doctest_known_answer_oracle(oracle_factory):
+    check_reacher_pin(lambda env_id, n: gymnasium_amd.make_vec(env_id, num_envs=n, _engine_factory=oracle_factory))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gymnasium"), reason="needs the reference tree")
+def test_bin_centres_equal_the_reference_wrapper():
+    """The action the discretised Reacher pin feeds is the reference wrapper's own (the wrapper is pure NumPy: run here over a stub env)."""
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, gymnasium as gym\n"
+            "from gymnasium.wrappers import DiscretizeAction\n"
+            "class E(gym.Env):\n"
+            "    action_space = gym.spaces.Box(-1.0, 1.0, (2,), np.float32)\n"
+            "    observation_space = gym.spaces.Box(-1.0, 1.0, (1,), np.float32)\n"
+            "a = DiscretizeAction(E(), bins=10).action(32); b = DiscretizeAction(E(), bins=10, multidiscrete=True).action([3, 2])\n"
+            "assert a.dtype == np.float32 and (a == b).all()\n"
+            "print(a.view(np.uint32).tolist())\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH="/root/reference", PYTHONDONTWRITEBYTECODE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert eval(r.stdout.strip().splitlines()[-1]) == discretized_reacher_action((3, 2)).view(np.uint32).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["default", "one-lane", "cooperative"])
+def test_halfcheetah_doctest_known_answer_gpu(kernel, monkeypatch):
+    """The HIP engine on the reference's `mujoco` known answer, through both physics kernels (MI355ENV_MJ_SERIAL / _COOP pick one)."""
+    monkeypatch.delenv("MI355ENV_MJ_SERIAL", raising=False), monkeypatch.delenv("MI355ENV_MJ_COOP", raising=False)
+    if kernel != "default":
+        monkeypatch.setenv("MI355ENV_MJ_SERIAL" if kernel == "one-lane" else "MI355ENV_MJ_COOP", "1")
+    check_halfcheetah_pin(lambda env_id, n: gymnasium_amd.make_vec(env_id, num_envs=n))
+
+
+@pytest.mark.gpu
+def test_reacher_doctest_known_answer_gpu():
+    check_reacher_pin(lambda env_id, n: gymnasium_amd.make_vec(env_id, num_envs=n))
+
+
+@pytest.mark.gpu
+def test_doctest_known_answers_in_a_large_batch_gpu():
+    """The same two known answers as sub-environments 0..1 (HalfCheetah: seeds 123, 124) / 0 (Reacher: seed 42) of a 4096-env batch with
+    device tensors: the lane a sub-environment sits in does not change its trajectory."""
+    import torch
+
+    n = 4096
+    env = gymnasium_amd.make_vec("HalfCheetah-v5", num_envs=n, output="torch")
+    env.reset(seed=123)
+    small = gymnasium_amd.make_vec("HalfCheetah-v5", num_envs=2)
+    small.action_space.seed(123)
+    a = torch.zeros((n, 6), dtype=torch.float32)
+    a[:2] = torch.from_numpy(small.action_space.sample())
+    infos = env.step(a.cuda())[4]
+    for k, want in HALFCHEETAH_PIN.items():
+        got = infos[k][:2].cpu().numpy()
+        assert got.dtype == want.dtype
+        np.testing.assert_allclose(got, want, rtol=0, atol=0 if want.dtype == np.float32 else PRINTED, err_msg=k)
+    env.close(), small.close()
+    env = gymnasium_amd.make_vec("Reacher-v5", num_envs=n, output="torch")
+    env.reset(seed=42)
+    a = torch.zeros((n, 2), dtype=torch.float64)
+    a[0] = torch.tensor([-0.3, -0.5], dtype=torch.float64)
+    obs = env.step(a.cuda())[0]
+    np.testing.assert_allclose(obs[0].cpu().numpy(), REACHER_PIN, rtol=0, atol=PRINTED)
+    env.close()
 
 
 def test_inverted_double_pendulum_max_height_oracle():
