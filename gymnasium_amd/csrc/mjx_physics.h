@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/mi355env.h"
 #include "envs_classic.h"
@@ -33,8 +34,13 @@ struct Args {
 // are skipped: the step kernel that follows resets them / reports the error.
 // PGS: the constraint solver of the model's MJCF (M::SOLVER == 1: humanoid.xml:8 `solver="PGS" iterations="50"`) or, false, the converged
 // primal Newton solver (every other robot's MJCF default; opt-in for the humanoids, MI_CFG_SOLVER_NEWTON).
+// MJX_MIN_WAVES_PER_EU (experiment switch, default 1): 2 caps the kernel at 256 registers (VGPRs + AGPRs) so that two wavefronts fit one SIMD --
+// measured in round 4 (profiles/r04_two_waves.txt); the shipped kernels use the whole register file of a SIMD for one wavefront.
+#ifndef MJX_MIN_WAVES_PER_EU
+#define MJX_MIN_WAVES_PER_EU 1
+#endif
 template <class E, bool SKIP_RESETTING, bool PGS>
-__global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const void *actions, double *extras) {
+__global__ __launch_bounds__(64, MJX_MIN_WAVES_PER_EU) void mj_physics_kernel(Args d, const void *actions, double *extras) {
     typedef typename E::Model M;
     constexpr int G = E::COOP_G, EPW = 64 / G;
     typedef mjx::coop::Sim<M, G, PGS> S;
@@ -79,23 +85,30 @@ __global__ __launch_bounds__(64) void mj_physics_kernel(Args d, const void *acti
     S::template write_extras<WHAT>(bb, r, lane, extras + (size_t)env * S::EX_TOTAL);
 }
 
+// MI355ENV_PHYS_EXTRA_LDS=<bytes> (experiment switch): dynamic LDS added to every launch -- a way to LOWER the number of resident workgroups per CU
+// without touching the kernel (round 4: the two-wavefronts-per-SIMD build measured at one wavefront per SIMD, profiles/r04_two_waves.txt)
+inline unsigned extra_lds() {
+    static const unsigned v = getenv("MI355ENV_PHYS_EXTRA_LDS") ? (unsigned)atoi(getenv("MI355ENV_PHYS_EXTRA_LDS")) : 0u;
+    return v;
+}
 template <class E>
 inline void launch_kind(const Args &a, bool skip_resetting, const void *actions, double *extras, hipStream_t stream) {
     constexpr int EPW = 64 / E::COOP_G;
     const dim3 grid((a.N + EPW - 1) / EPW), block(64);
+    const unsigned dyn = extra_lds();
     if constexpr (E::Model::SOLVER == 1) {
         if (!a.newton) {
             if (skip_resetting)
-                hipLaunchKernelGGL((mj_physics_kernel<E, true, true>), grid, block, 0, stream, a, actions, extras);
+                hipLaunchKernelGGL((mj_physics_kernel<E, true, true>), grid, block, dyn, stream, a, actions, extras);
             else
-                hipLaunchKernelGGL((mj_physics_kernel<E, false, true>), grid, block, 0, stream, a, actions, extras);
+                hipLaunchKernelGGL((mj_physics_kernel<E, false, true>), grid, block, dyn, stream, a, actions, extras);
             return;
         }
     }
     if (skip_resetting)
-        hipLaunchKernelGGL((mj_physics_kernel<E, true, false>), grid, block, 0, stream, a, actions, extras);
+        hipLaunchKernelGGL((mj_physics_kernel<E, true, false>), grid, block, dyn, stream, a, actions, extras);
     else
-        hipLaunchKernelGGL((mj_physics_kernel<E, false, false>), grid, block, 0, stream, a, actions, extras);
+        hipLaunchKernelGGL((mj_physics_kernel<E, false, false>), grid, block, dyn, stream, a, actions, extras);
 }
 
 // defined in physics16.hip / physics32.hip; `kind` is an mi_env_kind; returns false for a kind the unit does not hold

@@ -29,7 +29,7 @@ def compare_device_infos(env_id, factory, mode, steps=80, **kw):
         assert all(isinstance(v, (torch.Tensor, dict)) for v in ib.values()), "every info entry is a device tensor"
         for k, v in ia.items():
             if k not in ("final_obs", "final_info", "episode"):
-                assert np.array_equal(v, host(ib[k])), (mode, t, k)
+                assert np.array_equal(v, host(ib[k])) and v.dtype == host(ib[k]).dtype, (mode, t, k, v.dtype, host(ib[k]).dtype)
         assert set(ia) <= set(ib), "the device dict has a static key set: a superset of the host dict's"
         for k in set(ib) - set(ia):  # keys the host dict drops because no sub-env supplied them in this step
             if k.startswith("_") and not isinstance(ib[k], dict):
@@ -41,7 +41,7 @@ def compare_device_infos(env_id, factory, mode, steps=80, **kw):
             for i in np.flatnonzero(m):
                 assert np.array_equal(ia["final_obs"][i], host(ib["final_obs"][i]))
             for k, v in ia["final_info"].items():
-                assert np.array_equal(v, host(ib["final_info"][k])), k
+                assert np.array_equal(v, host(ib["final_info"][k])) and v.dtype == host(ib["final_info"][k]).dtype, k
         if "episode" in ia:
             seen_episode = True
             m = ia["_episode"]
@@ -60,7 +60,7 @@ def compare_device_infos(env_id, factory, mode, steps=80, **kw):
 
 
 @pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
-@pytest.mark.parametrize("env_id", ["Hopper-v5", "Ant-v5"])
+@pytest.mark.parametrize("env_id", ["Hopper-v5", "Ant-v5", "InvertedPendulum-v5"])  # (InvertedPendulum: an int64 info entry, reward_survive)
 def test_device_infos_equal_numpy_infos(env_id, mode, oracle_factory):
     compare_device_infos(env_id, oracle_factory, mode, steps=80 if env_id == "Hopper-v5" else 45)
 
@@ -79,3 +79,48 @@ def test_record_episode_statistics_wrapper_on_device_infos(oracle_factory):
         a.step(act), b.step(torch.from_numpy(act))
     assert a.episode_count == b.episode_count > 10
     assert list(a.return_queue) == list(b.return_queue) and list(a.length_queue) == list(b.length_queue)
+
+
+def test_episode_count_survives_a_switch_of_the_output_mode(oracle_factory):
+    """episode_count lives on the device with output="torch" (no read-back per step): re-allocating the buffers -- set_output(), enabling the
+    statistics late -- folds it into the host total instead of dropping it."""
+    import torch
+
+    env = gymnasium_amd.make_vec("CartPole-v1", num_envs=8, output="torch", record_episode_statistics=True, _engine_factory=oracle_factory)
+    env.reset(seed=3)
+    env.action_space.seed(1)
+    for _ in range(120):
+        env.step(torch.from_numpy(env.action_space.sample()))
+    before = env.episode_count
+    assert before > 5
+    env.set_output("numpy")
+    assert env.episode_count == before
+    env.reset(seed=3)
+    for _ in range(60):
+        env.step(env.action_space.sample())
+    mid = env.episode_count
+    assert mid > before
+    env.set_output("torch")
+    assert env.episode_count == mid
+    env.close()
+
+
+def test_device_info_masks_are_private_copies(oracle_factory):
+    """The masks handed out with the device infos are the caller's to edit: an in-place change must not reach the next step's bookkeeping."""
+    import torch
+
+    a = gymnasium_amd.make_vec("Hopper-v5", num_envs=6, output="torch", record_episode_statistics=True, max_episode_steps=7, _engine_factory=oracle_factory)
+    b = gymnasium_amd.make_vec("Hopper-v5", num_envs=6, output="torch", record_episode_statistics=True, max_episode_steps=7, _engine_factory=oracle_factory)
+    a.reset(seed=5), b.reset(seed=5)
+    a.action_space.seed(2)
+    for t in range(30):
+        act = torch.from_numpy(a.action_space.sample())
+        ra, rb = a.step(act), b.step(act)
+        for k in ("x_position", "_x_position", "_episode", "_x_velocity"):
+            assert torch.equal(ra[4][k], rb[4][k]), (t, k)
+        assert torch.equal(ra[4]["episode"]["l"], rb[4]["episode"]["l"])
+        for k, v in ra[4].items():  # vandalise every mask of env a
+            if k.startswith("_") and isinstance(v, torch.Tensor):
+                v.fill_(True) if t % 2 else v.zero_()
+    assert a.episode_count == b.episode_count > 0
+    a.close(), b.close()
