@@ -23,7 +23,9 @@ steps are not counted), whole job over all ranks.  The same JSON line also carri
   cpu_baseline      the C oracle (kind "port") on the host's cores: the batch sharded over one single-threaded process per core (count stated), bounded sample
   cpu_reference     Gymnasium's own AsyncVectorEnv (num_envs = os.cpu_count()) / SyncVectorEnv / NumPy CartPoleVectorEnv timed in
                     this run when `import gymnasium` works (GYM_REFERENCE or an installed package); the GPU box has neither, so there
-                    the numbers measured in the build container are carried as cpu_reference_recorded (hardware stated)
+                    the AsyncVectorEnv ARCHITECTURE restated (oracle/async_baseline.py, pinned on the real one by tests/test_async_baseline.py)
+                    is timed in this run on this host's cores (kind "port"), and the real gymnasium's numbers from the build container
+                    ride along as cpu_reference_recorded (hardware stated)
   api_step_device / api_step_numpy   the per-launch step() API -- never `value`
 
 N > 1: one process per GPU (torchrun), each rank owns its own num_envs sub-environments (global indices rank*num_envs ...; no
@@ -57,6 +59,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # (env, num_envs per GPU, vector steps per launch, launches) of the secondary lines: BASELINE.json configs[2..4] + the north_star's Ant @65536
 SECONDARY = [("Pendulum-v1", 65536, 128, 20), ("Acrobot-v1", 65536, 128, 10), ("MountainCarContinuous-v0", 65536, 128, 20),
              ("Ant-v5", 32768, 4, 6), ("Ant-v5", 65536, 4, 4), ("Humanoid-v5", 32768, 4, 3)]
+# The other contact regime of the two headline robots: the random policy with `terminate_when_unhealthy` ends a Humanoid
+# episode after ~22 steps, so the batch above is mostly robots still upright; with termination off and a warm-up of GROUND_WARM launches every
+# robot lies on the ground (many contacts, the PGS sweeps dominate).  A learner that keeps the robot alive lives between the two lines.
+GROUND_WARM = 40
+SECONDARY_GROUND = [("Ant-v5", 32768, 4), ("Humanoid-v5", 32768, 4)]
+F64_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz
 # the reference itself, measured in the build container (no gymnasium on the GPU box)
 CPU_REFERENCE_RECORDED = {
     "hardware": "8 vCPU Intel Xeon @ 2.10 GHz (build container), Python 3.10.12, NumPy 2.2.6, reference gymnasium v1.4.0",
@@ -104,21 +112,45 @@ def _oracle_rollouts(env_id, num_envs, offset, budget_s, start_at=None):
     return steps, dt, reps * T
 
 
+def usable_cpus():
+    """(logical CPUs this process may actually use, why): os.cpu_count() capped by the scheduler affinity and by the cgroup CPU quota.  The GPU box
+    reports 256 logical CPUs (2 x EPYC 9575F, SMT) but runs the job in a cgroup with cpu.max = 16 CPUs' worth of time: more worker processes
+    than that only time-slice (measured, scripts/r04/cpu_workers_probe.py: 32 workers 552 M env-steps/s, 64: 505 M, 256: 241 M)."""
+    n, why = os.cpu_count() or 1, "os.cpu_count()"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "sched_getaffinity"
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, -(-int(quota) // int(period)))
+            if q < n:
+                n, why = q, f"cgroup cpu.max = {quota} {period}"
+    except Exception:
+        pass
+    return n, why
+
+
 def cpu_baseline(env_id, num_envs, budget_s=12.0, workers=None):
     """The CPU oracle (C restatement of the reference's env + SyncVectorEnv semantics) on the same workload ON THE HOST'S CORES: the batch
-    is sharded over `workers` processes (default: every core, MI355ENV_CPU_WORKERS overrides; each process runs the single-threaded C
+    is sharded over `workers` processes (default: one per CPU this job may use -- usable_cpus(): the cgroup quota counts, not the 256 logical CPUs
+    the GPU box reports; rounds 1-3 used 64 there, which over-subscribed a 16-CPU quota -- MI355ENV_CPU_WORKERS overrides; each process runs the single-threaded C
     rollout on its contiguous block of sub-environments, like one rank of the GPU job), all started together and run for ~budget_s.
     value = env-steps of all processes / the longest process' time.  kind="port": the Python reference is not present on the GPU box."""
     cores = os.cpu_count() or 1
+    usable, why = usable_cpus()
     if workers is None:
-        workers = int(os.environ.get("MI355ENV_CPU_WORKERS", min(cores, 64)))
+        workers = int(os.environ.get("MI355ENV_CPU_WORKERS", usable))
     workers = max(1, min(workers, num_envs))
     if workers == 1:
         steps, dt, vsteps = _oracle_rollouts(env_id, num_envs, 0, budget_s)
         per = [(steps, dt, vsteps)]
     else:
         base, rem = divmod(num_envs, workers)
-        start_at = time.time() + 6.0 + 0.05 * workers  # interpreter start + imports + warm-up of every worker
+        start_at = time.time() + 3.0 + 0.02 * workers  # interpreter start + imports + warm-up of every worker (a late one just starts late: every worker times its own window)
         procs, off = [], 0
         env = dict(os.environ, OMP_NUM_THREADS="1")
         for w in range(workers):
@@ -135,7 +167,7 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0, workers=None):
             steps, dt, vsteps = _oracle_rollouts(env_id, num_envs, 0, budget_s)
             per, workers = [(steps, dt, vsteps)], 1
     steps, dt = sum(x[0] for x in per), max(x[1] for x in per)
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": workers, "host_cpu_count": cores, "kind": "port",
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": workers, "host_cpu_count": cores, "usable_cpus": usable, "usable_cpus_source": why, "kind": "port",
             "per_core_value": steps / dt / workers,
             "sample": f"{env_id} num_envs={num_envs} sharded over {workers} process(es) of the C oracle (one single-threaded rollout loop per core, "
                       f"same random policy, same outputs materialised), {steps} env-steps in {dt:.1f} s"}
@@ -151,7 +183,7 @@ def cpu_reference(budget_s=4.0):
         import gymnasium as gym
         from gymnasium.utils.performance import benchmark_vector_step
     except Exception:
-        return None
+        return cpu_reference_port(budget_s)
     cores = os.cpu_count() or 1
     out = {"cores": cores, "unit": "env-steps/s", "gymnasium": gym.__version__, "how": f"benchmark_vector_step, target_duration={budget_s} s"}
     for label, kw in ((f"AsyncVectorEnv CartPole-v1 num_envs={cores}", dict(num_envs=cores, vectorization_mode="async")),
@@ -163,6 +195,29 @@ def cpu_reference(budget_s=4.0):
             env.close()
         except Exception as e:  # a missing optional dependency must not cost the GPU numbers
             out[label] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
+def cpu_reference_port(budget_s=4.0):
+    """Where gymnasium itself is not importable (the GPU box): the reference's AsyncVectorEnv ARCHITECTURE restated (oracle/async_baseline.py:
+    one process per sub-environment, pipes, shared-memory observations, the scalar CartPole in Python; pinned on the real AsyncVectorEnv by
+    tests/test_async_baseline.py) and timed by the same counting rule as benchmark_vector_step -- in THIS run, on THIS host's cores.  It carries
+    less per-step overhead than the real thing (no PassiveEnvChecker / OrderEnforcing layers, no info-dict assembly): an upper bound of it."""
+    try:
+        from oracle import async_baseline as ab
+    except Exception:
+        return None
+    usable, why = usable_cpus()
+    out = {"kind": "port", "what": "oracle/async_baseline.py: AsyncVectorEnv's architecture (vector/async_vector_env.py) around a Python CartPole-v1, "
+                                   "NOT gymnasium itself (not installed on this host)", "unit": "env-steps/s", "usable_cpus": usable,
+           "usable_cpus_source": why, "host_cpu_count": os.cpu_count(), "how": f"benchmark_vector_step's loop and counting rule, target_duration={budget_s} s"}
+    for n in sorted({usable, 4 * usable}):  # the reference's own convention (num_envs = cores) and an over-subscribed one
+        try:
+            env = ab.AsyncCartPoleVectorEnv(n)
+            out[f"AsyncVectorEnv-port CartPole-v1 num_envs={n}"] = ab.benchmark_vector_step(env, target_duration=budget_s, seed=0)
+            env.close()
+        except Exception as e:
+            out[f"AsyncVectorEnv-port CartPole-v1 num_envs={n}"] = f"failed: {type(e).__name__}: {e}"
     return out
 
 
@@ -197,14 +252,23 @@ SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "S
 
 
 ISSUE_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]
+FLOP_COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64"]
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
 
 
-def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150, env_kwargs=None, want_issue=False):
+def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150, env_kwargs=None, want_issue=False, want_flops=False, warm=1):
     """HBM traffic per dispatch of `kernel` (WRITE_SIZE + 2 FETCH_SIZE, in KiB on gfx950; MI355X_MICROARCH.md HBM section: separate
     passes, FETCH_SIZE doubled) and, for the VALU-bound kernels, the SQ activity counters as shares of SQ_WAVE_CYCLES."""
-    args = ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", "1", "--env-kwargs", json.dumps(env_kwargs or {})]
+    args = ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", str(warm), "--env-kwargs", json.dumps(env_kwargs or {})]
     out = {}
+    if want_flops:
+        # EXECUTED fp64 vector instructions of the kernel, by kind (wave-level: one count per 64-lane instruction, whatever the EXEC mask)
+        fc = _rocprof_counters(args, FLOP_COUNTERS, kernel, timeout_s)
+        if fc and fc.get("SQ_INSTS_VALU", (0, 0))[0] > 0:
+            g = lambda k: fc.get(k, (0.0, 0))[0]  # noqa: E731
+            out["flops"] = {"fma_f64": g("SQ_INSTS_VALU_FMA_F64"), "mul_f64": g("SQ_INSTS_VALU_MUL_F64"), "add_f64": g("SQ_INSTS_VALU_ADD_F64"),
+                            "trans_f64": g("SQ_INSTS_VALU_TRANS_F64"), "mfma_mops_f64": g("SQ_INSTS_VALU_MFMA_MOPS_F64"), "valu": g("SQ_INSTS_VALU"),
+                            "dispatches": fc["SQ_INSTS_VALU"][1], "source": "rocprofv3 --pmc " + " ".join(FLOP_COUNTERS) + " on a child invocation in this run"}
     if want_traffic:
         f = _rocprof_counters(args, ["FETCH_SIZE"], kernel, timeout_s)
         w = _rocprof_counters(args, ["WRITE_SIZE"], kernel, timeout_s) if f else None
@@ -245,26 +309,13 @@ def recorded_traffic(env_id, N, inner):
 
 # ---- one configuration on this rank's GPU --------------------------------------------------------------------------------------
 class Config:
-    def __init__(self, env_id, N, inner, local_rank, rank, env_kwargs=None, engine="hip"):
+    def __init__(self, env_id, N, inner, local_rank, rank, env_kwargs=None):
         import torch
 
         import gymnasium_amd
         from gymnasium_amd import _native
 
-        self.torch, self.env_id, self.N, self.inner, self.env_kwargs, self.engine = torch, env_id, N, inner, env_kwargs, engine
-        if engine == "oracle":  # dry-run seam (tests/test_bench_multirank.py): the same control flow on the CPU checker, NumPy buffers
-            from oracle import oracle
-
-            env = gymnasium_amd.make_vec(env_id, num_envs=N, env_index_offset=rank * N, _engine_factory=oracle.engine_factory, **(env_kwargs or {}))
-            env.reset(seed=0)
-            env.action_space.seed(rank)
-            eng = env._engine
-            self.env, self.eng = env, eng
-            self.acts = np.zeros((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=eng.act_dtype)
-            self.obs = np.zeros((inner, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (inner, N, eng.obs_dim), eng.obs_dtype)
-            self.rew, self.te, self.tr = np.zeros((inner, N)), np.zeros((inner, N), np.bool_), np.zeros((inner, N), np.bool_)
-            eng.action_seed(_native.pcg_words(env.action_space.np_random))
-            return
+        self.torch, self.env_id, self.N, self.inner, self.env_kwargs = torch, env_id, N, inner, env_kwargs
         dev = torch.device("cuda", local_rank)
         env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", env_index_offset=rank * N, **(env_kwargs or {}))
         env.reset(seed=0)
@@ -283,25 +334,12 @@ class Config:
         eng.action_seed(_native.pcg_words(env.action_space.np_random))
 
     def launch(self):
-        if self.engine == "oracle":
-            self.eng.rollout(self.inner, None, self.acts, self.obs, self.rew, self.te, self.tr)
-            return
         self.eng.rollout(self.inner, None, self.acts.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(), self.te.data_ptr(), self.tr.data_ptr())
 
     def timed(self, K, sync):
         """K launches between two HIP events on the engine's stream (env._bind_stream() = torch's current stream).  One event on either
         side: an event after every launch would put a marker packet between the kernels (+9 us per 96 us launch, measured)."""
         t = self.torch
-        if self.engine == "oracle":  # synchronous CPU launches: the wall clock is the kernel clock
-            sync()
-            self.eng.reset_stats()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(K):
-                self.launch()
-            sync()
-            elapsed = time.perf_counter() - t0
-            return elapsed, elapsed / K, self.env.statistics()
         ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
         sync()
         self.eng.reset_stats()
@@ -333,7 +371,7 @@ class Config:
             return "tab_rollout_kernel"
         return "mj_physics_kernel" if self.env_id in MJ_COOP else "mj_rollout_kernel"
 
-    def roofline(self, kernel_s, pmc=()):
+    def roofline(self, kernel_s, pmc=(), warm=1, env_steps_per_s=None):
         """kernel_s = average duration of one rollout launch; pmc = which live counter passes to run ("traffic", "sq").  HBM-bound kernels: algorithmic bytes per launch / kernel_s against
         8 TB/s.  The cooperative MuJoCo kernels are VALU / latency bound (one wavefront per SIMD): frac is the
         measured share of wave cycles that issue VALU work, and the HBM side is reported as a traffic ratio."""
@@ -343,7 +381,7 @@ class Config:
         coop = self.env_id in MJ_COOP
         per = self.inner if coop else 1  # dispatches of the dominant kernel per rollout launch
         live = live_counters(self.env_id, self.N, self.inner, kernel, "traffic" in pmc, "sq" in pmc and coop, env_kwargs=self.env_kwargs,
-                             want_issue="issue" in pmc and not coop) if pmc else {}
+                             want_issue="issue" in pmc and not coop, want_flops="flops" in pmc and coop, warm=max(1, warm)) if pmc else {}
         traffic, src = live.get("traffic"), live.get("traffic_source")
         if traffic is not None:
             traffic *= per
@@ -354,9 +392,24 @@ class Config:
                 "traffic_over_algorithmic": (traffic / algo) if traffic else None}
         if coop:
             sq = live.get("sq")
-            return {"bound": "valu", "achieved": (sq or {}).get("active_inst_valu_frac"), "peak": 1.0, "unit": "share of wave cycles issuing VALU instructions (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), one wavefront per SIMD",
-                    "frac": (sq or {}).get("active_inst_valu_frac"), "sq": sq, "sq_source": live.get("sq_source"), "hbm_frac": achieved / HBM_PEAK_GBS,
-                    "avg_vector_step_ms": kernel_s * 1e3 / self.inner, **base}
+            out = {"bound": "valu", "achieved": (sq or {}).get("active_inst_valu_frac"), "peak": 1.0, "unit": "share of wave cycles issuing VALU instructions (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), one wavefront per SIMD",
+                   "frac": (sq or {}).get("active_inst_valu_frac"), "sq": sq, "sq_source": live.get("sq_source"), "hbm_frac": achieved / HBM_PEAK_GBS,
+                   "avg_vector_step_ms": kernel_s * 1e3 / self.inner, **base}
+            fl = live.get("flops")
+            if fl:
+                # A fraction of a PEAK next to the utilisation proxy above: fp64 flops the physics kernel EXECUTES per env-step (2 per FMA, 1 per
+                # MUL / ADD, x 64 lanes per wave-level instruction -- lanes switched off by the EXEC mask or carrying no body / dof are counted, so
+                # this is the rate the vector units are driven at, an upper bound of the useful rate) x env-steps/s, against the chip's vector fp64 peak.
+                per_dispatch = 64.0 * (2.0 * fl["fma_f64"] + fl["mul_f64"] + fl["add_f64"])
+                stepping = (env_steps_per_s * kernel_s / self.inner) if env_steps_per_s else float(self.N)  # sub-environments that take a real step per vector step
+                fl["flops_per_env_step"] = per_dispatch / max(stepping, 1.0)
+                fl["f64_instruction_share_of_valu"] = (fl["fma_f64"] + fl["mul_f64"] + fl["add_f64"] + fl["trans_f64"]) / fl["valu"]
+                rate = per_dispatch / (kernel_s / self.inner)  # dispatches of the physics kernel run back to back: one per vector step
+                out["flops"] = fl
+                out["achieved_tflops_f64"] = rate / 1e12
+                out["peak_tflops_f64"] = F64_PEAK_TFLOPS
+                out["frac_of_f64_peak"] = rate / 1e12 / F64_PEAK_TFLOPS
+            return out
         out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **base}
         if live.get("issue"):
             # The OTHER ceiling of this kernel: at one wavefront per SIMD the instruction issue rate bounds it before HBM does.
@@ -375,7 +428,9 @@ class Config:
 T_START = time.perf_counter()
 
 
-def main():
+def main(argv=None, harness=None):
+    """`harness` is None for every measurement.  tests/bench_dryrun.py (test infrastructure, not reachable from this script's command line)
+    passes an object that swaps the Config class and the process-group backend, so that the N > 1 control flow can be executed without GPUs."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed launches K (default: as many as fill ~1 s, so that clocks and thermals are in steady state)")
@@ -395,17 +450,15 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (BASELINE.json configs[2..4])")
     ap.add_argument("--env-kwargs", default="{}", help='JSON constructor kwargs of the env, e.g. \'{"solver": "Newton"}\' (Humanoid: opt-in solver)')
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
-    # dry-run seam (tests/test_bench_multirank.py): the N > 1 control flow -- pilot MAX all-reduce, barriers, sustained branch, rank-0 CPU legs,
-    # the JSON line -- on gloo with the CPU checker as the engine.  Never a measurement: the line says engine = "oracle".
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
-    ap.add_argument("--engine", choices=["hip", "oracle"], default="hip", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--pilot-seconds", type=float, default=1.0, help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
 
-    gpu = args.engine == "hip"
+    gpu = harness is None
+    backend = "nccl" if gpu else harness.backend
+    make_config = Config if gpu else harness.config_cls
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -413,14 +466,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     if gpu:
         torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank) if (gpu and args.backend == "nccl") else torch.device("cpu")
+    dev = torch.device("cuda", local_rank) if gpu else torch.device("cpu")
     N, K, W, inner = args.num_envs, args.steps, args.warmup, args.inner
 
     def sync_local():
@@ -433,7 +486,7 @@ def main():
         sync_local()
 
     env_kwargs = json.loads(args.env_kwargs)
-    cfg = Config(args.env, N, inner, local_rank, rank, env_kwargs, engine=args.engine)
+    cfg = make_config(args.env, N, inner, local_rank, rank, env_kwargs)
     if K is None:  # ~1 s of timed launches: a 50-launch burst is 5 ms, over before the clocks have ramped (round 1: the driver's sampler saw 0 % busy)
         for _ in range(3):
             cfg.launch()
@@ -472,19 +525,35 @@ def main():
     from gymnasium_amd import distributed as gd
 
     red = gd.reduce_statistics(st, elapsed_s=elapsed, device=dev)  # the only collective: a few dozen bytes over RCCL/xGMI
+    # What the collective itself proves about the job (n_gpus below is NOT read from the environment): an all-reduce of ones counts the ranks
+    # that took part, and every rank contributes the identity of the device it ran on -- N distinct UUIDs = N different GPUs.
+    ranks_seen, devices = 1, None
+    if gpu:
+        props = torch.cuda.get_device_properties(local_rank)
+        devices = [{"rank": rank, "local_rank": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}]
+    else:
+        devices = [{"rank": rank, "local_rank": local_rank, "name": "cpu (dry run)", "uuid": f"cpu-{rank}"}]
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
     elapsed = red["elapsed_s"]
     env_steps, episodes, return_sum = float(red["env_steps"]), float(red["episodes"]), float(red["return_sum"])
     single = rank == 0 and world == 1 and gpu
-    pmc_primary = ("traffic", "sq", "issue") if (single and args.pmc != "off") else ()
+    pmc_primary = ("traffic", "sq", "issue", "flops") if (single and args.pmc != "off") else ()
 
     result = None
     if rank == 0:
         result = {
             "metric": "env-steps/sec at num_envs=65536 (1/2/4/8 MI355X) vs CPU AsyncVectorEnv",
-            "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": ranks_seen, "steps": K, "warmup": W,
+            "rccl_ranks": ranks_seen, "world_size_env": world, "devices": devices, "distinct_devices": len({d["uuid"] for d in devices}),
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "clock_spinup": {"seconds": args.spinup, "launches": spin_launches, "note": "untimed, before the warmup launches"},
-            **({} if gpu else {"engine": "oracle (CPU checker: a dry run of the control flow, NOT a measurement)"}),
+            **({} if gpu else {"engine": harness.label}),
             "config": {"workload": f"{args.env} num_envs={N} per GPU, random policy (on-device action_space.sample()), "
                                    f"NEXT_STEP autoreset, TimeLimit, fused rollout of {inner} vector steps per launch, "
                                    "trajectory (actions, obs, rewards, terminated, truncated) written to HBM",
@@ -506,7 +575,7 @@ def main():
             result["sustained_value"] = float(red_s["env_steps"]) / red_s["elapsed_s"]
             result["sustained"] = {"launches": Ks, "seconds": red_s["elapsed_s"], "avg_kernel_ms": k_s * 1e3}
     if rank == 0:
-        result["roofline"] = cfg.roofline(kernel_s, pmc_primary)
+        result["roofline"] = cfg.roofline(kernel_s, pmc_primary, env_steps_per_s=result["value"])
 
     # ---- the per-launch step() API (rank 0, one GPU): device tensors and the NumPy path ----------------------------------------------
     if single and not args.no_api:
@@ -619,8 +688,8 @@ def main():
             # full: everything live.  auto: the SQ-activity pass for the VALU-bound MuJoCo kernels, and live FETCH / WRITE passes too while
             # the run is young enough (each pass is a child process of ~5-10 s); after that the recorded profile's value, stamped as such
             young = (time.perf_counter() - T_START) < args.pmc_budget
-            want = ("traffic", "sq") if args.pmc == "full" else ((("traffic",) if young else ()) + (("sq",) if env_id in MJ_COOP else ()) if args.pmc == "auto" else ())
-            line["roofline"] = c2.roofline(ks2, want)
+            want = ("traffic", "sq", "flops") if args.pmc == "full" else ((("traffic",) if young else ()) + (("sq", "flops") if env_id in MJ_COOP else ()) if args.pmc == "auto" else ())
+            line["roofline"] = c2.roofline(ks2, want, env_steps_per_s=v2)
             c2.close()
             opt = {"fast_math": True} if env_id in STEP_BYTES else ({"solver": "Newton"} if env_id in ("Humanoid-v5", "HumanoidStandup-v5") else None)
             if opt:  # the opt-in, faster configuration next to the default (reference-faithful) one
@@ -628,22 +697,35 @@ def main():
                 line["opt_in"] = {"env_kwargs": opt, "value": steady(c3)[0], "unit": "env-steps/s"}
                 c3.close()
             if not args.no_cpu_baseline:  # MuJoCo: a 512-env sample (the oracle's per-env cost does not depend on the batch size)
-                line["cpu_baseline"] = cpu_baseline(env_id, min(n2, 64 * min(os.cpu_count() or 1, 64)) if env_id in MJ_COOP else n2, budget_s=3.0)
+                line["cpu_baseline"] = cpu_baseline(env_id, min(n2, 64 * usable_cpus()[0]) if env_id in MJ_COOP else n2, budget_s=3.0)
+            result["secondary"].append(line)
+
+        # the on-the-ground regime of the two headline robots: termination off, GROUND_WARM launches before anything is timed or profiled
+        for env_id, n2, inner2 in SECONDARY_GROUND:
+            kw = {"terminate_when_unhealthy": False}
+            c2 = Config(env_id, n2, inner2, local_rank, 0, kw)
+            for _ in range(GROUND_WARM):
+                c2.launch()
+            v2, k2, ks2, el2 = steady(c2)
+            line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "sustained_value": v2, "seconds": el2,
+                    "unit": "env-steps/s", "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "env_kwargs": kw,
+                    "regime": f"robots on the ground: terminate_when_unhealthy=False, {GROUND_WARM} launches ({GROUND_WARM * inner2} vector steps) of warm-up before the timed region"}
+            want = ("sq", "flops") if args.pmc in ("auto", "full") else ()
+            line["roofline"] = c2.roofline(ks2, want, warm=GROUND_WARM, env_steps_per_s=v2)
+            c2.close()
             result["secondary"].append(line)
 
     # ---- CPU legs: the oracle port on rank 0 (every N), the reference's own vectorisers where importable -------------------------------
     if rank == 0:
         # the whole batch of one GPU on every host core (MuJoCo: a bounded sample of 64 sub-environments per core -- the oracle's per-env cost
         # does not depend on the batch size)
-        n_cpu = min(N, 64 * min(os.cpu_count() or 1, 64)) if args.env in MJ_COOP else N
+        n_cpu = min(N, 64 * usable_cpus()[0]) if args.env in MJ_COOP else N
         result["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.env, n_cpu, budget_s=args.cpu_budget)
         if not args.no_cpu_baseline and world == 1 and gpu:
             ref = cpu_reference()
-            if ref is not None:
-                result["cpu_reference"] = ref
-            else:
-                result["cpu_reference"] = None
-                result["cpu_reference_recorded"] = CPU_REFERENCE_RECORDED
+            result["cpu_reference"] = ref  # gymnasium's own vectorisers where importable, else the AsyncVectorEnv port (kind "port"), timed in this run
+            if ref is None or ref.get("kind") == "port":
+                result["cpu_reference_recorded"] = CPU_REFERENCE_RECORDED  # the real gymnasium's numbers from the build container, hardware stated
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,8 +1,8 @@
 """bench.py's N > 1 control flow, executed end to end before the driver's first multi-GPU run.
 
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` exactly as the driver launches it, with two hidden flags that
-swap the transport and the engine: `--backend gloo --engine oracle` (the CPU checker behind the same host class; there is no GPU in the
-build container).  What runs is everything that had never executed anywhere: the pilot's MAX all-reduce that fixes K on every rank, the
+`python -m torch.distributed.run --nproc-per-node N tests/bench_dryrun.py --gpus N ...` -- launched as the driver launches bench.py; the wrapper
+imports bench.main and injects a Config subclass on the CPU checker plus the gloo transport (there is no GPU in the build container; bench.py
+itself has no flag that selects the checker).  What runs is everything that had never executed anywhere: the pilot's MAX all-reduce that fixes K on every rank, the
 barrier + synchronise bracket, both `sustained` branches, the one statistics all-reduce, rank 0's CPU legs and the single JSON line with
 `n_gpus: N`.  The numbers are NOT measurements (the line says engine = oracle)."""
 import json
@@ -25,7 +25,7 @@ def _free_port():
 def _run(world, extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MI355ENV_CPU_WORKERS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--engine", "oracle",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", str(world),
            "--num-envs", "256", "--inner", "8", "--cpu-budget", "0.5", *extra]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -39,6 +39,8 @@ def test_default_flags_pilot_sets_k_on_every_rank(world):
     """No --steps: K comes from the pilot, all-reduced MAX over the ranks; a timed region that is long enough IS the sustained figure."""
     r = _run(world, ["--pilot-seconds", "0.9", "--sustained", "0.5"])
     assert r["n_gpus"] == world and r["scaling"] == "weak" and r["higher_is_better"] is True and r["unit"] == "env-steps/s"
+    # the rank count comes out of the collective, and every rank reported its own device
+    assert r["rccl_ranks"] == world == r["world_size_env"] and r["distinct_devices"] == world and sorted(d["rank"] for d in r["devices"]) == list(range(world))
     assert r["steps"] >= 20 and r["warmup"] >= 5
     # every rank timed the same K launches of 8 vector steps over its own 256 sub-environments; autoreset steps are not counted
     lanes = world * 256 * 8 * r["steps"]
@@ -56,3 +58,11 @@ def test_driver_style_explicit_steps_takes_the_separate_sustained_loop():
     assert r["steps"] == 6 and r["warmup"] == 2 and r["n_gpus"] == 2
     assert r["sustained"]["launches"] > 6 and r["sustained"]["seconds"] >= 0.05
     assert r["episodes"] > 0 and 9.0 < r["mean_episode_return"] < 60.0  # CartPole under the random policy: ~22 steps per episode
+
+
+def test_bench_py_cannot_be_pointed_at_the_checker():
+    """The product script has no --engine / --backend switch any more: the metric line can only come from the HIP engine."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "--engine" not in src and "--backend" not in src and "from oracle import oracle" in src  # (the cpu_baseline leg is the one allowed use)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "oracle"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "unrecognized arguments" in p.stderr

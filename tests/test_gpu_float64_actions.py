@@ -120,8 +120,8 @@ def test_mujoco_float64_rows_equal_the_oracle(env_id, oracle_factory):
         if t % 2:
             a = a.astype(np.float32)
         sg, sc = gpu.step(a), cpu.step(a)
-        np.testing.assert_allclose(sg[0], sc[0], rtol=0, atol=1e-6, err_msg=f"{env_id} obs t={t}")
-        np.testing.assert_allclose(sg[1], sc[1], rtol=1e-7, atol=1e-6, err_msg=f"{env_id} reward t={t}")
+        np.testing.assert_allclose(sg[0], sc[0], rtol=0, atol=1e-8, err_msg=f"{env_id} obs t={t}")
+        np.testing.assert_allclose(sg[1], sc[1], rtol=0, atol=1e-8, err_msg=f"{env_id} reward t={t}")
         assert np.array_equal(sg[2], sc[2]) and np.array_equal(sg[3], sc[3])
         for k in sc[4]:
             assert sg[4][k].dtype == sc[4][k].dtype, (env_id, k, t)
