@@ -64,6 +64,7 @@ struct DevEnv {
     int N;
     int max_steps;
     int solver_newton;   // MI_CFG_SOLVER_NEWTON (one-lane MuJoCo kernels; the cooperative kernel is chosen at launch)
+    int tab_fickle_rows; // MI_ENV_TABULAR with params[2] != 0 (Taxi's fickle passenger): the state has a third row (TabLane::aux)
     EnvParams P;
     TabTable tab;
 };
@@ -940,18 +941,23 @@ MI_DEV int tab_categorical(const double *csprob, int n, Pcg64 &rng) {
 }
 struct TabLane {
     double s, prob;
+    double aux;  // Taxi with fickle_passenger only: fickle_step | the generator's buffered 32-bit half << 1 (third state row)
     uint32_t elapsed, flags;
     double ep_ret;
     int32_t ep_len;
 };
+// Taxi's fickle passenger (taxi.py:436-451, :462-464): params[2] != 0 switches the rule on, params[3] = fickle_probability
+MI_DEV bool tab_fickle(const DevEnv &d) { return d.tab_fickle_rows != 0; }
 MI_DEV void tab_load(const DevEnv &d, int i, TabLane &L) {
     L.s = d.state[i], L.prob = d.state[(size_t)d.N + i];
+    L.aux = tab_fickle(d) ? d.state[(size_t)2 * d.N + i] : 0.0;
     const uint32_t m = d.meta[i];
     L.elapsed = m & kElapsedMask, L.flags = m >> kFlagShift;
     L.ep_ret = d.ep_ret[i], L.ep_len = d.ep_len[i];
 }
 MI_DEV void tab_store(const DevEnv &d, int i, const TabLane &L) {
     d.state[i] = L.s, d.state[(size_t)d.N + i] = L.prob;
+    if (tab_fickle(d)) d.state[(size_t)2 * d.N + i] = L.aux;
     d.meta[i] = (L.elapsed & kElapsedMask) | (L.flags << kFlagShift);
     d.ep_ret[i] = L.ep_ret, d.ep_len[i] = L.ep_len;
 }
@@ -1029,10 +1035,15 @@ MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L, Pcg64 *held = null
     Pcg64 local;
     if (!held) local = load_rng(d, i);
     Pcg64 &rng = held ? *held : local;
-    if (is_blackjack(d))
+    if (is_blackjack(d)) {
         bj_reset(rng, L.s, L.prob);
-    else
+    } else {
         L.s = (double)tab_categorical(d.tab.isd, d.tab.nS, rng), L.prob = 1.0;
+        if (tab_fickle(d)) {  // taxi.py:462-464: fickle_step = fickle_passenger and np_random.random() < fickle_probability -- one more draw
+            const double flag = rng.next_double() < d.P.p[3] ? 1.0 : 0.0;
+            L.aux = floor(L.aux * 0.5) * 2.0 + flag;
+        }
+    }
     if (!held) store_rng_state(d, i, rng);
     L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
 }
@@ -1069,8 +1080,23 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
         } else {
             const size_t cell = (size_t)L.s * d.tab.nA + (size_t)a, row = cell * d.tab.K;
             const int k = tab_categorical(d.tab.csprob + row, d.tab.count[cell], rng);
+            int next = d.tab.next[row + k];
+            if (tab_fickle(d) && ((int64_t)L.aux & 1)) {
+                // taxi.py:436-451: the passenger was in the taxi before this step (shadow pass_loc == 4) and the step moved the taxi: once per episode
+                // the destination is re-drawn among the other three -- Generator.choice = a Lemire-bounded 32-bit draw on the buffered halves (bj_bounded)
+                const int old = (int)L.s;
+                const int srow = old / 100, scol = old / 20 % 5, spass = old / 4 % 5, sdest = old % 4;
+                const int nrow = next / 100, ncol = next / 20 % 5, npass = next / 4 % 5;
+                if (spass == 4 && (nrow != srow || ncol != scol)) {
+                    double half = floor(L.aux * 0.5);
+                    const int pick = (int)bj_bounded(rng, half, 3);
+                    const int dest = pick + (pick >= sdest ? 1 : 0);  // possible_destinations = [i for i in range(4) if i != shadow_dest_idx]
+                    L.aux = half * 2.0;                                // fickle_step = False
+                    next = ((nrow * 5 + ncol) * 5 + npass) * 4 + dest;
+                }
+            }
             if (!held) store_rng_state(d, i, rng);
-            L.s = (double)d.tab.next[row + k], L.prob = d.tab.prob[row + k];
+            L.s = (double)next, L.prob = d.tab.prob[row + k];
             reward = d.tab.reward[row + k], te = d.tab.term[row + k] != 0;
         }
         L.elapsed += 1;
@@ -1206,6 +1232,7 @@ __global__ void seed_words_kernel(DevEnv d, const uint64_t *words, const uint8_t
 #pragma unroll
     for (int k = 0; k < 4; k++) d.rng[(size_t)k * d.N + i] = words[(size_t)4 * i + k];
     if (d.tab.nS < 0) d.state[(size_t)d.N + i] = 0.0;  // Blackjack: a fresh Generator has no buffered 32-bit half
+    if (d.tab_fickle_rows) d.state[(size_t)2 * d.N + i] = 0.0;  // fickle Taxi: likewise
 }
 
 __global__ void seed_sequence_kernel(DevEnv d, uint64_t first_seed, const uint8_t *mask) {
@@ -1218,6 +1245,7 @@ __global__ void seed_sequence_kernel(DevEnv d, uint64_t first_seed, const uint8_
     d.rng[i] = (uint64_t)(r.state >> 64), d.rng[(size_t)d.N + i] = (uint64_t)r.state;
     d.rng[(size_t)2 * d.N + i] = (uint64_t)(r.inc >> 64), d.rng[(size_t)3 * d.N + i] = (uint64_t)r.inc;
     if (d.tab.nS < 0) d.state[(size_t)d.N + i] = 0.0;  // Blackjack: a fresh Generator has no buffered 32-bit half
+    if (d.tab_fickle_rows) d.state[(size_t)2 * d.N + i] = 0.0;  // fickle Taxi: likewise
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1617,7 +1645,7 @@ static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
         v->d.tab.nS = -1, v->d.tab.nA = 2, v->d.tab.K = 0;  // the marker the kernels branch on (is_blackjack)
         v->tab_loaded = true;
     } else if (is_tab(cfg->kind)) {
-        const mi_layout l = {1, MI_I64, 1, MI_I64, 2, 1, {0, 0}};
+        const mi_layout l = {1, MI_I64, 1, MI_I64, cfg->params[2] != 0.0 ? 3 : 2, 1, {0, 0}};  // (the fickle Taxi keeps one more word per sub-env)
         v->lay = l;
     } else {
         v->lay = kLayouts[cfg->kind];
@@ -1645,6 +1673,7 @@ static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
     DevEnv &d = v->d;
     d.N = cfg->num_envs, d.max_steps = cfg->max_episode_steps;
     d.solver_newton = (cfg->reserved[0] & MI_CFG_SOLVER_NEWTON) ? 1 : 0;
+    d.tab_fickle_rows = (cfg->kind == MI_ENV_TABULAR && cfg->params[2] != 0.0) ? 1 : 0;
     for (int k = 0; k < 16; k++) d.P.p[k] = cfg->params[k];
     HIP_TRY(hipMalloc(&d.state, sizeof(double) * v->lay.state_dim * N));
     HIP_TRY(hipMalloc(&d.meta, sizeof(uint32_t) * N));

@@ -9,7 +9,9 @@ and integer lookups, so trajectories equal the reference's bit for bit (tests/go
 
   FrozenLakeVectorEnv    gymnasium/envs/toy_text/frozen_lake.py:226-360  (FrozenLake-v1, FrozenLake8x8-v1)
   CliffWalkingVectorEnv  gymnasium/envs/toy_text/cliffwalking.py:103-207 (CliffWalking-v1, CliffWalkingSlippery-v1)
-  TaxiVectorEnv          gymnasium/envs/toy_text/taxi.py:163-472         (Taxi-v4, is_rainy=False, fickle_passenger=False)
+  TaxiVectorEnv          gymnasium/envs/toy_text/taxi.py:163-472         (Taxi-v4 incl. is_rainy -- another table -- and fickle_passenger -- one
+                                                                          flag per sub-env, one reset draw, one Generator.choice in the kernel)
+  generate_random_map    gymnasium/envs/toy_text/frozen_lake.py:34-83    (FrozenLake's random maps; desc=None, map_name=None)
   BlackjackVectorEnv     gymnasium/envs/toy_text/blackjack.py:56-232     (Blackjack-v1; integer card game, not a table)
 """
 from __future__ import annotations
@@ -62,6 +64,11 @@ class TabularVectorEnv(HipVectorEnv):
     def _parse_reset_options(self, options):
         return None
 
+    def get_state(self):
+        """(state[N, state_dim], elapsed_steps, flags); state columns: state index, probability of the last transition (and, for Taxi with
+        fickle_passenger, the engine's word holding fickle_step and the generator's buffered 32-bit half)."""
+        return super().get_state()
+
     def _reset_infos(self, mask):
         sel = np.ones(self.num_envs, dtype=np.bool_) if mask is None else mask.view(np.bool_).copy()
         prob = np.where(sel, 1.0, 0.0)  # frozen_lake.py:348 / taxi.py:452: {"prob": 1}
@@ -88,13 +95,50 @@ FROZEN_LAKE_MAPS = {  # frozen_lake.py:20-32
 }
 
 
+def _goal_reachable(board, size: int) -> bool:
+    """frozen_lake.py:34-53 is_valid: is "G" reachable from (0, 0) over non-hole tiles (4-neighbourhood)?  (Any graph search gives the same answer.)"""
+    seen, stack = {(0, 0)}, [(0, 0)]
+    while stack:
+        r, c = stack.pop()
+        for r2, c2 in ((r + 1, c), (r, c + 1), (r - 1, c), (r, c - 1)):
+            if 0 <= r2 < size and 0 <= c2 < size and (r2, c2) not in seen:
+                if board[r2][c2] == "G":
+                    return True
+                if board[r2][c2] != "H":
+                    seen.add((r2, c2)), stack.append((r2, c2))
+    return False
+
+
+def generate_random_map(size: int = 8, p: float = 0.8, seed: int | None = None) -> list[str]:
+    """gymnasium.envs.toy_text.frozen_lake.generate_random_map (frozen_lake.py:56-83): boards of i.i.d. frozen ("F", probability p) / hole tiles from
+    `seeding.np_random(seed)`, start top-left, goal bottom-right, re-drawn until the goal is reachable.  Same generator calls as the reference
+    (Generator.choice with p: one `random((size, size))` block per attempt), so the same seed gives the same map (tests/golden/frozenlake_random_maps.npz)."""
+    from ..gym_api import seeding
+
+    rng, _ = seeding.np_random(seed)
+    while True:
+        p = min(1, p)
+        board = rng.choice(["F", "H"], (size, size), p=[p, 1 - p])
+        board[0][0], board[-1][-1] = "S", "G"
+        if _goal_reachable(board, size):
+            return ["".join(row) for row in board]
+
+
 class FrozenLakeVectorEnv(TabularVectorEnv):
     DEFAULT_MAX_EPISODE_STEPS = 100
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, desc=None, map_name: str = "4x4",
                  is_slippery: bool = True, success_rate: float = 1.0 / 3.0, reward_schedule=(1, 0, 0), **kwargs):
         if desc is None and map_name is None:
-            raise error.Error("random FrozenLake maps (map_name=None) are not supported by gymnasium_amd; pass desc=")
+            # frozen_lake.py:241-242: `desc = generate_random_map()` -- unseeded (OS entropy), so no two constructions agree by design.  The reference's
+            # SyncVectorEnv constructs num_envs scalar envs, i.e. draws one map PER SUB-ENVIRONMENT; the engine holds one transition table per vector
+            # env, so all its sub-environments share ONE random map.  (For reproducible or per-env maps pass desc=generate_random_map(size, p, seed).)
+            from ..gym_api import logger
+
+            desc = generate_random_map()
+            if num_envs > 1:
+                logger.warn("FrozenLake with map_name=None: the MI355X engine draws ONE random map for all sub-environments of this vector env "
+                            "(gymnasium's SyncVectorEnv draws one per sub-environment)")
         self.desc = [str(r) for r in (desc if desc is not None else FROZEN_LAKE_MAPS[map_name])]
         self.is_slippery, self.success_rate, self.reward_schedule = bool(is_slippery), success_rate, tuple(reward_schedule)
         super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
@@ -178,10 +222,14 @@ class TaxiVectorEnv(TabularVectorEnv):
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, is_rainy: bool = False,
                  fickle_passenger: bool = False, rainy_probability: float = 0.8, fickle_probability: float = 0.3, **kwargs):
-        if is_rainy or fickle_passenger:
-            raise error.Error("gymnasium_amd Taxi implements the default dry, non-fickle dynamics only")
+        self.is_rainy, self.fickle_passenger = bool(is_rainy), bool(fickle_passenger)
+        self.rainy_probability, self.fickle_probability = rainy_probability, fickle_probability
         super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
         self._action_mask = np.stack([self.action_mask(s) for s in range(self.nS)])
+
+    def _engine_params(self):
+        # params[2] != 0: the fickle-passenger rule of taxi.py:436-451 / :462-464 runs in the kernel (tab_fickle, engine.hip), params[3] = its probability
+        return (float(self.nS), float(self.nA), 1.0 if self.fickle_passenger else 0.0, float(self.fickle_probability))
 
     @staticmethod
     def encode(row, col, pass_loc, dest):
@@ -205,7 +253,42 @@ class TaxiVectorEnv(TabularVectorEnv):
         mask[5] = pass_loc == 4 and (row, col) in TAXI_LOCS
         return mask
 
+    @staticmethod
+    def _pickup_dropoff(a, row, col, pass_idx, dest):
+        """taxi.py:173-199 _pickup / _dropoff: (new passenger index, reward, terminated) of action 4 / 5."""
+        p2, reward, term = pass_idx, -1, False
+        if a == 4:
+            if pass_idx < 4 and (row, col) == TAXI_LOCS[pass_idx]:
+                p2 = 4
+            else:
+                reward = -10
+        elif (row, col) == TAXI_LOCS[dest] and pass_idx == 4:
+            p2, term, reward = dest, True, 20
+        elif (row, col) in TAXI_LOCS and pass_idx == 4:
+            p2 = TAXI_LOCS.index((row, col))
+        else:
+            reward = -10
+        return p2, reward, term
+
+    @staticmethod
+    def _can_move(a, row, col):
+        """Is the primary move of action a (0 south, 1 north, 2 east, 3 west) possible from (row, col)?  (taxi.py:271-276)"""
+        return ((a == 0 and row < 4) or (a == 1 and row > 0) or (a == 2 and TAXI_MAP[1 + row][2 * col + 2] == ":") or (a == 3 and TAXI_MAP[1 + row][2 * col] == ":"))
+
+    @staticmethod
+    def _lateral(row, col, dr, dc):
+        """taxi.py:230-245 _calc_new_position: where a sideways drift ends (an interior wall or the boundary leaves the taxi in place)."""
+        r2, c2 = max(0, min(row + dr, 4)), max(0, min(col + dc, 4))
+        if dc == 1 and TAXI_MAP[1 + r2][2 * c2] != ":":
+            return row, col
+        if dc == -1 and TAXI_MAP[1 + r2][2 * c2 + 2] != ":":
+            return row, col
+        return r2, c2
+
     def _build(self):
+        # (forward, left, right) of each heading (taxi.py:262-267)
+        moves = {0: ((1, 0), (0, 1), (0, -1)), 1: ((-1, 0), (0, -1), (0, 1)), 2: ((0, 1), (-1, 0), (1, 0)), 3: ((0, -1), (1, 0), (-1, 0))}
+        lateral_probability = (1.0 - self.rainy_probability) / 2.0
         P, isd = {}, np.zeros(500)
         for row in range(5):
             for col in range(5):
@@ -216,28 +299,22 @@ class TaxiVectorEnv(TabularVectorEnv):
                             isd[s] += 1
                         P[s] = {}
                         for a in range(6):
-                            r2, c2, p2, reward, term = row, col, pass_idx, -1, False
-                            if a == 0:
-                                r2 = min(row + 1, 4)
-                            elif a == 1:
-                                r2 = max(row - 1, 0)
-                            elif a == 2 and TAXI_MAP[1 + row][2 * col + 2] == ":":
-                                c2 = min(col + 1, 4)
-                            elif a == 3 and TAXI_MAP[1 + row][2 * col] == ":":
-                                c2 = max(col - 1, 0)
-                            elif a == 4:  # pickup
-                                if pass_idx < 4 and (row, col) == TAXI_LOCS[pass_idx]:
-                                    p2 = 4
-                                else:
-                                    reward = -10
-                            elif a == 5:  # dropoff
-                                if (row, col) == TAXI_LOCS[dest] and pass_idx == 4:
-                                    p2, term, reward = dest, True, 20
-                                elif (row, col) in TAXI_LOCS and pass_idx == 4:
-                                    p2 = TAXI_LOCS.index((row, col))
-                                else:
-                                    reward = -10
-                            P[s][a] = [(1.0, self.encode(r2, c2, p2, dest), reward, term)]
+                            if a >= 4:
+                                p2, reward, term = self._pickup_dropoff(a, row, col, pass_idx, dest)
+                                P[s][a] = [(1.0, self.encode(row, col, p2, dest), reward, term)]
+                            elif not self.is_rainy:  # taxi.py:201-228: a blocked move leaves the taxi where it is
+                                r2, c2 = row, col
+                                if self._can_move(a, row, col):
+                                    r2, c2 = max(0, min(row + moves[a][0][0], 4)), max(0, min(col + moves[a][0][1], 4))
+                                P[s][a] = [(1.0, self.encode(r2, c2, pass_idx, dest), -1, False)]
+                            else:  # taxi.py:247-308: intended move with rainy_probability, a drift to either side with the rest; a blocked move drifts nowhere
+                                fwd = left = right = (row, col)
+                                if self._can_move(a, row, col):
+                                    fwd = (max(0, min(row + moves[a][0][0], 4)), max(0, min(col + moves[a][0][1], 4)))
+                                    left, right = self._lateral(row, col, *moves[a][1]), self._lateral(row, col, *moves[a][2])
+                                P[s][a] = [(self.rainy_probability, self.encode(*fwd, pass_idx, dest), -1, False),
+                                           (lateral_probability, self.encode(*left, pass_idx, dest), -1, False),
+                                           (lateral_probability, self.encode(*right, pass_idx, dest), -1, False)]
         isd /= isd.sum()
         return P, isd
 

@@ -110,7 +110,10 @@ typedef enum mi_dtype {
  *     INVERTED_PENDULUM / INVERTED_DOUBLE_PENDULUM: [2] reset_noise_scale [4] frame_skip [6] healthy_reward (double pendulum)
  *       [12] ANT: include_cfrc_ext_in_observation / HUMANOID: include_cinert_in_observation
  *       [13],[14],[15] HUMANOID: include_cvel / include_qfrc_actuator / include_cfrc_ext _in_observation
- *     TABULAR                  params[0] = number of states, params[1] = number of actions (table: mi_tabular_load)
+ *     TABULAR                  params[0] = number of states, params[1] = number of actions (table: mi_tabular_load);
+ *                              params[2] != 0: Taxi's fickle passenger (envs/toy_text/taxi.py:436-451,462-464) with probability params[3] -- reset
+ *                              draws fickle_step, the first move with the passenger aboard re-draws the destination (Generator.choice);
+ *                              layout.state_dim is then 3 (state, prob, fickle_step | buffered 32-bit half << 1)
  */
 typedef struct mi_config {
     int32_t struct_size;         /* = sizeof(mi_config) */

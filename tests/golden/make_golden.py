@@ -301,12 +301,31 @@ def make_action_samples():
 
 
 TOYTEXT = {"frozenlake": "FrozenLake-v1", "frozenlake8x8": "FrozenLake8x8-v1", "cliffwalking": "CliffWalking-v1",
-           "cliffwalking_slippery": "CliffWalkingSlippery-v1", "taxi": "Taxi-v4"}
+           "cliffwalking_slippery": "CliffWalkingSlippery-v1", "taxi": "Taxi-v4",
+           # the constructor variants (taxi.py:247-334 is_rainy, :436-451,:462-464 fickle_passenger; frozen_lake.py:56-83 generate_random_map)
+           "taxi_rainy": ("Taxi-v4", {"is_rainy": True}), "taxi_fickle": ("Taxi-v4", {"fickle_passenger": True}),
+           "taxi_rainy_fickle": ("Taxi-v4", {"is_rainy": True, "fickle_passenger": True, "rainy_probability": 0.7, "fickle_probability": 0.6}),
+           "frozenlake_random": ("FrozenLake-v1", {"desc": "generate_random_map(size=6, p=0.75, seed=5)", "is_slippery": True})}
+
+
+def make_random_maps():
+    """generate_random_map (frozen_lake.py:56-83) for a grid of (size, p, seed): the maps themselves."""
+    from gymnasium.envs.toy_text.frozen_lake import generate_random_map
+
+    cases = [(4, 0.8, 0), (8, 0.8, 1), (8, 0.8, 123), (5, 0.6, 7), (12, 0.9, 42), (6, 0.75, 5), (3, 0.5, 9), (8, 1.5, 2)]
+    save("frozenlake_random_maps.npz", cases=np.array(cases, dtype=np.float64), maps=np.array(["|".join(generate_random_map(size=s, p=p, seed=seed)) for s, p, seed in cases]))
 
 
 def make_toytext():
-    for key, env_id in TOYTEXT.items():
-        e = gym.make(env_id).unwrapped
+    from gymnasium.envs.toy_text.frozen_lake import generate_random_map
+
+    make_random_maps()
+    for key, spec in TOYTEXT.items():
+        env_id, kw = (spec, {}) if isinstance(spec, str) else spec
+        kw = dict(kw)
+        if isinstance(kw.get("desc"), str):
+            kw["desc"] = generate_random_map(size=6, p=0.75, seed=5)
+        e = gym.make(env_id, **kw).unwrapped
         nS, nA = e.observation_space.n, e.action_space.n
         K = max(len(e.P[s][a]) for s in range(nS) for a in range(nA))
         prob, nxt, rew, term = np.zeros((nS, nA, K)), np.zeros((nS, nA, K), np.int32), np.zeros((nS, nA, K)), np.zeros((nS, nA, K), np.uint8)
@@ -317,7 +336,9 @@ def make_toytext():
                 for k, (p, ns, r, t) in enumerate(e.P[s][a]):
                     prob[s, a, k], nxt[s, a, k], rew[s, a, k], term[s, a, k] = p, ns, r, t
         n, T = 8, 400
-        v = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync")
+        if "fickle" in key:
+            T = 1500  # the fickle change of mind needs a pickup first: rare under a random policy
+        v = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync", **kw)
         obs0, info0 = v.reset(seed=7)
         v.action_space.seed(11)
         A, O, R, TE, TR, PR, PM, AM = [], [], [], [], [], [], [], []

@@ -338,6 +338,24 @@ def check_rollout_fused(key, factory, n=64, T=40, **kw):
 
 TOYTEXT_IDS = {"frozenlake": "FrozenLake-v1", "frozenlake8x8": "FrozenLake8x8-v1", "cliffwalking": "CliffWalking-v1",
                "cliffwalking_slippery": "CliffWalkingSlippery-v1", "taxi": "Taxi-v4"}
+# constructor variants: the same kwargs tests/golden/make_golden.py gave the reference
+TOYTEXT_VARIANTS = {"taxi_rainy": ("Taxi-v4", {"is_rainy": True}), "taxi_fickle": ("Taxi-v4", {"fickle_passenger": True}),
+                    "taxi_rainy_fickle": ("Taxi-v4", {"is_rainy": True, "fickle_passenger": True, "rainy_probability": 0.7, "fickle_probability": 0.6}),
+                    "frozenlake_random": ("FrozenLake-v1", {"desc": ("random", 6, 0.75, 5), "is_slippery": True})}
+TOYTEXT_ALL = list(TOYTEXT_IDS) + list(TOYTEXT_VARIANTS)
+
+
+def toytext_spec(key):
+    if key in TOYTEXT_IDS:
+        return TOYTEXT_IDS[key], {}
+    env_id, kw = TOYTEXT_VARIANTS[key]
+    kw = dict(kw)
+    if isinstance(kw.get("desc"), tuple):
+        from gymnasium_amd.envs.toy_text import generate_random_map
+
+        _, size, p, seed = kw["desc"]
+        kw["desc"] = generate_random_map(size=size, p=p, seed=seed)
+    return env_id, kw
 
 
 def check_toytext(key, factory):
@@ -345,7 +363,8 @@ def check_toytext(key, factory):
     action_space.seed(11), 400 random steps) is reproduced BIT-EXACTLY incl. info['prob'] / info['action_mask']."""
     g = golden(f"toytext_{key}.npz")
     n = g["obs0"].shape[0]
-    env = gymnasium_amd.make_vec(TOYTEXT_IDS[key], num_envs=n, _engine_factory=factory)
+    env_id, kw = toytext_spec(key)
+    env = gymnasium_amd.make_vec(env_id, num_envs=n, _engine_factory=factory, **kw)
     tab = env._tab
     assert np.array_equal(tab["count"], g["count"]) and np.array_equal(tab["next_state"], g["next_state"])
     assert np.array_equal(tab["prob"], g["prob"]) and np.array_equal(tab["reward"], g["reward_table"])

@@ -305,7 +305,7 @@ def test_full_size_spot_check_vs_oracle(oracle_factory):
 
 # ---- ToyText: bit-exact integer kernels ------------------------------------------------------------------------
 
-@pytest.mark.parametrize("key", list(ps.TOYTEXT_IDS))
+@pytest.mark.parametrize("key", ps.TOYTEXT_ALL)
 def test_toytext_bit_exact_vs_reference_golden(key):
     ps.check_toytext(key, None)
 
@@ -343,13 +343,13 @@ def test_partial_reset_during_pending_autoreset():
     ps.check_partial_reset_infos(None)
 
 
-@pytest.mark.parametrize("key", ["frozenlake", "taxi", "cliffwalking_slippery"])
+@pytest.mark.parametrize("key", ["frozenlake", "taxi", "cliffwalking_slippery", "taxi_rainy_fickle", "frozenlake_random"])
 def test_toytext_fused_rollout_and_full_size(key):
     import torch
 
-    eid = ps.TOYTEXT_IDS[key]
-    a = gymnasium_amd.make_vec(eid, num_envs=65536, output="torch")
-    b = gymnasium_amd.make_vec(eid, num_envs=65536, output="torch")
+    eid, kw = ps.toytext_spec(key)
+    a = gymnasium_amd.make_vec(eid, num_envs=65536, output="torch", **kw)
+    b = gymnasium_amd.make_vec(eid, num_envs=65536, output="torch", **kw)
     a.reset(seed=1), b.reset(seed=1)
     a.action_space.seed(2), b.action_space.seed(2)
     out = a.rollout(24)
@@ -363,6 +363,36 @@ def test_toytext_fused_rollout_and_full_size(key):
     sa, sb = a.statistics(), b.statistics()
     assert sa == sb and sa["env_steps"] + sa["reset_steps"] == 65536 * 24
     a.close(), b.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep"])
+def test_taxi_fickle_passenger_vs_oracle(mode, oracle_factory):
+    """taxi.py:436-451 in the kernel: 4096 sub-environments x 700 steps against the oracle (itself pinned on the reference recording,
+    tests/golden/toytext_taxi_*fickle.npz) -- observations, rewards, flags, the packed fickle word and every generator state."""
+    n, T = 4096, 700
+    kw = dict(fickle_passenger=True, is_rainy=(mode == "SameStep"), fickle_probability=0.5, autoreset_mode=mode)
+    gpu = gymnasium_amd.make_vec("Taxi-v4", num_envs=n, **kw)
+    cpu = gymnasium_amd.make_vec("Taxi-v4", num_envs=n, _engine_factory=oracle_factory, **kw)
+    og, _ = gpu.reset(seed=31)
+    oc, _ = cpu.reset(seed=31)
+    assert np.array_equal(og, oc)
+    gpu.action_space.seed(8)
+    changed = 0
+    prev, pend = oc.copy(), np.zeros(n, bool)
+    for t in range(T):
+        a = gpu.action_space.sample()
+        sg, sc = gpu.step(a), cpu.step(a)
+        for k in range(4):
+            assert np.array_equal(sg[k], sc[k]), (t, k)
+        assert np.array_equal(sg[4]["prob"], sc[4]["prob"]) and np.array_equal(sg[4]["action_mask"], sc[4]["action_mask"])
+        done = sc[2] | sc[3]
+        changed += int(((sc[0] % 4 != prev % 4) & ~pend & ~(done if mode == "SameStep" else np.zeros(n, bool))).sum())
+        prev, pend = sc[0].copy(), (done if mode == "NextStep" else np.zeros(n, bool))
+    assert changed > 50, "the passenger must actually change the destination in a good number of episodes"
+    sg, sc = gpu.get_state(), cpu.get_state()
+    assert sg[0].shape == (n, 3) and all(np.array_equal(x, y) for x, y in zip(sg, sc))
+    assert np.array_equal(gpu.get_rng_state(), cpu.get_rng_state())
+    gpu.close(), cpu.close()
 
 
 def test_step_async_wait_and_pinned_buffers():
