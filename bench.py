@@ -412,7 +412,7 @@ class Config:
             return out
         out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **base}
         if live.get("issue"):
-            # The OTHER ceiling of this kernel: at one wavefront per SIMD the instruction issue rate bounds it before HBM does (DESIGN.md section 9).
+            # The OTHER ceiling of this kernel: at one wavefront per SIMD the instruction issue rate bounds it before HBM does (DESIGN.md section 3).
             iss = dict(live["issue"])
             steps_per_s = self.N * self.inner / kernel_s  # lanes stepped per second by this kernel (autoreset lanes included: they execute too)
             iss["achieved_lane_steps_per_s"] = steps_per_s

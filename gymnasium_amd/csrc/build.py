@@ -35,8 +35,8 @@ ITERATIVE = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
 # History of the 16-lane unit: in round 2 its LIBRARY kernels (not the harness's) came out WRONG with this flag -- Ant-v5 produced NaNs, caught by
 # tests/test_gpu_scheduler_guard.py and tests/test_gpu_mujoco.py -- so it shipped with MachineLICM switched off instead (NO_MLICM).  The cause was never
 # isolated.  After the round-3 rewrites of the forward pass the same flag set builds a physics16.hip that is bit-identical to the
-# default-scheduler build on all four 16-lane robots, NaN-free, with 0 spilled VGPRs for the Ant (was 13 - 25) and +1.1 % (scripts/r03/gpu_call25.sh,
-# gpu_call26.sh, scripts/r03/guard_variant.py): both units now use ONE flag set.  The guard test stays what decides: if it ever fails again,
+# default-scheduler build on all four 16-lane robots, NaN-free, with 0 spilled VGPRs for the Ant (was 13 - 25) and +1.1 % (round-3 calls 25 / 26,
+# scripts/r03/README.md, scripts/r03/guard_variant.py): both units now use ONE flag set.  The guard test stays what decides: if it ever fails again,
 # NO_MLICM for physics16.hip is the known-good fallback.
 SINK = ["-mllvm", "-sink-insts-to-avoid-spills=true"]
 NO_MLICM = ["-mllvm", "-disable-machine-licm"]
@@ -119,6 +119,49 @@ def build_both(verbose: bool = True):
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
     return out, build(verbose=verbose, reference_scheduler=True)
+
+
+VERIFY_CHILD = r"""
+import sys, hashlib
+sys.path.insert(0, {root!r})
+import numpy as np
+import gymnasium_amd
+h = hashlib.sha256()
+for env_id, kw in (("Ant-v5", {{"max_episode_steps": 6}}), ("HalfCheetah-v5", {{}}), ("Humanoid-v5", {{}})):
+    env = gymnasium_amd.make_vec(env_id, num_envs=512, **kw)
+    obs, _ = env.reset(seed=3)
+    env.action_space.seed(1)
+    h.update(obs.tobytes())
+    for t in range(24 if env_id == "Humanoid-v5" else 10):
+        o, r, te, tr, _ = env.step(env.action_space.sample())
+        h.update(o.tobytes()), h.update(r.tobytes()), h.update(te.tobytes()), h.update(tr.tobytes())
+    h.update(env.get_state()[0].tobytes())
+    env.close()
+print("DIGEST", h.hexdigest())
+"""
+
+
+def verify_on_device(timeout_s: float = 300.0) -> str:
+    """On a GPU box: the shipped cooperative physics kernels (iterative scheduler + MachineLICM settings, TU_FLAGS) against the SAME sources under
+    hipcc's defaults (libmi355env_ref.so), every bit of a short trajectory that includes finished episodes and resets, each build in its own child
+    process.  The scheduler settings have a history of exposing a code-generation defect (scripts/repro/README.md); this is the check that a new
+    toolchain, box or source change did not bring it back, cheap enough to run with every smoke() (tests/test_gpu_scheduler_guard.py is the long
+    form).  Returns the common digest; raises if the builds differ.  (Spilling SGPRs to memory instead -- the documented cure of the defect -- costs
+    x0.45 - 0.6 on these kernels: profiles/r04_two_waves.txt.)"""
+    root = os.path.normpath(os.path.join(HERE, "..", ".."))
+    digests = {}
+    for lib in (OUT, OUT_REF):
+        if not os.path.exists(lib):
+            raise FileNotFoundError(f"{lib} missing: build with `python -m gymnasium_amd.csrc.build --ref`")
+        p = subprocess.run([sys.executable, "-c", VERIFY_CHILD.format(root=root)], env=dict(os.environ, MI355ENV_LIBRARY=lib), capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("DIGEST ")]
+        if p.returncode != 0 or not lines:
+            raise RuntimeError(f"verify_on_device: {os.path.basename(lib)} failed: {p.stdout[-500:]} {p.stderr[-1500:]}")
+        digests[lib] = lines[-1].split()[1]
+    if digests[OUT] != digests[OUT_REF]:
+        raise RuntimeError("the shipped cooperative physics kernels differ from the default-scheduler build of the same sources (miscompile guard, "
+                           f"gymnasium_amd/csrc/build.py TU_FLAGS): {digests}")
+    return digests[OUT]
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B builds of libmi355env.so: one translation unit recompiled with extra flags, linked with the product's other objects.
 
-    python scripts/build_variant.py <name> <unit.hip> [extra hipcc flags ...]   ->  gymnasium_amd/csrc/libmi355env_<name>.so
+    python scripts/build_variant.py <name> <unit.hip>[,<unit2.hip>...] [extra hipcc flags ...]   ->  gymnasium_amd/csrc/libmi355env_<name>.so
 
 Run the variant with MI355ENV_LIBRARY=<path> (gymnasium_amd/_native.py).  Experiment infrastructure: nothing in the package uses it."""
 import os
@@ -14,13 +14,18 @@ from gymnasium_amd.csrc import build as B  # noqa: E402
 
 
 def main():
-    name, unit, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+    name, units, extra = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]
     B.build(verbose=False)  # the product's objects must be current
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    obj = os.path.join(B.HERE, f"{os.path.splitext(unit)[0]}_{name}.o")
-    cmd = [hipcc, f"--offload-arch={B.ARCH}", *B.FLAGS, *B.TU_FLAGS.get(unit, []), *extra, "-c", "-o", obj, os.path.join(B.HERE, unit)]
-    subprocess.run(cmd, check=True, cwd=B.HERE)
-    objs = [obj if src == unit else os.path.join(B.HERE, os.path.splitext(src)[0] + ".o") for src in B.SOURCES]
+    jobs, variant = [], {}
+    for unit in units:  # the units compile side by side
+        obj = variant[unit] = os.path.join(B.HERE, f"{os.path.splitext(unit)[0]}_{name}.o")
+        cmd = [hipcc, f"--offload-arch={B.ARCH}", *B.FLAGS, *B.TU_FLAGS.get(unit, []), *extra, "-c", "-o", obj, os.path.join(B.HERE, unit)]
+        jobs.append((cmd, subprocess.Popen(cmd, cwd=B.HERE)))
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    objs = [variant.get(src, os.path.join(B.HERE, os.path.splitext(src)[0] + ".o")) for src in B.SOURCES]
     out = os.path.join(B.HERE, f"libmi355env_{name}.so")
     subprocess.run([hipcc, f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", out] + objs, check=True, cwd=B.HERE)
     print(out)

@@ -1,4 +1,4 @@
-// A/B microbenchmark for the MFMA question of the cooperative MuJoCo kernel: the Newton solver's Hessian assembly
+// A/B microbenchmark for the MFMA question of the cooperative MuJoCo kernel (docs/mujoco_design.md): the Newton solver's Hessian assembly
 //     H = M + sum_c J_c^T W_c J_c        (J_c: 3 x NV contact-frame Jacobian, W_c: symmetric 3 x 3, NV = 14 padded to 16)
 // for the FOUR sub-environments of a 16-lane-per-environment wavefront (Ant / HalfCheetah layout), with J_c and W_c on the LDS blackboard
 // as mjx_coop.h assemble() publishes them and the result as one Hessian row per dof lane (what the Cholesky consumes):
