@@ -114,6 +114,48 @@ def test_free_running_return_statistics(name, n, oracle_factory):
     gpu.close(), cpu.close()
 
 
+@pytest.mark.parametrize("name", ["ant", "humanoid", "walker2d", "half_cheetah"])
+def test_teacher_forced_fallen_poses(name, oracle_factory):
+    """Many-contact states the rollouts from reset reach late or never: every robot dropped in a random orientation just above the floor with random
+    joint angles and velocities (the root orientation uniformly random for the free-joint robots: backs, heads, arms and elbows on the ground,
+    capsule - capsule self-collision for the Humanoid), then 6 steps of HIP engine vs oracle from identical states.  This is where the unpinned
+    parts live -- free-joint RK4 with many contacts, PGS with 10 - 25 active rows -- so at least the three implementations must agree there."""
+    n = 384
+    kw = {} if name == "half_cheetah" else dict(terminate_when_unhealthy=False)
+    gpu = gymnasium_amd.make_vec(ALL[name], num_envs=n, **kw)
+    cpu = gymnasium_amd.make_vec(ALL[name], num_envs=n, _engine_factory=oracle_factory, **kw)
+    gpu.reset(seed=4), cpu.reset(seed=4)
+    st, el, fl = cpu.get_state()
+    rng = np.random.default_rng(12)
+    st = st.copy()
+    nq = {"ant": 15, "humanoid": 24, "walker2d": 9, "half_cheetah": 9}[name]
+    nv = nq - 1 if name in ("ant", "humanoid") else nq
+    if name in ("ant", "humanoid"):
+        q = rng.normal(size=(n, 4))
+        st[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)          # uniformly random root orientation
+        st[:, 2] = rng.uniform(0.15, 0.45, n) if name == "ant" else rng.uniform(0.05, 0.3, n)  # torso just above the floor
+        st[:, 7:nq] += rng.uniform(-0.5, 0.5, (n, nq - 7))
+    else:
+        st[:, 1] = rng.uniform(-1.0, -0.2, n) if name == "walker2d" else rng.uniform(-0.45, -0.1, n)  # root z slider: down towards the floor
+        st[:, 2] = rng.uniform(-1.5, 1.5, n)                                # pitched over
+        st[:, 3:nq] += rng.uniform(-0.6, 0.6, (n, nq - 3))
+    st[:, nq:nq + nv] = rng.uniform(-1.0, 1.0, (n, nv))
+    st[:, nq + nv:nq + 2 * nv] = 0.0
+    gpu.set_state(st, el, fl), cpu.set_state(st, el, fl)
+    gpu.action_space.seed(6)
+    worst = worst_r = 0.0
+    for t in range(6):
+        a = gpu.action_space.sample()
+        og, rg, teg, trg, _ = gpu.step(a)
+        oc, rc, tec, trc, _ = cpu.step(a)
+        assert np.isfinite(oc).all() and np.array_equal(teg, tec)
+        worst, worst_r = max(worst, float((np.abs(og - oc) / (1.0 + np.abs(oc))).max())), max(worst_r, float((np.abs(rg - rc) / (1.0 + np.abs(rc))).max()))
+    contacts = float((np.abs(oc[:, -6 * (14 if name == "ant" else 13):]) > 0).any(axis=1).mean()) if name in ("ant", "humanoid") else float("nan")
+    print(f"{name} fallen poses: max |obs diff| / (1 + |obs|) {worst:.3e}, rewards likewise {worst_r:.3e} over 6 steps x {n} envs; share of envs with contact forces {contacts:.2f}")
+    assert worst < 1e-8 and worst_r < 1e-9  # measured (round 4): 2.5e-13 (Ant) ... 4.6e-11 (Humanoid, HalfCheetah); rewards <= 8e-13
+    gpu.close(), cpu.close()
+
+
 @pytest.mark.parametrize("name", list(ALL))
 def test_fused_rollout_equals_stepping(name):
     import torch
