@@ -17,6 +17,9 @@ SOURCES = {  # translation unit -> the headers it depends on
     "physics16.hip": ["mjx_physics.h", "envs_classic.h", "sincos_exact.h", "pow_exact.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", os.path.join("generated", "mjx_models.h")],
     "physics32.hip": ["mjx_physics.h", "envs_classic.h", "sincos_exact.h", "pow_exact.h", "pcg64_dev.h", "mjx_core.h", "mjx_coop.h", "mjx_kernels.h", os.path.join("generated", "mjx_models.h")],
     "wrappers.hip": ["wrappers_internal.h", os.path.join("..", "..", "include", "mi355env.h")],
+    # engine.hip once more with MI_CLASSIC_TU: only the classic-control kernels and their launchers (namespace mi_classic)
+    "classic.hip": ["engine.hip", "envs_classic.h", "sincos_exact.h", "sincos_table.h", "pow_exact.h", "pow_tables.h", "wrappers_internal.h", "pcg64_dev.h",
+                    os.path.join("..", "..", "include", "mi355env.h")],
 }
 OUT = os.path.join(HERE, "libmi355env.so")
 ARCH = "gfx950"
@@ -40,7 +43,14 @@ ITERATIVE = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
 # NO_MLICM for physics16.hip is the known-good fallback.
 SINK = ["-mllvm", "-sink-insts-to-avoid-spills=true"]
 NO_MLICM = ["-mllvm", "-disable-machine-licm"]
-TU_FLAGS = {"physics16.hip": ITERATIVE + SINK, "physics32.hip": ITERATIVE + SINK}
+# classic.hip (round 4): the five classic-control kinds' kernels under LLVM's max-ILP machine scheduler -- one wavefront per SIMD at 65 536 sub-environments,
+# so a dependent instruction's latency is hidden by the wavefront's OWN independent instructions or not at all.  A/B on one box (whole engine.hip
+# rebuilt with the flag, scripts/ab_bench.py, profiles/r04_maxilp_classic.txt): CartPole +6.4 %, Pendulum +5.8 %, MountainCarContinuous +2.7 %, Acrobot -0.3 %;
+# Taxi -1.3 %, Hopper (one-lane) -2.0 % -- hence only the classic kernels moved.  Results are bit-identical by construction (no re-association; every
+# classic parity test is array_equal) and the two-build comparison of tests/test_gpu_scheduler_guard.py covers this unit as well.
+# (`iterative-ilp` crashes clang-22 on engine.hip, `iterative-maxocc` stops with "Illegal instruction detected: Operand has incorrect register class".)
+MAXILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+TU_FLAGS = {"physics16.hip": ITERATIVE + SINK, "physics32.hip": ITERATIVE + SINK, "classic.hip": MAXILP}
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
 
 
@@ -127,7 +137,7 @@ sys.path.insert(0, {root!r})
 import numpy as np
 import gymnasium_amd
 h = hashlib.sha256()
-for env_id, kw in (("Ant-v5", {{"max_episode_steps": 6}}), ("HalfCheetah-v5", {{}}), ("Humanoid-v5", {{}})):
+for env_id, kw in (("Ant-v5", {{"max_episode_steps": 6}}), ("HalfCheetah-v5", {{}}), ("Humanoid-v5", {{}}), ("CartPole-v1", {{}}), ("Pendulum-v1", {{}})):
     env = gymnasium_amd.make_vec(env_id, num_envs=512, **kw)
     obs, _ = env.reset(seed=3)
     env.action_space.seed(1)

@@ -27,13 +27,22 @@
 #include <string>
 #include <vector>
 
+// TWO translation units are made of this file (gymnasium_amd/csrc/build.py): engine.o (everything but the classic-control kernels) and, with
+// -DMI_CLASSIC_TU (classic.hip), classic.o: the step / reset / rollout / epilogue kernels of the five classic-control kinds and their launchers
+// (namespace mi_classic), compiled with LLVM's max-ILP machine scheduler.  Those kernels run ONE wavefront per SIMD at the benchmark's 65 536
+// sub-environments, where nothing hides a dependent instruction's latency but the wavefront's own independent instructions: max-ILP scheduling
+// measured +6.4 % (CartPole), +5.8 % (Pendulum), +2.7 % (MountainCarContinuous) against the default max-occupancy scheduler, with every result bit
+// unchanged (scheduling reorders, it does not re-associate; tests/test_gpu_parity.py compares array_equal) -- and -1 ... -2 % on the ToyText and
+// one-lane MuJoCo kernels, which therefore stay in engine.o on the default scheduler (profiles/r04_maxilp_classic.txt).
 #include "../../include/mi355env.h"
 #include "envs_classic.h"
 #include "wrappers_internal.h"
 #include "pcg64_dev.h"
+#ifndef MI_CLASSIC_TU
 #include "mjx_kernels.h"
 #include "mjx_coop.h"
 #include "mjx_physics.h"
+#endif
 
 using namespace mi;
 
@@ -43,6 +52,10 @@ constexpr int kBlock = 256;  // 4 wavefronts: one per SIMD of a CU
 constexpr int kErrInvalidAction = 1, kErrDisabledStepped = 2;
 constexpr uint32_t kFlagShift = 30, kElapsedMask = (1u << kFlagShift) - 1u;
 
+}  // namespace
+// Plain types that cross the boundary between the two translation units (launcher arguments, members of mi_vecenv): a named namespace, so that
+// mi_classic's functions have external linkage.
+namespace mi_internal {
 // Transition table of a tabular (ToyText) environment, device pointers (mi_tabular_load).
 struct TabTable {
     int nS, nA, K;
@@ -68,6 +81,9 @@ struct DevEnv {
     EnvParams P;
     TabTable tab;
 };
+}  // namespace mi_internal
+using namespace mi_internal;
+namespace {
 
 struct LaneStats {
     uint32_t env_steps, reset_steps, episodes;
@@ -399,6 +415,8 @@ MI_DEV void block_accumulate(const DevEnv &d, const LaneStats &st) {
 // Together: 2 launches per wrapped step (3 beyond 262144 sub-environments) instead of 1 + 4 + 5 + 1 with the stand-alone passes.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kEpiObsMax = 6, kEpiCols = 2 * kEpiObsMax + 3, kEpiFoldMax = 1024;
+}  // namespace
+namespace mi_internal {
 struct EpiDev {
     int obs_on, obs_update, ret_on, ret_update, same_step, clip_pre, clip_post, fold_in_finish;  // clip_*: bit 0 = has min, bit 1 = has max
     int step_blocks;
@@ -410,6 +428,8 @@ struct EpiDev {
     uint8_t *prev_done;
     double *partial;   // [step_blocks][kEpiCols]
 };
+}  // namespace mi_internal
+namespace {
 MI_DEV double clip_to(double v, int flags, double lo, double hi) {  // np.clip(reward, min_reward, max_reward)
     if (flags & 1) v = v < lo ? lo : v;
     if (flags & 2) v = v > hi ? hi : v;
@@ -570,6 +590,8 @@ __global__ __launch_bounds__(kBlock) void epilogue_finish(EpiDev e, int N, float
     }
 }
 
+}  // namespace
+namespace mi_internal {
 struct StepPtrs {
     const void *actions;
     float *obs;
@@ -579,6 +601,8 @@ struct StepPtrs {
     double *ep_ret;
     int32_t *ep_len;
 };
+}  // namespace mi_internal
+namespace {
 
 template <class E, int MODE, bool EPI = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, EpiDev epi) {
@@ -632,6 +656,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevEnv d, const uint8_t *
     }
 }
 
+}  // namespace
+namespace mi_internal {
 // Action stream of the batched action space: ONE PCG64 generator drawn in sub-environment index order, so lane i
 // consumes draw number t*N + i of the stream at step t.  jump[j] advances by 2^j draws; jump_n advances by N.
 struct ActionStream {
@@ -647,6 +673,15 @@ struct RolloutPtrs {
     double *reward;
     uint8_t *terminated, *truncated;
 };
+}  // namespace mi_internal
+// The classic-control kernels behind plain launch functions (defined in the MI_CLASSIC_TU unit, called from the other): what mi_step / mi_reset /
+// mi_rollout do for the kinds CARTPOLE ... MOUNTAIN_CAR_CONTINUOUS once the arguments are validated and the buffers chosen.
+namespace mi_classic {
+int step(mi_vecenv *v, const mi_internal::StepPtrs &p, int act_kind);                                           // launch_step<E> of the env's kind
+int reset(mi_vecenv *v, const uint8_t *device_mask, int has_bounds, double b0, double b1, float *device_obs);  // reset_kernel<E>
+int rollout(mi_vecenv *v, const mi_internal::RolloutPtrs &p, const mi_internal::ActionStream &as, int T, bool sample, int actions_in_kind);
+}  // namespace mi_classic
+namespace {
 
 // FULL: every trajectory output is materialised -- the per-store null checks (five taken branches per step for a
 // wavefront that runs alone on its SIMD) disappear from the loop.
@@ -707,6 +742,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
 }
 
 
+#ifndef MI_CLASSIC_TU
 // ---------------------------------------------------------------------------------------------------------
 // MuJoCo-family kernels (mjx_kernels.h): same vectoriser state machine, float64 observations, float32 action rows
 // ---------------------------------------------------------------------------------------------------------
@@ -1248,33 +1284,40 @@ __global__ void seed_sequence_kernel(DevEnv d, uint64_t first_seed, const uint8_
     if (d.tab_fickle_rows) d.state[(size_t)2 * d.N + i] = 0.0;  // fickle Taxi: likewise
 }
 
+#endif  // !MI_CLASSIC_TU
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, const char *detail = "") {
-    snprintf(g_err, sizeof g_err, fmt, detail);
-    return code;
-}
-
 }  // namespace
 // shared with the other translation units of the library (hidden visibility): sets mi_last_error(), returns `code`
 namespace mi_internal {
+#ifndef MI_CLASSIC_TU
+thread_local char g_err[512] = "";
 int set_error(int code, const char *msg) {
     snprintf(g_err, sizeof g_err, "%s", msg);
     return code;
 }
+#else
+int set_error(int code, const char *msg);
+#endif
 }  // namespace mi_internal
 namespace {
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    char msg[512];
+    snprintf(msg, sizeof msg, fmt, detail);
+    return mi_internal::set_error(code, msg);
+}
 
 #define HIP_TRY(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess) {                                                                           \
-            snprintf(g_err, sizeof g_err, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return (int)MI_ERR_HIP;                                                                       \
+            char msg_[512];                                                                               \
+            snprintf(msg_, sizeof msg_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return mi_internal::set_error((int)MI_ERR_HIP, msg_);                                          \
         }                                                                                                 \
     } while (0)
 
@@ -1375,6 +1418,7 @@ int dispatch_kind_act(int kind, bool fast_math, int act_kind, F &&f) {
     return fast_math ? dispatch_kind_act_math<FastMath>(kind, act_kind, f) : dispatch_kind_act_math<ExactMath>(kind, act_kind, f);
 }
 
+#ifndef MI_CLASSIC_TU
 typedef mjx::MjEnv<mjx::HalfCheetahModel, mjx::kHalfCheetah> HalfCheetahEnv;
 typedef mjx::MjEnv<mjx::AntModel, mjx::kAnt> AntEnv;
 typedef mjx::MjEnv<mjx::HumanoidModel, mjx::kHumanoid> HumanoidEnv;
@@ -1386,8 +1430,10 @@ typedef mjx::MjEnv<mjx::ReacherModel, mjx::kReacher> ReacherEnv;
 typedef mjx::MjEnv<mjx::HumanoidStandupModel, mjx::kHumanoidStandup> HumanoidStandupEnv;
 typedef mjx::MjEnv<mjx::SwimmerModel, mjx::kSwimmer> SwimmerEnv;
 typedef mjx::MjEnv<mjx::PusherModel, mjx::kPusher> PusherEnv;
+#endif
 bool is_mj(int kind) { return (kind >= kClassicKinds && kind <= MI_ENV_HUMANOID) || (kind >= MI_ENV_HOPPER && kind <= MI_ENV_INVERTED_DOUBLE_PENDULUM) || kind == MI_ENV_REACHER || kind == MI_ENV_HUMANOID_STANDUP || kind == MI_ENV_SWIMMER || kind == MI_ENV_PUSHER; }
 bool is_tab(int kind) { return kind == MI_ENV_TABULAR || kind == MI_ENV_BLACKJACK; }  // Blackjack rides on the tabular kernels
+#ifndef MI_CLASSIC_TU
 template <class F>
 int dispatch_mj(int kind, F &&f) {
     switch (kind) {
@@ -1419,6 +1465,8 @@ int check_device_error(mi_vecenv *v) {
     HIP_TRY(hipStreamSynchronize(v->stream));
     return raise_device_error(v);
 }
+
+#endif  // !MI_CLASSIC_TU
 
 // the statistics handles' current buffer sets into the device view (they swap after every step that updated them)
 void epilogue_bind(mi_vecenv *v) {
@@ -1495,6 +1543,29 @@ int launch_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, i
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
+
+}  // namespace
+
+#ifdef MI_CLASSIC_TU
+// ---- the launchers the other translation unit calls (this unit is compiled with the max-ILP scheduler, see the head of the file) ----------------
+namespace mi_classic {
+int step(mi_vecenv *v, const StepPtrs &p, int act_kind) {
+    return dispatch_kind_act(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, act_kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
+}
+int reset(mi_vecenv *v, const uint8_t *dm, int has_bounds, double b0, double b1, float *dobs) {
+    return dispatch_kind(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, [&](auto env) -> int {
+        using E = decltype(env);
+        hipLaunchKernelGGL((reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, has_bounds, b0, b1, dobs);
+        HIP_TRY(hipGetLastError());
+        return (int)MI_OK;
+    });
+}
+int rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample, int in_kind) {
+    return dispatch_kind_act(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, in_kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
+}
+}  // namespace mi_classic
+#else
+namespace {
 
 // One vector step of a MuJoCo env: [cooperative physics ->] per-lane glue (autoreset state machine, reward, observation, stats)
 template <class E>
@@ -1580,7 +1651,7 @@ int set_device(const mi_vecenv *v) {
 extern "C" {
 
 int mi_abi_version(void) { return MI355ENV_ABI_VERSION; }
-const char *mi_last_error(void) { return g_err; }
+const char *mi_last_error(void) { return mi_internal::g_err; }
 
 int mi_device_count(void) {
     int n = 0;
@@ -1883,12 +1954,7 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
         hipLaunchKernelGGL((mj_reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, (double *)dobs, v->lay.obs_dim);
         HIP_TRY(hipGetLastError());
         return (int)MI_OK;
-    }) : dispatch_kind(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, [&](auto env) -> int {
-        using E = decltype(env);
-        hipLaunchKernelGGL((reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, has_bounds, b0, b1, (float *)dobs);
-        HIP_TRY(hipGetLastError());
-        return (int)MI_OK;
-    });
+    }) : mi_classic::reset(v, dm, has_bounds, b0, b1, (float *)dobs);
     if (rc) return rc;
     v->was_reset = true;
     if (loc == MI_HOST) {
@@ -1982,7 +2048,7 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
         if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int { return launch_mj_step<decltype(env)>(v, mp); });
     } else {
-        rc = dispatch_kind_act(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, act_kind, [&](auto env) -> int { return launch_step<decltype(env)>(v, p); });
+        rc = mi_classic::step(v, p, act_kind);
     }
     if (rc) return rc;
     if (loc == MI_HOST) {
@@ -2142,7 +2208,7 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
             return (int)MI_OK;
         });
     } else {
-        rc = dispatch_kind_act(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, in_kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
+        rc = mi_classic::rollout(v, p, as, T, sample, in_kind);
     }
     if (rc) return rc;
     if (sample) {  // the host copy of the generator moves past the T*N draws the kernel consumes
@@ -2224,3 +2290,4 @@ int mi_set_state(mi_vecenv *v, const double *state, const int32_t *elapsed, cons
 
 }  // extern "C"
 #pragma GCC visibility pop
+#endif  // MI_CLASSIC_TU

@@ -1,6 +1,6 @@
 """-m gpu: the shipped cooperative physics kernels (physics16.hip / physics32.hip, compiled with LLVM's iterative GCN scheduler and the
-MachineLICM settings of gymnasium_amd/csrc/build.py TU_FLAGS) against the SAME sources under hipcc's defaults (libmi355env_ref.so, built next
-to the product by __graft_entry__.build()).
+MachineLICM settings of gymnasium_amd/csrc/build.py TU_FLAGS) -- and, since round 4, the classic-control unit (classic.hip, max-ILP scheduler) --
+against the SAME sources under hipcc's defaults (libmi355env_ref.so, built next to the product by __graft_entry__.build()).
 
 Why this is a test: the iterative schedulers were measured to MISCOMPILE the 16-lane instantiation when the RK4 stage update is inlined
 (every environment differs after one sub-step); keeping `rk4_stage` out of line makes all instantiations
@@ -55,10 +55,14 @@ def run_build(lib, env_id, kw, path):
                                            ("Humanoid-v5", "Newton"), ("HumanoidStandup-v5", "Newton"),
                                            # round 4: episodes that END inside the window -- the kernel's early exit for a resetting sub-environment
                                            # (half of a Humanoid wavefront retires while the other half keeps running) and the reset glue
-                                           ("Humanoid-v5", "resets"), ("Ant-v5", "resets"), ("Walker2d-v5", "resets")])
+                                           ("Humanoid-v5", "resets"), ("Ant-v5", "resets"), ("Walker2d-v5", "resets"),
+                                           # round 4: the classic-control unit (classic.hip, max-ILP scheduler) against its default-scheduler twin
+                                           ("CartPole-v1", "classic"), ("Pendulum-v1", "classic"), ("Acrobot-v1", "classic"), ("MountainCarContinuous-v0", "classic")])
 def test_iterative_scheduler_build_is_bit_identical_to_default_scheduler_build(env_id, solver, tmp_path):
     assert os.path.exists(REF), f"{REF} missing: run __graft_entry__.build() (python -m gymnasium_amd.csrc.build --ref)"
     kw = {} if env_id in ("HalfCheetah-v5", "HumanoidStandup-v5") else dict(terminate_when_unhealthy=False)  # keep every env stepping real physics
+    if solver == "classic":
+        kw, solver = {}, None
     if solver == "resets":
         kw, solver = ({"max_episode_steps": 9} if env_id == "Ant-v5" else {}), None  # Humanoid / Walker2d fall within ~20 steps; the Ant is cut by the TimeLimit
     if solver:
