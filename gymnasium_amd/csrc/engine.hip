@@ -707,6 +707,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
         ResetQueue<E> q;
         q.have = false;
         q.rng = load_rng(d, i);
+        // (per-kind unroll factor: 2 for Acrobot -- its long loop body schedules better as two steps, +4.6 %; 1 = none for the others, where 2 and 4
+        //  measured +-0.1 %; Acrobot x4: -6 %.  profiles/r04_maxilp_classic.txt)
+#pragma unroll E::ROLLOUT_UNROLL
         for (int t = 0; t < T; t++) {
             if ((t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
             typename E::Act a;

@@ -182,6 +182,7 @@ struct CartPoleT {
     static constexpr int S = 4, OBS = 4, N_ACTIONS = 2;
     static constexpr bool DISCRETE = true;
     static constexpr int ACT_KIND = MI_I64;
+    static constexpr int ROLLOUT_UNROLL = 1;  // engine.hip rollout_kernel: steps per unrolled loop body
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.05, b1 = 0.05; }
@@ -242,6 +243,7 @@ struct PendulumT {
     static constexpr bool USES_POW = true, USES_POWF = ACT_KIND == MI_F32;
     static constexpr int S = 2, OBS = 3;
     static constexpr bool DISCRETE = false;
+    static constexpr int ROLLOUT_UNROLL = 1;
     typedef typename AK::T Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
@@ -318,6 +320,7 @@ struct AcrobotT {
     static constexpr int S = 4, OBS = 6, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
     static constexpr int ACT_KIND = MI_I64;
+    static constexpr int ROLLOUT_UNROLL = 2;  // engine.hip rollout_kernel: steps per unrolled loop body
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.1, b1 = 0.1; }
@@ -421,6 +424,7 @@ struct MountainCarT {
     static constexpr int S = 2, OBS = 2, N_ACTIONS = 3;
     static constexpr bool DISCRETE = true;
     static constexpr int ACT_KIND = MI_I64;
+    static constexpr int ROLLOUT_UNROLL = 1;  // engine.hip rollout_kernel: steps per unrolled loop body
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
@@ -467,6 +471,7 @@ struct MountainCarContinuousT {
     static constexpr bool USES_POW = ACT_KIND != MI_F32, USES_POWF = false;  // math.pow(action[0], 2): exact for a float32 value, libm's rounding for a float64 one
     static constexpr int S = 2, OBS = 2;
     static constexpr bool DISCRETE = false;
+    static constexpr int ROLLOUT_UNROLL = 1;
     typedef typename AK::T Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
