@@ -22,11 +22,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, extra):
+def _run(world, extra, num_envs=256, inner=8):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MI355ENV_CPU_WORKERS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", str(world),
-           "--num-envs", "256", "--inner", "8", "--cpu-budget", "0.5", *extra]
+           "--num-envs", str(num_envs), "--inner", str(inner), "--cpu-budget", "0.5", *extra]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -58,6 +58,17 @@ def test_driver_style_explicit_steps_takes_the_separate_sustained_loop():
     assert r["steps"] == 6 and r["warmup"] == 2 and r["n_gpus"] == 2
     assert r["sustained"]["launches"] > 6 and r["sustained"]["seconds"] >= 0.05
     assert r["episodes"] > 0 and 9.0 < r["mean_episode_return"] < 60.0  # CartPole under the random policy: ~22 steps per episode
+
+
+def test_baseline_config4_command_line_humanoid_sharded():
+    """BASELINE.json configs[4] -- Humanoid-v5 sharded over the ranks -- with the driver's flags (`--env Humanoid-v5 --num-envs N --inner 4`): the MuJoCo
+    branch of the line (algorithmic bytes of a cooperative robot, `bound: "valu"`, the CPU leg's bounded sample) on two gloo ranks."""
+    r = _run(2, ["--env", "Humanoid-v5", "--steps", "2", "--warmup", "1", "--sustained", "0"], num_envs=6, inner=2)
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["config"]["env"] == "Humanoid-v5" and r["config"]["num_envs_per_gpu"] == 6
+    lanes = 2 * 6 * 2 * r["steps"]
+    assert 0 < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= lanes
+    assert r["roofline"]["bound"] == "valu" and r["roofline"]["kernel"] == "mj_physics_kernel" and r["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert r["cpu_baseline"]["value"] > 0 and "Humanoid-v5" in r["cpu_baseline"]["sample"]
 
 
 def test_bench_py_cannot_be_pointed_at_the_checker():
