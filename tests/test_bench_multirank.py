@@ -66,7 +66,7 @@ def test_baseline_config4_command_line_humanoid_sharded():
     r = _run(2, ["--env", "Humanoid-v5", "--steps", "2", "--warmup", "1", "--sustained", "0"], num_envs=6, inner=2)
     assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["config"]["env"] == "Humanoid-v5" and r["config"]["num_envs_per_gpu"] == 6
     lanes = 2 * 6 * 2 * r["steps"]
-    assert 0 < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= lanes
+    assert 0 < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= lanes * (1 + 1e-9)  # (no episode ends in 4 steps: exactly `lanes` env-steps, up to rounding)
     assert r["roofline"]["bound"] == "valu" and r["roofline"]["kernel"] == "mj_physics_kernel" and r["roofline"]["algorithmic_bytes_per_launch"] > 0
     assert r["cpu_baseline"]["value"] > 0 and "Humanoid-v5" in r["cpu_baseline"]["sample"]
 
