@@ -525,21 +525,9 @@ def main(argv=None, harness=None):
     from gymnasium_amd import distributed as gd
 
     red = gd.reduce_statistics(st, elapsed_s=elapsed, device=dev)  # the only collective: a few dozen bytes over RCCL/xGMI
-    # What the collective itself proves about the job (n_gpus below is NOT read from the environment): an all-reduce of ones counts the ranks
-    # that took part, and every rank contributes the identity of the device it ran on -- N distinct UUIDs = N different GPUs.
-    ranks_seen, devices = 1, None
-    if gpu:
-        props = torch.cuda.get_device_properties(local_rank)
-        devices = [{"rank": rank, "local_rank": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}]
-    else:
-        devices = [{"rank": rank, "local_rank": local_rank, "name": "cpu (dry run)", "uuid": f"cpu-{rank}"}]
-    if world > 1:
-        ones = torch.ones(1, dtype=torch.int64, device=dev)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        ranks_seen = int(ones.item())
-        gathered = [None] * world
-        dist.all_gather_object(gathered, devices[0])
-        devices = gathered
+    # What the collective itself proves about the job (n_gpus below is NOT read from the environment): gymnasium_amd/distributed.py census()
+    cen = gd.census(rank, local_rank, device=dev)
+    ranks_seen, devices = cen["ranks"], cen["devices"]
     elapsed = red["elapsed_s"]
     env_steps, episodes, return_sum = float(red["env_steps"]), float(red["episodes"]), float(red["return_sum"])
     single = rank == 0 and world == 1 and gpu
@@ -550,7 +538,7 @@ def main(argv=None, harness=None):
         result = {
             "metric": "env-steps/sec at num_envs=65536 (1/2/4/8 MI355X) vs CPU AsyncVectorEnv",
             "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": ranks_seen, "steps": K, "warmup": W,
-            "rccl_ranks": ranks_seen, "world_size_env": world, "devices": devices, "distinct_devices": len({d["uuid"] for d in devices}),
+            "rccl_ranks": ranks_seen, "world_size_env": world, "devices": devices, "distinct_devices": cen["distinct_devices"],
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "clock_spinup": {"seconds": args.spinup, "launches": spin_launches, "note": "untimed, before the warmup launches"},
             **({} if gpu else {"engine": harness.label}),

@@ -51,3 +51,27 @@ def reduce_statistics(stats: dict, elapsed_s: float | None = None, device=None) 
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         out["elapsed_s"] = float(e[0])
     return out
+
+
+def census(rank: int, local_rank: int, device=None, force_collective: bool = False) -> dict:
+    """What the collective itself proves about the job: ``ranks`` = an all-reduce of ones (the ranks that really took part -- not WORLD_SIZE
+    read from the environment) and ``devices`` = every rank's own device identity (name, UUID, PCI bus id), gathered: N distinct UUIDs = N
+    different GPUs.  Without a process group (or at world size 1, unless ``force_collective``) nothing is communicated."""
+    import torch
+    import torch.distributed as dist
+
+    on_gpu = device is not None and getattr(device, "type", "cpu") == "cuda"
+    if on_gpu:
+        props = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "local_rank": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    else:
+        me = {"rank": rank, "local_rank": local_rank, "name": "cpu (dry run)", "uuid": f"cpu-{rank}"}
+    ranks, devices = 1, [me]
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective):
+        ones = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks = int(ones.item())
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, me)
+        devices = gathered
+    return {"ranks": ranks, "devices": devices, "distinct_devices": len({d["uuid"] for d in devices})}

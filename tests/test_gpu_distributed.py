@@ -41,6 +41,9 @@ assert torch.equal(t, before) and float(e[0]) == 1.25
 red = gd.reduce_statistics(st, elapsed_s=0.5, device=dev)
 assert red["env_steps"] == st["env_steps"] and red["elapsed_s"] == 0.5
 assert st["env_steps"] + st["reset_steps"] == 4096 * 32
+# the rank / device census of the bench line, with its collectives forced at world size 1: all-reduce of ones + all_gather_object on RCCL
+cen = gd.census(0, 0, device=dev, force_collective=True)
+assert cen["ranks"] == 1 and cen["distinct_devices"] == 1 and cen["devices"][0]["rank"] == 0 and len(cen["devices"][0]["uuid"]) > 8, cen
 env.close()
 dist.destroy_process_group()
 print("RCCL_OK")
