@@ -169,3 +169,13 @@ def benchmark_vector_step(env, target_duration=5.0, seed=0):
             end = time.monotonic()
             break
     return steps / (end - start)
+
+
+if __name__ == "__main__":  # python -m oracle.async_baseline <num_envs> <seconds>: prints env-steps/s (bench.py runs it in a clean process: no HIP context to fork)
+    import sys
+
+    _env = AsyncCartPoleVectorEnv(int(sys.argv[1]))
+    try:
+        print(benchmark_vector_step(_env, target_duration=float(sys.argv[2]), seed=0))
+    finally:
+        _env.close()
