@@ -586,6 +586,24 @@ def main(argv=None, harness=None):
         result["api_step_device"] = {"value": N * reps / dt, "unit": "vector-env lanes/s (incl. autoreset lanes)",
                                      "us_per_step_wall": dt / reps * 1e6, "us_per_step_gpu": step_kernel_s * 1e6,
                                      "roofline_frac": (STEP_BYTES[args.env] * N / step_kernel_s / 1e9 / HBM_PEAK_GBS) if args.env in STEP_BYTES else None}
+        # the same steps as ONE HIP graph (HipVectorEnv.capture_steps): what is left when the host is out of the loop
+        G_STEPS, g_reps = 32, 30
+        graphed = env.capture_steps(actions=a_dev, steps=G_STEPS)
+        for _ in range(3):
+            graphed.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(g_reps):
+            graphed.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        dtg = time.perf_counter() - t0
+        result["api_step_graph"] = {"value": N * G_STEPS * g_reps / dtg, "unit": "vector-env lanes/s (incl. autoreset lanes)", "steps_per_graph": G_STEPS,
+                                    "us_per_step_wall": dtg / (G_STEPS * g_reps) * 1e6, "us_per_step_gpu": e0.elapsed_time(e1) * 1e3 / (G_STEPS * g_reps),
+                                    "roofline_frac": (STEP_BYTES[args.env] * N / (dtg / (G_STEPS * g_reps)) / 1e9 / HBM_PEAK_GBS) if args.env in STEP_BYTES else None,
+                                    "what": f"{G_STEPS} step() calls captured into one hipGraph, replayed {g_reps} times"}
+        del graphed
         env_np = gymnasium_amd.make_vec(args.env, num_envs=N, device=local_rank, copy=False)
         env_np.reset(seed=0)
         env_np.action_space.seed(0)

@@ -262,6 +262,23 @@ class Engine:
         io.episode_return, io.episode_length, io.info = _ptr(episode_return), _ptr(episode_length), _ptr(info)
         self.lib.check(self.lib.step(self.handle, C.byref(io), loc))
 
+    def bind_step(self, obs, reward, terminated, truncated, final_obs=None, episode_return=None, episode_length=None, loc=MI_HOST, info=None,
+                  final_info=None):
+        """Fix the output addresses of the step_bound() calls that follow: a vector env steps into the same buffers thousands of times, and
+        at 65 536 CartPoles filling eleven struct fields from Python costs more than the kernel runs.  The caller keeps the buffers alive."""
+        io = MiStepIO()
+        io.obs, io.reward, io.terminated, io.truncated, io.final_obs = _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated), _ptr(final_obs)
+        io.episode_return, io.episode_length, io.info, io.final_info = _ptr(episode_return), _ptr(episode_length), _ptr(info), _ptr(final_info)
+        self._bound = (io, C.byref(io), int(loc), self.lib.step, self.handle)
+
+    def step_bound(self, actions: int, actions_dtype: int):
+        """mi_step into the buffers of bind_step(); `actions` is a raw address."""
+        io, ref, loc, fn, handle = self._bound
+        io.actions, io.actions_dtype = actions, actions_dtype
+        rc = fn(handle, ref, loc)
+        if rc:
+            self.lib.check(rc)
+
     def _fill_io(self, actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info, actions_dtype=MI_F32):
         io = self._step_io
         io.actions_dtype = int(actions_dtype)

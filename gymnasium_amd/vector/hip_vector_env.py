@@ -205,7 +205,7 @@ class HipVectorEnv(VectorEnv):
         """Episodes finished so far (RecordEpisodeStatistics.episode_count); with device-resident infos the count lives on the device and
         reading it synchronises."""
         dev = self.__dict__.get("_episode_count_t")
-        return self._episode_count + (int(dev.item()) if dev is not None else 0)
+        return getattr(self, "_episode_count", 0) + (int(dev.item()) if dev is not None else 0)
 
     def set_output(self, output: str):
         """Switch between NumPy batches ("numpy": the engine's pinned host block, one H2D + one D2H per step) and device tensors ("torch": the engine writes
@@ -262,6 +262,11 @@ class HipVectorEnv(VectorEnv):
                 self._episode_start_t = torch.zeros((N,), dtype=torch.float64, device=dev)
                 self._prev_dones_t = torch.zeros((N,), dtype=torch.bool, device=dev)
                 self._episode_count_t = torch.zeros((), dtype=torch.int64, device=dev)
+            # the addresses step() writes to never change between two allocations: hand them to the binding once (Engine.bind_step)
+            eng.bind_step(self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc), self._p(self._final), self._p(self._ep_r),
+                          self._p(self._ep_l), self._loc, self._p(self._info), self._p(self._final_info))
+            self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if self._engine_factory is None else None
+            self._stream_bound = None
         else:
             self._obs_shape = (N,) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (N, eng.obs_dim)
             same = self.autoreset_mode == AutoresetMode.SAME_STEP
@@ -293,8 +298,13 @@ class HipVectorEnv(VectorEnv):
         return buf.clone() if self.output == "torch" else buf.copy()
 
     def _bind_stream(self):
+        """The engine enqueues on torch's CURRENT stream of its device (asked at every step; the engine is told only when it changed)."""
         if self.output == "torch" and self._engine_factory is None:
-            self._engine.set_stream(self._torch.cuda.current_stream(self._tdev).cuda_stream)
+            raw = self._raw_stream
+            st = raw(self._device_index) if raw is not None else self._torch.cuda.current_stream(self._tdev).cuda_stream
+            if st != self._stream_bound:
+                self._engine.set_stream(st)
+                self._stream_bound = st
 
     # -- seeding ---------------------------------------------------------------------------------------
     def _seed_engines(self, seed, mask):
@@ -381,13 +391,14 @@ class HipVectorEnv(VectorEnv):
                 self._prev_dones[mask.view(np.bool_)] = False
         if self._device_infos:
             keep = None if mask is None else ~dmask.view(self._torch.bool)
-            self._was_done_t = self._was_done_t & keep if keep is not None else self._torch.zeros_like(self._was_done_t)
+            # (every update of the device-side bookkeeping is IN PLACE: a HIP graph captured around step() keeps reading and writing these tensors)
+            self._was_done_t.logical_and_(keep) if keep is not None else self._was_done_t.zero_()
             if self.record_episode_statistics:
                 if keep is None:
                     self._episode_start_t.fill_(now), self._prev_dones_t.zero_()
                 else:
-                    self._episode_start_t = self._torch.where(keep, self._episode_start_t, now)
-                    self._prev_dones_t = self._prev_dones_t & keep
+                    self._episode_start_t.copy_(self._torch.where(keep, self._episode_start_t, now))
+                    self._prev_dones_t.logical_and_(keep)
         return self._out(self._obs), self._reset_infos(mask)
 
     def _reset_infos(self, mask) -> dict:
@@ -444,11 +455,13 @@ class HipVectorEnv(VectorEnv):
         self._bind_stream()
         self._sync_epilogue()
         try:
-            self._engine.step(aptr, self._p(self._obs), self._p(self._rew), self._p(self._term), self._p(self._trunc),
-                              self._p(self._final), self._p(self._ep_r), self._p(self._ep_l), self._loc, self._p(self._info),
-                              self._p(self._final_info), actions_dtype=adt)
-            if self.strict_actions and self.output == "torch":
-                self._engine.synchronize()  # raises the device error word of this very step
+            if self.output == "torch":
+                self._engine.step_bound(aptr, adt)
+                if self.strict_actions:
+                    self._engine.synchronize()  # raises the device error word of this very step
+            else:
+                self._engine.step(aptr, self._obs, self._rew, self._term, self._trunc, self._final, self._ep_r, self._ep_l, self._loc, self._info,
+                                  self._final_info, actions_dtype=adt)
         except _native.NativeError as e:
             if e.code == -1:  # MI_ERR_INVALID_ARGUMENT: action outside the space (cartpole.py:165-167 asserts)
                 raise AssertionError(e.message) from e
@@ -573,18 +586,18 @@ class HipVectorEnv(VectorEnv):
             infos["final_info"], infos["_final_info"] = finfo, dones
         # (private copies: `dones` itself is handed to the caller as the `_episode` / `_final_obs` / `_final_info` masks, and an in-place edit of
         # those must not reach the next step's autoreset bookkeeping -- the NumPy path returns copies as well)
-        self._was_done_t = dones.clone() if not same_step else t.zeros_like(dones)
+        self._was_done_t.copy_(dones) if not same_step else self._was_done_t.zero_()
         if self.record_episode_statistics:
             now = time.perf_counter()
             if not same_step:
-                self._episode_start_t = t.where(self._prev_dones_t, now, self._episode_start_t)
-            self._prev_dones_t = dones.clone()
+                self._episode_start_t.copy_(t.where(self._prev_dones_t, now, self._episode_start_t))
+            self._prev_dones_t.copy_(dones)
             infos["episode"] = {"r": self._out(self._ep_r), "l": self._ep_l.to(t.int64),
                                 "t": t.where(dones, t.round((now - self._episode_start_t) * 1e6) / 1e6, 0.0)}
             infos["_episode"] = dones
-            self._episode_count_t = self._episode_count_t + dones.sum()
+            self._episode_count_t.add_(dones.sum())
             if same_step:
-                self._episode_start_t = t.where(dones, now, self._episode_start_t)
+                self._episode_start_t.copy_(t.where(dones, now, self._episode_start_t))
         return infos
 
     def _build_infos(self) -> dict:
@@ -688,10 +701,41 @@ class HipVectorEnv(VectorEnv):
         self._obs.copy_(obs[-1]); self._rew.copy_(rew[-1]); self._term.copy_(term[-1]); self._trunc.copy_(trunc[-1])
         if self.autoreset_mode == AutoresetMode.NEXT_STEP:  # the sub-envs that finished in the last step reset in the next one
             if self._device_infos:
-                self._was_done_t = term[-1] | trunc[-1]
+                self._was_done_t.copy_(term[-1] | trunc[-1])
             else:
                 self._was_done = (term[-1] | trunc[-1]).cpu().numpy()
         return out
+
+    # -- HIP graphs ------------------------------------------------------------------------------------
+    def capture_steps(self, actions=None, steps: int = 1, policy=None):
+        """Capture ``steps`` consecutive ``step()`` calls -- and, with ``policy``, the policy between them -- into ONE HIP graph
+        (``torch.cuda.CUDAGraph``, which on ROCm is a hipGraph) and return a :class:`GraphedSteps` whose ``replay()`` runs them with a
+        single launch.  At 65 536 CartPoles a step kernel runs ~3 us and its launch from Python costs more than that: the per-step API is
+        launch-bound, and a replayed graph takes the host out of the loop.
+
+        ``actions``: a device tensor the captured steps READ at replay time (write the next actions into it with ``copy_`` before
+        ``replay()``); or ``policy``: a callable ``obs -> actions`` of torch ops, captured with the steps (its first input is the current
+        observation buffer).  Capturing executes nothing: the sub-environments advance only when the graph is replayed.  What a replay does not
+        do: the host-side checks of step() (an invalid action raises at the next eager call or ``synchronize()``), and the wall-clock ``t`` of
+        the episode statistics (a host value, frozen at capture).  Requires output="torch" and one eager step()/reset() before (kernels load
+        on first use, which a capture must not trigger).  The reference has no counterpart: its step is a Python loop (sync_vector_env.py:253-323)."""
+        self._check_open()
+        self._check_not_pending("capture_steps")
+        if self.output != "torch" or self._engine_factory is not None:
+            raise error.Error("capture_steps() needs device tensors on a GPU: create the env with output='torch'")
+        if not self._has_reset:
+            raise AssertionError("Call reset before using capture_steps.")
+        if self.strict_actions:
+            raise error.Error("strict_actions=True synchronises after every step, which a graph capture cannot contain")
+        if (self.INFO_KEYS or self.autoreset_mode == AutoresetMode.SAME_STEP or self.record_episode_statistics) and not self._device_infos:
+            raise error.Error("this environment assembles its infos on the host: its step() cannot be captured")
+        st = self.__dict__.get("_fused")
+        if st is not None and st["chain"]:
+            raise error.Error("vector wrappers are fused into this env's step kernel (their running statistics double-buffer on the host side): "
+                              "its step() cannot be captured")
+        if (actions is None) == (policy is None):
+            raise ValueError("capture_steps() takes either `actions` (a device tensor read at replay time) or `policy`")
+        return GraphedSteps(self, actions, int(steps), policy)
 
     # -- bookkeeping -----------------------------------------------------------------------------------
     def statistics(self) -> dict:
@@ -711,7 +755,7 @@ class HipVectorEnv(VectorEnv):
         if flags is not None:  # keep the host mirror of the pending-autoreset set in step with the device flags
             self._was_done = (np.asarray(flags, dtype=np.uint8) & _native.FLAG_NEEDS_RESET) != 0
             if self._device_infos:
-                self._was_done_t = self._torch.from_numpy(self._was_done.copy()).to(self._tdev)
+                self._was_done_t.copy_(self._torch.from_numpy(self._was_done.copy()))
 
     def get_rng_state(self) -> np.ndarray:
         """Per-env PCG64 words [N, 4] = {state_hi, state_lo, inc_hi, inc_lo}."""
@@ -749,6 +793,48 @@ class HipVectorEnv(VectorEnv):
                 self._pinned = False
             eng.close()
             self._engine = None
+
+
+class GraphedSteps:
+    """``steps`` step() calls of a :class:`HipVectorEnv` (plus the policy between them) as one HIP graph; see ``HipVectorEnv.capture_steps``.
+
+    ``results``: the (obs, rewards, terminations, truncations, infos) tuple of every captured step -- static device tensors that each
+    ``replay()`` overwrites (with ``copy=False`` the observation / reward / flag tensors of all steps are the env's own buffers, i.e. they hold
+    the LAST step's values; with ``copy=True`` every step has its own)."""
+
+    def __init__(self, env: "HipVectorEnv", actions, steps: int, policy):
+        t = env._torch
+        if steps < 1:
+            raise ValueError("steps must be >= 1")
+        if actions is not None:
+            keep, _, _ = env._coerce_actions(actions)
+            if keep is not actions:
+                raise ValueError("the captured steps read `actions` in place at replay time: pass a contiguous tensor on the env's device with "
+                                 "the action space's dtype (int64, or float32 / float64 rows for Box spaces)")
+        self.env, self.steps, self.actions = env, steps, actions
+        self.graph = t.cuda.CUDAGraph()
+        self.results = []
+        env.synchronize()
+        try:
+            with t.cuda.graph(self.graph):
+                obs = env._obs
+                for _ in range(steps):
+                    out = env.step(actions if policy is None else policy(obs))
+                    obs = out[0]
+                    self.results.append(out)
+        finally:
+            env._stream_bound = None  # (the capture bound the engine to the capture stream)
+            env._bind_stream()
+
+    def replay(self):
+        """Run the captured steps (one graph launch on torch's current stream, asynchronous like step() with device tensors); returns the
+        last step's tuple."""
+        env = self.env
+        env._check_open()
+        env._check_not_pending("replay")
+        env._bind_stream()  # statistics() / synchronize() wait on the engine's stream: keep it the one the replay runs on
+        self.graph.replay()
+        return self.results[-1]
 
 
 def _resolve_device(device) -> int:

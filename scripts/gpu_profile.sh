@@ -11,7 +11,9 @@ export TMPDIR=/tmp
 cd /tmp
 # PROF_STEPS=default: bench.py's own default timed region (~1 s), so that the kernel trace's average duration is the one of the bench line
 if [ "${PROF_STEPS:-20}" = default ]; then STEPS=""; else STEPS="--steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-3}"; fi
-CMD="python $ROOT/bench.py $STEPS --no-api --no-cpu-baseline $*"
+# PROF_API=1: keep the per-launch step() API section of bench.py in the profiled command (step_kernel durations)
+if [ "${PROF_API:-0}" = 1 ]; then NOAPI=""; else NOAPI="--no-api"; fi
+CMD="python $ROOT/bench.py $STEPS $NOAPI --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -- $CMD > "$OUT/${TAG}_stats.log" 2>&1
 PMC=()
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -25,4 +27,4 @@ cd "$ROOT"
 python scripts/rocpd_summary.py --stats "$OUT/${TAG}_stats" --pmc "${PMC[@]}" --cmd "$CMD" -o "$OUT/${TAG}.txt" > /dev/null
 # keep the merge-back small: the raw databases are not needed once summarised
 rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_FETCH_SIZE" "$OUT/${TAG}_WRITE_SIZE" "$OUT/${TAG}_SQ" "$OUT/${TAG}_SQ2"
-tail -n +1 "$OUT/${TAG}.txt" | grep -i "rollout_kernel\|mj_" | head -40
+tail -n +1 "$OUT/${TAG}.txt" | grep -i "rollout_kernel\|mj_\|step_kernel" | head -40
