@@ -109,6 +109,41 @@ MI_DEV void load_lane(const DevEnv &d, int i, Lane<E> &L) {
     L.ep_ret = d.ep_ret[i], L.ep_len = d.ep_len[i];
     trig_invalidate(L.trig);
 }
+// step_kernel's form of load_lane + load_rng: the raw words are REQUESTED here and looked at only after the math tables are staged (arrive()),
+// held opaque in between -- the compiler otherwise starts on them at once (the first 128-bit multiply of the generator is speculated out of
+// the reset branch), i.e. waits for this trip to memory before it requests the tables: two trips in a row where one does.
+template <class T>
+MI_DEV void hold_opaque(T &x) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two VGPRs");
+    asm volatile("" : "+v"(x));
+}
+template <class E>
+struct LaneRequest {
+    double s[E::S], ep_ret;
+    uint32_t meta;
+    int32_t ep_len;
+    uint64_t g[4];
+    typename E::Act a;
+    MI_DEV void request(const DevEnv &d, const void *actions, int i, bool with_generator) {
+#pragma unroll
+        for (int k = 0; k < E::S; k++) s[k] = d.state[(size_t)k * d.N + i];
+        meta = d.meta[i], ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
+        a = static_cast<const typename E::Act *>(actions)[i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) g[k] = with_generator ? d.rng[(size_t)k * d.N + i] : 0;
+    }
+    MI_DEV void arrive(Lane<E> &L, Pcg64 &gen) {
+#pragma unroll
+        for (int k = 0; k < E::S; k++) hold_opaque(s[k]), L.s[k] = s[k];
+        hold_opaque(meta), hold_opaque(ep_ret), hold_opaque(ep_len), hold_opaque(a);
+#pragma unroll
+        for (int k = 0; k < 4; k++) hold_opaque(g[k]);
+        L.elapsed = meta & kElapsedMask, L.flags = meta >> kFlagShift;
+        L.ep_ret = ep_ret, L.ep_len = ep_len;
+        trig_invalidate(L.trig);
+        gen.state = make_u128(g[0], g[1]), gen.inc = make_u128(g[2], g[3]);
+    }
+};
 template <class E>
 MI_DEV void store_lane(const DevEnv &d, int i, const Lane<E> &L) {
 #pragma unroll
@@ -163,8 +198,8 @@ struct ResetQueue {
 constexpr int kRefillPeriod = 8;
 
 template <class E>
-MI_DEV void draw_reset_values(const DevEnv &d, int i, double u[E::NDRAWS]) {
-    Pcg64 rng = load_rng(d, i);
+MI_DEV void draw_reset_values(const DevEnv &d, int i, double u[E::NDRAWS], const Pcg64 *preloaded = nullptr) {
+    Pcg64 rng = preloaded ? *preloaded : load_rng(d, i);
 #pragma unroll
     for (int k = 0; k < E::NDRAWS; k++) u[k] = rng.next_double();
     store_rng_state(d, i, rng);
@@ -172,7 +207,7 @@ MI_DEV void draw_reset_values(const DevEnv &d, int i, double u[E::NDRAWS]) {
 
 // Reset of one lane from its own stream, with the reference's default bounds (autoreset: reset() has no options).
 template <class E>
-MI_DEV void lane_autoreset(const DevEnv &d, int i, Lane<E> &L, ResetQueue<E> *q) {
+MI_DEV void lane_autoreset(const DevEnv &d, int i, Lane<E> &L, ResetQueue<E> *q, const Pcg64 *preloaded = nullptr) {
     double u[E::NDRAWS];
     if (q) {
         if (!q->have) q->refill();  // rare: two episode ends within one refill period
@@ -180,7 +215,7 @@ MI_DEV void lane_autoreset(const DevEnv &d, int i, Lane<E> &L, ResetQueue<E> *q)
         for (int k = 0; k < E::NDRAWS; k++) u[k] = q->u[k];
         q->have = false;
     } else {
-        draw_reset_values<E>(d, i, u);
+        draw_reset_values<E>(d, i, u, preloaded);
     }
     double b0, b1;
     E::default_bounds(b0, b1);
@@ -201,13 +236,13 @@ struct StepOut {
 // One lockstep step of one sub-environment: sync_vector_env.py:277-329 + TimeLimit + RecordEpisodeStatistics.
 template <class E, int MODE>
 MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, StepOut<E> &o, LaneStats &st,
-                      ResetQueue<E> *q = nullptr) {
+                      ResetQueue<E> *q = nullptr, const Pcg64 *preloaded = nullptr) {
     bool te = false, tr = false;
     double rew = 0.0;
     o.has_final = false;
     if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
         // :279-284 the step after a finished episode resets, ignores the action, returns reward 0 / not done
-        lane_autoreset<E>(d, i, L, q);
+        lane_autoreset<E>(d, i, L, q, preloaded);
         st.reset_steps++;
     } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
         // :295 `assert not self._autoreset_envs[i]`: report through the sticky error word, leave the lane untouched
@@ -242,7 +277,7 @@ MI_DEV void lane_step(const DevEnv &d, int i, Lane<E> &L, typename E::Act a, Ste
         // :302-319 final_obs, then reset within the same step
         E::obs(L.s, L.flags, o.final_obs, L.trig);
         o.has_final = true;
-        lane_autoreset<E>(d, i, L, q);
+        lane_autoreset<E>(d, i, L, q, preloaded);
     }
     E::obs(L.s, L.flags, o.obs, L.trig);
     o.reward = rew, o.terminated = te, o.truncated = tr;
@@ -371,7 +406,24 @@ MI_DEV uint64_t wave_sum(uint64_t v) {
 
 // Per-workgroup totals: wavefront butterflies, 4 partials through LDS, one plain read-modify-write of the
 // workgroup's own slot (no atomics: 1024 same-address atomics would cost more than the whole step).
-MI_DEV void block_accumulate(const DevEnv &d, const LaneStats &st) {
+// The workgroup's previous totals as step_kernel loads them AHEAD (with the lane's state): the read-modify-write at the end of the kernel is
+// then a plain store, not one more dependent trip to memory in a kernel whose whole run time is a handful of such trips.
+struct BlockTotals {
+    uint64_t count;  // threads 0..3: blk_count[block][thread]
+    double ret;      // thread 64: blk_ret[block]
+    bool loaded;
+};
+MI_DEV BlockTotals block_totals_load(const DevEnv &d) {
+    BlockTotals t = {0ull, 0.0, true};
+    if (threadIdx.x < 4) t.count = d.blk_count[(size_t)blockIdx.x * 4 + threadIdx.x];
+    if (threadIdx.x == 64) {
+        uint32_t zero = 0;  // (an offset the compiler cannot see through: a VECTOR load that stays in flight -- the uniform address would make it an s_load, which the wavefront waits for on the spot)
+        hold_opaque(zero);
+        t.ret = d.blk_ret[(size_t)blockIdx.x + zero];
+    }
+    return t;
+}
+MI_DEV void block_accumulate(const DevEnv &d, const LaneStats &st, const BlockTotals &before = BlockTotals{0ull, 0.0, false}) {
     __shared__ uint64_t sh_c[4][kBlock / 64];
     __shared__ double sh_r[kBlock / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -385,12 +437,15 @@ MI_DEV void block_accumulate(const DevEnv &d, const LaneStats &st) {
         uint64_t t = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; w++) t += sh_c[threadIdx.x][w];
-        if (t) d.blk_count[(size_t)blockIdx.x * 4 + threadIdx.x] += t;
+        if (t) {
+            uint64_t *slot = &d.blk_count[(size_t)blockIdx.x * 4 + threadIdx.x];
+            *slot = (before.loaded ? before.count : *slot) + t;
+        }
     } else if (threadIdx.x == 64) {
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; w++) t += sh_r[w];
-        if (t != 0.0) d.blk_ret[blockIdx.x] += t;
+        if (t != 0.0) d.blk_ret[blockIdx.x] = (before.loaded ? before.ret : d.blk_ret[blockIdx.x]) + t;
     }
 }
 
@@ -606,15 +661,23 @@ namespace {
 
 template <class E, int MODE, bool EPI = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, EpiDev epi) {
-    tables_init<E>();
+    // One step is ~200 instructions per lane between trips to memory that take a microsecond each: everything the step may read -- the lane's
+    // state and action, its generator (consumed only by a reset, which some lane of a 64-CartPole wavefront needs on ~95 % of the steps) and the
+    // workgroup's running totals -- is requested BEFORE the math tables are staged into LDS, so that all of it is ONE trip, not four in a row.
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     StepOut<E> o;
+    LaneRequest<E> rq;
+    if (i < d.N) rq.request(d, io.actions, i, MODE != MI_AUTORESET_DISABLED);
+    BlockTotals before = block_totals_load(d);
+    tables_init<E>();
+    hold_opaque(before.count), hold_opaque(before.ret);
     if (i < d.N) {
         Lane<E> L;
-        load_lane<E>(d, i, L);
-        const typename E::Act a = static_cast<const typename E::Act *>(io.actions)[i];
-        lane_step<E, MODE>(d, i, L, a, o, st);
+        Pcg64 gen;
+        rq.arrive(L, gen);
+        const typename E::Act a = rq.a;
+        lane_step<E, MODE>(d, i, L, a, o, st, nullptr, MODE != MI_AUTORESET_DISABLED ? &gen : nullptr);
         store_lane<E>(d, i, L);
         if (io.obs) store_row<E::OBS>(io.obs + (size_t)i * E::OBS, o.obs);
         if (!EPI && io.reward) io.reward[i] = o.reward;
@@ -630,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, Epi
         epilogue_phase1<E>(epi, i, i < d.N, o.obs, r, i < d.N && o.terminated);
         if (i < d.N && io.reward) io.reward[i] = r;
     }
-    block_accumulate(d, st);
+    block_accumulate(d, st, before);
 }
 
 template <class E>
