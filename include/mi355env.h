@@ -226,7 +226,11 @@ void mi_destroy(mi_vecenv *env);
 int mi_get_layout(const mi_vecenv *env, mi_layout *out);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work.  NULL means the legacy
  * default stream (what torch.cuda.current_stream().cuda_stream is by default).  Until this is called the env
- * uses the engine's non-blocking stream of its device (one per device and process, shared by all envs). */
+ * uses the engine's non-blocking stream of its device (one per device and process, shared by all envs).
+ * Stream capture: mi_step with loc == MI_DEVICE (without a step epilogue) only launches kernels on this stream -- no synchronising HIP call,
+ * no host-side state that changes from step to step -- so a caller may put the stream into capture (hipStreamBeginCapture) and record any
+ * number of steps into a hipGraph (gymnasium_amd.HipVectorEnv.capture_steps does; tests/test_gpu_graph_capture.py).  The host-side checks of
+ * mi_step (the sticky device error word) are made at capture time only: after replays, mi_synchronize / the next eager call raises it. */
 int mi_set_stream(mi_vecenv *env, void *hip_stream);
 int mi_synchronize(mi_vecenv *env);
 
