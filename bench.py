@@ -452,6 +452,7 @@ def main(argv=None, harness=None):
     ap.add_argument("--pilot-seconds", type=float, default=1.0, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (already exported on the GPU boxes: the host driver only supports dmabuf IPC, which RCCL needs across ranks)
     import torch
 
     gpu = harness is None
