@@ -807,6 +807,226 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
     block_accumulate(d, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The collector's rollout (NEXT_STEP, on-device policy, every output materialised) as TWO wavefronts per 64 sub-environments.
+//
+// At the benchmark's 65 536 sub-environments rollout_kernel puts ONE wavefront on every SIMD, and a wavefront that runs alone has nothing but
+// its own independent instructions to cover a dependent instruction's latency: 0.63 of the issue slots are used (bench.py issue_bound), while
+// the same kernel at 4 wavefronts per SIMD (262 144 lanes) reaches 0.6 of the HBM roofline instead of 0.43.  The sub-environments are the only
+// parallelism the problem has, but a step is not one indivisible chain: the policy's action stream does not depend on the environment at all,
+// and everything that happens to a step's results (episode return / length, the metric totals, five coalesced stores) is off the path that
+// leads to the next state.  So a workgroup is 256 sub-environments and 512 lanes: wavefronts 0..3 ("env") integrate, decide termination /
+// truncation / autoreset and produce the observation; wavefronts 4..7 ("aux"; wavefront w + 4 serves wavefront w and shares its SIMD: measured,
+// the pairing (2j, 2j + 1) puts two env wavefronts on one SIMD and is 25 % slower) draw the actions ahead, keep the episode statistics and write
+// the whole trajectory.  They meet through LDS rings, a chunk of DuoTraits::CHUNK steps at a time:
+//   phase p:  aux draws the actions of chunk p -> A[p & 1] (and stores them);  env steps chunk p - 1 from A[(p - 1) & 1] -> O[(p - 1) & 1];
+//             aux consumes O[p & 1] (chunk p - 2): bookkeeping and stores;  one workgroup barrier.
+// The arithmetic of every value is the one of rollout_kernel / lane_step_fused (same operations on the same operands: bit-identical
+// trajectories, tests/test_gpu_parity.py); only WHICH lane issues an instruction changed.  MI355ENV_ROLLOUT_DUO=0 restores the one-role kernel.
+constexpr int kDuoBlock = 2 * kBlock;
+template <class E>
+struct DuoTraits {
+    static constexpr int CHUNK = E::OBS <= 4 ? 4 : 2;  // steps per phase (the rings live in static LDS: Acrobot's rows are 6 floats)
+};
+
+// env role: lane_step_fused<E, false> without the episode statistics; `bits`: 1 terminated, 2 truncated, 4 this was the autoreset step
+template <class E>
+MI_DEV void duo_env_step(const DevEnv &d, Lane<E> &L, typename E::Act a, ResetQueue<E> &q, float obs[E::OBS], double &reward, uint32_t &bits) {
+    const bool resetting = (L.flags & kNeedsReset) != 0;
+    if (__builtin_expect(resetting && !q.have, 0)) q.refill();  // rare: two episode ends within one refill period
+    const double (&rs)[E::S] = q.rs;
+    const uint32_t rflags = ResetQueue<E>::reset_flags(L.flags & ~kNeedsReset);
+    double rew;
+    bool te;
+    uint32_t sflags = L.flags;
+    if constexpr (E::SPLIT_TERMINAL) {
+        E::integrate(L.s, sflags, a, L.trig);
+#pragma unroll
+        for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
+        E::obs(L.s, sflags, obs, L.trig);
+        E::terminal_after_obs(L.s, L.trig, rew, te);
+    } else {
+        E::step(L.s, sflags, a, d.P, rew, te, L.trig);
+    }
+    const uint32_t elapsed = L.elapsed + 1u;  // TimeLimit.step (wrappers/common.py:129-133)
+    const bool tr = d.max_steps > 0 && (int)elapsed >= d.max_steps;
+    const bool done = !resetting && (te || tr);
+    if constexpr (!E::SPLIT_TERMINAL) {
+#pragma unroll
+        for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
+    }
+    L.flags = resetting ? rflags : (done ? (sflags | kNeedsReset) : sflags);
+    L.elapsed = resetting ? 0u : elapsed;
+    q.have = q.have && !resetting;
+    if constexpr (!E::SPLIT_TERMINAL) E::obs(L.s, L.flags, obs, L.trig);
+    reward = resetting ? 0.0 : rew;
+    bits = (resetting ? 4u : 0u) | ((!resetting && te) ? 1u : 0u) | ((!resetting && tr) ? 2u : 0u);
+}
+
+template <class E>
+__global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
+    typedef typename E::Act Act;
+    constexpr int C = DuoTraits<E>::CHUNK;
+    __shared__ Act sh_act[2][C][kBlock];
+    __shared__ float sh_obs[2][C][kBlock][E::OBS];
+    __shared__ double sh_rew[2][C][kBlock];
+    __shared__ uint8_t sh_bits[2][C][kBlock];
+    __shared__ uint64_t sh_c[4][kBlock / 64];
+    __shared__ double sh_r[kBlock / 64];
+    tables_init<E>();
+    const bool is_env = threadIdx.x < kBlock;  // wavefronts j (env) and j + 4 (aux) share a SIMD and 64 sub-environments
+    const int slot = threadIdx.x & (kBlock - 1);
+    const int i = blockIdx.x * kBlock + slot;
+    const bool active = i < d.N;
+    const size_t N = (size_t)d.N;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    // env role
+    Lane<E> L;
+    ResetQueue<E> q;
+    // aux role
+    u128 astate = 0;
+    double ep_ret = 0.0;
+    int32_t ep_len = 0;
+    if (active) {
+        if (is_env) {
+            load_lane<E>(d, i, L);
+            q.have = false;
+            q.rng = load_rng(d, i);
+        } else {
+            ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
+            astate = make_u128(as.state_hi, as.state_lo);  // skip ahead by (i + 1) draws: one affine map per set bit of (i + 1)
+            uint32_t delta = (uint32_t)i + 1u;
+            for (int j = 0; delta; j++, delta >>= 1)
+                if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
+        }
+    }
+    const int chunks = T / C;  // (the launcher sends a T that C does not divide to the one-role kernel)
+#ifdef MI_DUO_TIMING
+    unsigned long long t_work = 0, t_wait = 0, t_mark = __builtin_readcyclecounter();
+#endif
+#pragma unroll 1
+    for (int p = 0; p < chunks + 2; p++) {
+        if (active) {
+            if (is_env) {
+                const int c = p - 1;
+                if (c >= 0 && c < chunks) {
+                    const int buf = c & 1;
+                    // (rolled: with a partner wavefront on the SIMD the LDS read of the action at the top of a step is covered, and four copies
+                    //  of the step body -- libm slow paths included -- are 30 KB of instruction cache: measured +5 % against the unrolled form)
+#pragma unroll 1
+                    for (int k = 0; k < C; k++) {
+                        const int t = c * C + k;
+                        if ((t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
+                        float o[E::OBS];
+                        double rew;
+                        uint32_t bits;
+                        duo_env_step<E>(d, L, sh_act[buf][k][slot], q, o, rew, bits);
+#pragma unroll
+                        for (int j = 0; j < E::OBS; j++) sh_obs[buf][k][slot][j] = o[j];
+                        sh_rew[buf][k][slot] = rew, sh_bits[buf][k][slot] = (uint8_t)bits;
+                    }
+                }
+            } else {
+                if (p < chunks) {  // the policy: action_space.sample() for chunk p (spaces/multi_discrete.py:176-178, spaces/box.py:463-465)
+                    const int buf = p & 1;
+#pragma unroll
+                    for (int k = 0; k < C; k++) {
+                        const size_t t = (size_t)p * C + k;
+                        const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate;
+                        const uint64_t x = hi ^ lo;
+                        const unsigned rot = (unsigned)(hi >> 58);
+                        const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+                        const Act a = E::SAMPLE_FROM_BITS ? E::sample_bits(out) : E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
+                        astate = as.jump_n.mult * astate + as.jump_n.plus;
+                        sh_act[buf][k][slot] = a;
+                        static_cast<Act *>(io.actions_out)[t * N + i] = a;
+                    }
+                }
+                const int c = p - 2;
+                if (c >= 0) {  // what became of chunk c: episode statistics (RecordEpisodeStatistics order: the raw reward), totals, the trajectory rows
+                    const int buf = c & 1;
+#pragma unroll
+                    for (int k = 0; k < C; k++) {
+                        const size_t t = (size_t)c * C + k;
+                        float o[E::OBS];
+#pragma unroll
+                        for (int j = 0; j < E::OBS; j++) o[j] = sh_obs[buf][k][slot][j];
+                        const double rew = sh_rew[buf][k][slot];
+                        const uint32_t bits = sh_bits[buf][k][slot];
+                        const bool resetting = (bits & 4u) != 0, te = (bits & 1u) != 0, tr = (bits & 2u) != 0;
+                        const bool done = te || tr;
+                        const double ret = ep_ret + rew;
+                        const int32_t len = ep_len + 1;
+                        ep_ret = resetting ? 0.0 : ret;
+                        ep_len = resetting ? 0 : len;
+                        st.reset_steps += resetting ? 1u : 0u;
+                        st.env_steps += resetting ? 0u : 1u;
+                        st.episodes += done ? 1u : 0u;
+                        st.return_sum += done ? ret : 0.0;
+                        st.length_sum += done ? (uint64_t)len : 0ull;
+                        store_row<E::OBS>(static_cast<float *>(io.obs) + (t * N + i) * E::OBS, o);
+                        io.reward[t * N + i] = rew;
+                        io.terminated[t * N + i] = te;
+                        io.truncated[t * N + i] = tr;
+                    }
+                }
+            }
+        }
+#ifdef MI_DUO_TIMING
+        {
+            const unsigned long long now = __builtin_readcyclecounter();
+            t_work += now - t_mark, t_mark = now;
+        }
+#endif
+        __syncthreads();
+#ifdef MI_DUO_TIMING
+        {
+            const unsigned long long now = __builtin_readcyclecounter();
+            t_wait += now - t_mark, t_mark = now;
+        }
+#endif
+    }
+#ifdef MI_DUO_TIMING  // scripts/r04/duo_timing.py: where each role's time goes
+    if (blockIdx.x == 7 && (threadIdx.x & 63) == 0)
+        printf("duo timing: wave %d (%s) work %llu wait-at-barrier %llu cycles over %d phases\n", (int)(threadIdx.x >> 6), is_env ? "env" : "aux", t_work, t_wait, chunks + 2);
+#endif
+    if (active) {
+        if (is_env) {
+            // (ep_ret / ep_len belong to the aux role: store_lane without them)
+#pragma unroll
+            for (int k = 0; k < E::S; k++) d.state[(size_t)k * d.N + i] = L.s[k];
+            d.meta[i] = (L.elapsed & kElapsedMask) | (L.flags << kFlagShift);
+            if (q.have) {  // hand the unconsumed draws back to the env's generator
+#pragma unroll
+                for (int k = 0; k < E::NDRAWS; k++) q.rng.unstep();
+            }
+            store_rng_state(d, i, q.rng);
+        } else {
+            d.ep_ret[i] = ep_ret, d.ep_len[i] = ep_len;
+        }
+    }
+    // the workgroup's totals (block_accumulate for two roles: only the aux wavefronts carry any)
+    const int wave = slot >> 6, lane = threadIdx.x & 63;
+    if (!is_env) {
+        const uint32_t c0 = wave_sum(st.env_steps), c1 = wave_sum(st.reset_steps), c2 = wave_sum(st.episodes);
+        const uint64_t c3 = c2 ? wave_sum(st.length_sum) : 0;
+        const double r = c2 ? wave_sum(st.return_sum) : 0.0;
+        if (lane == 0) sh_c[0][wave] = c0, sh_c[1][wave] = c1, sh_c[2][wave] = c2, sh_c[3][wave] = c3, sh_r[wave] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sh_c[threadIdx.x][w];
+        if (t) d.blk_count[(size_t)blockIdx.x * 4 + threadIdx.x] += t;
+    } else if (threadIdx.x == 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sh_r[w];
+        if (t != 0.0) d.blk_ret[blockIdx.x] += t;
+    }
+}
+
 
 #ifndef MI_CLASSIC_TU
 // ---------------------------------------------------------------------------------------------------------
@@ -1596,8 +1816,13 @@ int launch_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, i
             launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, false, false>(v, p, as, T);
         else
             launch_rollout_variant<E, MI_AUTORESET_SAME_STEP, false, false>(v, p, as, T);
-    } else if (next_step && sample && full)  // the collector's configuration (bench.py)
-        launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, true>(v, p, as, T);
+    } else if (next_step && sample && full) {  // the collector's configuration (bench.py)
+        const char *duo = getenv("MI355ENV_ROLLOUT_DUO");
+        if (!(duo && duo[0] == '0') && T % DuoTraits<E>::CHUNK == 0)
+            hipLaunchKernelGGL((rollout_duo_kernel<E>), dim3(v->grid), dim3(kDuoBlock), 0, v->stream, v->d, p, as, T);
+        else
+            launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, true>(v, p, as, T);
+    }
     else if (next_step && sample)
         launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, false>(v, p, as, T);
     else if (next_step)
