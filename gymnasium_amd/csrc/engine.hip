@@ -863,9 +863,12 @@ MI_DEV void duo_env_step(const DevEnv &d, Lane<E> &L, typename E::Act a, ResetQu
     bits = (resetting ? 4u : 0u) | ((!resetting && te) ? 1u : 0u) | ((!resetting && tr) ? 2u : 0u);
 }
 
+// (Measured and not kept: the aux role split once more into "policy" and "book" wavefronts for three per SIMD: CartPole 78.9 us against 76.4 us --
+//  the vector pipe is the limit now, not latency; s_setprio(3) for the env wavefronts: no change.  docs/classic_kernels.md)
 template <class E>
 __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
     typedef typename E::Act Act;
+    constexpr int ROLES = 2;
     constexpr int C = DuoTraits<E>::CHUNK;
     __shared__ Act sh_act[2][C][kBlock];
     __shared__ float sh_obs[2][C][kBlock][E::OBS];
@@ -874,7 +877,8 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     __shared__ uint64_t sh_c[4][kBlock / 64];
     __shared__ double sh_r[kBlock / 64];
     tables_init<E>();
-    const bool is_env = threadIdx.x < kBlock;  // wavefronts j (env) and j + 4 (aux) share a SIMD and 64 sub-environments
+    const int role = threadIdx.x / kBlock;  // wavefronts j (env), j + 4 (aux / policy) and j + 8 (book) share a SIMD and 64 sub-environments
+    const bool is_env = role == 0, is_policy = role == 1, is_book = role == ROLES - 1;
     const int slot = threadIdx.x & (kBlock - 1);
     const int i = blockIdx.x * kBlock + slot;
     const bool active = i < d.N;
@@ -892,8 +896,9 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
             load_lane<E>(d, i, L);
             q.have = false;
             q.rng = load_rng(d, i);
-        } else {
-            ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
+        }
+        if (is_book) ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
+        if (is_policy) {
             astate = make_u128(as.state_hi, as.state_lo);  // skip ahead by (i + 1) draws: one affine map per set bit of (i + 1)
             uint32_t delta = (uint32_t)i + 1u;
             for (int j = 0; delta; j++, delta >>= 1)
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                     }
                 }
             } else {
-                if (p < chunks) {  // the policy: action_space.sample() for chunk p (spaces/multi_discrete.py:176-178, spaces/box.py:463-465)
+                if (is_policy && p < chunks) {  // the policy: action_space.sample() for chunk p (spaces/multi_discrete.py:176-178, spaces/box.py:463-465)
                     const int buf = p & 1;
 #pragma unroll
                     for (int k = 0; k < C; k++) {
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                     }
                 }
                 const int c = p - 2;
-                if (c >= 0) {  // what became of chunk c: episode statistics (RecordEpisodeStatistics order: the raw reward), totals, the trajectory rows
+                if (is_book && c >= 0) {  // what became of chunk c: episode statistics (RecordEpisodeStatistics order: the raw reward), totals, the trajectory rows
                     const int buf = c & 1;
 #pragma unroll
                     for (int k = 0; k < C; k++) {
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     }
 #ifdef MI_DUO_TIMING  // scripts/r04/duo_timing.py: where each role's time goes
     if (blockIdx.x == 7 && (threadIdx.x & 63) == 0)
-        printf("duo timing: wave %d (%s) work %llu wait-at-barrier %llu cycles over %d phases\n", (int)(threadIdx.x >> 6), is_env ? "env" : "aux", t_work, t_wait, chunks + 2);
+        printf("duo timing: wave %d (role %d) work %llu wait-at-barrier %llu cycles over %d phases\n", (int)(threadIdx.x >> 6), role, t_work, t_wait, chunks + 2);
 #endif
     if (active) {
         if (is_env) {
@@ -1001,13 +1006,13 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                 for (int k = 0; k < E::NDRAWS; k++) q.rng.unstep();
             }
             store_rng_state(d, i, q.rng);
-        } else {
+        } else if (is_book) {
             d.ep_ret[i] = ep_ret, d.ep_len[i] = ep_len;
         }
     }
-    // the workgroup's totals (block_accumulate for two roles: only the aux wavefronts carry any)
+    // the workgroup's totals (block_accumulate for several roles: only the book-keeping wavefronts carry any)
     const int wave = slot >> 6, lane = threadIdx.x & 63;
-    if (!is_env) {
+    if (is_book) {
         const uint32_t c0 = wave_sum(st.env_steps), c1 = wave_sum(st.reset_steps), c2 = wave_sum(st.episodes);
         const uint64_t c3 = c2 ? wave_sum(st.length_sum) : 0;
         const double r = c2 ? wave_sum(st.return_sum) : 0.0;
@@ -1817,11 +1822,13 @@ int launch_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, i
         else
             launch_rollout_variant<E, MI_AUTORESET_SAME_STEP, false, false>(v, p, as, T);
     } else if (next_step && sample && full) {  // the collector's configuration (bench.py)
-        const char *duo = getenv("MI355ENV_ROLLOUT_DUO");
-        if (!(duo && duo[0] == '0') && T % DuoTraits<E>::CHUNK == 0)
-            hipLaunchKernelGGL((rollout_duo_kernel<E>), dim3(v->grid), dim3(kDuoBlock), 0, v->stream, v->d, p, as, T);
-        else
-            launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, true>(v, p, as, T);
+        bool duo = false;
+        if constexpr (E::DUO_ROLLOUT) {
+            const char *env = getenv("MI355ENV_ROLLOUT_DUO");  // "0": the one-role kernel (A/B: scripts/r04/duo_ab_bench.sh)
+            duo = !(env && env[0] == '0') && T % DuoTraits<E>::CHUNK == 0;
+            if (duo) hipLaunchKernelGGL((rollout_duo_kernel<E>), dim3(v->grid), dim3(kDuoBlock), 0, v->stream, v->d, p, as, T);
+        }
+        if (!duo) launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, true>(v, p, as, T);
     }
     else if (next_step && sample)
         launch_rollout_variant<E, MI_AUTORESET_NEXT_STEP, true, false>(v, p, as, T);
