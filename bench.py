@@ -254,6 +254,9 @@ FLOP_COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F6
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
 
 
+DUO_CHUNK = {"CartPole-v1": 4, "MountainCar-v0": 8, "MountainCarContinuous-v0": 8}  # envs_classic.h DUO_ROLLOUT / DUO_CHUNK
+
+
 def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150, env_kwargs=None, want_issue=False, want_flops=False, warm=1):
     """HBM traffic per dispatch of `kernel` (WRITE_SIZE + 2 FETCH_SIZE, in KiB on gfx950; MI355X_MICROARCH.md HBM section: separate
     passes, FETCH_SIZE doubled) and, for the VALU-bound kernels, the SQ activity counters as shares of SQ_WAVE_CYCLES."""
@@ -277,13 +280,16 @@ def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150
     if want_issue:
         ic = _rocprof_counters(args, ISSUE_COUNTERS, kernel, timeout_s)
         if ic and ic.get("SQ_WAVES", (0, 0))[0] > 0:
-            waves = ic["SQ_WAVES"][0]
-            valu, salu = ic["SQ_INSTS_VALU"][0] / waves / inner, ic["SQ_INSTS_SALU"][0] / waves / inner
-            out["issue"] = {"valu_per_env_step": valu, "salu_per_env_step": salu,
-                            # a SIMD issues at most one 64-lane fp64 VALU instruction per 4 cycles; with ONE wavefront per SIMD (num_envs = 65536)
-                            # scalar instructions are not hidden behind another wavefront's VALU work, so they take issue slots too
-                            "ceiling_env_steps_per_s": SIMDS * 64 * CLOCK_HZ / (4.0 * (valu + salu)),
-                            "assumptions": f"{SIMDS} SIMDs x 64 lanes, one instruction per 4 cycles at {CLOCK_HZ / 1e9:.1f} GHz, VALU + SALU of one wavefront per SIMD",
+            waves, groups = ic["SQ_WAVES"][0], N / 64.0  # a group = 64 sub-environments: ONE wavefront in the one-role kernels, an env + an aux wavefront in rollout_duo_kernel
+            valu, salu = ic["SQ_INSTS_VALU"][0] / groups / inner, ic["SQ_INSTS_SALU"][0] / groups / inner
+            per_group = waves / groups
+            # a SIMD issues at most one 64-lane VALU instruction per 4 cycles.  With ONE wavefront per SIMD scalar instructions are not hidden behind
+            # another wavefront's vector work and take issue slots too; with two (the two-role kernel) they issue beside the partner's VALU work.
+            slots = valu + salu if per_group < 1.5 else valu
+            out["issue"] = {"valu_per_env_step": valu, "salu_per_env_step": salu, "wavefronts_per_64_envs": per_group,
+                            "ceiling_env_steps_per_s": SIMDS * 64 * CLOCK_HZ / (4.0 * slots),
+                            "assumptions": (f"{SIMDS} SIMDs x 64 lanes, one instruction per 4 cycles at {CLOCK_HZ / 1e9:.1f} GHz; issue slots per env-step = "
+                                            + ("VALU + SALU (one wavefront per SIMD)" if per_group < 1.5 else "VALU (two wavefronts per SIMD: scalar instructions issue beside the partner's vector instructions)")),
                             "source": "rocprofv3 --pmc " + " ".join(ISSUE_COUNTERS) + " on a child invocation in this run"}
     if want_sq:
         sq = _rocprof_counters(args, SQ_COUNTERS, kernel, timeout_s)
@@ -364,6 +370,11 @@ class Config:
 
     def dominant_kernel(self):
         if self.env_id in ROLLOUT_BYTES:
+            # the collector's configuration of CartPole / MountainCar / MountainCarContinuous runs the two-role kernel (engine.hip rollout_duo_kernel)
+            # when its chunk divides the number of fused steps; MI355ENV_ROLLOUT_DUO=0 is the A/B switch back to rollout_kernel
+            chunk = DUO_CHUNK.get(self.env_id)
+            if chunk and self.inner % chunk == 0 and os.environ.get("MI355ENV_ROLLOUT_DUO", "1")[:1] != "0":
+                return "rollout_duo_kernel"
             return "rollout_kernel"
         if self.eng.obs_dtype is np.int64:
             return "tab_rollout_kernel"

@@ -27,4 +27,4 @@ cd "$ROOT"
 python scripts/rocpd_summary.py --stats "$OUT/${TAG}_stats" --pmc "${PMC[@]}" --cmd "$CMD" -o "$OUT/${TAG}.txt" > /dev/null
 # keep the merge-back small: the raw databases are not needed once summarised
 rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_FETCH_SIZE" "$OUT/${TAG}_WRITE_SIZE" "$OUT/${TAG}_SQ" "$OUT/${TAG}_SQ2"
-tail -n +1 "$OUT/${TAG}.txt" | grep -i "rollout_kernel\|mj_\|step_kernel" | head -40
+tail -n +1 "$OUT/${TAG}.txt" | grep -i "rollout_kernel\|rollout_duo\|mj_\|step_kernel" | head -40
