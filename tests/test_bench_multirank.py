@@ -22,12 +22,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _torchrun(cmd_for_port, **kw):
+    """Launch with a fresh rendezvous port; a port another (parallel) test grabbed between _free_port() and torchrun's bind is retried."""
+    for _ in range(4):
+        p = subprocess.run(cmd_for_port(_free_port()), capture_output=True, text=True, **kw)
+        if p.returncode == 0 or not any(m in p.stderr for m in ("Address already in use", "EADDRINUSE", "address already in use")):
+            break
+    return p
+
+
 def _run(world, extra, num_envs=256, inner=8):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MI355ENV_CPU_WORKERS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", str(world),
-           "--num-envs", str(num_envs), "--inner", str(inner), "--cpu-budget", "0.5", *extra]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    cmd = lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",  # noqa: E731
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", str(world),
+                        "--num-envs", str(num_envs), "--inner", str(inner), "--cpu-budget", "0.5", *extra]
+    p = _torchrun(cmd, env=env, cwd=ROOT, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"exactly one JSON line from rank 0, got {len(lines)}: {p.stdout[-2000:]}"

@@ -18,6 +18,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _torchrun(cmd_for_port, **kw):
+    """Launch with a fresh rendezvous port; a port another (parallel) test grabbed between _free_port() and torchrun's bind is retried."""
+    for _ in range(4):
+        p = subprocess.run(cmd_for_port(_free_port()), capture_output=True, text=True, **kw)
+        if p.returncode == 0 or not any(m in p.stderr for m in ("Address already in use", "EADDRINUSE", "address already in use")):
+            break
+    return p
+
+
 def test_shard_range_partitions_exactly():
     for total in (1, 7, 8, 65536, 262144):
         for world in (1, 2, 3, 8):
@@ -37,9 +46,9 @@ def test_shard_range_partitions_exactly():
 def test_sharded_ranks_reproduce_single_process(tmp_path, env_id, world, total):
     out = tmp_path / "result.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_mp_worker.py"), env_id, str(total), "60", str(out)]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    cmd = lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",  # noqa: E731
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "_mp_worker.py"), env_id, str(total), "60", str(out)]
+    p = _torchrun(cmd, env=env, cwd=ROOT, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     res = json.load(open(out))
     assert res["world"] == world
