@@ -873,7 +873,10 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     constexpr int C = DuoTraits<E>::CHUNK;
     __shared__ Act sh_act[2][C][kBlock];
     __shared__ float sh_obs[2][C][kBlock][E::OBS];
-    __shared__ double sh_rew[E::REWARD_FROM_TERMINATED ? 1 : 2][E::REWARD_FROM_TERMINATED ? 1 : C][kBlock];  // (not transferred when the aux role can recompute it)
+    // (Measured and not kept: Pendulum with its reward -- three exact pow and an fmod, none of which feeds the next state -- evaluated by the aux role from
+    //  the pre-step state passed through LDS: bit-identical, 168.7 us against 168.7 us for the one-role kernel.  Its instruction count is the limit.)
+    constexpr bool PASS_REWARD = !E::REWARD_FROM_TERMINATED;  // (not transferred when the aux role can recompute it)
+    __shared__ double sh_rew[PASS_REWARD ? 2 : 1][PASS_REWARD ? C : 1][kBlock];
     // (the flag word's width is tuning, measured per environment at T = 128: CartPole +2.3 % with a dword, MountainCarContinuous +2.9 % with a byte)
     typedef typename std::conditional<E::REWARD_FROM_TERMINATED && E::OBS == 4, uint32_t, uint8_t>::type MI_DUO_FLAG_T;
     __shared__ MI_DUO_FLAG_T sh_bits[2][C][kBlock];
@@ -931,26 +934,11 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                         duo_env_step<E>(d, L, sh_act[buf][k][slot], q, o, rew, bits);
 #pragma unroll
                         for (int j = 0; j < E::OBS; j++) sh_obs[buf][k][slot][j] = o[j];
-                        if constexpr (!E::REWARD_FROM_TERMINATED) sh_rew[buf][k][slot] = rew;
+                        if constexpr (PASS_REWARD) sh_rew[buf][k][slot] = rew;
                         sh_bits[buf][k][slot] = (MI_DUO_FLAG_T)bits;
                     }
                 }
             } else {
-                if (is_policy && p < chunks) {  // the policy: action_space.sample() for chunk p (spaces/multi_discrete.py:176-178, spaces/box.py:463-465)
-                    const int buf = p & 1;
-#pragma unroll
-                    for (int k = 0; k < C; k++) {
-                        const size_t t = (size_t)p * C + k;
-                        const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate;
-                        const uint64_t x = hi ^ lo;
-                        const unsigned rot = (unsigned)(hi >> 58);
-                        const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
-                        const Act a = E::SAMPLE_FROM_BITS ? E::sample_bits(out) : E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
-                        astate = as.jump_n.mult * astate + as.jump_n.plus;
-                        sh_act[buf][k][slot] = a;
-                        static_cast<Act *>(io.actions_out)[t * N + i] = a;
-                    }
-                }
                 const int c = p - 2;
                 if (is_book && c >= 0) {  // what became of chunk c: episode statistics (RecordEpisodeStatistics order: the raw reward), totals, the trajectory rows
                     const int buf = c & 1;
@@ -963,10 +951,11 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                         const uint32_t bits = sh_bits[buf][k][slot];
                         const bool resetting = (bits & 4u) != 0, te = (bits & 1u) != 0, tr = (bits & 2u) != 0;
                         double rew;
-                        if constexpr (E::REWARD_FROM_TERMINATED)
+                        if constexpr (E::REWARD_FROM_TERMINATED) {
                             rew = resetting ? 0.0 : E::reward_from_terminated(te, d.P);
-                        else
+                        } else {
                             rew = sh_rew[buf][k][slot];
+                        }
                         const bool done = te || tr;
                         const double ret = ep_ret + rew;
                         const int32_t len = ep_len + 1;
@@ -981,6 +970,21 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                         io.reward[t * N + i] = rew;
                         io.terminated[t * N + i] = te;
                         io.truncated[t * N + i] = tr;
+                    }
+                }
+                if (is_policy && p < chunks) {  // the policy: action_space.sample() for chunk p (spaces/multi_discrete.py:176-178, spaces/box.py:463-465)
+                    const int buf = p & 1;
+#pragma unroll
+                    for (int k = 0; k < C; k++) {
+                        const size_t t = (size_t)p * C + k;
+                        const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate;
+                        const uint64_t x = hi ^ lo;
+                        const unsigned rot = (unsigned)(hi >> 58);
+                        const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+                        const Act a = E::SAMPLE_FROM_BITS ? E::sample_bits(out) : E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
+                        astate = as.jump_n.mult * astate + as.jump_n.plus;
+                        sh_act[buf][k][slot] = a;
+                        static_cast<Act *>(io.actions_out)[t * N + i] = a;
                     }
                 }
             }

@@ -252,7 +252,7 @@ struct PendulumT {
     static constexpr int S = 2, OBS = 3;
     static constexpr bool DISCRETE = false;
     static constexpr int ROLLOUT_UNROLL = 1;
-    static constexpr bool DUO_ROLLOUT = false;  // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments): measured -0.5 %: 215 registers, the libm work dwarfs what moves
+    static constexpr bool DUO_ROLLOUT = false;  // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments): measured -0.5 % (215 registers), and +-0 with the reward evaluated by the aux role: the instruction count is the limit
     typedef typename AK::T Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
@@ -277,13 +277,15 @@ struct PendulumT {
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
 
-    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &t) {
-        const double max_speed = 8, max_torque = 2.0, dt = 0.05, m = 1.0, l = 1.0;
-        const double g = P.p[0];
-        const double th = s[0], thdot = s[1];
-        Act u = action;  // np.clip(u, -2, 2)[0] stays np.float32 for a float32 row; a float64 row (or a list's) makes it an np.float64
+    static MI_DEV Act clip_torque(Act u) {  // np.clip(u, -2, 2)[0] stays np.float32 for a float32 row; a float64 row (or a list's) makes it an np.float64
+        const double max_torque = 2.0;
         u = u < (Act)-max_torque ? (Act)-max_torque : u;
         u = u > (Act)max_torque ? (Act)max_torque : u;
+        return u;
+    }
+    // pendulum.py:131  costs = angle_normalize(th) ** 2 + 0.1 * thdot ** 2 + 0.001 * (u ** 2), of the state BEFORE the step; reward = -costs.
+    static MI_DEV double reward_of(double th, double thdot, Act action) {
+        const Act u = clip_torque(action);
         // angle_normalize: ((x + pi) % (2 pi)) - pi with Python floor-modulo
         double md = M::fmod_2pi(th + kPi);
         if (md != 0.0) {
@@ -292,14 +294,25 @@ struct PendulumT {
             md = 0.0;
         }
         const double an = md - kPi;
-        double cu, tu;
-        if constexpr (ACT_KIND == MI_F32) {
-            cu = (double)(0.001f * M::sqf(u));                 // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
-            tu = (double)((float)(3.0 / (m * (l * l))) * u);  // float32: 3.0 / (m l^2) * u
-        } else {
-            cu = 0.001 * M::sq(u), tu = 3.0 / (m * (l * l)) * u;  // all float64
-        }
+        double cu;
+        if constexpr (ACT_KIND == MI_F32)
+            cu = (double)(0.001f * M::sqf(u));  // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
+        else
+            cu = 0.001 * M::sq(u);  // all float64
         const double costs = M::sq(an) + 0.1 * M::sq(thdot) + cu;
+        return -costs;
+    }
+    // pendulum.py:133-141 the dynamics alone
+    static MI_DEV void advance(double s[S], Act action, const EnvParams &P, Trig &t) {
+        const double max_speed = 8, dt = 0.05, m = 1.0, l = 1.0;
+        const double g = P.p[0];
+        const double th = s[0], thdot = s[1];
+        const Act u = clip_torque(action);
+        double tu;
+        if constexpr (ACT_KIND == MI_F32)
+            tu = (double)((float)(3.0 / (m * (l * l))) * u);  // float32: 3.0 / (m l^2) * u
+        else
+            tu = 3.0 / (m * (l * l)) * u;
         if (!t.ok) t.sn = M::sin(th);  // (else: the observation of the previous step evaluated sin of this very angle)
         const double sn = t.sn;
         t.ok = false;
@@ -308,7 +321,10 @@ struct PendulumT {
         newthdot = newthdot > max_speed ? max_speed : newthdot;
         const double newth = th + newthdot * dt;
         s[0] = newth, s[1] = newthdot;
-        reward = -costs;
+    }
+    static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &t) {
+        reward = reward_of(s[0], s[1], action);
+        advance(s, action, P, t);
         terminated = false;
     }
 };
