@@ -84,3 +84,17 @@ def test_cooperative_mujoco_kernels_keep_their_lds_and_register_budget():
         for r in rows:
             if robot + "," in r["name"]:
                 assert r.get("vgpr_spill_count", 0) == 0, f"{r['name']}: {r['vgpr_spill_count']} spilled VGPRs (build.py TU_FLAGS, DESIGN.md section 7)"
+
+
+def test_two_role_rollout_kernels_fit_two_wavefronts_per_simd():
+    """rollout_duo_kernel runs an env and an aux wavefront of the same 64 sub-environments on one SIMD (engine.hip): a workgroup is 8 wavefronts on the 4
+    SIMDs of a CU, so each wavefront may use at most half the register file, nothing may spill, and the rings must fit the CU's LDS."""
+    from kernel_resources import resources
+
+    rows = [r for r in resources(LIB) if "rollout_duo_kernel" in r["name"]]
+    assert len(rows) == 6, [r["name"] for r in rows]  # CartPole, MountainCar, MountainCarContinuous x (exact, fast math)
+    assert not any("PendulumT" in r["name"] or "AcrobotT" in r["name"] for r in rows), "Pendulum / Acrobot keep the one-role kernel (envs_classic.h DUO_ROLLOUT)"
+    for r in rows:
+        assert r["vgpr_count"] + r.get("agpr_count", 0) <= 256, f"{r['name']}: {r['vgpr_count']} registers: two wavefronts no longer fit a SIMD"
+        assert r.get("vgpr_spill_count", 0) == 0 and r.get("private_segment_fixed_size", 0) == 0, r["name"]
+        assert r["group_segment_fixed_size"] <= 160 * 1024, r["name"]
