@@ -164,7 +164,7 @@ MI_DEV void store_rng_state(const DevEnv &d, int i, const Pcg64 &r) {
 
 // The next E::NDRAWS values of the lane's own stream, drawn AHEAD of the reset that will consume them.
 // In a wavefront of 64 CartPoles some lane finishes an episode in ~95 % of the steps, so a reset path executed
-// on demand costs every wavefront four 128-bit LCG steps (40 quarter-rate integer multiplies) on almost every
+// on demand costs every wavefront four 128-bit LCG steps (40 integer multiplies) on almost every
 // step for the benefit of ~3 lanes.  A fused rollout instead refills all empty queues of a wavefront together
 // every kRefillPeriod steps and a reset merely moves the queued values into the state.  The stream order is
 // unchanged (the env's generator is consumed by resets only), and unconsumed draws are handed back at the end of
