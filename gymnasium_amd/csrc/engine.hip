@@ -865,7 +865,7 @@ MI_DEV void duo_env_step(const DevEnv &d, Lane<E> &L, typename E::Act a, ResetQu
 }
 
 // (Measured and not kept: the aux role split once more into "policy" and "book" wavefronts for three per SIMD: CartPole 78.9 us against 76.4 us --
-//  the vector pipe is the limit now, not latency; s_setprio(3) for the env wavefronts: no change.  docs/classic_kernels.md)
+//  more wavefronts do not help any more; s_setprio(3) for the env wavefronts: no change.  docs/classic_kernels.md)
 template <class E>
 __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
     typedef typename E::Act Act;
