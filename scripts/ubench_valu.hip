@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O2 -o scripts/ubench_valu.bin scripts/ubench_valu.hip ; prints cycles per wave-instruction.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -198,13 +199,16 @@ static double run(kern_t k, int blocks, double *sink, unsigned long long *dcyc) 
     return s / blocks / (ITERS * 8.0);
 }
 
-int main() {
-    const int blocks = 1024;  // one 64-lane workgroup per SIMD
+int main(int argc, char **argv) {
+    // argv[1] = wavefronts per SIMD (default 1).  With W > 1 the per-wavefront cost of an instruction is W x its share of the SIMD's vector pipe:
+    // cost / W is the pipe time of the instruction (4 cycles for a full-rate one), which one wavefront alone (issue cadence ~5 cycles) cannot show.
+    const int per_simd = argc > 1 ? atoi(argv[1]) : 1;
+    const int blocks = 1024 * per_simd;  // 64-lane workgroups; 1024 SIMDs
     double *sink;
     unsigned long long *dcyc;
     hipMalloc(&sink, sizeof(double) * blocks * 64);
     hipMalloc(&dcyc, sizeof(unsigned long long) * blocks);
-    printf("%-16s %10s %10s   (s_memtime cycles per wave-instruction, one wavefront per SIMD)\n", "instruction", "8 chains", "1 chain");
+    printf("%-16s %10s %10s   (s_memtime cycles per wave-instruction, %d wavefront(s) per SIMD)\n", "instruction", "8 chains", "1 chain", per_simd);
 #define ROW2(N) printf("%-16s %10.2f %10.2f\n", #N, run(N##_indep, blocks, sink, dcyc), run(N##_dep, blocks, sink, dcyc));
 #define ROW1(N) printf("%-16s %10.2f %10s\n", #N, run(N##_indep, blocks, sink, dcyc), "-");
     ROW2(fma_f64) ROW2(add_f64) ROW2(mul_f64) ROW2(rcp_f64) ROW2(ldexp_f64) ROW2(lshl_add_u64) ROW2(mov_b64)
