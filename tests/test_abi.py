@@ -91,3 +91,22 @@ def test_no_cpu_fallback():
     for f in src:
         text = open(f).read()
         assert "liboracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_bench_knows_which_envs_run_the_two_role_rollout():
+    """bench.py names the dominant kernel for its rocprofv3 counter passes: its table must follow the traits in envs_classic.h."""
+    import re
+
+    import bench
+
+    src = open(os.path.join(ROOT, "gymnasium_amd", "csrc", "envs_classic.h")).read()
+    traits = {}
+    for m in re.finditer(r"struct (\w+)T \{(.*?)\n\};", src, re.S):
+        body = m.group(2)
+        duo = re.search(r"static constexpr bool DUO_ROLLOUT = (true|false)", body)
+        chunk = re.search(r"static constexpr int DUO_CHUNK = (\d+)", body)
+        if duo:
+            traits[m.group(1)] = int(chunk.group(1)) if duo.group(1) == "true" else None
+    ids = {"CartPole": "CartPole-v1", "Pendulum": "Pendulum-v1", "Acrobot": "Acrobot-v1", "MountainCar": "MountainCar-v0", "MountainCarContinuous": "MountainCarContinuous-v0"}
+    assert set(traits) == set(ids), traits
+    assert {ids[k]: v for k, v in traits.items() if v} == bench.DUO_CHUNK

@@ -124,3 +124,16 @@ def test_device_info_masks_are_private_copies(oracle_factory):
                 v.fill_(True) if t % 2 else v.zero_()
     assert a.episode_count == b.episode_count > 0
     a.close(), b.close()
+
+
+def test_capture_steps_needs_a_gpu_engine(oracle_factory):
+    """HipVectorEnv.capture_steps records step() into a HIP graph: refused, with a message, for NumPy output and for the CPU checker backend
+    (the GPU behaviour: tests/test_gpu_graph_capture.py)."""
+    from gymnasium_amd.gym_api import error
+
+    for kw in ({}, {"output": "torch"}):
+        env = gymnasium_amd.make_vec("CartPole-v1", num_envs=4, _engine_factory=oracle_factory, **kw)
+        env.reset(seed=0)
+        with pytest.raises(error.Error, match="output='torch'"):
+            env.capture_steps(actions=np.zeros(4, dtype=np.int64))
+        env.close()
