@@ -823,7 +823,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
 //   phase p:  aux draws the actions of chunk p -> A[p & 1] (and stores them);  env steps chunk p - 1 from A[(p - 1) & 1] -> O[(p - 1) & 1];
 //             aux consumes O[p & 1] (chunk p - 2): bookkeeping and stores;  one workgroup barrier.
 // The arithmetic of every value is the one of rollout_kernel / lane_step_fused (same operations on the same operands: bit-identical
-// trajectories, tests/test_gpu_parity.py); only WHICH lane issues an instruction changed.  MI355ENV_ROLLOUT_DUO=0 restores the one-role kernel.
+// trajectories, tests/test_gpu_rollout_roles.py, tests/test_gpu_parity.py); only WHICH lane issues an instruction changed.  MI355ENV_ROLLOUT_DUO=0
+// restores the one-role kernel.  The measurements behind every choice here: profiles/r04_two_role_rollout.txt, profiles/r04_ubench_valu_waves.txt.
 constexpr int kDuoBlock = 2 * kBlock;
 template <class E>
 struct DuoTraits {
