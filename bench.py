@@ -3,37 +3,32 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--env CartPole-v1] [--num-envs 65536] [--inner 128]
 
-Primary workload (BASELINE.json configs[1]): CartPole-v1, num_envs = 65536 PER GPU, random policy.  One bench "step" is one
-launch of the hot path over the whole batch: `rollout(inner)` = `inner` lockstep vector steps of all sub-environments with the
-random policy `action_space.sample()` evaluated on device (bit-identical to the host policy) and the full trajectory (actions,
-observations, rewards, terminated, truncated) written to HBM.  Inputs are resident in HBM when the timed region starts; nothing
-crosses PCIe inside it.
+Primary workload (BASELINE.json configs[1]): CartPole-v1, num_envs = 65536 PER GPU, random policy.  One bench "step" is one launch of the
+hot path over the whole batch: `mi_rollout(inner)` = `inner` lockstep vector steps of all sub-environments with the random policy
+`action_space.sample()` evaluated on device and the full trajectory (actions, observations, rewards, terminated, truncated) written to
+HBM.  Inputs are resident in HBM when the timed region starts; nothing crosses PCIe inside it.
 
-value = env-steps/s counted like the reference's benchmark_vector_step (gymnasium/utils/performance.py:88-90: NEXT_STEP autoreset
-steps are not counted), whole job over all ranks.  The same JSON line also carries (rank 0, --gpus 1):
+Order of events on every rank: W untimed warm-up launches (after an untimed clock spin-up) -> the sub-environments are RE-ARMED
+(`reset(seed=0)`, policy stream seeded with the rank: a few microseconds, outside the timed region) -> barrier + synchronise -> EXACTLY K
+timed launches between two HIP events -> synchronise + barrier.  Re-arming makes the first timed launch a known-answer computation: its
+trajectory lands in its own buffers, `output_sha256` is the digest of those bytes, and the `verified` object says how they compare with
+the CPU oracle run on the same seeds in this run (classic control / ToyText: every byte of all sub-environments; MuJoCo kinds: a strided
+subset within 1e-8).  tests/test_bench_digest.py computes the same digest on the CPU for configs[1]'s exact shape.
 
-  sustained_value   the same launch repeated for >= --sustained seconds (clock / thermal steady state).  Without --steps the timed region
-                    itself is ~1 s (K chosen from a 5-launch pilot) and sustained_value repeats `value`
-  secondary         BASELINE.json configs[2..4]: Pendulum / Acrobot / MountainCarContinuous @65536, Ant-v5 @32768 and @65536,
-                    Humanoid-v5 @32768 (per GPU), each with its own roofline and cpu_baseline
-  roofline          dominant kernel: HBM-bound classic kernels as algorithmic bytes / launch time vs 8 TB/s with `traffic` from
-                    rocprofv3 PMC passes run BY THIS COMMAND on a short child invocation (FETCH_SIZE x2 + WRITE_SIZE, separate
-                    passes); the cooperative MuJoCo kernels are VALU / latency bound: `bound: "valu"`, frac = SQ_ACTIVE_INST_VALU /
-                    SQ_WAVE_CYCLES of the same kind of pass, plus the scratch-inclusive traffic ratio
-  cpu_baseline      the C oracle (kind "port") on the host's cores: the batch sharded over one single-threaded process per core (count stated), bounded sample
-  cpu_reference     Gymnasium's own AsyncVectorEnv (num_envs = os.cpu_count()) / SyncVectorEnv / NumPy CartPoleVectorEnv timed in
-                    this run when `import gymnasium` works (GYM_REFERENCE or an installed package); the GPU box has neither, so there
-                    the AsyncVectorEnv ARCHITECTURE restated (oracle/async_baseline.py, pinned on the real one by tests/test_async_baseline.py)
-                    is timed in this run on this host's cores (kind "port"), and the real gymnasium's numbers from the build container
-                    ride along as cpu_reference_recorded (hardware stated)
-  api_step_device / api_step_numpy   the per-launch step() API -- never `value`
+value = env-steps/s counted like the reference's benchmark_vector_step (gymnasium/utils/performance.py:88-90: NEXT_STEP autoreset steps
+are not counted), whole job over all ranks.  The ONE stdout line is kept under 4 KB (round 4's 20 KB line could not be parsed by the
+driver); everything else -- BASELINE.json configs[2..4] with their own rooflines, the per-launch step() API, the opt-in configurations, the
+reference's own vectorisers -- is measured by scripts/bench_extras.py (a child process of this command at --gpus 1) and written to the
+sidecar file the line names in `full`; the line carries only their headline values in `secondary`.
 
-N > 1: one process per GPU (torchrun), each rank owns its own num_envs sub-environments (global indices rank*num_envs ...; no
-data-path collective), one RCCL all-reduce of {env_steps, episodes, return_sum} at the end.  BASELINE.json configs[4]
-(Humanoid-v5, 262144 envs over 8 GPUs) is `torchrun --nproc-per-node 8 bench.py --gpus 8 --env Humanoid-v5 --num-envs 32768 --inner 4`.
+N > 1: one process per GPU (torchrun), each rank owns its own num_envs sub-environments (global indices rank*num_envs ...; no data-path
+collective), one RCCL all-reduce of {env_steps, episodes, return_sum} at the end.  BASELINE.json configs[4] (Humanoid-v5, 262144 envs
+over 8 GPUs) is `torchrun --nproc-per-node 8 bench.py --gpus 8 --env Humanoid-v5 --num-envs 32768 --inner 4`.
 """
 import argparse
+import copy
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -48,36 +43,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic bytes per env-step (DESIGN.md "Kernels"): fused rollout = what one env-step must write (+ amortised state)
+METRIC = "env-steps/sec at num_envs=65536 (1/2/4/8 MI355X) vs CPU AsyncVectorEnv"
+LINE_LIMIT = 4096  # bytes of the one stdout line (tests/test_gpu_bench_contract.py)
+# algorithmic bytes per env-step (DESIGN.md "Kernels"): fused rollout = what one env-step must write (+ the state row once per launch)
 ROLLOUT_BYTES = {"CartPole-v1": 34, "Pendulum-v1": 26, "Acrobot-v1": 42, "MountainCar-v0": 26, "MountainCarContinuous-v0": 22}
 STATE_BYTES = {"CartPole-v1": 96, "Pendulum-v1": 64, "Acrobot-v1": 96, "MountainCar-v0": 64, "MountainCarContinuous-v0": 64}
-STEP_BYTES = {"CartPole-v1": 108, "Pendulum-v1": 68, "Acrobot-v1": 116, "MountainCar-v0": 68, "MountainCarContinuous-v0": 64}
-# MuJoCo family on the cooperative kernel: a rollout launch = `inner` x [mj_sample_kernel, mj_physics_kernel, mj_step_kernel]; the
-# physics kernel is > 98 % of the time (profiles/r01_z_ant_coop_physics.txt)
-MJ_COOP = ("Ant-v5", "Humanoid-v5", "HumanoidStandup-v5", "HalfCheetah-v5")
+# MuJoCo family on the cooperative kernel: a rollout launch = `inner` x [mj_sample_kernel, mj_physics_kernel, mj_step_kernel]
+MJ_COOP = ("Ant-v5", "Humanoid-v5", "HumanoidStandup-v5", "HalfCheetah-v5", "Walker2d-v5")
+MJ_IDS = MJ_COOP + ("Hopper-v5", "InvertedPendulum-v5", "InvertedDoublePendulum-v5", "Reacher-v5", "Swimmer-v5", "Pusher-v5")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# (env, num_envs per GPU, vector steps per launch, launches) of the secondary lines: BASELINE.json configs[2..4] + the north_star's Ant @65536
-SECONDARY = [("Pendulum-v1", 65536, 128, 20), ("Acrobot-v1", 65536, 128, 10), ("MountainCarContinuous-v0", 65536, 128, 20),
-             ("Ant-v5", 32768, 4, 6), ("Ant-v5", 65536, 4, 4), ("Humanoid-v5", 32768, 4, 3)]
-# The other contact regime of the two headline robots: the random policy with `terminate_when_unhealthy` ends a Humanoid
-# episode after ~22 steps, so the batch above is mostly robots still upright; with termination off and a warm-up of GROUND_WARM launches every
-# robot lies on the ground (many contacts, the PGS sweeps dominate).  A learner that keeps the robot alive lives between the two lines.
-GROUND_WARM = 40
-SECONDARY_GROUND = [("Ant-v5", 32768, 4), ("Humanoid-v5", 32768, 4)]
-F64_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz
-# the reference itself, measured in the build container (no gymnasium on the GPU box)
-CPU_REFERENCE_RECORDED = {
-    "hardware": "8 vCPU Intel Xeon @ 2.10 GHz (build container), Python 3.10.12, NumPy 2.2.6, reference gymnasium v1.4.0",
-    "how": "gymnasium.utils.performance.benchmark_vector_step, 2-3 s runs (BASELINE.md section 2)", "unit": "env-steps/s",
-    "AsyncVectorEnv CartPole-v1": {"num_envs=4": 10.0e3, "num_envs=8": 14.6e3, "num_envs=16": 16.8e3, "cores": 8},
-    "SyncVectorEnv CartPole-v1": {"num_envs=4": 51e3, "num_envs=64": 74e3, "num_envs=1024": 84e3, "cores": 1},
-    "NumPy CartPoleVectorEnv (vector_entry_point)": {"num_envs=1024": 7.3e6, "num_envs=65536": 13.7e6, "cores": 1},
-    "single env gym.make": {"CartPole-v1": 82e3, "MountainCar-v0": 70e3, "MountainCarContinuous-v0": 35e3, "Pendulum-v1": 20e3, "Acrobot-v1": 16e3, "cores": 1},
-    "MuJoCo ids": "unavailable: `mujoco` is not installed in the build container either",
-}
+DUO_CHUNK = {"CartPole-v1": 4, "MountainCar-v0": 8, "MountainCarContinuous-v0": 8}  # envs_classic.h DUO_ROLLOUT / DUO_CHUNK
 
 
-# ---- CPU legs -----------------------------------------------------------------------------------------------------------------
+# ---- CPU legs: the oracle as the timed baseline and as the checker of the first timed launch ----------------------------------------
 def _oracle_rollouts(env_id, num_envs, offset, budget_s, start_at=None):
     """One process' share of the CPU baseline: `num_envs` sub-environments (global indices from `offset`) of the C oracle stepping the
     same fused random-policy rollout for ~budget_s seconds.  Returns (env_steps, seconds, vector_steps)."""
@@ -136,9 +114,9 @@ def usable_cpus():
 
 def cpu_baseline(env_id, num_envs, budget_s=12.0, workers=None):
     """The CPU oracle (C restatement of the reference's env + SyncVectorEnv semantics) on the same workload ON THE HOST'S CORES: the batch
-    is sharded over `workers` processes (default: one per CPU this job may use -- usable_cpus(): the cgroup quota counts, not the 256 logical CPUs
-    the GPU box reports; rounds 1-3 used 64 there, which over-subscribed a 16-CPU quota -- MI355ENV_CPU_WORKERS overrides; each process runs the single-threaded C
-    rollout on its contiguous block of sub-environments, like one rank of the GPU job), all started together and run for ~budget_s.
+    is sharded over `workers` processes (default: one per CPU this job may use -- usable_cpus(): the cgroup quota counts, not the 256 logical
+    CPUs the GPU box reports; MI355ENV_CPU_WORKERS overrides; each process runs the single-threaded C rollout on its contiguous block of
+    sub-environments, like one rank of the GPU job), all started together and run for ~budget_s.
     value = env-steps of all processes / the longest process' time.  kind="port": the Python reference is not present on the GPU box."""
     cores = os.cpu_count() or 1
     usable, why = usable_cpus()
@@ -146,8 +124,7 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0, workers=None):
         workers = int(os.environ.get("MI355ENV_CPU_WORKERS", usable))
     workers = max(1, min(workers, num_envs))
     if workers == 1:
-        steps, dt, vsteps = _oracle_rollouts(env_id, num_envs, 0, budget_s)
-        per = [(steps, dt, vsteps)]
+        per = [_oracle_rollouts(env_id, num_envs, 0, budget_s)]
     else:
         base, rem = divmod(num_envs, workers)
         start_at = time.time() + 3.0 + 0.02 * workers  # interpreter start + imports + warm-up of every worker (a late one just starts late: every worker times its own window)
@@ -164,59 +141,76 @@ def cpu_baseline(env_id, num_envs, budget_s=12.0, workers=None):
             if p.returncode == 0 and out.strip():
                 per.append(tuple(json.loads(out.strip().splitlines()[-1])))
         if len(per) != workers:  # a worker died: fall back to what one process measures
-            steps, dt, vsteps = _oracle_rollouts(env_id, num_envs, 0, budget_s)
-            per, workers = [(steps, dt, vsteps)], 1
+            per, workers = [_oracle_rollouts(env_id, num_envs, 0, budget_s)], 1
     steps, dt = sum(x[0] for x in per), max(x[1] for x in per)
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": workers, "host_cpu_count": cores, "usable_cpus": usable, "usable_cpus_source": why, "kind": "port",
-            "per_core_value": steps / dt / workers,
-            "sample": f"{env_id} num_envs={num_envs} sharded over {workers} process(es) of the C oracle (one single-threaded rollout loop per core, "
-                      f"same random policy, same outputs materialised), {steps} env-steps in {dt:.1f} s"}
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": workers, "kind": "port", "host_cpu_count": cores, "usable_cpus": usable,
+            "usable_cpus_source": why, "per_core_value": steps / dt / workers,
+            "sample": f"{env_id} num_envs={num_envs} over {workers} single-threaded C-oracle process(es), same random policy, same outputs written, "
+                      f"{steps} env-steps in {dt:.1f} s"}
 
 
-def cpu_reference(budget_s=4.0):
-    """Gymnasium's own vectorisers on this host's cores, if the package is importable (utils/performance.py:57-103).  Returns None
-    where it is not (the GPU box): the caller then carries the numbers recorded in the build container."""
-    ref = os.environ.get("GYM_REFERENCE", "/root/reference")
-    if os.path.isdir(os.path.join(ref, "gymnasium")) and ref not in sys.path:
-        sys.path.append(ref)
-    try:
-        import gymnasium as gym
-        from gymnasium.utils.performance import benchmark_vector_step
-    except Exception:
-        return cpu_reference_port(budget_s)
-    cores = os.cpu_count() or 1
-    out = {"cores": cores, "unit": "env-steps/s", "gymnasium": gym.__version__, "how": f"benchmark_vector_step, target_duration={budget_s} s"}
-    for label, kw in ((f"AsyncVectorEnv CartPole-v1 num_envs={cores}", dict(num_envs=cores, vectorization_mode="async")),
-                      ("SyncVectorEnv CartPole-v1 num_envs=1024", dict(num_envs=1024, vectorization_mode="sync")),
-                      ("NumPy CartPoleVectorEnv num_envs=65536", dict(num_envs=65536, vectorization_mode="vector_entry_point"))):
-        try:
-            env = gym.make_vec("CartPole-v1", **kw)
-            out[label] = benchmark_vector_step(env, target_duration=budget_s, seed=0)
-            env.close()
-        except Exception as e:  # a missing optional dependency must not cost the GPU numbers
-            out[label] = f"failed: {type(e).__name__}: {e}"
-    return out
+def trajectory_digest(traj) -> str:
+    """sha256 over the bytes of (actions, observations, rewards, terminated, truncated), time-major, in that order."""
+    h = hashlib.sha256()
+    for a in traj:
+        h.update(np.ascontiguousarray(a).view(np.uint8).reshape(-1).data)
+    return h.hexdigest()
 
 
-def cpu_reference_port(budget_s=4.0):
-    """Where gymnasium itself is not importable (the GPU box): the reference's AsyncVectorEnv ARCHITECTURE restated (oracle/async_baseline.py:
-    one process per sub-environment, pipes, shared-memory observations, the scalar CartPole in Python; pinned on the real AsyncVectorEnv by
-    tests/test_async_baseline.py) and timed by the same counting rule as benchmark_vector_step -- in THIS run, on THIS host's cores.  It carries
-    less per-step overhead than the real thing (no PassiveEnvChecker / OrderEnforcing layers, no info-dict assembly): an upper bound of it."""
-    if not os.path.exists(os.path.join(ROOT, "oracle", "async_baseline.py")):
-        return None
-    usable, why = usable_cpus()
-    out = {"kind": "port", "what": "oracle/async_baseline.py: AsyncVectorEnv's architecture (vector/async_vector_env.py) around a Python CartPole-v1, "
-                                   "NOT gymnasium itself (not installed on this host)", "unit": "env-steps/s", "usable_cpus": usable,
-           "usable_cpus_source": why, "host_cpu_count": os.cpu_count(), "how": f"benchmark_vector_step's loop and counting rule, target_duration={budget_s} s"}
-    for n in sorted({usable, 4 * usable}):  # the reference's own convention (num_envs = cores) and an over-subscribed one
-        key = f"AsyncVectorEnv-port CartPole-v1 num_envs={n}"
-        try:  # in a fresh interpreter: its worker processes are forked from a process without a HIP context or RCCL threads
-            p = subprocess.run([sys.executable, "-m", "oracle.async_baseline", str(n), str(budget_s)], cwd=ROOT, capture_output=True, text=True, timeout=budget_s * 3 + 120)
-            out[key] = float(p.stdout.strip().splitlines()[-1])
-        except Exception as e:
-            out[key] = f"failed: {type(e).__name__}: {e}"
-    return out
+def oracle_trajectory(env_id, N, T, offset=0, policy_seed=0, env_kwargs=None, actions=None, env_indices=None):
+    """The reference computation of one bench launch on the CPU checker: sub-environments with global indices `offset + env_indices` (default
+    all N) are reset with seed 0 (env g <- seed 0 + g, sync_vector_env.py:207-208) and stepped T times, either under the random policy
+    `action_space.seed(policy_seed); action_space.sample()` or teacher-forced with `actions`.  Returns (actions, obs, rewards, terminated, truncated)."""
+    import gymnasium_amd
+    from gymnasium_amd import _native
+    from oracle import oracle
+
+    if env_indices is None:
+        n, kw, seed = N, {"env_index_offset": offset}, 0
+    else:
+        n, kw, seed = len(env_indices), {}, [int(offset + g) for g in env_indices]
+    env = gymnasium_amd.make_vec(env_id, num_envs=n, _engine_factory=oracle.engine_factory, **kw, **(env_kwargs or {}))
+    env.reset(seed=seed)
+    eng = env._engine
+    obs = np.zeros((T, n) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (T, n, eng.obs_dim), eng.obs_dtype)
+    rew, te, tr = np.zeros((T, n)), np.zeros((T, n), np.bool_), np.zeros((T, n), np.bool_)
+    if actions is None:
+        env.action_space.seed(policy_seed)
+        eng.action_seed(_native.pcg_words(env.action_space.np_random))
+        acts = np.zeros((T, n) if eng.act_dtype is np.int64 else (T, n, eng.act_dim), dtype=eng.act_dtype)
+        eng.rollout(T, None, acts, obs, rew, te, tr)
+    else:
+        acts = np.ascontiguousarray(actions)
+        eng.rollout(T, acts, None, obs, rew, te, tr)
+    env.close()
+    return acts, obs, rew, te, tr
+
+
+def oracle_check(cfg, traj):
+    """`traj` = the first timed launch of this rank, on the host.  (1) its actions are the host policy's: `action_space.seed(rank)` + T x
+    `sample()` of the batched space (spaces/multi_discrete.py:176-178, spaces/box.py:463-465); (2) the oracle, reset with the same seeds and
+    teacher-forced with those actions, produces the same observations / rewards / flags: every sub-environment, bit for bit, for the
+    bit-exact kinds (classic control, ToyText); <= 256 strided sub-environments within 1e-8 for the MuJoCo kinds."""
+    acts, obs, rew, te, tr = traj
+    T, N = cfg.inner, cfg.N
+    sp = copy.deepcopy(cfg.env.action_space)
+    sp.seed(cfg.rank)
+    host_acts = np.stack([sp.sample() for _ in range(T)]).reshape(acts.shape)
+    policy_ok = bool(np.array_equal(host_acts.astype(acts.dtype), acts))
+    exact = cfg.env_id not in MJ_IDS
+    stride = 1 if exact else max(1, N // 256)
+    idx = None if stride == 1 else np.arange(0, N, stride)
+    sel = (lambda a: a) if idx is None else (lambda a: np.ascontiguousarray(a[:, idx]))
+    _, o2, r2, te2, tr2 = oracle_trajectory(cfg.env_id, N, T, offset=cfg.rank * N, env_kwargs=cfg.env_kwargs, actions=sel(acts), env_indices=idx)
+    flags_ok = bool(np.array_equal(sel(te), te2) and np.array_equal(sel(tr), tr2))
+    if exact:
+        vals_ok = bool(np.array_equal(sel(obs), o2) and np.array_equal(sel(rew), r2))
+        worst = 0.0 if vals_ok else float(max(np.nanmax(np.abs(sel(obs).astype(np.float64) - o2)), np.nanmax(np.abs(sel(rew) - r2))))
+    else:
+        worst = float(max(np.max(np.abs(sel(obs) - o2)), np.max(np.abs(sel(rew) - r2))))
+        vals_ok = worst <= 1e-8
+    return {"ok": policy_ok and flags_ok and vals_ok, "against": "oracle/ (C restatement), same seeds, in this run", "envs": N if idx is None else len(idx),
+            "steps": T, "compare": "array_equal" if exact else "atol 1e-8", "max_abs_diff": worst, "policy_equals_host_sample": policy_ok}
 
 
 # ---- live PMC passes (rocprofv3 on a short child invocation of this file) --------------------------------------------------------
@@ -246,116 +240,100 @@ def _rocprof_counters(args, counters, kernel_like, timeout_s):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
+def child_args(env_id, N, inner, env_kwargs=None, warm=1):
+    return ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", str(warm), "--env-kwargs", json.dumps(env_kwargs or {})]
 
 
-ISSUE_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]
-FLOP_COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64"]
-SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
-
-
-DUO_CHUNK = {"CartPole-v1": 4, "MountainCar-v0": 8, "MountainCarContinuous-v0": 8}  # envs_classic.h DUO_ROLLOUT / DUO_CHUNK
-
-
-def live_counters(env_id, N, inner, kernel, want_traffic, want_sq, timeout_s=150, env_kwargs=None, want_issue=False, want_flops=False, warm=1):
-    """HBM traffic per dispatch of `kernel` (WRITE_SIZE + 2 FETCH_SIZE, in KiB on gfx950; MI355X_MICROARCH.md HBM section: separate
-    passes, FETCH_SIZE doubled) and, for the VALU-bound kernels, the SQ activity counters as shares of SQ_WAVE_CYCLES."""
-    args = ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", str(warm), "--env-kwargs", json.dumps(env_kwargs or {})]
-    out = {}
-    if want_flops:
-        # EXECUTED fp64 vector instructions of the kernel, by kind (wave-level: one count per 64-lane instruction, whatever the EXEC mask)
-        fc = _rocprof_counters(args, FLOP_COUNTERS, kernel, timeout_s)
-        if fc and fc.get("SQ_INSTS_VALU", (0, 0))[0] > 0:
-            g = lambda k: fc.get(k, (0.0, 0))[0]  # noqa: E731
-            out["flops"] = {"fma_f64": g("SQ_INSTS_VALU_FMA_F64"), "mul_f64": g("SQ_INSTS_VALU_MUL_F64"), "add_f64": g("SQ_INSTS_VALU_ADD_F64"),
-                            "trans_f64": g("SQ_INSTS_VALU_TRANS_F64"), "mfma_mops_f64": g("SQ_INSTS_VALU_MFMA_MOPS_F64"), "valu": g("SQ_INSTS_VALU"),
-                            "dispatches": fc["SQ_INSTS_VALU"][1], "source": "rocprofv3 --pmc " + " ".join(FLOP_COUNTERS) + " on a child invocation in this run"}
-    if want_traffic:
-        f = _rocprof_counters(args, ["FETCH_SIZE"], kernel, timeout_s)
-        w = _rocprof_counters(args, ["WRITE_SIZE"], kernel, timeout_s) if f else None
-        if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
-            out["traffic"] = 1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0])
-            out["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, FETCH_SIZE doubled) on a child invocation in this run, "
-                                     f"{f['FETCH_SIZE'][1]} dispatches of {kernel}")
-    if want_issue:
-        ic = _rocprof_counters(args, ISSUE_COUNTERS, kernel, timeout_s)
-        if ic and ic.get("SQ_WAVES", (0, 0))[0] > 0:
-            waves, groups = ic["SQ_WAVES"][0], N / 64.0  # a group = 64 sub-environments: ONE wavefront in the one-role kernels, an env + an aux wavefront in rollout_duo_kernel
-            valu, salu = ic["SQ_INSTS_VALU"][0] / groups / inner, ic["SQ_INSTS_SALU"][0] / groups / inner
-            per_group = waves / groups
-            # a SIMD issues at most one 64-lane VALU instruction per 4 cycles.  With ONE wavefront per SIMD scalar instructions are not hidden behind
-            # another wavefront's vector work and take issue slots too; with two (the two-role kernel) they issue beside the partner's VALU work.
-            slots = valu + salu if per_group < 1.5 else valu
-            out["issue"] = {"valu_per_env_step": valu, "salu_per_env_step": salu, "wavefronts_per_64_envs": per_group,
-                            "ceiling_env_steps_per_s": SIMDS * 64 * CLOCK_HZ / (4.0 * slots),
-                            "assumptions": (f"{SIMDS} SIMDs x 64 lanes, one instruction per 4 cycles at {CLOCK_HZ / 1e9:.1f} GHz; issue slots per env-step = "
-                                            + ("VALU + SALU (one wavefront per SIMD)" if per_group < 1.5 else "VALU (two wavefronts per SIMD: scalar instructions issue beside the partner's vector instructions)")),
-                            "source": "rocprofv3 --pmc " + " ".join(ISSUE_COUNTERS) + " on a child invocation in this run"}
-    if want_sq:
-        sq = _rocprof_counters(args, SQ_COUNTERS, kernel, timeout_s)
-        if sq and sq.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
-            wc = sq["SQ_WAVE_CYCLES"][0]
-            out["sq"] = {k[3:].lower() + "_frac": sq[k][0] / wc for k in SQ_COUNTERS[1:] if k in sq}
-            out["sq_source"] = "rocprofv3 --pmc " + " ".join(SQ_COUNTERS) + " on a child invocation in this run"
-    return out
+def live_traffic(env_id, N, inner, kernel, env_kwargs=None, warm=1, timeout_s=150):
+    """HBM bytes per dispatch of `kernel`: WRITE_SIZE + 2 x FETCH_SIZE, in KiB on gfx950, from two separate rocprofv3 --pmc passes
+    (MI355X_MICROARCH.md, HBM section).  (bytes, provenance) or (None, None)."""
+    args = child_args(env_id, N, inner, env_kwargs, warm)
+    f = _rocprof_counters(args, ["FETCH_SIZE"], kernel, timeout_s)
+    w = _rocprof_counters(args, ["WRITE_SIZE"], kernel, timeout_s) if f else None
+    if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
+        return 1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0]), f"live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run ({f['FETCH_SIZE'][1]} dispatches)"
+    return None, None
 
 
 def recorded_traffic(env_id, N, inner):
-    """(bytes per launch, provenance) from profiles/pmc_traffic.json -- PMC passes of an earlier run of the same command; the file's
-    `_recorded_at` names the commit / round whose kernels were profiled (a later kernel change does not update it by itself)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    """(bytes per launch, provenance) from profiles/pmc_traffic.json -- PMC passes of an earlier run of the same command."""
     try:
-        rec = json.load(open(path))
-        return rec.get(f"{env_id}:{N}:{inner}"), rec.get("_recorded_at", "unstamped")
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        v = rec.get(f"{env_id}:{N}:{inner}")
+        return v, (None if v is None else f"profiles/pmc_traffic.json ({rec.get('_recorded_at', 'unstamped')}); no live pass in this run")
     except Exception:
         return None, None
 
 
 # ---- one configuration on this rank's GPU --------------------------------------------------------------------------------------
 class Config:
+    """One (env id, num_envs, fused steps) configuration on this rank's GPU: the env, two sets of trajectory buffers (`first`: written by
+    the first timed launch only and read back for the digest; `rest`: reused by every other launch, as a collector hands them to the
+    learner), the launch, and the timed region.  tests/bench_dryrun.py subclasses the four device-specific methods."""
+
     def __init__(self, env_id, N, inner, local_rank, rank, env_kwargs=None):
+        self.env_id, self.N, self.inner, self.local_rank, self.rank, self.env_kwargs = env_id, N, inner, local_rank, rank, env_kwargs
+        self.env = self.make_env()
+        self.eng = self.env._engine
+        self.first, self.rest = self.alloc_trajectory(), self.alloc_trajectory()
+        self.rearm()
+
+    # -- device-specific ----------------------------------------------------------------------------------
+    def make_env(self):
+        import gymnasium_amd
+
+        return gymnasium_amd.make_vec(self.env_id, num_envs=self.N, device=self.local_rank, output="torch", env_index_offset=self.rank * self.N,
+                                      **(self.env_kwargs or {}))
+
+    def alloc_trajectory(self):
         import torch
 
-        import gymnasium_amd
-        from gymnasium_amd import _native
-
-        self.torch, self.env_id, self.N, self.inner, self.env_kwargs = torch, env_id, N, inner, env_kwargs
-        dev = torch.device("cuda", local_rank)
-        env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", env_index_offset=rank * N, **(env_kwargs or {}))
-        env.reset(seed=0)
-        env.action_space.seed(rank)
-        eng = env._engine
-        self.env, self.eng = env, eng
-        # preallocated trajectory buffers, reused every launch (a real collector would hand them to the learner)
-        act_dtype = torch.int64 if env._discrete else torch.float32
+        env, eng, T, N = self.env, self.eng, self.inner, self.N
+        dev = torch.device("cuda", self.local_rank)
         obs_dtype = {np.float64: torch.float64, np.float32: torch.float32, np.int64: torch.int64}[eng.obs_dtype]
-        self.acts = torch.empty((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=act_dtype, device=dev)
-        self.obs = torch.empty((inner, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (inner, N, eng.obs_dim), dtype=obs_dtype, device=dev)
-        self.rew = torch.empty((inner, N), dtype=torch.float64, device=dev)
-        self.te = torch.empty((inner, N), dtype=torch.bool, device=dev)
-        self.tr = torch.empty((inner, N), dtype=torch.bool, device=dev)
-        env._bind_stream()
-        eng.action_seed(_native.pcg_words(env.action_space.np_random))
+        bufs = (torch.empty((T, N) if env._discrete else (T, N, eng.act_dim), dtype=torch.int64 if env._discrete else torch.float32, device=dev),
+                torch.empty((T, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (T, N, eng.obs_dim), dtype=obs_dtype, device=dev),
+                torch.empty((T, N), dtype=torch.float64, device=dev), torch.empty((T, N), dtype=torch.bool, device=dev),
+                torch.empty((T, N), dtype=torch.bool, device=dev))
+        return bufs, tuple(b.data_ptr() for b in bufs)
 
-    def launch(self):
-        self.eng.rollout(self.inner, None, self.acts.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(), self.te.data_ptr(), self.tr.data_ptr())
+    def host_trajectory(self):
+        return tuple(b.cpu().numpy() for b in self.first[0])
 
     def timed(self, K, sync):
         """K launches between two HIP events on the engine's stream (env._bind_stream() = torch's current stream).  One event on either
-        side: an event after every launch would put a marker packet between the kernels (+9 us per 96 us launch, measured)."""
-        t = self.torch
-        ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        side: an event after every launch would put a marker packet between the kernels (+9 us per 96 us launch, measured).
+        Returns (wall seconds, average seconds per launch by the events, statistics of the K launches)."""
+        import torch
+
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         sync()
         self.eng.reset_stats()
         sync()
         t0 = time.perf_counter()
         ev0.record()
-        for _ in range(K):
+        self.launch(self.first)
+        for _ in range(K - 1):
             self.launch()
         ev1.record()
         sync()
         elapsed = time.perf_counter() - t0
         return elapsed, ev0.elapsed_time(ev1) * 1e-3 / K, self.env.statistics()
+
+    # -- common --------------------------------------------------------------------------------------------
+    def rearm(self):
+        """Bring the sub-environments and the policy stream to the known start: reset(seed=0) (env g <- seed g, global index) and
+        `action_space.seed(rank)` handed to the engine.  The launch that follows is reproducible by anyone (oracle_trajectory)."""
+        from gymnasium_amd import _native
+
+        self.env.reset(seed=0)
+        self.env.action_space.seed(self.rank)
+        self.env._bind_stream()
+        self.eng.action_seed(_native.pcg_words(self.env.action_space.np_random))
+
+    def launch(self, bufs=None):
+        p = (bufs or self.rest)[1]
+        self.eng.rollout(self.inner, None, p[0], p[1], p[2], p[3], p[4])
 
     def algorithmic_bytes_per_launch(self):
         eng, env = self.eng, self.env
@@ -380,61 +358,71 @@ class Config:
             return "tab_rollout_kernel"
         return "mj_physics_kernel" if self.env_id in MJ_COOP else "mj_rollout_kernel"
 
-    def roofline(self, kernel_s, pmc=(), warm=1, env_steps_per_s=None):
-        """kernel_s = average duration of one rollout launch; pmc = which live counter passes to run ("traffic", "sq").  HBM-bound kernels: algorithmic bytes per launch / kernel_s against
-        8 TB/s.  The cooperative MuJoCo kernels are VALU / latency bound (one wavefront per SIMD): frac is the
-        measured share of wave cycles that issue VALU work, and the HBM side is reported as a traffic ratio."""
+    def roofline(self, kernel_s, live=False, warm=1):
+        """The contract's roofline object for the dominant kernel.  achieved = algorithmic bytes per launch / the average launch duration the
+        HIP events measured; traffic = HBM bytes per launch from the PMC counters (live passes on a child invocation when `live`, else the
+        recorded profile, else null).  The cooperative MuJoCo kernels are VALU / latency bound: `bound` says so, the
+        HBM numbers are still reported, and their issue / flop counters live in the sidecar (scripts/bench_extras.py)."""
         algo = self.algorithmic_bytes_per_launch()
         achieved = algo / kernel_s / 1e9
         kernel = self.dominant_kernel()
-        coop = self.env_id in MJ_COOP
-        per = self.inner if coop else 1  # dispatches of the dominant kernel per rollout launch
-        live = live_counters(self.env_id, self.N, self.inner, kernel, "traffic" in pmc, "sq" in pmc and coop, env_kwargs=self.env_kwargs,
-                             want_issue="issue" in pmc and not coop, want_flops="flops" in pmc and coop, warm=max(1, warm)) if pmc else {}
-        traffic, src = live.get("traffic"), live.get("traffic_source")
+        per = self.inner if self.env_id in MJ_COOP else 1  # dispatches of the dominant kernel per rollout launch
+        traffic, src = live_traffic(self.env_id, self.N, self.inner, kernel, self.env_kwargs, warm) if live else (None, None)
         if traffic is not None:
             traffic *= per
         else:
-            traffic, stamp = recorded_traffic(self.env_id, self.N, self.inner)
-            src = None if traffic is None else f"profiles/pmc_traffic.json, recorded at {stamp} by a rocprofv3 run of the same command (no live pass in this run)"
-        base = {"kernel": kernel, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": kernel_s * 1e3,
-                "traffic_over_algorithmic": (traffic / algo) if traffic else None}
-        if coop:
-            sq = live.get("sq")
-            out = {"bound": "valu", "achieved": (sq or {}).get("active_inst_valu_frac"), "peak": 1.0, "unit": "share of wave cycles issuing VALU instructions (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), one wavefront per SIMD",
-                   "frac": (sq or {}).get("active_inst_valu_frac"), "sq": sq, "sq_source": live.get("sq_source"), "hbm_frac": achieved / HBM_PEAK_GBS,
-                   "avg_vector_step_ms": kernel_s * 1e3 / self.inner, **base}
-            fl = live.get("flops")
-            if fl:
-                # A fraction of a PEAK next to the utilisation proxy above: fp64 flops the physics kernel EXECUTES per env-step (2 per FMA, 1 per
-                # MUL / ADD, x 64 lanes per wave-level instruction -- lanes switched off by the EXEC mask or carrying no body / dof are counted, so
-                # this is the rate the vector units are driven at, an upper bound of the useful rate) x env-steps/s, against the chip's vector fp64 peak.
-                per_dispatch = 64.0 * (2.0 * fl["fma_f64"] + fl["mul_f64"] + fl["add_f64"])
-                stepping = (env_steps_per_s * kernel_s / self.inner) if env_steps_per_s else float(self.N)  # sub-environments that take a real step per vector step
-                fl["flops_per_env_step"] = per_dispatch / max(stepping, 1.0)
-                fl["f64_instruction_share_of_valu"] = (fl["fma_f64"] + fl["mul_f64"] + fl["add_f64"] + fl["trans_f64"]) / fl["valu"]
-                rate = per_dispatch / (kernel_s / self.inner)  # dispatches of the physics kernel run back to back: one per vector step
-                out["flops"] = fl
-                out["achieved_tflops_f64"] = rate / 1e12
-                out["peak_tflops_f64"] = F64_PEAK_TFLOPS
-                out["frac_of_f64_peak"] = rate / 1e12 / F64_PEAK_TFLOPS
-            return out
-        out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **base}
-        if live.get("issue"):
-            # The OTHER ceiling of this kernel: at one wavefront per SIMD the instruction issue rate bounds it before HBM does (DESIGN.md section 3).
-            iss = dict(live["issue"])
-            steps_per_s = self.N * self.inner / kernel_s  # lanes stepped per second by this kernel (autoreset lanes included: they execute too)
-            iss["achieved_lane_steps_per_s"] = steps_per_s
-            iss["frac_of_issue_ceiling"] = steps_per_s / iss["ceiling_env_steps_per_s"]
-            iss["hbm_ceiling_env_steps_per_s"] = HBM_PEAK_GBS * 1e9 / (algo / (self.N * self.inner))
-            out["issue_bound"] = iss
-        return out
+            traffic, src = recorded_traffic(self.env_id, self.N, self.inner)
+        return {"bound": "valu" if self.env_id in MJ_COOP else "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": algo,
+                "avg_kernel_ms": kernel_s * 1e3, "traffic_over_algorithmic": (traffic / algo) if traffic else None}
 
     def close(self):
         self.env.close()
 
 
 T_START = time.perf_counter()
+
+
+def fit_line(result, limit=LINE_LIMIT):
+    """Serialise strictly (no NaN / Infinity) and keep the line under `limit` bytes by dropping optional detail, least important first."""
+    for drop in (None, "secondary", "devices", "sustained", "clock_spinup"):
+        if drop is not None:
+            result.pop(drop, None)
+        line = json.dumps(result, allow_nan=False, separators=(",", ":"))
+        if len(line) < limit:
+            return line
+    raise AssertionError(f"bench line is {len(line)} bytes even without its optional parts")
+
+
+def run_extras(args, full_path, primary):
+    """BASELINE.json configs[2..4], the step() API, the opt-in configurations and the reference's own vectorisers: scripts/bench_extras.py in a
+    child process (its own HIP context; a failure there cannot take the primary line with it).  Returns the headline dict for `secondary`."""
+    script = os.path.join(ROOT, "scripts", "bench_extras.py")
+    if not os.path.exists(script):
+        return {"skipped": "scripts/bench_extras.py not present"}
+    os.makedirs(os.path.dirname(full_path), exist_ok=True)
+    tmp = full_path + ".primary.json"
+    with open(tmp, "w") as f:
+        json.dump(primary, f, allow_nan=False)
+    cmd = [sys.executable, script, "--out", full_path, "--primary", tmp, "--pmc", args.pmc, "--budget", str(args.extras_budget),
+           "--started", str(time.time() - (time.perf_counter() - T_START))]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_api:
+        cmd.append("--no-api")
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=args.extras_budget + 240)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"failed": f"exit {p.returncode}: {p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else 'no output'}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"failed": f"timed out after {args.extras_budget + 240:.0f} s"}
+    except Exception as e:  # the primary line must survive anything that happens here
+        return {"failed": f"{type(e).__name__}: {e}"[:200]}
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def main(argv=None, harness=None):
@@ -449,14 +437,13 @@ def main(argv=None, harness=None):
     ap.add_argument("--inner", type=int, default=128, help="vector steps fused into one launch (one bench step)")
     ap.add_argument("--spinup", type=float, default=0.5, help="seconds of untimed launches before the warm-up, so that the timed region runs at sustained clocks (0 = off)")
     ap.add_argument("--sustained", type=float, default=1.5, help="seconds of back-to-back launches for sustained_value (0 = skip)")
-    ap.add_argument("--pmc", choices=["auto", "full", "off"], default="auto",
-                    help="live rocprofv3 counter passes on a child invocation: auto = primary traffic, then SQ activity of the MuJoCo secondaries and live "
-                         "traffic of every secondary while the run is younger than --pmc-budget seconds (recorded values, stamped with the profile's "
-                         "commit, after that); full = everything live; off = recorded values only")
-    ap.add_argument("--pmc-budget", type=float, default=150.0, help="auto: no further live traffic passes for the secondaries once the run is this old (s)")
+    ap.add_argument("--pmc", choices=["auto", "full", "off"], default="auto", help="live rocprofv3 counter passes on child invocations (off = recorded values only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-api", action="store_true", help="skip the per-launch step() API measurements")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (BASELINE.json configs[2..4])")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the first timed launch (the digest is still reported)")
+    ap.add_argument("--no-api", action="store_true", help="extras: skip the per-launch step() API measurements")
+    ap.add_argument("--no-secondary", "--no-extras", dest="no_secondary", action="store_true", help="skip scripts/bench_extras.py (BASELINE.json configs[2..4], API, opt-in lines)")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"), help="sidecar file with everything the line leaves out")
+    ap.add_argument("--extras-budget", type=float, default=150.0, help="extras: seconds after which no further optional measurement is started")
     ap.add_argument("--env-kwargs", default="{}", help='JSON constructor kwargs of the env, e.g. \'{"solver": "Newton"}\' (Humanoid: opt-in solver)')
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
@@ -513,8 +500,7 @@ def main(argv=None, harness=None):
         W = max(5, K // 10)
     # Clock spin-up (untimed, BEFORE the W warm-up launches, reported as `clock_spinup`): a GPU that has been idle starts in a low power state and
     # takes a few hundred milliseconds of load to reach its sustained clocks -- round 2's 20-launch runs (2 ms) measured 99 us per launch where
-    # the steady state is 90.  With explicit --steps the timed region can be that short, so the device is brought to steady state first; with the
-    # default (~1 s) timed region the spin-up is the same load a few hundred milliseconds earlier.  --spinup 0 switches it off.
+    # the steady state is 90.  --spinup 0 switches it off.
     spin_launches = 0
     if args.spinup > 0 and not args.child:
         t_spin = time.perf_counter()
@@ -530,223 +516,80 @@ def main(argv=None, harness=None):
             cfg.launch()
         sync_local()
         cfg.close()
-        return
+        return 0
+    cfg.rearm()  # known start of the timed region: its first launch is the known-answer rollout (output_sha256 / verified)
     elapsed, kernel_s, st = cfg.timed(K, sync_all)
     from gymnasium_amd import distributed as gd
 
     red = gd.reduce_statistics(st, elapsed_s=elapsed, device=dev)  # the only collective: a few dozen bytes over RCCL/xGMI
-    # What the collective itself proves about the job (n_gpus below is NOT read from the environment): gymnasium_amd/distributed.py census()
-    cen = gd.census(rank, local_rank, device=dev)
-    ranks_seen, devices = cen["ranks"], cen["devices"]
     elapsed = red["elapsed_s"]
     env_steps, episodes, return_sum = float(red["env_steps"]), float(red["episodes"]), float(red["return_sum"])
-    single = rank == 0 and world == 1 and gpu
-    pmc_primary = ("traffic", "sq", "issue", "flops") if (single and args.pmc != "off") else ()
 
-    result = None
-    if rank == 0:
-        result = {
-            "metric": "env-steps/sec at num_envs=65536 (1/2/4/8 MI355X) vs CPU AsyncVectorEnv",
-            "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": ranks_seen, "steps": K, "warmup": W,
-            "rccl_ranks": ranks_seen, "world_size_env": world, "devices": devices, "distinct_devices": cen["distinct_devices"],
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", "clock_spinup": {"seconds": args.spinup, "launches": spin_launches, "note": "untimed, before the warmup launches"},
-            **({} if gpu else {"engine": harness.label}),
-            "config": {"workload": f"{args.env} num_envs={N} per GPU, random policy (on-device action_space.sample()), "
-                                   f"NEXT_STEP autoreset, TimeLimit, fused rollout of {inner} vector steps per launch, "
-                                   "trajectory (actions, obs, rewards, terminated, truncated) written to HBM",
-                       "env": args.env, "env_kwargs": env_kwargs, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
-                       "parallelism": f"env-sharded x{world} (no data-path collective)"},
-            "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
-        }
-
+    # ---- the first timed launch: digest on every rank, oracle comparison (the checker; never the thing measured) ----------------------
+    traj = cfg.host_trajectory()
+    digest = trajectory_digest(traj)
+    verified = None
+    if not args.no_verify:
+        try:
+            verified = oracle_check(cfg, traj)
+        except Exception as e:
+            verified = {"ok": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    del traj
     # ---- sustained: the same launch back to back for >= args.sustained seconds (all ranks, same barrier discipline) ----------------
+    sustained = None
     if args.sustained > 0 and elapsed >= 0.8:  # (elapsed is the all-reduced maximum: every rank takes the same branch)
-        if rank == 0:
-            result["sustained_value"] = result["value"]
-            result["sustained"] = {"launches": K, "seconds": elapsed, "avg_kernel_ms": kernel_s * 1e3, "note": "the timed region itself is the sustained measurement"}
+        sustained = {"value": env_steps / elapsed, "launches": K, "seconds": elapsed, "avg_kernel_ms": kernel_s * 1e3, "note": "the timed region itself"}
     elif args.sustained > 0:
         Ks = max(K, int(args.sustained / max(kernel_s, 1e-7)) + 1)
         el_s, k_s, st_s = cfg.timed(Ks, sync_all)
         red_s = gd.reduce_statistics(st_s, elapsed_s=el_s, device=dev)
-        if rank == 0:
-            result["sustained_value"] = float(red_s["env_steps"]) / red_s["elapsed_s"]
-            result["sustained"] = {"launches": Ks, "seconds": red_s["elapsed_s"], "avg_kernel_ms": k_s * 1e3}
+        sustained = {"value": float(red_s["env_steps"]) / red_s["elapsed_s"], "launches": Ks, "seconds": red_s["elapsed_s"], "avg_kernel_ms": k_s * 1e3}
+    # What the collective itself proves about the job (n_gpus below is NOT read from the environment): gymnasium_amd/distributed.py census()
+    cen = gd.census(rank, local_rank, device=dev, extra={"output_sha256": digest[:16], "verified": None if verified is None else verified["ok"]})
+    ranks_seen = cen["ranks"]
+    single = rank == 0 and world == 1 and gpu
+
+    result = None
     if rank == 0:
-        result["roofline"] = cfg.roofline(kernel_s, pmc_primary, env_steps_per_s=result["value"])
-
-    # ---- the per-launch step() API (rank 0, one GPU): device tensors and the NumPy path ----------------------------------------------
-    if single and not args.no_api:
-        import gymnasium_amd
-
-        env, eng = cfg.env, cfg.eng
-        a_dev = torch.randint(0, 2, (N,), device=dev) if env._discrete else (torch.rand((N, eng.act_dim), device=dev) * 0.8 - 0.4)
-        env.copy = False
-        for _ in range(20):
-            env.step(a_dev)
-        torch.cuda.synchronize()
-        reps = 300
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(reps):
-            env.step(a_dev)
-        e1.record()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        step_kernel_s = e0.elapsed_time(e1) * 1e-3 / reps
-        result["api_step_device"] = {"value": N * reps / dt, "unit": "vector-env lanes/s (incl. autoreset lanes)",
-                                     "us_per_step_wall": dt / reps * 1e6, "us_per_step_gpu": step_kernel_s * 1e6,
-                                     "roofline_frac": (STEP_BYTES[args.env] * N / step_kernel_s / 1e9 / HBM_PEAK_GBS) if args.env in STEP_BYTES else None}
-        # the same steps as ONE HIP graph (HipVectorEnv.capture_steps): what is left when the host is out of the loop
-        G_STEPS, g_reps = 32, 30
-        graphed = env.capture_steps(actions=a_dev, steps=G_STEPS)
-        for _ in range(3):
-            graphed.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(g_reps):
-            graphed.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        dtg = time.perf_counter() - t0
-        result["api_step_graph"] = {"value": N * G_STEPS * g_reps / dtg, "unit": "vector-env lanes/s (incl. autoreset lanes)", "steps_per_graph": G_STEPS,
-                                    "us_per_step_wall": dtg / (G_STEPS * g_reps) * 1e6, "us_per_step_gpu": e0.elapsed_time(e1) * 1e3 / (G_STEPS * g_reps),
-                                    "roofline_frac": (STEP_BYTES[args.env] * N / (dtg / (G_STEPS * g_reps)) / 1e9 / HBM_PEAK_GBS) if args.env in STEP_BYTES else None,
-                                    "what": f"{G_STEPS} step() calls captured into one hipGraph, replayed {g_reps} times"}
-        del graphed
-        env_np = gymnasium_amd.make_vec(args.env, num_envs=N, device=local_rank, copy=False)
-        env_np.reset(seed=0)
-        env_np.action_space.seed(0)
-        actions = [env_np.action_space.sample() for _ in range(8)]
-        t0 = time.perf_counter()
-        for _ in range(40):
-            env_np.action_space.sample()
-        sample_us = (time.perf_counter() - t0) / 40 * 1e6
-        reps = 100
-
-        def timed_steps(use_pinned):
-            for k in range(5):
-                env_np.step(actions[k % 8])
-            t0 = time.perf_counter()
-            for k in range(reps):
-                if use_pinned:  # the caller's policy writes straight into the pinned upload array
-                    env_np.step(env_np.action_buffer)
-                else:
-                    env_np.step(actions[k % 8])
-            return (time.perf_counter() - t0) / reps
-
-        dt_page = timed_steps(False)
-        env_np.action_buffer[...] = actions[0]
-        dt_pin = timed_steps(True)
-        result["api_step_numpy"] = {"value": N / dt_page, "unit": "vector-env lanes/s (NumPy in / NumPy out over PCIe: the step kernel reads the actions from and writes its outputs to one page-locked block, no copy-engine hand-off; "
-                                                                 "host action sampling excluded)",
-                                    "us_per_step_wall": dt_page * 1e6, "us_per_step_wall_actions_in_pinned_buffer": dt_pin * 1e6,
-                                    "host_action_space_sample_us": sample_us}
-        env_np.close()
-        # the reference's stateful wrappers on top (ClipReward(NormalizeReward(NormalizeObservation(env)))), device tensors in and out
-        if args.env in STEP_BYTES:
-            from gymnasium_amd import wrappers as gw
-
-            wrapped = {}
-            for mode in ("fused", "standalone"):
-                env_w = gymnasium_amd.make_vec(args.env, num_envs=N, device=local_rank, output="torch", copy=False)
-                if mode == "standalone":
-                    env_w.FUSES_WRAPPERS = False
-                w = gw.ClipReward(gw.NormalizeReward(gw.NormalizeObservation(env_w)), -5.0, 5.0)
-                w.reset(seed=0)
-                for _ in range(10):
-                    w.step(a_dev)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(100):
-                    w.step(a_dev)
-                torch.cuda.synchronize()
-                wrapped[mode] = (time.perf_counter() - t0) / 100 * 1e6
-                w.close()
-            result["api_step_wrapped"] = {"wrappers": "ClipReward(NormalizeReward(NormalizeObservation(env)))", "us_per_step_wall_fused": wrapped["fused"],
-                                          "us_per_step_wall_standalone_passes": wrapped["standalone"], "launches_per_step_fused": 2 if N <= 262144 else 3,
-                                          "launches_per_step_standalone": 11, "evidence": "profiles/r02_wrappers_fused.txt"}
+        all_ok = [d.get("verified") for d in cen["devices"]]
+        result = {
+            "metric": METRIC, "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": ranks_seen, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            **({} if gpu else {"engine": harness.label}),
+            "config": {"workload": f"{args.env} num_envs={N} per GPU, random policy (on-device action_space.sample()), NEXT_STEP autoreset, TimeLimit, "
+                                   f"fused rollout of {inner} vector steps per launch, trajectory (actions, obs, rewards, terminated, truncated) written to HBM",
+                       "env": args.env, "env_kwargs": env_kwargs, "num_envs_per_gpu": N, "vector_steps_per_launch": inner,
+                       "parallelism": f"env-sharded x{world} (no data-path collective)"},
+            "roofline": cfg.roofline(kernel_s, live=single and args.pmc != "off"),
+            "cpu_baseline": None,
+            "output_sha256": digest, "verified": verified, "verified_all_ranks": (all(v is True for v in all_ok) if not args.no_verify else None),
+            "rccl_ranks": ranks_seen, "world_size_env": world, "distinct_devices": cen["distinct_devices"],
+            "devices": [{k: d.get(k) for k in ("rank", "uuid", "output_sha256", "verified")} for d in cen["devices"]],
+            "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
+            "sustained_value": sustained["value"] if sustained else None, "sustained": sustained,
+            "clock_spinup": {"seconds": args.spinup, "launches": spin_launches, "note": "untimed, before the warmup launches"},
+        }
     cfg.close()
-    if single and args.env in STEP_BYTES and not env_kwargs:  # the opt-in configuration next to the default (bit-exact libm) one
-        c_opt = Config(args.env, N, inner, local_rank, 0, {"fast_math": True})
-        for _ in range(2):
-            c_opt.launch()
-        el_o, _, st_o = c_opt.timed(K, sync_local)
-        result["opt_in"] = {"env_kwargs": {"fast_math": True}, "value": st_o["env_steps"] / el_o, "unit": "env-steps/s",
-                            "note": "device sin / cos and x * x instead of the bit-exact libm restatements (tolerance parity, tests/test_gpu_parity.py)"}
-        c_opt.close()
 
-    # ---- secondary configurations (rank 0, one GPU) -------------------------------------------------------------------------------------
-    if single and not args.no_secondary and args.env == "CartPole-v1":
-        result["secondary"] = []
-        def steady(c, seconds=0.7):
-            """~`seconds` of back-to-back launches after a tenth of that as warm-up: (env-steps/s, launches, avg kernel s)"""
-            for _ in range(2):
-                c.launch()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                c.launch()
-            torch.cuda.synchronize()
-            k = int(min(20000, max(3, round(seconds / max((time.perf_counter() - t0) / 3, 1e-6)))))
-            for _ in range(max(1, k // 10)):
-                c.launch()
-            el, ks, st = c.timed(k, sync_local)
-            return st["env_steps"] / el, k, ks, el
-
-        for env_id, n2, inner2, k2 in SECONDARY:
-            c2 = Config(env_id, n2, inner2, local_rank, 0)
-            v2, k2, ks2, el2 = steady(c2)
-            line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "sustained_value": v2, "seconds": el2,
-                    "unit": "env-steps/s", "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64"}
-            # full: everything live.  auto: the SQ-activity pass for the VALU-bound MuJoCo kernels, and live FETCH / WRITE passes too while
-            # the run is young enough (each pass is a child process of ~5-10 s); after that the recorded profile's value, stamped as such
-            young = (time.perf_counter() - T_START) < args.pmc_budget
-            want = ("traffic", "sq", "flops") if args.pmc == "full" else ((("traffic",) if young else ()) + (("sq", "flops") if env_id in MJ_COOP else ()) if args.pmc == "auto" else ())
-            line["roofline"] = c2.roofline(ks2, want, env_steps_per_s=v2)
-            c2.close()
-            opt = {"fast_math": True} if env_id in STEP_BYTES else ({"solver": "Newton"} if env_id in ("Humanoid-v5", "HumanoidStandup-v5") else None)
-            if opt:  # the opt-in, faster configuration next to the default (reference-faithful) one
-                c3 = Config(env_id, n2, inner2, local_rank, 0, opt)
-                line["opt_in"] = {"env_kwargs": opt, "value": steady(c3)[0], "unit": "env-steps/s"}
-                c3.close()
-            if not args.no_cpu_baseline:  # MuJoCo: a 512-env sample (the oracle's per-env cost does not depend on the batch size)
-                line["cpu_baseline"] = cpu_baseline(env_id, min(n2, 64 * usable_cpus()[0]) if env_id in MJ_COOP else n2, budget_s=3.0)
-            result["secondary"].append(line)
-
-        # the on-the-ground regime of the two headline robots: termination off, GROUND_WARM launches before anything is timed or profiled
-        for env_id, n2, inner2 in SECONDARY_GROUND:
-            kw = {"terminate_when_unhealthy": False}
-            c2 = Config(env_id, n2, inner2, local_rank, 0, kw)
-            for _ in range(GROUND_WARM):
-                c2.launch()
-            v2, k2, ks2, el2 = steady(c2)
-            line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "sustained_value": v2, "seconds": el2,
-                    "unit": "env-steps/s", "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "env_kwargs": kw,
-                    "regime": f"robots on the ground: terminate_when_unhealthy=False, {GROUND_WARM} launches ({GROUND_WARM * inner2} vector steps) of warm-up before the timed region"}
-            want = ("sq", "flops") if args.pmc in ("auto", "full") else ()
-            line["roofline"] = c2.roofline(ks2, want, warm=GROUND_WARM, env_steps_per_s=v2)
-            c2.close()
-            result["secondary"].append(line)
-
-    # ---- CPU legs: the oracle port on rank 0 (every N), the reference's own vectorisers where importable -------------------------------
-    if rank == 0:
+    # ---- CPU leg: the oracle port on rank 0 (every N) ---------------------------------------------------------------------------------------
+    if rank == 0 and not args.no_cpu_baseline:
         # the whole batch of one GPU on every host core (MuJoCo: a bounded sample of 64 sub-environments per core -- the oracle's per-env cost
         # does not depend on the batch size)
         n_cpu = min(N, 64 * usable_cpus()[0]) if args.env in MJ_COOP else N
-        result["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.env, n_cpu, budget_s=args.cpu_budget)
-        if not args.no_cpu_baseline and world == 1 and gpu:
-            ref = cpu_reference()
-            result["cpu_reference"] = ref  # gymnasium's own vectorisers where importable, else the AsyncVectorEnv port (kind "port"), timed in this run
-            if ref is None or ref.get("kind") == "port":
-                result["cpu_reference_recorded"] = CPU_REFERENCE_RECORDED  # the real gymnasium's numbers from the build container, hardware stated
+        result["cpu_baseline"] = cpu_baseline(args.env, n_cpu, budget_s=args.cpu_budget)
+    # ---- everything else (rank 0, one GPU): a child process, a sidecar file, headline values in the line ------------------------------------
+    if single and not args.no_secondary:
+        result["secondary"] = run_extras(args, args.full_out, result)
+        result["full"] = os.path.relpath(args.full_out, ROOT)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(fit_line(result), flush=True)
+        if verified is not None and verified.get("ok") is False:
+            print("bench.py: the first timed launch does NOT equal the oracle's trajectory -- the number above is not a measurement", file=sys.stderr)
+            return 1
+    return 0
 
 
 if __name__ == "__main__":
@@ -754,4 +597,4 @@ if __name__ == "__main__":
         _, _, w_env, w_n, w_off, w_budget, w_start = sys.argv
         print(json.dumps(_oracle_rollouts(w_env, int(w_n), int(w_off), float(w_budget), float(w_start))))
     else:
-        main()
+        sys.exit(main())

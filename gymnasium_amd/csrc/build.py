@@ -151,12 +151,20 @@ print("DIGEST", h.hexdigest())
 """
 
 
+class MiscompileError(RuntimeError):
+    """The shipped build and the default-scheduler build of the same sources produced different bits (verify_on_device)."""
+
+
+class GuardNotRun(RuntimeError):
+    """verify_on_device could not run one of its children (GPU busy, out of memory, import error ...): infrastructure, not a verdict."""
+
+
 def verify_on_device(timeout_s: float = 300.0) -> str:
     """On a GPU box: the shipped cooperative physics kernels (iterative scheduler + MachineLICM settings, TU_FLAGS) against the SAME sources under
     hipcc's defaults (libmi355env_ref.so), every bit of a short trajectory that includes finished episodes and resets, each build in its own child
     process.  The scheduler settings have a history of exposing a code-generation defect (scripts/repro/README.md); this is the check that a new
     toolchain, box or source change did not bring it back, cheap enough to run with every smoke() (tests/test_gpu_scheduler_guard.py is the long
-    form).  Returns the common digest; raises if the builds differ.  (Spilling SGPRs to memory instead -- the documented cure of the defect -- costs
+    form).  Returns the common digest; raises MiscompileError if the builds differ and GuardNotRun when a child process failed for any other reason.  (Spilling SGPRs to memory instead -- the documented cure of the defect -- costs
     x0.45 - 0.6 on these kernels: profiles/r04_two_waves.txt.)"""
     root = os.path.normpath(os.path.join(HERE, "..", ".."))
     digests = {}
@@ -166,10 +174,10 @@ def verify_on_device(timeout_s: float = 300.0) -> str:
         p = subprocess.run([sys.executable, "-c", VERIFY_CHILD.format(root=root)], env=dict(os.environ, MI355ENV_LIBRARY=lib), capture_output=True, text=True, timeout=timeout_s)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("DIGEST ")]
         if p.returncode != 0 or not lines:
-            raise RuntimeError(f"verify_on_device: {os.path.basename(lib)} failed: {p.stdout[-500:]} {p.stderr[-1500:]}")
+            raise GuardNotRun(f"verify_on_device: {os.path.basename(lib)} failed: {p.stdout[-500:]} {p.stderr[-1500:]}")
         digests[lib] = lines[-1].split()[1]
     if digests[OUT] != digests[OUT_REF]:
-        raise RuntimeError("the shipped cooperative physics kernels differ from the default-scheduler build of the same sources (miscompile guard, "
+        raise MiscompileError("the shipped cooperative physics kernels differ from the default-scheduler build of the same sources (miscompile guard, "
                            f"gymnasium_amd/csrc/build.py TU_FLAGS): {digests}")
     return digests[OUT]
 

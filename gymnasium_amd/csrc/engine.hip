@@ -2176,7 +2176,15 @@ int mi_set_stream(mi_vecenv *v, void *hip_stream) {
     hipStream_t s = (hipStream_t)hip_stream;  // NULL is the legacy default stream (torch's default current stream)
     if (s != v->stream) {
         if (set_device(v)) return MI_ERR_HIP;
-        HIP_TRY(hipStreamSynchronize(v->stream));  // order the hand-over between streams
+        // Order the hand-over between streams with a host synchronise -- unless the NEW stream is being captured into a graph: a synchronising call
+        // during a (global-mode) capture is not allowed by the stream-capture rules, even on another stream.  HipVectorEnv.capture_steps synchronises
+        // the engine BEFORE it opens the capture, so nothing is pending on the old stream then.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &cap) != hipSuccess) {
+            (void)hipGetLastError();
+            cap = hipStreamCaptureStatusNone;
+        }
+        if (cap == hipStreamCaptureStatusNone) HIP_TRY(hipStreamSynchronize(v->stream));
         v->stream = s;
     }
     return MI_OK;

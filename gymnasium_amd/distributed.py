@@ -53,10 +53,11 @@ def reduce_statistics(stats: dict, elapsed_s: float | None = None, device=None) 
     return out
 
 
-def census(rank: int, local_rank: int, device=None, force_collective: bool = False) -> dict:
+def census(rank: int, local_rank: int, device=None, force_collective: bool = False, extra: dict | None = None) -> dict:
     """What the collective itself proves about the job: ``ranks`` = an all-reduce of ones (the ranks that really took part -- not WORLD_SIZE
     read from the environment) and ``devices`` = every rank's own device identity (name, UUID, PCI bus id), gathered: N distinct UUIDs = N
-    different GPUs.  Without a process group (or at world size 1, unless ``force_collective``) nothing is communicated."""
+    different GPUs.  ``extra`` rides along in this rank's entry (bench.py: the digest of its first timed launch and the oracle's verdict on it).
+    Without a process group (or at world size 1, unless ``force_collective``) nothing is communicated."""
     import torch
     import torch.distributed as dist
 
@@ -66,6 +67,8 @@ def census(rank: int, local_rank: int, device=None, force_collective: bool = Fal
         me = {"rank": rank, "local_rank": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
     else:
         me = {"rank": rank, "local_rank": local_rank, "name": "cpu (dry run)", "uuid": f"cpu-{rank}"}
+    if extra:
+        me.update(extra)
     ranks, devices = 1, [me]
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective):
         ones = torch.ones(1, dtype=torch.int64, device=device)

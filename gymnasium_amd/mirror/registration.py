@@ -97,57 +97,73 @@ def spec(env_id: str) -> EnvSpec:
     return _find_spec(env_id)
 
 
+# ---- make_vec: the plug-in route only -------------------------------------------------------------------------------------------------------
+# Written from the contract of SURVEY.md section 8(b), not from the reference's function body:
+#   * `id` is a registered id (optionally "module:id", which imports the module first) or an EnvSpec;
+#   * the four vectorisation arguments may also live in the spec's own kwargs (a spec recorded by an earlier make_vec carries them) -- the spec wins;
+#   * every remaining keyword goes to the creator, on top of the spec's kwargs; the spec's max_episode_steps is the creator's default;
+#   * a vector_entry_point creator takes neither `vector_kwargs` nor `wrappers` nor spec-level additional wrappers;
+#   * the returned env remembers how it was made: `env.unwrapped.spec` = the spec with the creator's kwargs plus num_envs (when not 1) and the mode,
+#     so that `make_vec(env.spec)` builds the same env again;
+#   * the env is expected to advertise its AutoresetMode in `metadata` (a warning otherwise).
+_VECTOR_ARGUMENTS = ("num_envs", "vectorization_mode", "vector_kwargs", "wrappers")
+
+
+def _as_mode(value, has_vector_entry_point: bool) -> VectorizeMode:
+    if value is None:
+        return VectorizeMode.VECTOR_ENTRY_POINT if has_vector_entry_point else VectorizeMode.SYNC
+    if isinstance(value, VectorizeMode):
+        return value
+    for mode in VectorizeMode:
+        if mode.value == value:
+            return mode
+    raise ValueError(f"Invalid vectorization mode: {value!r}, valid modes: {[m.value for m in VectorizeMode]}")
+
+
+def _plugin_route_only(spec_: EnvSpec, shown_id, mode: VectorizeMode, vector_kwargs, wrappers):
+    """Everything that cannot be honoured by a vector_entry_point creator is refused before the creator runs."""
+    if mode is not VectorizeMode.VECTOR_ENTRY_POINT:
+        raise error.Error(f"vectorization_mode={mode.value!r} wraps scalar Python environments on the CPU; that is the reference's own path "
+                          "(gymnasium.vector.SyncVectorEnv/AsyncVectorEnv) and is not provided by gymnasium_amd. Install gymnasium for it.")
+    problems = {
+        "`vector_kwargs`": vector_kwargs,  # the creator is configured through plain keyword arguments
+        "the `wrappers` argument": wrappers,
+        "the spec's `additional_wrappers`": spec_.additional_wrappers,
+    }
+    for what, value in problems.items():
+        if value:
+            raise error.Error(f"A `vector_entry_point` environment cannot be combined with {what} (got {value}): pass constructor arguments as keywords of make_vec.")
+    if spec_.vector_entry_point is None:
+        raise error.Error(f"{shown_id} has no `vector_entry_point`: there is nothing for vectorization_mode='vector_entry_point' to call.")
+
+
 def make_vec(id, num_envs: int = 1, vectorization_mode=None, vector_kwargs: dict[str, Any] | None = None, wrappers=None, **kwargs):
-    vector_kwargs = {} if vector_kwargs is None else vector_kwargs
-    wrappers = [] if wrappers is None else wrappers
     if isinstance(id, EnvSpec):
-        env_spec = id
+        found = id
     elif isinstance(id, str):
-        env_spec = _find_spec(id)
+        found = _find_spec(id)
     else:
         raise error.Error(f"Invalid id type: {type(id)}. Expected `str` or `EnvSpec`")
-    env_spec = copy.deepcopy(env_spec)
-    env_spec_kwargs = env_spec.kwargs
-    env_spec.kwargs = dict()
-    num_envs = env_spec_kwargs.pop("num_envs", num_envs)
-    vectorization_mode = env_spec_kwargs.pop("vectorization_mode", vectorization_mode)
-    vector_kwargs = env_spec_kwargs.pop("vector_kwargs", vector_kwargs)
-    wrappers = env_spec_kwargs.pop("wrappers", wrappers)
-    env_spec_kwargs.update(kwargs)
+    recorded = copy.deepcopy(found)  # the caller's / the registry's spec is never modified
+    creator_kwargs = dict(recorded.kwargs)
+    given = {"num_envs": num_envs, "vectorization_mode": vectorization_mode, "vector_kwargs": vector_kwargs or {}, "wrappers": wrappers or []}
+    for name in _VECTOR_ARGUMENTS:  # vectorisation arguments stored in the spec take precedence over the call's
+        if name in creator_kwargs:
+            given[name] = creator_kwargs.pop(name)
+    creator_kwargs.update(kwargs)
+    mode = _as_mode(given["vectorization_mode"], recorded.vector_entry_point is not None)
+    _plugin_route_only(recorded, id, mode, given["vector_kwargs"], given["wrappers"])
 
-    if vectorization_mode is None:
-        vectorization_mode = VectorizeMode.VECTOR_ENTRY_POINT if env_spec.vector_entry_point is not None else VectorizeMode.SYNC
-    else:
-        try:
-            vectorization_mode = VectorizeMode(vectorization_mode)
-        except ValueError as e:
-            raise ValueError(f"Invalid vectorization mode: {vectorization_mode!r}, valid modes: {[m.value for m in VectorizeMode]}") from e
+    creator = recorded.vector_entry_point if callable(recorded.vector_entry_point) else load_env_creator(recorded.vector_entry_point)
+    if recorded.max_episode_steps is not None:
+        creator_kwargs.setdefault("max_episode_steps", recorded.max_episode_steps)
+    env = creator(num_envs=given["num_envs"], **creator_kwargs)
 
-    if vectorization_mode != VectorizeMode.VECTOR_ENTRY_POINT:
-        raise error.Error(f"vectorization_mode={vectorization_mode.value!r} wraps scalar Python environments on the CPU; that is the reference's "
-                          "own path (gymnasium.vector.SyncVectorEnv/AsyncVectorEnv) and is not provided by gymnasium_amd. Install gymnasium for it.")
-    if len(vector_kwargs) > 0:
-        raise error.Error(f"Custom vector environment can be passed arguments only through kwargs and `vector_kwargs` is not empty ({vector_kwargs})")
-    if len(wrappers) > 0:
-        raise error.Error(f"Cannot use `vector_entry_point` vectorization mode with the wrappers argument ({wrappers}).")
-    if len(env_spec.additional_wrappers) > 0:
-        raise error.Error(f"Cannot use `vector_entry_point` vectorization mode with the additional_wrappers parameter in spec being not empty ({env_spec.additional_wrappers}).")
-    entry_point = env_spec.vector_entry_point
-    if entry_point is None:
-        raise error.Error(f"Cannot create vectorized environment for {id} because it doesn't have a vector entry point defined.")
-    env_creator = entry_point if callable(entry_point) else load_env_creator(entry_point)
-    if env_spec.max_episode_steps is not None and "max_episode_steps" not in env_spec_kwargs:
-        env_spec_kwargs["max_episode_steps"] = env_spec.max_episode_steps
-    env = env_creator(num_envs=num_envs, **env_spec_kwargs)
-
-    copied = copy.deepcopy(env_spec)
-    copied.kwargs = env_spec_kwargs.copy()
-    if num_envs != 1:
-        copied.kwargs["num_envs"] = num_envs
-    copied.kwargs["vectorization_mode"] = vectorization_mode.value
-    env.unwrapped.spec = copied
-    if "autoreset_mode" not in env.metadata:
-        logger.warn(f"The VectorEnv ({env}) is missing AutoresetMode metadata, metadata={env.metadata}")
-    elif not isinstance(env.metadata["autoreset_mode"], AutoresetMode):
-        logger.warn(f"The VectorEnv ({env}) metadata['autoreset_mode'] is not an instance of AutoresetMode, {type(env.metadata['autoreset_mode'])}.")
+    recorded.kwargs = dict(creator_kwargs, vectorization_mode=mode.value)
+    if given["num_envs"] != 1:
+        recorded.kwargs["num_envs"] = given["num_envs"]
+    env.unwrapped.spec = recorded
+    advertised = env.metadata.get("autoreset_mode", None)
+    if not isinstance(advertised, AutoresetMode):
+        logger.warn(f"The VectorEnv ({env}) does not advertise an AutoresetMode in metadata['autoreset_mode'] (found {advertised!r}, metadata={env.metadata})")
     return env

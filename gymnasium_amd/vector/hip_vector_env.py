@@ -25,7 +25,7 @@ from typing import Any
 import numpy as np
 
 from .. import _native
-from ..gym_api import AutoresetMode, VectorEnv, batch_space, error, seeding
+from ..gym_api import AutoresetMode, VectorEnv, batch_space, error, logger, seeding
 
 _U64 = (1 << 64) - 1
 
@@ -411,9 +411,12 @@ class HipVectorEnv(VectorEnv):
         Box action spaces: the reference hands every sub-environment its row of the caller's array AS IT IS (sync_vector_env.py:274 iterate();
         pendulum.py:127-134, continuous_mountain_car.py:153, mujoco_env.py:148 `data.ctrl[:] = ctrl`) -- a float64 array is not rounded to the
         space's float32, and NumPy's promotion rules then make parts of the step float64 arithmetic.  So float64 rows (and integer arrays:
-        exact in float64) go to the engine un-rounded with actions_dtype = MI_F64; float32 and float16 rows take the float32 path, which is
-        also the on-device sampler's type.  A list of Python lists reaches the scalar envs as Python lists: `action[0]` is then a Python
-        float, which NumPy 2 treats as WEAK (np.float32 + float stays float32) -- MI_F64_WEAK; only MountainCarContinuous tells it from MI_F64."""
+        exact in float64) go to the engine un-rounded with actions_dtype = MI_F64; float32 rows take the float32 path, which is also the
+        on-device sampler's type.  A list of Python lists reaches the scalar envs as Python lists: `action[0]` is then a Python float, which
+        NumPy 2 treats as WEAK (np.float32 + float stays float32) -- MI_F64_WEAK; only MountainCarContinuous tells it from MI_F64.  A row of
+        NumPy scalars (`[[np.float64(x)], ...]`) is STRONG, like an ndarray row: only exact Python floats / ints are weak.
+        NOT reproduced: float16 / bfloat16 rows.  The reference would then compute parts of the step in half precision; the engine widens
+        them to float32 (one warning per env), so those trajectories are within tolerance of, not bit-equal to, the reference's."""
         eng = self._engine
         if self.output == "torch" and hasattr(actions, "data_ptr"):
             t = self._torch
@@ -421,6 +424,8 @@ class HipVectorEnv(VectorEnv):
                 want = t.int64
             else:
                 want = t.float32 if actions.dtype in (t.float32, t.float16, t.bfloat16) else t.float64
+                if actions.dtype in (t.float16, t.bfloat16):
+                    self._warn_half_precision(actions.dtype)
             if actions.device != self._tdev or actions.dtype != want or not actions.is_contiguous():
                 actions = actions.to(device=self._tdev, dtype=want).contiguous()
             if actions.numel() != self.num_envs * eng.act_dim:
@@ -433,9 +438,13 @@ class HipVectorEnv(VectorEnv):
                 raise AssertionError(f"{actions!r} ({type(actions)}) invalid")
             a = np.ascontiguousarray(a, dtype=np.int64)
         elif a.dtype in (np.float32, np.float16):
+            if a.dtype == np.float16:
+                self._warn_half_precision(a.dtype)
             a = np.ascontiguousarray(a, dtype=np.float32)
         else:
-            weak = isinstance(actions, (list, tuple)) and len(actions) > 0 and all(isinstance(r, (list, tuple)) for r in actions)
+            # weak = every leaf is an exact Python float / int (NEP 50); np.generic scalars inside the lists are strong like an ndarray's elements
+            weak = (isinstance(actions, (list, tuple)) and len(actions) > 0
+                    and all(isinstance(r, (list, tuple)) and all(type(x) in (float, int) for x in r) for r in actions))
             a, dtype = np.ascontiguousarray(a, dtype=np.float64), (_native.MI_F64_WEAK if weak else _native.MI_F64)
         if a.size != self.num_envs * eng.act_dim:
             raise ValueError(f"actions must have shape {self._act_shape}, got {a.shape}")
@@ -443,6 +452,12 @@ class HipVectorEnv(VectorEnv):
             ta = self._torch.from_numpy(a).to(self._tdev)
             return ta, ta.data_ptr(), dtype
         return a, a, dtype
+
+    def _warn_half_precision(self, dtype):
+        if not getattr(self, "_warned_half", False):
+            self._warned_half = True
+            logger.warn(f"{dtype} action rows are widened to float32: the reference computes parts of the step in half precision for such rows, "
+                        "so this trajectory is within tolerance of the reference's, not bit-equal to it")
 
     def step(self, actions):
         """One lockstep step of every sub-environment: (obs, rewards, terminations, truncations, infos)."""

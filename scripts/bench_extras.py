@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Everything bench.py's one line leaves out, measured on ONE GPU by a child process of `python bench.py --gpus 1` (or by hand):
+
+    python scripts/bench_extras.py --out gpurun_out/bench_full.json [--primary primary.json] [--pmc auto|full|off] [--budget 150]
+
+  secondary         BASELINE.json configs[2..4]: Pendulum / Acrobot / MountainCarContinuous @65536, Ant-v5 @32768 and @65536, Humanoid-v5 @32768
+                    (per GPU), each with its own roofline (bench.Config.roofline) and, for the cooperative MuJoCo kernels, the SQ activity
+                    share and the executed-fp64 rate; then the on-the-ground regime of the two headline robots
+  primary_counters  issue-slot ceiling of the primary kernel (SQ_INSTS_VALU / SALU per env-step)
+  api_step_*        the per-launch step() API: device tensors, one HIP graph, NumPy over PCIe, the three fused wrappers -- never `value`
+  opt_in            fast_math / Newton-solver configurations next to the default (reference-faithful) ones
+  cpu_reference     Gymnasium's own AsyncVectorEnv / SyncVectorEnv / NumPy CartPoleVectorEnv where `import gymnasium` works (GYM_REFERENCE or an
+                    installed package); elsewhere (the GPU box) the AsyncVectorEnv ARCHITECTURE restated (oracle/async_baseline.py, pinned on the
+                    real one by tests/test_async_baseline.py) timed in this run, with the build container's real numbers as cpu_reference_recorded
+
+The sidecar file is rewritten after every section (a run that is cut short leaves what it had); the LAST stdout line is the headline dict that
+bench.py puts into its line as `secondary`.  No optional measurement STARTS once the run is older than --budget seconds."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from bench import HBM_PEAK_GBS, MJ_COOP, Config, _rocprof_counters, child_args, cpu_baseline, usable_cpus  # noqa: E402
+
+STEP_BYTES = {"CartPole-v1": 108, "Pendulum-v1": 68, "Acrobot-v1": 116, "MountainCar-v0": 68, "MountainCarContinuous-v0": 64}
+# (env, num_envs per GPU, vector steps per launch) of the secondary lines: BASELINE.json configs[2..4] + the north_star's Ant @65536
+SECONDARY = [("Pendulum-v1", 65536, 128), ("Acrobot-v1", 65536, 128), ("MountainCarContinuous-v0", 65536, 128),
+             ("Ant-v5", 32768, 4), ("Ant-v5", 65536, 4), ("Humanoid-v5", 32768, 4)]
+# The other contact regime of the two headline robots: the random policy with `terminate_when_unhealthy` ends a Humanoid episode after ~22 steps, so
+# the batch above is mostly robots still upright; with termination off and a warm-up of GROUND_WARM launches every robot lies on the ground (many
+# contacts, the PGS sweeps dominate).  A learner that keeps the robot alive lives between the two lines.
+GROUND_WARM = 40
+SECONDARY_GROUND = [("Ant-v5", 32768, 4), ("Humanoid-v5", 32768, 4)]
+F64_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
+ISSUE_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]
+FLOP_COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64"]
+# the reference itself, measured in the build container (no gymnasium on the GPU box)
+CPU_REFERENCE_RECORDED = {
+    "hardware": "8 vCPU Intel Xeon @ 2.10 GHz (build container), Python 3.10.12, NumPy 2.2.6, reference gymnasium v1.4.0",
+    "how": "gymnasium.utils.performance.benchmark_vector_step, 2-3 s runs (BASELINE.md section 2)", "unit": "env-steps/s",
+    "AsyncVectorEnv CartPole-v1": {"num_envs=4": 10.0e3, "num_envs=8": 14.6e3, "num_envs=16": 16.8e3, "cores": 8},
+    "SyncVectorEnv CartPole-v1": {"num_envs=4": 51e3, "num_envs=64": 74e3, "num_envs=1024": 84e3, "cores": 1},
+    "NumPy CartPoleVectorEnv (vector_entry_point)": {"num_envs=1024": 7.3e6, "num_envs=65536": 13.7e6, "cores": 1},
+    "single env gym.make": {"CartPole-v1": 82e3, "MountainCar-v0": 70e3, "MountainCarContinuous-v0": 35e3, "Pendulum-v1": 20e3, "Acrobot-v1": 16e3, "cores": 1},
+    "MuJoCo ids": "unavailable: `mujoco` is not installed in the build container either",
+}
+
+
+# ---- counters -------------------------------------------------------------------------------------------------------------------------
+def issue_counters(c: Config, kernel_s, timeout_s=150):
+    """The OTHER ceiling of a classic rollout kernel: at one wavefront per SIMD the instruction issue rate bounds it before HBM does."""
+    ic = _rocprof_counters(child_args(c.env_id, c.N, c.inner, c.env_kwargs), ISSUE_COUNTERS, c.dominant_kernel(), timeout_s)
+    if not ic or ic.get("SQ_WAVES", (0, 0))[0] <= 0:
+        return None
+    waves, groups = ic["SQ_WAVES"][0], c.N / 64.0  # a group = 64 sub-environments: ONE wavefront in the one-role kernels, an env + an aux wavefront in rollout_duo_kernel
+    valu, salu = ic["SQ_INSTS_VALU"][0] / groups / c.inner, ic["SQ_INSTS_SALU"][0] / groups / c.inner
+    per_group = waves / groups
+    slots = valu + salu if per_group < 1.5 else valu  # with two wavefronts per SIMD scalar instructions issue beside the partner's vector instructions
+    ceiling = SIMDS * 64 * CLOCK_HZ / (4.0 * slots)
+    lane_steps = c.N * c.inner / kernel_s
+    return {"valu_per_env_step": valu, "salu_per_env_step": salu, "wavefronts_per_64_envs": per_group, "ceiling_env_steps_per_s": ceiling,
+            "achieved_lane_steps_per_s": lane_steps, "frac_of_issue_ceiling": lane_steps / ceiling,
+            "hbm_ceiling_env_steps_per_s": HBM_PEAK_GBS * 1e9 / (c.algorithmic_bytes_per_launch() / (c.N * c.inner)),
+            "assumptions": f"{SIMDS} SIMDs x 64 lanes, one instruction per 4 cycles at {CLOCK_HZ / 1e9:.1f} GHz",
+            "source": "rocprofv3 --pmc " + " ".join(ISSUE_COUNTERS) + " on a child invocation in this run"}
+
+
+def coop_counters(c: Config, kernel_s, env_steps_per_s, warm=1, timeout_s=150):
+    """Cooperative MuJoCo physics kernel: share of wave cycles that issue VALU work, and the fp64 flops it EXECUTES against the vector fp64 peak
+    (2 per FMA, 1 per MUL / ADD, x 64 lanes per wave-level instruction -- masked lanes are counted: the rate the vector units are driven at)."""
+    out, args, kernel = {}, child_args(c.env_id, c.N, c.inner, c.env_kwargs, warm), c.dominant_kernel()
+    sq = _rocprof_counters(args, SQ_COUNTERS, kernel, timeout_s)
+    if sq and sq.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
+        wc = sq["SQ_WAVE_CYCLES"][0]
+        out["sq"] = {k[3:].lower() + "_frac": sq[k][0] / wc for k in SQ_COUNTERS[1:] if k in sq}
+    fc = _rocprof_counters(args, FLOP_COUNTERS, kernel, timeout_s)
+    if fc and fc.get("SQ_INSTS_VALU", (0, 0))[0] > 0:
+        g = lambda k: fc.get(k, (0.0, 0))[0]  # noqa: E731
+        per_dispatch = 64.0 * (2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64"))
+        stepping = (env_steps_per_s * kernel_s / c.inner) if env_steps_per_s else float(c.N)
+        rate = per_dispatch / (kernel_s / c.inner)  # dispatches of the physics kernel run back to back: one per vector step
+        out["flops"] = {"fma_f64": g("SQ_INSTS_VALU_FMA_F64"), "mul_f64": g("SQ_INSTS_VALU_MUL_F64"), "add_f64": g("SQ_INSTS_VALU_ADD_F64"),
+                        "trans_f64": g("SQ_INSTS_VALU_TRANS_F64"), "mfma_mops_f64": g("SQ_INSTS_VALU_MFMA_MOPS_F64"), "valu": g("SQ_INSTS_VALU"),
+                        "flops_per_env_step": per_dispatch / max(stepping, 1.0), "achieved_tflops_f64": rate / 1e12, "peak_tflops_f64": F64_PEAK_TFLOPS,
+                        "frac_of_f64_peak": rate / 1e12 / F64_PEAK_TFLOPS}
+    return out
+
+
+# ---- the reference's own vectorisers ---------------------------------------------------------------------------------------------------------
+def cpu_reference(budget_s=4.0):
+    """Gymnasium's own vectorisers on this host's cores, if the package is importable (utils/performance.py:57-103); else the port."""
+    ref = os.environ.get("GYM_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref, "gymnasium")) and ref not in sys.path:
+        sys.path.append(ref)
+    try:
+        import gymnasium as gym
+        from gymnasium.utils.performance import benchmark_vector_step
+    except Exception:
+        return cpu_reference_port(budget_s)
+    cores = os.cpu_count() or 1
+    out = {"cores": cores, "unit": "env-steps/s", "gymnasium": gym.__version__, "how": f"benchmark_vector_step, target_duration={budget_s} s"}
+    for label, kw in ((f"AsyncVectorEnv CartPole-v1 num_envs={cores}", dict(num_envs=cores, vectorization_mode="async")),
+                      ("SyncVectorEnv CartPole-v1 num_envs=1024", dict(num_envs=1024, vectorization_mode="sync")),
+                      ("NumPy CartPoleVectorEnv num_envs=65536", dict(num_envs=65536, vectorization_mode="vector_entry_point"))):
+        try:
+            env = gym.make_vec("CartPole-v1", **kw)
+            out[label] = benchmark_vector_step(env, target_duration=budget_s, seed=0)
+            env.close()
+        except Exception as e:  # a missing optional dependency must not cost the GPU numbers
+            out[label] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
+def cpu_reference_port(budget_s=4.0):
+    """Where gymnasium itself is not importable (the GPU box): the reference's AsyncVectorEnv ARCHITECTURE restated (oracle/async_baseline.py:
+    one process per sub-environment, pipes, shared-memory observations, the scalar CartPole in Python) and timed by the same counting rule as
+    benchmark_vector_step -- in THIS run, on THIS host's cores.  It carries less per-step overhead than the real thing: an upper bound of it."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "async_baseline.py")):
+        return None
+    usable, why = usable_cpus()
+    out = {"kind": "port", "what": "oracle/async_baseline.py: AsyncVectorEnv's architecture (vector/async_vector_env.py) around a Python CartPole-v1, "
+                                   "NOT gymnasium itself (not installed on this host)", "unit": "env-steps/s", "usable_cpus": usable,
+           "usable_cpus_source": why, "host_cpu_count": os.cpu_count(), "how": f"benchmark_vector_step's loop and counting rule, target_duration={budget_s} s"}
+    for n in sorted({usable, 4 * usable}):  # the reference's own convention (num_envs = cores) and an over-subscribed one
+        key = f"AsyncVectorEnv-port CartPole-v1 num_envs={n}"
+        try:  # in a fresh interpreter: its worker processes are forked from a process without a HIP context
+            p = subprocess.run([sys.executable, "-m", "oracle.async_baseline", str(n), str(budget_s)], cwd=ROOT, capture_output=True, text=True, timeout=budget_s * 3 + 120)
+            out[key] = float(p.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            out[key] = f"failed: {type(e).__name__}: {e}"
+    return out
+
+
+# ---- the per-launch step() API ---------------------------------------------------------------------------------------------------------------
+def api_legs(env_id, N, local_rank=0):
+    import torch
+
+    import gymnasium_amd
+    from gymnasium_amd.gym_api import error
+
+    out = {}
+    dev = torch.device("cuda", local_rank)
+    env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", copy=False)
+    env.reset(seed=0)
+    eng = env._engine
+    a_dev = torch.randint(0, 2, (N,), device=dev) if env._discrete else (torch.rand((N, eng.act_dim), device=dev) * 0.8 - 0.4)
+    for _ in range(20):
+        env.step(a_dev)
+    torch.cuda.synchronize()
+    reps = 300
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        env.step(a_dev)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    step_kernel_s = e0.elapsed_time(e1) * 1e-3 / reps
+    out["api_step_device"] = {"value": N * reps / dt, "unit": "vector-env lanes/s (incl. autoreset lanes)", "us_per_step_wall": dt / reps * 1e6,
+                              "us_per_step_gpu": step_kernel_s * 1e6,
+                              "roofline_frac": (STEP_BYTES[env_id] * N / step_kernel_s / 1e9 / HBM_PEAK_GBS) if env_id in STEP_BYTES else None}
+    # the same steps as ONE HIP graph (HipVectorEnv.capture_steps): what is left when the host is out of the loop
+    G_STEPS, g_reps = 32, 30
+    try:
+        graphed = env.capture_steps(actions=a_dev, steps=G_STEPS)
+        for _ in range(3):
+            graphed.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(g_reps):
+            graphed.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        dtg = time.perf_counter() - t0
+        out["api_step_graph"] = {"value": N * G_STEPS * g_reps / dtg, "unit": "vector-env lanes/s (incl. autoreset lanes)", "steps_per_graph": G_STEPS,
+                                 "us_per_step_wall": dtg / (G_STEPS * g_reps) * 1e6, "us_per_step_gpu": e0.elapsed_time(e1) * 1e3 / (G_STEPS * g_reps),
+                                 "roofline_frac": (STEP_BYTES[env_id] * N / (dtg / (G_STEPS * g_reps)) / 1e9 / HBM_PEAK_GBS) if env_id in STEP_BYTES else None}
+        del graphed
+    except error.Error as e:  # envs that assemble infos on the host (ToyText) or carry fused wrappers cannot be captured: say so, do not abort
+        out["api_step_graph"] = {"skipped": str(e)[:200]}
+    env.close()
+    env_np = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, copy=False)
+    env_np.reset(seed=0)
+    env_np.action_space.seed(0)
+    actions = [env_np.action_space.sample() for _ in range(8)]
+    t0 = time.perf_counter()
+    for _ in range(40):
+        env_np.action_space.sample()
+    sample_us = (time.perf_counter() - t0) / 40 * 1e6
+    reps = 100
+
+    def timed_steps(use_pinned):
+        for k in range(5):
+            env_np.step(actions[k % 8])
+        t0 = time.perf_counter()
+        for k in range(reps):
+            env_np.step(env_np.action_buffer if use_pinned else actions[k % 8])  # pinned: the caller's policy writes straight into the upload array
+        return (time.perf_counter() - t0) / reps
+
+    dt_page = timed_steps(False)
+    env_np.action_buffer[...] = actions[0]
+    dt_pin = timed_steps(True)
+    out["api_step_numpy"] = {"value": N / dt_page, "unit": "vector-env lanes/s (NumPy in / NumPy out over PCIe, host action sampling excluded)",
+                             "us_per_step_wall": dt_page * 1e6, "us_per_step_wall_actions_in_pinned_buffer": dt_pin * 1e6, "host_action_space_sample_us": sample_us}
+    env_np.close()
+    if env_id in STEP_BYTES:  # the reference's stateful wrappers on top, device tensors in and out
+        from gymnasium_amd import wrappers as gw
+
+        wrapped = {}
+        for mode in ("fused", "standalone"):
+            env_w = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", copy=False)
+            if mode == "standalone":
+                env_w.FUSES_WRAPPERS = False
+            w = gw.ClipReward(gw.NormalizeReward(gw.NormalizeObservation(env_w)), -5.0, 5.0)
+            w.reset(seed=0)
+            for _ in range(10):
+                w.step(a_dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                w.step(a_dev)
+            torch.cuda.synchronize()
+            wrapped[mode] = (time.perf_counter() - t0) / 100 * 1e6
+            w.close()
+        out["api_step_wrapped"] = {"wrappers": "ClipReward(NormalizeReward(NormalizeObservation(env)))", "us_per_step_wall_fused": wrapped["fused"],
+                                   "us_per_step_wall_standalone_passes": wrapped["standalone"], "launches_per_step_fused": 2 if N <= 262144 else 3,
+                                   "launches_per_step_standalone": 11}
+    return out
+
+
+def steady(c, seconds=0.7):
+    """~`seconds` of back-to-back launches after a tenth of that as warm-up: (env-steps/s, launches, avg kernel s, elapsed)"""
+    import torch
+
+    for _ in range(2):
+        c.launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        c.launch()
+    torch.cuda.synchronize()
+    k = int(min(20000, max(3, round(seconds / max((time.perf_counter() - t0) / 3, 1e-6)))))
+    for _ in range(max(1, k // 10)):
+        c.launch()
+    el, ks, st = c.timed(k, torch.cuda.synchronize)
+    return st["env_steps"] / el, k, ks, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--primary", default=None, help="JSON file with bench.py's primary result (copied into the sidecar)")
+    ap.add_argument("--pmc", choices=["auto", "full", "off"], default="auto")
+    ap.add_argument("--budget", type=float, default=150.0)
+    ap.add_argument("--started", type=float, default=None, help="time.time() at which the parent command started (budget reference)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true")
+    ap.add_argument("--only", default=None, help="comma-separated env ids: restrict the secondary lines")
+    args = ap.parse_args()
+    t_ref = args.started if args.started else time.time()
+    young = lambda: args.pmc == "full" or (time.time() - t_ref) < args.budget  # noqa: E731
+    import torch
+
+    torch.cuda.set_device(0)
+    full = {"primary": json.load(open(args.primary)) if args.primary and os.path.exists(args.primary) else None, "secondary": []}
+    head = {}
+
+    def flush():
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out + ".tmp", "w") as f:
+            json.dump(full, f, indent=1, default=float)
+        os.replace(args.out + ".tmp", args.out)
+
+    only = set(args.only.split(",")) if args.only else None
+    for env_id, n2, inner2 in SECONDARY:
+        if only and env_id not in only:
+            continue
+        c2 = Config(env_id, n2, inner2, 0, 0)
+        v2, k2, ks2, el2 = steady(c2)
+        line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "seconds": el2, "unit": "env-steps/s",
+                "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "roofline": c2.roofline(ks2, live=args.pmc == "full")}
+        head[f"{env_id}@{n2}"] = float(f"{v2:.4g}")
+        if env_id not in MJ_COOP:
+            head.setdefault("hbm_frac", {})[env_id] = round(line["roofline"]["frac"], 4)
+        full["secondary"].append(line)
+        flush()
+        if env_id in MJ_COOP and args.pmc != "off" and young():
+            line["roofline"].update(coop_counters(c2, ks2, v2))
+        c2.close()
+        opt = {"fast_math": True} if env_id in STEP_BYTES else ({"solver": "Newton"} if env_id in ("Humanoid-v5", "HumanoidStandup-v5") else None)
+        if opt and young():  # the opt-in, faster configuration next to the default (reference-faithful) one
+            c3 = Config(env_id, n2, inner2, 0, 0, opt)
+            line["opt_in"] = {"env_kwargs": opt, "value": steady(c3)[0], "unit": "env-steps/s"}
+            c3.close()
+        if not args.no_cpu_baseline and young():  # MuJoCo: a bounded sample (the oracle's per-env cost does not depend on the batch size)
+            line["cpu_baseline"] = cpu_baseline(env_id, min(n2, 64 * usable_cpus()[0]) if env_id in MJ_COOP else n2, budget_s=3.0)
+        flush()
+    # the on-the-ground regime of the two headline robots: termination off, GROUND_WARM launches before anything is timed or profiled
+    for env_id, n2, inner2 in SECONDARY_GROUND:
+        if only and env_id not in only:
+            continue
+        kw = {"terminate_when_unhealthy": False}
+        c2 = Config(env_id, n2, inner2, 0, 0, kw)
+        for _ in range(GROUND_WARM):
+            c2.launch()
+        v2, k2, ks2, el2 = steady(c2)
+        line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "seconds": el2, "unit": "env-steps/s",
+                "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "env_kwargs": kw,
+                "regime": f"robots on the ground: terminate_when_unhealthy=False, {GROUND_WARM} launches ({GROUND_WARM * inner2} vector steps) of warm-up before the timed region",
+                "roofline": c2.roofline(ks2)}
+        head[f"{env_id}@{n2} on the ground"] = float(f"{v2:.4g}")
+        if args.pmc != "off" and young():
+            line["roofline"].update(coop_counters(c2, ks2, v2, warm=GROUND_WARM))
+        c2.close()
+        full["secondary"].append(line)
+        flush()
+    prim = (full["primary"] or {}).get("config", {})
+    env_id, N, inner = prim.get("env", "CartPole-v1"), prim.get("num_envs_per_gpu", 65536), prim.get("vector_steps_per_launch", 128)
+    if not args.no_api and not only:
+        try:
+            full.update(api_legs(env_id, N))
+            head["step_api_us_gpu"] = round(full["api_step_device"]["us_per_step_gpu"], 2)
+            if "us_per_step_gpu" in full.get("api_step_graph", {}):
+                head["step_graph_us_gpu"] = round(full["api_step_graph"]["us_per_step_gpu"], 2)
+        except Exception as e:
+            full["api_error"] = f"{type(e).__name__}: {e}"
+        flush()
+    if env_id in STEP_BYTES and not prim.get("env_kwargs") and not only and young():
+        c_opt = Config(env_id, N, inner, 0, 0, {"fast_math": True})
+        v_o, _, ks_o, _ = steady(c_opt)
+        full["opt_in"] = {"env_kwargs": {"fast_math": True}, "value": v_o, "unit": "env-steps/s",
+                          "note": "device sin / cos and x * x instead of the bit-exact libm restatements (tolerance parity, tests/test_gpu_parity.py)"}
+        c_opt.close()
+        flush()
+    if args.pmc != "off" and env_id in STEP_BYTES and not only and young():
+        c1 = Config(env_id, N, inner, 0, 0, prim.get("env_kwargs") or None)
+        _, _, ks1, _ = steady(c1, 0.3)
+        full["primary_counters"] = {"issue_bound": issue_counters(c1, ks1)}
+        c1.close()
+        if full["primary_counters"]["issue_bound"]:
+            head["issue_frac"] = round(full["primary_counters"]["issue_bound"]["frac_of_issue_ceiling"], 3)
+        flush()
+    if not args.no_cpu_baseline and not only and young():
+        ref = cpu_reference()
+        full["cpu_reference"] = ref
+        if ref is None or ref.get("kind") == "port":
+            full["cpu_reference_recorded"] = CPU_REFERENCE_RECORDED
+        if ref:
+            best = [v for k, v in ref.items() if k.startswith("AsyncVectorEnv") and isinstance(v, float)]
+            if best:
+                head["cpu_async_vector_env" + ("_port" if ref.get("kind") == "port" else "")] = float(f"{max(best):.4g}")
+        flush()
+    head["seconds"] = round(time.time() - t_ref, 1)
+    full["headline"] = head
+    flush()
+    print(json.dumps(head, allow_nan=False))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,33 +18,35 @@ import bench  # noqa: E402
 
 
 class OracleConfig(bench.Config):
-    def __init__(self, env_id, N, inner, local_rank, rank, env_kwargs=None):
-        import torch
+    """bench.Config with its four device-specific methods on the CPU checker: NumPy buffers, synchronous launches (the wall clock is the kernel clock)."""
 
+    def make_env(self):
         import gymnasium_amd
-        from gymnasium_amd import _native
         from oracle import oracle
 
-        self.torch, self.env_id, self.N, self.inner, self.env_kwargs = torch, env_id, N, inner, env_kwargs
-        env = gymnasium_amd.make_vec(env_id, num_envs=N, env_index_offset=rank * N, _engine_factory=oracle.engine_factory, **(env_kwargs or {}))
-        env.reset(seed=0)
-        env.action_space.seed(rank)
-        eng = env._engine
-        self.env, self.eng = env, eng
-        self.acts = np.zeros((inner, N) if env._discrete else (inner, N, eng.act_dim), dtype=eng.act_dtype)
-        self.obs = np.zeros((inner, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (inner, N, eng.obs_dim), eng.obs_dtype)
-        self.rew, self.te, self.tr = np.zeros((inner, N)), np.zeros((inner, N), np.bool_), np.zeros((inner, N), np.bool_)
-        eng.action_seed(_native.pcg_words(env.action_space.np_random))
+        return gymnasium_amd.make_vec(self.env_id, num_envs=self.N, env_index_offset=self.rank * self.N, _engine_factory=oracle.engine_factory,
+                                      **(self.env_kwargs or {}))
 
-    def launch(self):
-        self.eng.rollout(self.inner, None, self.acts, self.obs, self.rew, self.te, self.tr)
+    def alloc_trajectory(self):
+        env, eng, T, N = self.env, self.eng, self.inner, self.N
+        return (np.zeros((T, N) if env._discrete else (T, N, eng.act_dim), dtype=eng.act_dtype),
+                np.zeros((T, N) if (eng.obs_dtype is np.int64 and eng.obs_dim == 1) else (T, N, eng.obs_dim), eng.obs_dtype),
+                np.zeros((T, N)), np.zeros((T, N), np.bool_), np.zeros((T, N), np.bool_)), None
+
+    def host_trajectory(self):
+        return tuple(b.copy() for b in self.first[0])
+
+    def launch(self, bufs=None):
+        b = (bufs or self.rest)[0]
+        self.eng.rollout(self.inner, None, b[0], b[1], b[2], b[3], b[4])
 
     def timed(self, K, sync):
         sync()
         self.eng.reset_stats()
         sync()
         t0 = time.perf_counter()
-        for _ in range(K):
+        self.launch(self.first)
+        for _ in range(K - 1):
             self.launch()
         sync()
         elapsed = time.perf_counter() - t0

@@ -10,6 +10,20 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Where Farama gymnasium itself can be imported from the read-only reference tree (the build container), the WHOLE CPU suite runs under it: `HipVectorEnv`
+# is then a gymnasium.vector.VectorEnv, the ids live in gymnasium's registry and tests/test_real_gymnasium.py compares against gymnasium's own
+# SyncVectorEnv in this interpreter (no skips).  tests/test_mirror_configuration.py re-runs the interface tests in a child interpreter with the
+# from-scratch mirror forced -- the configuration of the GPU box, where neither gymnasium nor the tree exists (every -m gpu test runs on the mirror).
+REFERENCE = os.environ.get("GYMNASIUM_REFERENCE_TREE", "/root/reference")
+if os.environ.get("GYMNASIUM_AMD_FORCE_MIRROR", "0") != "1" and os.path.isdir(os.path.join(REFERENCE, "gymnasium")) and REFERENCE not in sys.path:
+    try:
+        import gymnasium  # noqa: F401  (already installed: nothing to add)
+    except ImportError:
+        sys.path.append(REFERENCE)
+        sys.dont_write_bytecode = True  # never write __pycache__ into the read-only tree
+        os.environ["PYTHONPATH"] = os.pathsep.join(x for x in (os.environ.get("PYTHONPATH", ""), REFERENCE) if x)  # child interpreters (gloo workers, bench dry runs)
+        os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
 ENV_IDS = {
     "cartpole": "CartPole-v1",
     "pendulum": "Pendulum-v1",

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""The known answer of bench.py's first timed launch, computed BY THE REFERENCE ITSELF (build container only; ~4 minutes):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_bench_digest.py
+
+BASELINE.json configs[1] at its exact shape: gymnasium.make_vec("CartPole-v1", num_envs=65536, vectorization_mode="sync") -- 65 536 scalar
+CartPoleEnv objects behind TimeLimit in one SyncVectorEnv (vector/sync_vector_env.py:187-337) -- reset(seed=0), action_space.seed(0), then 128 x
+step(action_space.sample()).  Writes bench_digest.json: the sha256 over the bytes of (actions int64 [T,N], observations float32 [T,N,4],
+rewards float64 [T,N], terminated bool [T,N], truncated bool [T,N]) -- what bench.trajectory_digest() computes over the trajectory the rollout
+kernel writes to HBM -- plus digests of strided slices for debugging.  tests/test_bench_digest.py requires the oracle to reproduce it on the CPU and
+tests/test_gpu_bench_contract.py requires `output_sha256` of the bench line to equal it."""
+import hashlib
+import json
+import os
+import sys
+import time
+
+REF = os.environ.get("GYM_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+
+import gymnasium as gym  # noqa: E402
+
+assert int(np.__version__.split(".")[0]) >= 2
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def digest(arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).view(np.uint8).reshape(-1).data)
+    return h.hexdigest()
+
+
+def main(env_id="CartPole-v1", N=65536, T=128):
+    t0 = time.time()
+    env = gym.make_vec(env_id, num_envs=N, vectorization_mode="sync")
+    print(f"{N} scalar envs built in {time.time() - t0:.0f} s", flush=True)
+    env.reset(seed=0)
+    env.action_space.seed(0)
+    acts, obs, rew, te, tr = [], [], [], [], []
+    for t in range(T):
+        a = env.action_space.sample()
+        o, r, d, u, _ = env.step(a)
+        acts.append(a.copy()), obs.append(o.copy()), rew.append(r.copy()), te.append(d.copy()), tr.append(u.copy())
+        if t % 16 == 0:
+            print(f"step {t} at {time.time() - t0:.0f} s", flush=True)
+    traj = tuple(np.stack(x) for x in (acts, obs, rew, te, tr))
+    assert traj[0].dtype == np.int64 and traj[1].dtype == np.float32 and traj[2].dtype == np.float64 and traj[3].dtype == np.bool_ and traj[4].dtype == np.bool_
+    out = {"what": f"gymnasium {gym.__version__} make_vec({env_id!r}, {N}, 'sync'), reset(seed=0), action_space.seed(0), {T} x step(sample()); "
+                   "sha256 over (actions, obs, rewards, terminated, truncated) bytes, time-major",
+           "numpy": np.__version__, f"{env_id}:{N}:{T}:rank0": digest(traj),
+           f"{env_id}:{N}:{T}:rank0:first_1024_envs": digest(tuple(np.ascontiguousarray(x[:, :1024]) for x in traj)),
+           f"{env_id}:{N}:{T}:rank0:every_64th_env": digest(tuple(np.ascontiguousarray(x[:, ::64]) for x in traj)),
+           "episodes_finished": int((traj[3] | traj[4]).sum()), "reward_sum": float(traj[2].sum())}
+    with open(os.path.join(OUT, "bench_digest.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1), f"\n{time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

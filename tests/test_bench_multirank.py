@@ -56,6 +56,10 @@ def test_default_flags_pilot_sets_k_on_every_rank(world):
     assert 0.8 * lanes < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= lanes
     assert r["config"]["parallelism"] == f"env-sharded x{world} (no data-path collective)" and "oracle" in r["engine"]
     assert r["sustained_value"] == r["value"] or r["sustained"]["launches"] >= r["steps"]
+    # every rank's first timed launch was compared with the oracle on its own global indices, and the verdicts travelled with the census
+    assert r["verified"]["ok"] is True and r["verified_all_ranks"] is True and all(d["verified"] is True for d in r["devices"])
+    assert len({d["output_sha256"] for d in r["devices"]}) == world and r["devices"][0]["output_sha256"] == r["output_sha256"][:16]
+    assert len(json.dumps(r, separators=(",", ":"))) < 4096
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["algorithmic_bytes_per_launch"] == (34 * 8 + 96) * 256
     assert r["cpu_baseline"]["cores"] == 2 and r["cpu_baseline"]["value"] > 0
     assert "secondary" not in r and "api_step_device" not in r  # one-GPU extras stay out of the N > 1 line
@@ -65,7 +69,7 @@ def test_driver_style_explicit_steps_takes_the_separate_sustained_loop():
     """--steps K --warmup W as the driver passes them: EXACTLY K timed launches; a short timed region is followed by the separate sustained loop."""
     r = _run(2, ["--steps", "6", "--warmup", "2", "--sustained", "0.3"])
     assert r["steps"] == 6 and r["warmup"] == 2 and r["n_gpus"] == 2
-    assert r["sustained"]["launches"] > 6 and r["sustained"]["seconds"] >= 0.05
+    assert r["sustained"]["launches"] > 6 and r["sustained"]["seconds"] > 0  # (a launch count, not a wall-clock threshold: the oracle's speed varies with the host's load)
     assert r["episodes"] > 0 and 9.0 < r["mean_episode_return"] < 60.0  # CartPole under the random policy: ~22 steps per episode
 
 
@@ -77,6 +81,7 @@ def test_baseline_config4_command_line_humanoid_sharded():
     lanes = 2 * 6 * 2 * r["steps"]
     assert 0 < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= lanes * (1 + 1e-9)  # (no episode ends in 4 steps: exactly `lanes` env-steps, up to rounding)
     assert r["roofline"]["bound"] == "valu" and r["roofline"]["kernel"] == "mj_physics_kernel" and r["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert r["verified"]["ok"] is True and r["verified"]["compare"] == "atol 1e-8" and r["verified_all_ranks"] is True
     assert r["cpu_baseline"]["value"] > 0 and "Humanoid-v5" in r["cpu_baseline"]["sample"]
 
 

@@ -7,9 +7,8 @@ compare every step's (obs, reward, terminated, truncated, infos) with `gymnasium
 reference's SyncVectorEnv -- using the reference's own strict `data_equivalence(..., exact=True)`
 (utils/env_checker.py:34-74): types, dtypes, shapes, dict keys, masks and values.
 
-gymnasium is not installed in the build container or on the GPU box; it is importable from the read-only reference tree.
-When it is not already importable and /root/reference exists, `test_suite_under_reference_tree` re-runs THIS file in a
-child interpreter with PYTHONPATH=/root/reference, so the default CPU suite exercises it; without the tree it skips.
+gymnasium is not installed in the build container or on the GPU box; it is importable from the read-only reference tree, which
+tests/conftest.py puts on the path when it exists -- so the default CPU suite RUNS these tests here; without the tree they skip.
 """
 import os
 import re
@@ -37,18 +36,6 @@ needs_gymnasium = pytest.mark.skipif(not HAVE, reason="Farama gymnasium is not i
 CLASSIC = ["CartPole-v1", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0"]
 TOYTEXT = ["FrozenLake-v1", "FrozenLake8x8-v1", "CliffWalking-v1", "Taxi-v4", "Blackjack-v1"]
 MODES = ["NextStep", "SameStep", "Disabled"]
-
-
-@pytest.mark.skipif(HAVE or not os.path.isdir(os.path.join(REFERENCE, "gymnasium")), reason="gymnasium already importable, or no reference tree to import it from")
-def test_suite_under_reference_tree():
-    env = dict(os.environ, PYTHONPATH=REFERENCE + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONDONTWRITEBYTECODE="1")
-    env.pop("GYMNASIUM_AMD_FORCE_MIRROR", None)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    tail = (r.stdout + r.stderr)[-4000:]
-    assert r.returncode == 0, tail
-    m = re.search(r"(\d+) passed", r.stdout)
-    assert m and int(m.group(1)) >= 41, tail  # the child must have RUN the suite, not skipped it
 
 
 def _ulp1_f32(a, b):
@@ -130,8 +117,10 @@ def test_float64_action_rows_equal_sync_vector_env(env_id, mode, oracle_factory)
     rng = np.random.default_rng(4)
     hi = float(ref.single_action_space.high[0])
     for t in range(T):
-        kind = t % 5
-        if kind == 0:
+        kind = t % 6
+        if kind == 5:
+            a = [[np.float64(x)] for x in rng.uniform(-hi, hi, n)]  # lists of NumPy scalars: STRONG float64 (NEP 50), unlike lists of Python floats
+        elif kind == 0:
             a = rng.uniform(-hi, hi, (n, 1))  # float64
         elif kind == 1:
             a = rng.uniform(-1.5 * hi, 1.5 * hi, (n, 1))  # float64, some beyond the bounds
