@@ -14,7 +14,10 @@ from .envs.mujoco.envs import ENV_TABLE as _MUJOCO_TABLE
 from .gym_api import AutoresetMode, VectorEnv, register, registry, spaces  # noqa: F401
 from .vector import HipVectorEnv  # noqa: F401
 
+from .envs.classic_control import StockCartPoleVectorEnv
+
 __version__ = "0.1.0"
+STOCK_CREATORS = {"CartPole-v1": StockCartPoleVectorEnv}
 NAMESPACE = "MI355X"
 MUJOCO_IDS = frozenset(_MUJOCO_TABLE)
 
@@ -36,7 +39,9 @@ def register_envs(override_stock_ids: bool = False) -> None:
                     # the stock id keeps Farama's `mujoco`-backed env: ours is not pinned against it
                     gym_api.logger.warn(f"{env_id}: not overriding the stock id -- the MI355X restatement of MuJoCo is parity-unpinned; use {name}")
                 elif override_stock_ids:
-                    registry[env_id].vector_entry_point = creator
+                    # CartPole-v1 already HAS a vector_entry_point in gymnasium (the NumPy CartPoleVectorEnv: one shared generator, float32
+                    # rewards): the stock id gets the engine in THAT class's semantics, so no seeded trajectory of a make_vec("CartPole-v1") user changes
+                    registry[env_id].vector_entry_point = STOCK_CREATORS.get(env_id, creator)
             else:
                 register(id=env_id, vector_entry_point=creator, max_episode_steps=max_steps, reward_threshold=threshold, kwargs=kw)
 

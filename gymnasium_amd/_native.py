@@ -18,7 +18,8 @@ MI_F64_WEAK = 3  # action rows only: float64 values that were Python floats on t
 FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
 CFG_SOLVER_NEWTON = 1  # MI_CFG_SOLVER_NEWTON
 CFG_FAST_MATH = 2  # MI_CFG_FAST_MATH (classic control: device sin / cos and x * x instead of the libm restatements)
-ABI_VERSION = 5
+CFG_SHARED_RNG = 4  # MI_CFG_SHARED_RNG (CartPole: the reference's CartPoleVectorEnv semantics -- one generator for all sub-environments)
+ABI_VERSION = 6
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
              "half_cheetah": 5, "ant": 6, "humanoid": 7, "tabular": 8,
@@ -64,9 +65,9 @@ class MiRolloutIO(C.Structure):
 
 
 class MiTabularTable(C.Structure):
-    _fields_ = [("num_states", C.c_int32), ("num_actions", C.c_int32), ("max_outcomes", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("num_states", C.c_int32), ("num_actions", C.c_int32), ("max_outcomes", C.c_int32), ("num_tables", C.c_int32),
                 ("csprob", C.c_void_p), ("prob", C.c_void_p), ("next_state", C.c_void_p), ("reward", C.c_void_p),
-                ("terminated", C.c_void_p), ("count", C.c_void_p), ("isd_csprob", C.c_void_p)]
+                ("terminated", C.c_void_p), ("count", C.c_void_p), ("isd_csprob", C.c_void_p), ("env_table", C.c_void_p)]
 
 
 class MiStepEpilogue(C.Structure):
@@ -357,10 +358,18 @@ class Engine:
             flags = np.ascontiguousarray(flags, dtype=np.uint8)
         self.lib.check(self.lib.set_state(self.handle, _ptr(state), _ptr(elapsed), _ptr(flags)))
 
-    def load_table(self, csprob, prob, next_state, reward, terminated, count, isd_csprob):
-        """Hand a finite MDP's transition table to the engine (mi_tabular_load)."""
+    def load_table(self, csprob, prob, next_state, reward, terminated, count, isd_csprob, env_table=None):
+        """Hand a finite MDP's transition table to the engine (mi_tabular_load): arrays [nS, nA, K], or -- with ``env_table`` [num_envs] naming each
+        sub-environment's table -- [num_tables, nS, nA, K]."""
         t = MiTabularTable()
-        t.num_states, t.num_actions, t.max_outcomes = csprob.shape
+        if env_table is None:
+            t.num_states, t.num_actions, t.max_outcomes = csprob.shape
+            t.num_tables, t.env_table = 1, None
+        else:
+            t.num_tables, t.num_states, t.num_actions, t.max_outcomes = csprob.shape
+            env_table = np.ascontiguousarray(env_table, np.int32)
+            assert env_table.shape == (self.num_envs,) and t.num_tables > 1
+            t.env_table = env_table.ctypes.data
         keep = [np.ascontiguousarray(csprob, np.float64), np.ascontiguousarray(prob, np.float64), np.ascontiguousarray(next_state, np.int32),
                 np.ascontiguousarray(reward, np.float64), np.ascontiguousarray(terminated, np.uint8), np.ascontiguousarray(count, np.int32),
                 np.ascontiguousarray(isd_csprob, np.float64)]

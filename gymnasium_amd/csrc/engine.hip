@@ -63,6 +63,7 @@ struct TabTable {
     const double *csprob, *prob, *reward, *isd;
     const int32_t *next, *count;
     const uint8_t *term;
+    const int32_t *env_table;  // [N] table of each sub-environment when there are several (mi_tabular_table.num_tables > 1), else nullptr
 };
 
 // Device view of one vector environment (passed by value as a kernel argument).
@@ -737,6 +738,16 @@ struct RolloutPtrs {
     double *reward;
     uint8_t *terminated, *truncated;
 };
+// MI_CFG_SHARED_RNG (include/mi355env.h): CartPoleVectorEnv's ONE generator on the device.  It is kept as a fixed BASE state (what mi_seed gave) plus
+// the number of draws taken since: draw number n of the stream is the output after skipping n steps ahead of the base (Brown's O(log n) jump through
+// the pow2 table), so every lane finds its own draws without a serial pass and nothing but two counters ever changes.
+struct SharedRng {
+    uint64_t *words;       // [8] device: base {state_hi, state_lo, inc_hi, inc_lo}, [4] consumed, [5] pos_base = first draw of the call in flight, [6] k = sub-envs it re-draws
+    const PcgJump *pow2;   // [64] device: jump by 2^j steps of the base generator's increment
+    uint32_t *blk_done;    // [grid] sub-environments of each step workgroup that finished an episode in the previous step
+    uint32_t *blk_prefix;  // [grid] exclusive scan of blk_done (shared_scan_kernel)
+    double low, high;      // self.low / self.high (cartpole.py:489-491): the bounds of the last reset() serve the autoresets
+};
 }  // namespace mi_internal
 // The classic-control kernels behind plain launch functions (defined in the MI_CLASSIC_TU unit, called from the other): what mi_step / mi_reset /
 // mi_rollout do for the kinds CARTPOLE ... MOUNTAIN_CAR_CONTINUOUS once the arguments are validated and the buffers chosen.
@@ -744,6 +755,12 @@ namespace mi_classic {
 int step(mi_vecenv *v, const mi_internal::StepPtrs &p, int act_kind);                                           // launch_step<E> of the env's kind
 int reset(mi_vecenv *v, const uint8_t *device_mask, int has_bounds, double b0, double b1, float *device_obs);  // reset_kernel<E>
 int rollout(mi_vecenv *v, const mi_internal::RolloutPtrs &p, const mi_internal::ActionStream &as, int T, bool sample, int actions_in_kind);
+// MI_CFG_SHARED_RNG (CartPole only): reset = [bookkeeping, reset kernel]; step = [scan of the finished sub-environments, step kernel];
+// rollout = T x [policy sample,] step; recount = blk_done from the flag words (after mi_set_state)
+int shared_reset(mi_vecenv *v, float *device_obs);
+int shared_step(mi_vecenv *v, const mi_internal::StepPtrs &p);
+int shared_rollout(mi_vecenv *v, const mi_internal::RolloutPtrs &p, const mi_internal::ActionStream &as, int T, bool sample);
+int shared_recount(mi_vecenv *v);
 }  // namespace mi_classic
 namespace {
 
@@ -1045,6 +1062,167 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MI_CFG_SHARED_RNG: the reference's NumPy vector environment CartPoleVectorEnv (cartpole.py:353-505) -- one generator for all sub-environments,
+// drawn component-major over the sub-environments that reset (see include/mi355env.h).  Same dynamics (E::step), other bookkeeping.
+// ---------------------------------------------------------------------------------------------------------
+MI_DEV double shared_draw(const SharedRng &sr, uint64_t n) {  // draw number n (0-based) of the stream that starts at the base state
+    Pcg64 g;
+    g.state = make_u128(sr.words[0], sr.words[1]), g.inc = make_u128(sr.words[2], sr.words[3]);
+    for (int j = 0; n; j++, n >>= 1)
+        if (n & 1ull) g.state = sr.pow2[j].mult * g.state + sr.pow2[j].plus;
+    return g.next_double();
+}
+
+// One workgroup, before every reset (fixed_draws = 4 N) / step (fixed_draws = 0: 4 k, k = the sub-environments that finished in the previous step):
+// exclusive scan of the per-workgroup counts, and the stream bookkeeping -- the call in flight draws from pos_base, the next one after it.
+__global__ __launch_bounds__(kBlock) void shared_scan_kernel(SharedRng sr, int grid, uint64_t fixed_draws) {
+    __shared__ uint32_t part[kBlock];
+    const int per = (grid + kBlock - 1) / kBlock, lo = threadIdx.x * per, hi = min(grid, lo + per);
+    uint32_t sum = 0;
+    if (!fixed_draws)
+        for (int b = lo; b < hi; b++) sum += sr.blk_done[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < kBlock; t++) {
+            const uint32_t c = part[t];
+            part[t] = run, run += c;
+        }
+        const uint64_t consumed = sr.words[4];
+        sr.words[5] = consumed, sr.words[6] = run;
+        sr.words[4] = consumed + (fixed_draws ? fixed_draws : 4ull * run);
+    }
+    __syncthreads();
+    if (!fixed_draws) {
+        uint32_t run = part[threadIdx.x];
+        for (int b = lo; b < hi; b++) sr.blk_prefix[b] = run, run += sr.blk_done[b];
+    }
+}
+
+MI_DEV void shared_store_done_count(const SharedRng &sr, bool done) {  // this workgroup's entry of blk_done for the next step's scan
+    __shared__ uint32_t sh[kBlock / 64];
+    const uint64_t bal = __ballot(done);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sh[w];
+        sr.blk_done[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void shared_count_kernel(DevEnv d, SharedRng sr) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    shared_store_done_count(sr, i < d.N && ((d.meta[i] >> kFlagShift) & kNeedsReset));
+}
+
+// reset(): state[c][i] = uniform(low, high) from draw c * N + i (cartpole.py:493-500: size=(4, N))
+template <class E>
+__global__ __launch_bounds__(kBlock) void shared_reset_kernel(DevEnv d, SharedRng sr, float *obs) {
+    tables_init<E>();
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < d.N) {
+        Lane<E> L;
+        load_lane<E>(d, i, L);
+        double u[E::NDRAWS];
+#pragma unroll
+        for (int c = 0; c < E::NDRAWS; c++) u[c] = shared_draw(sr, sr.words[5] + (uint64_t)c * (uint64_t)d.N + (uint64_t)i);
+        L.flags = 0;
+        E::reset_u(u, L.s, L.flags, sr.low, sr.high);
+        L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+        store_lane<E>(d, i, L);
+        if (obs) {
+            float o[E::OBS];
+            E::obs(L.s, L.flags, o, L.trig);
+            store_row<E::OBS>(obs + (size_t)i * E::OBS, o);
+        }
+    }
+    shared_store_done_count(sr, false);
+}
+
+// step() (cartpole.py:421-479): a sub-environment that finished in the PREVIOUS step takes the j-th column of uniform(low, high, size=(4, k)) --
+// j = its rank among the k such sub-environments, in index order: workgroup prefix (scan kernel) + wavefront ballots -- with steps 0, reward 0, not
+// done; every other one integrates.  `-np.array(terminated, dtype=np.float32)` makes the Sutton-Barto reward of a surviving pole -0.0 (:466).
+template <class E>
+__global__ __launch_bounds__(kBlock) void shared_step_kernel(DevEnv d, StepPtrs io, SharedRng sr) {
+    __shared__ uint32_t sh_wave[kBlock / 64];
+    tables_init<E>();
+    const int i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    Lane<E> L;
+    const bool active = i < d.N;
+    if (active) load_lane<E>(d, i, L);
+    const bool resetting = active && (L.flags & kNeedsReset);
+    const uint64_t bal = __ballot(resetting);
+    if (lane == 0) sh_wave[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) rank += sh_wave[w];
+    bool done = false;
+    if (active) {
+        double rew = 0.0, ep_ret = 0.0;
+        int32_t ep_len = 0;
+        bool te = false, tr = false, untouched = false;
+        if (resetting) {
+            const uint64_t k = sr.words[6], first = sr.words[5] + (uint64_t)sr.blk_prefix[blockIdx.x] + (uint64_t)rank;
+            double u[E::NDRAWS];
+#pragma unroll
+            for (int c = 0; c < E::NDRAWS; c++) u[c] = shared_draw(sr, first + (uint64_t)c * k);
+            L.flags = 0;
+            E::reset_u(u, L.s, L.flags, sr.low, sr.high);
+            L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
+            st.reset_steps++;
+        } else {
+            const typename E::Act a = static_cast<const typename E::Act *>(io.actions)[i];
+            if (!E::valid(a)) {  // cartpole.py:424-426 asserts before it touches anything: the sticky error word, this sub-environment untouched
+                *d.error = kErrInvalidAction;
+                untouched = true;
+            } else {
+                E::step(L.s, L.flags, a, d.P, rew, te, L.trig);
+                if (d.P.p[0] != 0.0 && !te) rew = -0.0;
+                L.elapsed += 1;
+                tr = d.max_steps > 0 && (int)L.elapsed >= d.max_steps;  // self.steps >= self.max_episode_steps (:461)
+                L.ep_ret += rew, L.ep_len += 1;
+                st.env_steps++;
+                done = te || tr;
+                if (done) {
+                    ep_ret = L.ep_ret, ep_len = L.ep_len;
+                    st.episodes++, st.return_sum += L.ep_ret, st.length_sum += (uint64_t)L.ep_len;
+                    L.flags |= kNeedsReset;  // self.prev_done (:479)
+                }
+            }
+        }
+        if (!untouched) store_lane<E>(d, i, L);
+        float o[E::OBS];
+        E::obs(L.s, L.flags, o, L.trig);
+        if (io.obs) store_row<E::OBS>(io.obs + (size_t)i * E::OBS, o);
+        if (io.reward) io.reward[i] = rew;
+        if (io.terminated) io.terminated[i] = te;
+        if (io.truncated) io.truncated[i] = tr;
+        if (io.ep_ret) io.ep_ret[i] = ep_ret;
+        if (io.ep_len) io.ep_len[i] = ep_len;
+    }
+    shared_store_done_count(sr, done);
+    block_accumulate(d, st);
+}
+
+// the policy of a shared-generator rollout's step t: draw t * N + i of the batched action space's stream (what rollout_kernel computes inline)
+template <class E>
+__global__ __launch_bounds__(kBlock) void shared_sample_kernel(DevEnv d, ActionStream as, int t, typename E::Act *out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.N) return;
+    u128 s = make_u128(as.state_hi, as.state_lo);
+    uint64_t n = (uint64_t)t * (uint64_t)d.N + (uint64_t)i + 1ull;
+    for (int j = 0; n; j++, n >>= 1)
+        if (n & 1ull) s = as.pow2[j].mult * s + as.pow2[j].plus;
+    const uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s, x = hi ^ lo;
+    const unsigned rot = (unsigned)(hi >> 58);
+    const uint64_t bits = (x >> rot) | (x << ((0u - rot) & 63u));
+    out[i] = E::SAMPLE_FROM_BITS ? E::sample_bits(bits) : E::sample((double)(bits >> 11) * (1.0 / 9007199254740992.0));
+}
 
 #ifndef MI_CLASSIC_TU
 // ---------------------------------------------------------------------------------------------------------
@@ -1378,7 +1556,8 @@ MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L, Pcg64 *held = null
     if (is_blackjack(d)) {
         bj_reset(rng, L.s, L.prob);
     } else {
-        L.s = (double)tab_categorical(d.tab.isd, d.tab.nS, rng), L.prob = 1.0;
+        const size_t tb = d.tab.env_table ? (size_t)d.tab.env_table[i] : 0;  // the sub-environment's own table (its own random map, ...)
+        L.s = (double)tab_categorical(d.tab.isd + tb * d.tab.nS, d.tab.nS, rng), L.prob = 1.0;
         if (tab_fickle(d)) {  // taxi.py:462-464: fickle_step = fickle_passenger and np_random.random() < fickle_probability -- one more draw
             const double flag = rng.next_double() < d.P.p[3] ? 1.0 : 0.0;
             L.aux = floor(L.aux * 0.5) * 2.0 + flag;
@@ -1418,7 +1597,8 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
             bj_step(rng, L.s, L.prob, a, d.P.p[0] != 0.0, d.P.p[1] != 0.0, reward, te);
             if (!held) store_rng_state(d, i, rng);
         } else {
-            const size_t cell = (size_t)L.s * d.tab.nA + (size_t)a, row = cell * d.tab.K;
+            const size_t tb = d.tab.env_table ? (size_t)d.tab.env_table[i] : 0;
+            const size_t cell = (tb * d.tab.nS + (size_t)L.s) * d.tab.nA + (size_t)a, row = cell * d.tab.K;
             const int k = tab_categorical(d.tab.csprob + row, d.tab.count[cell], rng);
             int next = d.tab.next[row + k];
             if (tab_fickle(d) && ((int64_t)L.aux & 1)) {
@@ -1672,7 +1852,7 @@ struct mi_vecenv {
     mi_step_io pending;     // user pointers of a step that was enqueued by mi_step_async and not waited for yet
     size_t pending_bytes;
     bool has_pending;
-    void *tab_bufs[7];
+    void *tab_bufs[8];
     bool tab_loaded;
     // MuJoCo family: cooperative physics kernel (default) or the one-lane simulator (MI355ENV_MJ_SERIAL=1, cross-check)
     bool mj_coop;
@@ -1680,6 +1860,11 @@ struct mi_vecenv {
     double *d_extras;       // [N][EX_TOTAL]
     float *d_act_scratch;   // [N][NU] actions of the current rollout step when the caller does not keep them
     void *d_obs_scratch;    // [N][obs_dim] observations of the current rollout step when the caller does not keep them
+    // MI_CFG_SHARED_RNG (CartPoleVectorEnv's semantics): the one generator and the bookkeeping of its draw positions, all device memory
+    bool shared_rng;
+    SharedRng shared;
+    PcgJump *d_shared_pow2;
+    Pcg64 shared_base;      // host copy of the base generator (mi_get_rng: base advanced by the device's `consumed` counter)
 };
 
 namespace {
@@ -1874,6 +2059,57 @@ int reset(mi_vecenv *v, const uint8_t *dm, int has_bounds, double b0, double b1,
 int rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample, int in_kind) {
     return dispatch_kind_act(v->cfg.kind, (v->cfg.reserved[0] & MI_CFG_FAST_MATH) != 0, in_kind, [&](auto env) -> int { return launch_rollout<decltype(env)>(v, p, as, T, sample); });
 }
+// ---- MI_CFG_SHARED_RNG: MI_ENV_CARTPOLE only (mi_create refuses the bit for every other kind) ---------------------------------------------
+template <class F>
+static int dispatch_shared(mi_vecenv *v, F &&f) {
+    if (v->cfg.reserved[0] & MI_CFG_FAST_MATH) return f(CartPoleT<FastMath>());
+    return f(CartPoleT<ExactMath>());
+}
+int shared_reset(mi_vecenv *v, float *dobs) {
+    hipLaunchKernelGGL(shared_scan_kernel, dim3(1), dim3(kBlock), 0, v->stream, v->shared, v->grid, (uint64_t)4 * (uint64_t)v->cfg.num_envs);
+    return dispatch_shared(v, [&](auto env) -> int {
+        hipLaunchKernelGGL((shared_reset_kernel<decltype(env)>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, v->shared, dobs);
+        HIP_TRY(hipGetLastError());
+        return (int)MI_OK;
+    });
+}
+int shared_step(mi_vecenv *v, const StepPtrs &p) {
+    hipLaunchKernelGGL(shared_scan_kernel, dim3(1), dim3(kBlock), 0, v->stream, v->shared, v->grid, (uint64_t)0);
+    return dispatch_shared(v, [&](auto env) -> int {
+        hipLaunchKernelGGL((shared_step_kernel<decltype(env)>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p, v->shared);
+        HIP_TRY(hipGetLastError());
+        return (int)MI_OK;
+    });
+}
+int shared_rollout(mi_vecenv *v, const RolloutPtrs &p, const ActionStream &as, int T, bool sample) {
+    const size_t N = (size_t)v->cfg.num_envs;
+    for (int t = 0; t < T; t++) {
+        StepPtrs sp;
+        memset(&sp, 0, sizeof sp);
+        if (sample) {
+            int64_t *dst = p.actions_out ? static_cast<int64_t *>(p.actions_out) + (size_t)t * N : static_cast<int64_t *>(v->d_actions);
+            const int rc = dispatch_shared(v, [&](auto env) -> int {
+                hipLaunchKernelGGL((shared_sample_kernel<decltype(env)>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, as, t, dst);
+                return (int)MI_OK;
+            });
+            if (rc) return rc;
+            sp.actions = dst;
+        } else {
+            sp.actions = static_cast<const int64_t *>(p.actions_in) + (size_t)t * N;
+        }
+        sp.obs = p.obs ? static_cast<float *>(p.obs) + (size_t)t * N * CartPole::OBS : nullptr;
+        sp.reward = p.reward ? p.reward + (size_t)t * N : nullptr;
+        sp.terminated = p.terminated ? p.terminated + (size_t)t * N : nullptr;
+        sp.truncated = p.truncated ? p.truncated + (size_t)t * N : nullptr;
+        if (const int rc = shared_step(v, sp)) return rc;
+    }
+    return MI_OK;
+}
+int shared_recount(mi_vecenv *v) {
+    hipLaunchKernelGGL(shared_count_kernel, dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, v->shared);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
 }  // namespace mi_classic
 #else
 namespace {
@@ -1981,6 +2217,8 @@ int mi_create(const mi_config *cfg, int device, mi_vecenv **out) {
     if (cfg->num_envs < 1) return fail(MI_ERR_INVALID_ARGUMENT, "num_envs must be >= 1");
     if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2) return fail(MI_ERR_INVALID_ARGUMENT, "bad autoreset mode");
     if (cfg->max_episode_steps > (int)kElapsedMask) return fail(MI_ERR_INVALID_ARGUMENT, "max_episode_steps too large");
+    if ((cfg->reserved[0] & MI_CFG_SHARED_RNG) && (cfg->kind != MI_ENV_CARTPOLE || cfg->autoreset_mode != MI_AUTORESET_NEXT_STEP))
+        return fail(MI_ERR_UNSUPPORTED, "MI_CFG_SHARED_RNG is CartPoleVectorEnv's semantics: MI_ENV_CARTPOLE with NEXT_STEP autoreset only");
     const int ndev = mi_device_count();
     if (ndev == 0)
         return fail(MI_ERR_NO_DEVICE, "no HIP device visible: libmi355env runs on MI355X (gfx950) only and has no CPU fallback");
@@ -2065,6 +2303,17 @@ static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
     HIP_TRY(hipMalloc(&d.blk_count, sizeof(uint64_t) * 4 * v->grid));
     HIP_TRY(hipMalloc(&d.blk_ret, sizeof(double) * v->grid));
     HIP_TRY(hipMalloc(&v->d_pow2, sizeof(PcgJump) * 64));
+    v->shared_rng = (cfg->reserved[0] & MI_CFG_SHARED_RNG) != 0;
+    if (v->shared_rng) {
+        HIP_TRY(hipMalloc(&v->shared.words, sizeof(uint64_t) * 8));
+        HIP_TRY(hipMalloc(&v->d_shared_pow2, sizeof(PcgJump) * 64));
+        HIP_TRY(hipMalloc(&v->shared.blk_done, sizeof(uint32_t) * v->grid));
+        HIP_TRY(hipMalloc(&v->shared.blk_prefix, sizeof(uint32_t) * v->grid));
+        HIP_TRY(hipMemsetAsync(v->shared.words, 0, sizeof(uint64_t) * 8, v->stream));
+        HIP_TRY(hipMemsetAsync(v->shared.blk_done, 0, sizeof(uint32_t) * v->grid, v->stream));
+        HIP_TRY(hipMemsetAsync(v->shared.blk_prefix, 0, sizeof(uint32_t) * v->grid, v->stream));
+        v->shared.pow2 = v->d_shared_pow2, v->shared.low = -0.05, v->shared.high = 0.05;
+    }
     HIP_TRY(hipMemsetAsync(d.state, 0, sizeof(double) * v->lay.state_dim * N, v->stream));
     HIP_TRY(hipMemsetAsync(d.meta, 0, sizeof(uint32_t) * N, v->stream));
     HIP_TRY(hipMemsetAsync(d.rng, 0, sizeof(uint64_t) * 4 * N, v->stream));
@@ -2120,7 +2369,8 @@ void mi_destroy(mi_vecenv *v) {
     (void)hipSetDevice(v->device);
     (void)hipStreamSynchronize(v->stream);
     void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d_out,
-                    v->d_pow2, v->d_actions, v->d_mask, v->d_words, v->d_extras, v->d_act_scratch, v->d_obs_scratch};
+                    v->d_pow2, v->d_actions, v->d_mask, v->d_words, v->d_extras, v->d_act_scratch, v->d_obs_scratch,
+                    v->shared.words, v->d_shared_pow2, v->shared.blk_done, v->shared.blk_prefix};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (v->h_out) (void)hipHostFree(v->h_out);
@@ -2136,6 +2386,7 @@ void mi_destroy(mi_vecenv *v) {
 // The reference's stateful vector wrappers as the output stage of the classic-control step kernel (include/mi355env.h mi_step_epilogue).
 int mi_set_step_epilogue(mi_vecenv *v, const mi_step_epilogue *e) {
     if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (v->shared_rng && e) return fail(MI_ERR_UNSUPPORTED, "MI_CFG_SHARED_RNG: the step epilogue belongs to the per-sub-environment step kernel");
     if (set_device(v)) return MI_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(v->stream));
     if (!e) {
@@ -2204,9 +2455,27 @@ static int upload_mask(mi_vecenv *v, const uint8_t *mask, const uint8_t **d_mask
     return MI_OK;
 }
 
+// MI_CFG_SHARED_RNG: (re)base the one generator -- its words, a zero draw counter and the jump table of its increment
+static int shared_rebase(mi_vecenv *v, const Pcg64 &g) {
+    v->shared_base = g;
+    const uint64_t words[8] = {(uint64_t)(g.state >> 64), (uint64_t)g.state, (uint64_t)(g.inc >> 64), (uint64_t)g.inc, 0, 0, 0, 0};
+    PcgJump tab[64];
+    for (int j = 0; j < 64; j++) tab[j] = pcg_jump(g.inc, (u128)1 << j);
+    HIP_TRY(hipMemcpyAsync(v->shared.words, words, sizeof words, hipMemcpyHostToDevice, v->stream));
+    HIP_TRY(hipMemcpyAsync(v->d_shared_pow2, tab, sizeof tab, hipMemcpyHostToDevice, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));  // both sources are on this stack frame
+    v->seeded = true;
+    return MI_OK;
+}
+
 int mi_seed(mi_vecenv *v, const uint64_t *pcg, const uint8_t *mask) {
     if (!v || !pcg) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     if (set_device(v)) return MI_ERR_HIP;
+    if (v->shared_rng) {
+        Pcg64 g;
+        g.state = make_u128(pcg[0], pcg[1]), g.inc = make_u128(pcg[2], pcg[3]);
+        return shared_rebase(v, g);
+    }
     const uint8_t *dm;
     if (int rc = upload_mask(v, mask, &dm)) return rc;
     HIP_TRY(hipMemcpyAsync(v->d_words, pcg, sizeof(uint64_t) * 4 * (size_t)v->cfg.num_envs, hipMemcpyHostToDevice, v->stream));
@@ -2220,6 +2489,14 @@ int mi_seed(mi_vecenv *v, const uint64_t *pcg, const uint8_t *mask) {
 int mi_seed_sequence(mi_vecenv *v, uint64_t base_seed, uint64_t first_index, const uint8_t *mask) {
     if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
     if (set_device(v)) return MI_ERR_HIP;
+    if (v->shared_rng) {  // Generator(PCG64(SeedSequence(seed))) -- the same host arithmetic seed_sequence_kernel runs per lane
+        if (first_index != 0) return fail(MI_ERR_UNSUPPORTED, "MI_CFG_SHARED_RNG: one generator for all sub-environments, they do not shard (first_index must be 0)");
+        uint64_t w[4];
+        seed_sequence_words(base_seed, w);
+        Pcg64 g;
+        g.srandom(w);
+        return shared_rebase(v, g);
+    }
     const uint8_t *dm;
     if (int rc = upload_mask(v, mask, &dm)) return rc;
     hipLaunchKernelGGL(seed_sequence_kernel, dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, base_seed + first_index, dm);
@@ -2233,6 +2510,18 @@ int mi_get_rng(mi_vecenv *v, uint64_t *pcg) {
     if (!v || !pcg) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     if (set_device(v)) return MI_ERR_HIP;
     const size_t N = (size_t)v->cfg.num_envs;
+    if (v->shared_rng) {  // the base generator advanced by the draws the device has taken: every row reports the one generator
+        uint64_t words[8];
+        HIP_TRY(hipMemcpyAsync(words, v->shared.words, sizeof words, hipMemcpyDeviceToHost, v->stream));
+        HIP_TRY(hipStreamSynchronize(v->stream));
+        const PcgJump j = pcg_jump(v->shared_base.inc, (u128)words[4]);
+        const u128 st = j.mult * v->shared_base.state + j.plus;
+        for (size_t i = 0; i < N; i++) {
+            pcg[4 * i] = (uint64_t)(st >> 64), pcg[4 * i + 1] = (uint64_t)st;
+            pcg[4 * i + 2] = (uint64_t)(v->shared_base.inc >> 64), pcg[4 * i + 3] = (uint64_t)v->shared_base.inc;
+        }
+        return MI_OK;
+    }
     std::vector<uint64_t> soa(4 * N);
     HIP_TRY(hipMemcpyAsync(soa.data(), v->d.rng, sizeof(uint64_t) * 4 * N, hipMemcpyDeviceToHost, v->stream));
     HIP_TRY(hipStreamSynchronize(v->stream));
@@ -2273,7 +2562,12 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
         hipLaunchKernelGGL((mj_reset_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, dm, (double *)dobs, v->lay.obs_dim);
         HIP_TRY(hipGetLastError());
         return (int)MI_OK;
-    }) : mi_classic::reset(v, dm, has_bounds, b0, b1, (float *)dobs);
+    }) : v->shared_rng ? MI_OK : mi_classic::reset(v, dm, has_bounds, b0, b1, (float *)dobs);
+    if (v->shared_rng) {  // CartPoleVectorEnv.reset (cartpole.py:481-503): every sub-environment, bounds kept for the autoresets
+        if (mask) return fail(MI_ERR_UNSUPPORTED, "MI_CFG_SHARED_RNG: CartPoleVectorEnv.reset resets every sub-environment (no reset_mask)");
+        v->shared.low = has_bounds ? b0 : -0.05, v->shared.high = has_bounds ? b1 : 0.05;
+        rc = mi_classic::shared_reset(v, (float *)dobs);
+    }
     if (rc) return rc;
     v->was_reset = true;
     if (loc == MI_HOST) {
@@ -2366,6 +2660,9 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
                                p.ep_ret, p.ep_len, dinfo, dfinfo, v->lay.obs_dim, nullptr, act_kind != MI_F32};
         if (!mp.obs) return fail(MI_ERR_INVALID_ARGUMENT, "obs is NULL");
         rc = dispatch_mj(v->cfg.kind, [&](auto env) -> int { return launch_mj_step<decltype(env)>(v, mp); });
+    } else if (v->shared_rng) {
+        if (p.final_obs) return fail(MI_ERR_INVALID_ARGUMENT, "MI_CFG_SHARED_RNG is NEXT_STEP only: no final_obs");
+        rc = mi_classic::shared_step(v, p);
     } else {
         rc = mi_classic::step(v, p, act_kind);
     }
@@ -2424,12 +2721,22 @@ int mi_host_buffers(mi_vecenv *v, mi_step_io *out) {
 int mi_tabular_load(mi_vecenv *v, const mi_tabular_table *t) {
     if (!v || !t) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     if (v->cfg.kind != MI_ENV_TABULAR) return fail(MI_ERR_INVALID_ARGUMENT, "not a tabular environment");
-    if (t->num_states < 1 || t->num_actions < 1 || t->max_outcomes < 1) return fail(MI_ERR_INVALID_ARGUMENT, "empty table");
+    if (t->num_states < 1 || t->num_actions < 1 || t->max_outcomes < 1 || t->num_tables < 0) return fail(MI_ERR_INVALID_ARGUMENT, "empty table");
+    const size_t M = t->num_tables > 1 ? (size_t)t->num_tables : 1;
+    if ((M > 1) != (t->env_table != nullptr)) return fail(MI_ERR_INVALID_ARGUMENT, "env_table goes with num_tables > 1");
+    if (M > 1 && v->cfg.params[2] != 0.0) return fail(MI_ERR_UNSUPPORTED, "the fickle Taxi has one table");
+    for (size_t i = 0; M > 1 && i < (size_t)v->cfg.num_envs; i++)
+        if (t->env_table[i] < 0 || (size_t)t->env_table[i] >= M) return fail(MI_ERR_INVALID_ARGUMENT, "env_table entry out of range");
     if (set_device(v)) return MI_ERR_HIP;
-    const size_t cells = (size_t)t->num_states * t->num_actions, n = cells * t->max_outcomes;
-    const void *src[7] = {t->csprob, t->prob, t->reward, t->isd_csprob, t->next_state, t->count, t->terminated};
-    const size_t bytes[7] = {n * 8, n * 8, n * 8, (size_t)t->num_states * 8, n * 4, cells * 4, n};
-    for (int k = 0; k < 7; k++) {
+    const size_t cells = M * (size_t)t->num_states * t->num_actions, n = cells * t->max_outcomes;
+    const void *src[8] = {t->csprob, t->prob, t->reward, t->isd_csprob, t->next_state, t->count, t->terminated, t->env_table};
+    const size_t bytes[8] = {n * 8, n * 8, n * 8, M * (size_t)t->num_states * 8, n * 4, cells * 4, n, (size_t)v->cfg.num_envs * 4};
+    for (int k = 0; k < 8; k++) {
+        if (k == 7 && M == 1) {
+            if (v->tab_bufs[k]) (void)hipFree(v->tab_bufs[k]);
+            v->tab_bufs[k] = nullptr;
+            continue;
+        }
         if (!src[k]) return fail(MI_ERR_INVALID_ARGUMENT, "null table array");
         if (v->tab_bufs[k]) (void)hipFree(v->tab_bufs[k]);
         HIP_TRY(hipMalloc(&v->tab_bufs[k], bytes[k]));
@@ -2440,7 +2747,7 @@ int mi_tabular_load(mi_vecenv *v, const mi_tabular_table *t) {
     tab.nS = t->num_states, tab.nA = t->num_actions, tab.K = t->max_outcomes;
     tab.csprob = (const double *)v->tab_bufs[0], tab.prob = (const double *)v->tab_bufs[1], tab.reward = (const double *)v->tab_bufs[2];
     tab.isd = (const double *)v->tab_bufs[3], tab.next = (const int32_t *)v->tab_bufs[4], tab.count = (const int32_t *)v->tab_bufs[5];
-    tab.term = (const uint8_t *)v->tab_bufs[6];
+    tab.term = (const uint8_t *)v->tab_bufs[6], tab.env_table = (const int32_t *)v->tab_bufs[7];
     v->tab_loaded = true;
     return MI_OK;
 }
@@ -2492,7 +2799,7 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
         const bool next = v->cfg.autoreset_mode == MI_AUTORESET_NEXT_STEP;
         // table in LDS when it fits next to the 160 KB of a CU and the copy is amortised over enough steps (Blackjack has no table)
         size_t lds = 0;
-        if (v->d.tab.nS > 0 && T >= 8) {
+        if (v->d.tab.nS > 0 && T >= 8 && !v->d.tab.env_table) {  // (per-sub-environment tables stay in HBM / L2)
             const size_t cells = (size_t)v->d.tab.nS * v->d.tab.nA, rows = cells * v->d.tab.K;
             lds = (3 * rows + v->d.tab.nS) * sizeof(double) + (rows + cells) * sizeof(int32_t) + rows;
             lds = (lds + 15) & ~(size_t)15;
@@ -2526,6 +2833,8 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
             HIP_TRY(hipGetLastError());
             return (int)MI_OK;
         });
+    } else if (v->shared_rng) {
+        rc = mi_classic::shared_rollout(v, p, as, T, sample);
     } else {
         rc = mi_classic::rollout(v, p, as, T, sample, in_kind);
     }
@@ -2602,6 +2911,8 @@ int mi_set_state(mi_vecenv *v, const double *state, const int32_t *elapsed, cons
         }
         HIP_TRY(hipMemcpyAsync(v->d.meta, meta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice, v->stream));
         HIP_TRY(hipStreamSynchronize(v->stream));
+        if (v->shared_rng && flags)  // the per-workgroup counts of finished sub-environments follow the new flag words
+            if (int rc = mi_classic::shared_recount(v)) return rc;
     }
     v->was_reset = true;
     return MI_OK;

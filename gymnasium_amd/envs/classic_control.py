@@ -17,7 +17,9 @@ import math
 
 import numpy as np
 
-from ..gym_api import spaces
+from .. import _native
+from ..gym_api import AutoresetMode, error, spaces
+from ..gym_api import VectorEnv as VectorEnvBase
 from ..vector.hip_vector_env import HipVectorEnv, _verify_number_and_cast, parse_low_high
 
 DEFAULT_X = np.pi  # pendulum.py:14-15
@@ -42,12 +44,83 @@ class _ClassicControlVectorEnv(HipVectorEnv):
 
 
 class CartPoleVectorEnv(_ClassicControlVectorEnv):
+    """``rng="per_env"`` (default): the semantics of ``SyncVectorEnv`` over scalar ``CartPoleEnv`` objects -- sub-environment ``i`` owns the stream
+    ``default_rng(seed + i)``, float64 rewards -- which is what the north_star's parity oracle is and what shards across GPUs.
+
+    ``rng="shared"``: the semantics of the reference's own NumPy vector environment of the same name (cartpole.py:353-505; what stock
+    ``gymnasium.make_vec("CartPole-v1", n)`` returns, because the id registers it as ``vector_entry_point``): ONE generator for all
+    sub-environments -- ``reset(seed=s)`` draws ``uniform(low, high, size=(4, n))`` from ``default_rng(s)``, a step re-draws the ``k``
+    sub-environments that finished in the previous step with ``size=(4, k)`` --, float32 rewards, reset bounds that persist for the autoresets,
+    no ``reset_mask``, NEXT_STEP only.  Trajectories are ``array_equal`` to that class's (tests/golden/cartpole_vector_entry_point.npz);
+    ``register_envs(override_stock_ids=True)`` attaches this mode to the stock id, so that switching changes no seeded trajectory."""
+
     KIND = "cartpole"
     DEFAULT_MAX_EPISODE_STEPS = 500
+    DEFAULT_RNG = "per_env"
 
-    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, sutton_barto_reward: bool = False, **kwargs):
+    def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, sutton_barto_reward: bool = False, rng: str | None = None, **kwargs):
         self._sutton_barto_reward = bool(sutton_barto_reward)
+        rng = self.DEFAULT_RNG if rng is None else rng
+        if rng not in ("per_env", "shared"):
+            raise ValueError(f"rng must be 'per_env' or 'shared', got {rng!r}")
+        self._shared_rng = rng == "shared"
+        if self._shared_rng:
+            mode = kwargs.get("autoreset_mode", AutoresetMode.NEXT_STEP)
+            if (mode if isinstance(mode, AutoresetMode) else AutoresetMode(mode)) != AutoresetMode.NEXT_STEP:
+                raise error.Error("rng='shared' is CartPoleVectorEnv's semantics (cartpole.py:353-505): NEXT_STEP autoreset only")
+            if kwargs.get("env_index_offset", 0):
+                raise error.Error("rng='shared': one generator for all sub-environments -- they do not shard across devices (env_index_offset must be 0)")
+            self.FUSES_WRAPPERS = False  # (the step epilogue belongs to the per-sub-environment step kernel)
         super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
+
+    def _engine_options(self) -> int:
+        return super()._engine_options() | (_native.CFG_SHARED_RNG if self._shared_rng else 0)
+
+    # -- rng="shared": VectorEnv.np_random IS the generator the sub-environments draw from (cartpole.py:475, 497) ------------------------
+    def _seed_engines(self, seed, mask):
+        if not self._shared_rng:
+            return super()._seed_engines(seed, mask)
+        if seed is None:
+            if not self._seeded:  # Env.np_random's lazy OS-entropy seeding
+                self._engine.seed(np.tile(_native.pcg_words(super().np_random), (self.num_envs, 1)), None)  # (one generator: the engine reads row 0)
+                self._seeded = True
+            return
+        if not (isinstance(seed, (int, np.integer)) and not isinstance(seed, bool)) or int(seed) < 0:
+            raise error.Error(f"Seed must be a python integer, actual type: {type(seed)}" if not isinstance(seed, (int, np.integer)) else
+                              f"Seed must be greater or equal to zero, actual value: {seed}")
+        # (HipVectorEnv.reset has just seeded the host generator through VectorEnv.reset(seed=...): hand ITS words to the engine, so the two
+        # cannot disagree whatever width the seed has)
+        self._engine.seed(np.tile(_native.pcg_words(super().np_random), (self.num_envs, 1)), None)  # (one generator: the engine reads row 0)
+        self._seeded = True
+
+    @property
+    def np_random(self):
+        """The generator of ``reset`` / the autoresets.  With rng="shared" the draws happen on the device: reading this property brings the
+        host object up to date with them (one small device-to-host copy; synchronises)."""
+        gen = VectorEnvBase.np_random.fget(self)
+        if getattr(self, "_shared_rng", False) and getattr(self, "_seeded", False) and getattr(self, "_engine", None) is not None:
+            _native.set_pcg_words(gen, self._engine.get_rng()[0])
+        return gen
+
+    @np_random.setter
+    def np_random(self, value):
+        VectorEnvBase.np_random.fset(self, value)
+        if getattr(self, "_shared_rng", False) and getattr(self, "_engine", None) is not None:
+            self._engine.seed(np.tile(_native.pcg_words(value), (self.num_envs, 1)), None)
+            self._seeded = True
+
+    def reset(self, *, seed=None, options=None):
+        if self._shared_rng and options is not None and "reset_mask" in options:
+            options = {k: v for k, v in options.items() if k != "reset_mask"}  # CartPoleVectorEnv.reset knows no reset_mask: every sub-environment resets
+        return super().reset(seed=seed, options=options)
+
+    def step(self, actions):
+        out = super().step(actions)
+        if not self._shared_rng:
+            return out
+        rew = out[1]
+        rew = rew.to(self._torch.float32) if self.output == "torch" else rew.astype(np.float32)  # reward arrays of cartpole.py:466-468 are float32
+        return (out[0], rew) + tuple(out[2:])
 
     def _single_spaces(self):
         theta_threshold_radians = 12 * 2 * math.pi / 360
@@ -132,6 +205,13 @@ class MountainCarContinuousVectorEnv(_MountainCarBase):
 
     def _single_spaces(self):
         return self._obs_space(), spaces.Box(low=-1.0, high=1.0, shape=(1,), dtype=np.float32)
+
+
+class StockCartPoleVectorEnv(CartPoleVectorEnv):
+    """What ``register_envs(override_stock_ids=True)`` attaches to the STOCK id ``CartPole-v1``: the engine with the semantics of the class it
+    replaces there (the reference's NumPy CartPoleVectorEnv), so that a seeded ``gymnasium.make_vec("CartPole-v1", n)`` user sees the same numbers."""
+
+    DEFAULT_RNG = "shared"
 
 
 # id -> (creator, max_episode_steps, reward_threshold): gymnasium/envs/__init__.py:26-59

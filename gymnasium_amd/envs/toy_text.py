@@ -33,7 +33,21 @@ class TabularVectorEnv(HipVectorEnv):
         """Return (P, initial_state_distrib): P[s][a] = list of (prob, next_state, reward, terminated)."""
         raise NotImplementedError
 
+    def _build_tables(self, num_envs: int):
+        """Environments whose sub-environments do NOT share one MDP (FrozenLake with a map per sub-environment) return the engine's arrays
+        directly: dict(csprob, prob, next_state, reward, terminated, count [num_tables, nS, nA(, K)], isd_csprob [num_tables, nS], env_table [num_envs]);
+        None (default): one table for all, from _build()."""
+        return None
+
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, **kwargs):
+        many = self._build_tables(int(num_envs))
+        if many is not None:
+            self._tab = many
+            self.P = self.initial_state_distrib = None  # one per sub-environment: see `desc`
+            _, self.nS, self.nA, _ = many["csprob"].shape
+            super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
+            self._engine.load_table(**self._tab)
+            return
         P, isd = self._build()
         self.P, self.initial_state_distrib = P, np.asarray(isd, dtype=np.float64)
         self.nS, self.nA = len(P), len(P[0])
@@ -95,6 +109,19 @@ FROZEN_LAKE_MAPS = {  # frozen_lake.py:20-32
 }
 
 
+def _board(desc) -> list:
+    """A board as a list of row strings, whatever the caller passed (list of str, bytes, or a NumPy 'c' / str array like FrozenLakeEnv.desc)."""
+    rows = []
+    for r in desc:
+        if isinstance(r, (bytes, np.bytes_)):
+            rows.append(r.decode())
+        elif isinstance(r, (str, np.str_)):
+            rows.append(str(r))
+        else:
+            rows.append("".join(x.decode() if isinstance(x, (bytes, np.bytes_)) else str(x) for x in r))
+    return rows
+
+
 def _goal_reachable(board, size: int) -> bool:
     """frozen_lake.py:34-53 is_valid: is "G" reachable from (0, 0) over non-hole tiles (4-neighbourhood)?  (Any graph search gives the same answer.)"""
     seen, stack = {(0, 0)}, [(0, 0)]
@@ -129,19 +156,65 @@ class FrozenLakeVectorEnv(TabularVectorEnv):
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, render_mode=None, desc=None, map_name: str = "4x4",
                  is_slippery: bool = True, success_rate: float = 1.0 / 3.0, reward_schedule=(1, 0, 0), **kwargs):
+        # frozen_lake.py:241-242: `desc = generate_random_map()` -- unseeded (OS entropy).  The reference's SyncVectorEnv constructs num_envs scalar
+        # envs, i.e. draws one map PER SUB-ENVIRONMENT: so does this class (one transition table per sub-environment, mi_tabular_table.env_table).
+        # `desc` may also be a list of num_envs boards -- one map per sub-environment, reproducibly: [generate_random_map(8, 0.8, seed + i) for i in ...].
+        self.descs = None
         if desc is None and map_name is None:
-            # frozen_lake.py:241-242: `desc = generate_random_map()` -- unseeded (OS entropy), so no two constructions agree by design.  The reference's
-            # SyncVectorEnv constructs num_envs scalar envs, i.e. draws one map PER SUB-ENVIRONMENT; the engine holds one transition table per vector
-            # env, so all its sub-environments share ONE random map.  (For reproducible or per-env maps pass desc=generate_random_map(size, p, seed).)
-            from ..gym_api import logger
-
-            desc = generate_random_map()
-            if num_envs > 1:
-                logger.warn("FrozenLake with map_name=None: the MI355X engine draws ONE random map for all sub-environments of this vector env "
-                            "(gymnasium's SyncVectorEnv draws one per sub-environment)")
-        self.desc = [str(r) for r in (desc if desc is not None else FROZEN_LAKE_MAPS[map_name])]
+            self.descs = [generate_random_map() for _ in range(int(num_envs))]
+        elif desc is not None and len(desc) > 0 and not isinstance(desc[0], (str, bytes, np.str_, np.bytes_)) and not np.isscalar(desc[0]) \
+                and isinstance(desc[0][0], (str, bytes, np.str_, np.bytes_)) and len(desc[0][0]) > 1:
+            self.descs = [_board(b) for b in desc]
+            if len(self.descs) != int(num_envs):
+                raise ValueError(f"a list of boards must have one board per sub-environment: got {len(self.descs)} for num_envs={num_envs}")
+            if len({(len(b), len(b[0])) for b in self.descs}) != 1:
+                raise ValueError("the boards of one vector environment must have the same shape (one observation space)")
+        self.desc = self.descs[0] if self.descs is not None else _board(desc if desc is not None else FROZEN_LAKE_MAPS[map_name])
         self.is_slippery, self.success_rate, self.reward_schedule = bool(is_slippery), success_rate, tuple(reward_schedule)
         super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)
+
+    def _build_tables(self, num_envs):
+        """One transition table per DISTINCT board, built for all of them at once (the same rules as _build(), as array arithmetic over the boards)."""
+        if self.descs is None:
+            return None
+        letters = np.array([[list(row) for row in b] for b in self.descs])  # [N, nrow, ncol] of 1-character strings
+        boards, env_table = np.unique(letters.reshape(len(self.descs), -1), axis=0, return_inverse=True)
+        env_table = env_table.reshape(-1)
+        M, (nrow, ncol) = len(boards), letters.shape[1:]
+        if M == 1:  # all sub-environments share the board after all
+            self.descs = None
+            return None
+        boards = boards.reshape(M, nrow, ncol)
+        nS = nrow * ncol
+        row, col = np.divmod(np.arange(nS), ncol)
+        r2 = np.stack([row, np.minimum(row + 1, nrow - 1), row, np.maximum(row - 1, 0)], 1)  # [nS, 4 directions]: LEFT, DOWN, RIGHT, UP
+        c2 = np.stack([np.maximum(col - 1, 0), col, np.minimum(col + 1, ncol - 1), col], 1)
+        landed = boards[:, r2, c2]  # [M, nS, 4] letter of the tile a move in direction b ends on
+        sched = np.asarray(self.reward_schedule, dtype=np.float64)
+        rew_b = np.where(landed == "G", sched[0], np.where(landed == "H", sched[1], sched[2]))
+        term_b = (landed == "G") | (landed == "H")
+        next_b = np.broadcast_to(r2 * ncol + c2, (M, nS, 4))
+        here_terminal = np.isin(boards.reshape(M, nS), ("G", "H"))  # [M, nS]
+        K = 3 if self.is_slippery else 1
+        fail_rate = (1.0 - self.success_rate) / 2.0
+        a = np.arange(4)
+        b_of = np.stack([(a - 1) % 4, a, (a + 1) % 4], 1) if self.is_slippery else a[:, None]  # [4 actions, K] direction of outcome k
+        p_of = np.where(b_of == a[:, None], self.success_rate, fail_rate) if self.is_slippery else np.ones((4, 1))
+        prob = np.broadcast_to(p_of, (M, nS, 4, K)).copy()
+        nxt, rew, term = next_b[:, :, b_of].copy(), rew_b[:, :, b_of].copy(), term_b[:, :, b_of].copy()
+        count = np.full((M, nS, 4), K, dtype=np.int32)
+        # a sub-environment standing on G / H has one outcome: (1.0, s, 0, True)
+        t = here_terminal
+        prob[t], nxt[t], rew[t], term[t] = 0.0, 0, 0.0, False
+        prob[t, :, 0], term[t, :, 0], count[t] = 1.0, True, 1
+        nxt[t, :, 0] = np.broadcast_to(np.arange(nS), (M, nS))[t][:, None]
+        csprob = np.ones((M, nS, 4, K))
+        for k in range(K):  # np.cumsum of the valid outcomes (categorical_sample, utils.py:4-8); entries beyond `count` stay 1.0
+            csprob[..., k] = np.where(k < count, np.cumsum(prob, axis=-1)[..., k], 1.0)
+        isd = (boards.reshape(M, nS) == "S").astype(np.float64)
+        isd /= isd.sum(axis=1, keepdims=True)
+        return dict(csprob=csprob, prob=prob, next_state=nxt.astype(np.int32), reward=rew, terminated=term.astype(np.uint8), count=count,
+                    isd_csprob=np.cumsum(isd, axis=1), env_table=env_table.astype(np.int32))
 
     def _build(self):
         desc, nrow, ncol = self.desc, len(self.desc), len(self.desc[0])

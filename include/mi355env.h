@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355ENV_ABI_VERSION 5
+#define MI355ENV_ABI_VERSION 6
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -133,6 +133,18 @@ typedef struct mi_config {
  * pendulum.py:131, acrobot.py:263-283).  This bit selects the device's own sin / cos (<= 1 ulp away) and x * x instead: ~1.2-2x the
  * env-steps/s, results within the tolerances of tests/test_gpu_parity.py's fast-math cases.  Opt-in only. */
 #define MI_CFG_FAST_MATH 2
+/* MI_CFG_SHARED_RNG (MI_ENV_CARTPOLE only): the semantics of the reference's own NumPy vector environment `CartPoleVectorEnv`
+ * (envs/classic_control/cartpole.py:353-505; what `make_vec("CartPole-v1")` returns by default: it is the id's vector_entry_point) instead of
+ * SyncVectorEnv's.  The dynamics are the same expressions; what differs:
+ *   - ONE generator for all sub-environments.  reset() draws `uniform(low, high, size=(4, N))` -- component-major: draw c * N + i is component c
+ *     of sub-environment i (cartpole.py:493-500); a step re-draws the k sub-environments that finished in the previous step with
+ *     `uniform(low, high, size=(4, k))` in index order (draw c * k + j for the j-th of them, :475-478).  mi_seed reads ONE generator (pcg[0..3]),
+ *     mi_seed_sequence seeds it with SeedSequence(base_seed) (first_index must be 0), mi_get_rng reports it in every row.
+ *   - reset bounds given to mi_reset PERSIST for the autoresets that follow (self.low / self.high, :489-491); mi_reset takes no mask.
+ *   - NEXT_STEP autoreset only; with sutton_barto_reward a sub-environment that did not terminate is rewarded -0.0 (`-np.array(terminated)`, :466).
+ *   The reference returns float32 rewards there (:466-468): the values (+-1, +-0) are exact in either type; mi_step_io.reward stays float64 and the host
+ *   class casts.  Sub-environments do not shard across devices in this mode (draw positions depend on every other sub-environment's episode ends). */
+#define MI_CFG_SHARED_RNG 4
 
 typedef struct mi_layout {
     int32_t obs_dim;      /* observation row length (elements) */
@@ -273,15 +285,19 @@ int mi_host_buffers(mi_vecenv *env, mi_step_io *out);
  *   prob / next_state / reward / terminated [nS][nA][K]   the outcome tuples; count[nS][nA] outcomes are valid
  *   isd_csprob[nS]      np.cumsum(initial_state_distrib)
  * step: i = argmax(csprob[s][a] > rng.random()); reset: s = argmax(isd_csprob > rng.random()).  Observations are int64
- * states; layout.info_dim = 1 (the "prob" entry of the info dict). */
+ * states; layout.info_dim = 1 (the "prob" entry of the info dict).
+ * num_tables > 1 (ABI 6): every array above gains a leading [num_tables] axis and env_table[N] names each sub-environment's table -- SyncVectorEnv over
+ * scalar envs that were constructed differently, e.g. FrozenLake with map_name=None, where every sub-environment draws its own random map
+ * (frozen_lake.py:241-242).  All tables share num_states / num_actions / max_outcomes.  num_tables 0 or 1 with env_table NULL: one table for all. */
 typedef struct mi_tabular_table {
-    int32_t num_states, num_actions, max_outcomes, reserved;
+    int32_t num_states, num_actions, max_outcomes, num_tables;
     const double *csprob, *prob;
     const int32_t *next_state;
     const double *reward;
     const uint8_t *terminated;
     const int32_t *count;
     const double *isd_csprob;
+    const int32_t *env_table; /* [N] host pointer: table index of each sub-environment, or NULL */
 } mi_tabular_table;
 int mi_tabular_load(mi_vecenv *env, const mi_tabular_table *table);
 

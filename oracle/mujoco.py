@@ -48,7 +48,13 @@ def dll():
             fn = getattr(_DLL, "orc_mj_" + name)
             fn.restype, fn.argtypes = None, args
         _DLL.orc_mj_get.restype, _DLL.orc_mj_get.argtypes = C.c_int, [vp, vp, C.c_char_p, vp, C.c_int]
+        _DLL.orc_mj_set_pgs_tolerance.restype, _DLL.orc_mj_set_pgs_tolerance.argtypes = None, [C.c_double]
     return _DLL
+
+
+def set_pgs_tolerance(tol: float = 1e-8):
+    """TEST KNOB: the early-termination threshold of the oracle's PGS sweeps (MuJoCo's default option tolerance, 1e-8)."""
+    dll().orc_mj_set_pgs_tolerance(float(tol))
 
 
 class OracleModel:

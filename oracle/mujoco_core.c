@@ -22,6 +22,10 @@
 #define MINVAL 1e-15
 #define MINIMP 0.0001
 #define MAXIMP 0.9999
+/* PGS early termination: MuJoCo's default option tolerance (1e-8 on the scaled cost improvement of a sweep).  TEST KNOB: convergence studies lift it
+ * together with the sweep cap (tests/test_mujoco_closed_forms.py: PGS must meet the Newton solution of the same convex problem). */
+static double g_pgs_tolerance = 1e-8;
+__attribute__((visibility("default"))) void orc_mj_set_pgs_tolerance(double tol) { g_pgs_tolerance = tol; }
 
 /* ---- small vector helpers ----------------------------------------------------------------------------------- */
 static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -900,7 +904,7 @@ static void solve_pgs(const mjo_model *m, mjo_data *d) {
             f[r] = nw;
             improvement -= delta * (0.5 * delta * AR[r][r] + res);
         }
-        if (improvement * scale < 1e-8) {
+        if (improvement * scale < g_pgs_tolerance) {
             it++;
             break;
         }

@@ -20,6 +20,9 @@ weak-scalar promotion) and records
   toytext_<env>.npz         FrozenLake / CliffWalking / Taxi: the reference's transition table P and initial distribution,
                             plus a gym.make_vec(id, 8, "sync") trajectory with the info dict entries (prob, action_mask)
 
+  toytext_frozenlake_per_env_maps.npz   SyncVectorEnv over FrozenLake envs with one (seeded random) map each: per-sub-environment transition tables
+  cartpole_vector_entry_point.npz   the reference's own NumPy CartPoleVectorEnv (one shared generator, float32 rewards): what `rng="shared"` reproduces
+
   infos_*.npz               SAME_STEP info dicts (final_info / reset info at top level) and a partial reset during a pending autoreset
 
 Nothing here is read at run time by the product; tests compare the oracle (oracle/) and the HIP engine to it.
@@ -357,6 +360,31 @@ def make_toytext():
         v.close()
 
 
+def make_frozenlake_per_env_maps():
+    """SyncVectorEnv over FrozenLake envs that each have their OWN map -- what `make_vec("FrozenLake-v1", n, "sync", map_name=None)` builds
+    (frozen_lake.py:241-242: every scalar env draws `generate_random_map()` from OS entropy), made reproducible by handing each sub-environment a seeded
+    random map.  Two of the eight boards coincide on purpose (sub-environments may share a table)."""
+    from gymnasium.envs.toy_text.frozen_lake import generate_random_map
+
+    maps = [generate_random_map(size=6, p=0.8, seed=100 + (i if i != 5 else 2)) for i in range(8)]
+    out = {"maps": np.array(maps)}
+    for tag, slippery in (("slip", True), ("det", False)):
+        v = gym.vector.SyncVectorEnv([(lambda d=d: gym.make("FrozenLake-v1", desc=d, is_slippery=slippery)) for d in maps])
+        obs0, info0 = v.reset(seed=21)
+        v.action_space.seed(22)
+        A, O, R, TE, TR, PR, PM = [], [], [], [], [], [], []
+        for _ in range(300):
+            a = v.action_space.sample()
+            o, r, te, tr, info = v.step(a)
+            A.append(a), O.append(o), R.append(r), TE.append(te), TR.append(tr)
+            PR.append(np.asarray(info["prob"], dtype=np.float64)), PM.append(info["_prob"])
+        out.update({f"{tag}_obs0": obs0, f"{tag}_actions": np.stack(A), f"{tag}_obs": np.stack(O), f"{tag}_reward": np.stack(R), f"{tag}_term": np.stack(TE),
+                    f"{tag}_trunc": np.stack(TR), f"{tag}_prob_info": np.stack(PR), f"{tag}_prob_mask": np.stack(PM),
+                    f"{tag}_rng_after": np.stack([pcg_words(x.unwrapped.np_random) for x in v.envs])})
+        v.close()
+    save("toytext_frozenlake_per_env_maps.npz", **out)
+
+
 def make_blackjack():
     """Blackjack-v1 (toy_text/blackjack.py): gym.make_vec(id, 8, "sync") trajectories for the registered rules (sab) and for
     natural=True; observations are the batched Tuple (three int64 arrays), stored as (T, 3, N)."""
@@ -480,7 +508,47 @@ def make_wrappers():
     raw.close(), w.close()
 
 
+def make_cartpole_vector_entry_point():
+    """The reference's OWN vector environment of CartPole-v1 (cartpole.py:353-505: the id's vector_entry_point, i.e. what stock make_vec returns): one
+    generator for all sub-environments, float32 rewards.  Segments: a seeded run; the same env re-seeded with custom reset bounds that persist for
+    the autoresets; reset(seed=None) continuing the stream; a short TimeLimit; the Sutton-Barto reward (-0.0 for a surviving pole)."""
+    out = {}
+
+    def run(tag, env, T, aseed, **reset_kw):
+        obs0, _ = env.reset(**reset_kw)
+        env.action_space.seed(aseed)
+        acts, obs, rew, te, tr = [], [], [], [], []
+        for _ in range(T):
+            a = env.action_space.sample()
+            o, r, d, u, info = env.step(a)
+            assert info == {} and r.dtype == np.float32
+            acts.append(a.copy()), obs.append(o.copy()), rew.append(r.copy()), te.append(d.copy()), tr.append(u.copy())
+        out.update({f"{tag}_reset_obs": obs0.copy(), f"{tag}_actions": np.stack(acts), f"{tag}_obs": np.stack(obs), f"{tag}_rewards": np.stack(rew),
+                    f"{tag}_terminated": np.stack(te), f"{tag}_truncated": np.stack(tr), f"{tag}_rng_after": pcg_words(env.np_random)})
+
+    env = gym.make_vec("CartPole-v1", num_envs=8, vectorization_mode="vector_entry_point")
+    assert type(env).__name__ == "CartPoleVectorEnv"
+    run("a", env, 400, 1, seed=123)
+    run("b", env, 200, 2, seed=7, options={"low": -0.1, "high": 0.08})  # wider bounds: kept for the autoresets that follow
+    run("c", env, 100, 3)  # no seed: the stream continues, the bounds go back to the defaults
+    env.close()
+    env = gym.make_vec("CartPole-v1", num_envs=300, vectorization_mode="vector_entry_point", max_episode_steps=17)  # more than one workgroup; truncations
+    run("d", env, 60, 4, seed=2**40 + 5)
+    env.close()
+    env = gym.make_vec("CartPole-v1", num_envs=5, vectorization_mode="vector_entry_point", sutton_barto_reward=True)
+    run("e", env, 150, 5, seed=0)
+    out["e_reward_signbit"] = np.signbit(out["e_rewards"])
+    env.close()
+    save("cartpole_vector_entry_point.npz", **out)
+
+
 if __name__ == "__main__":
+    if "--per-env-maps-only" in sys.argv:
+        make_frozenlake_per_env_maps()
+        sys.exit(0)
+    if "--cartpole-vector-only" in sys.argv:
+        make_cartpole_vector_entry_point()
+        sys.exit(0)
     if "--toytext-only" in sys.argv:
         make_toytext()
         sys.exit(0)
@@ -509,3 +577,5 @@ if __name__ == "__main__":
     make_wrappers()
     make_blackjack()
     make_same_step_infos()
+    make_cartpole_vector_entry_point()
+    make_frozenlake_per_env_maps()

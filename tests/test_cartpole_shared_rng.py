@@ -1,0 +1,78 @@
+"""rng="shared": the semantics of the reference's own NumPy vector environment CartPoleVectorEnv (cartpole.py:353-505) -- one generator for all
+sub-environments, float32 rewards, persistent reset bounds -- against trajectories recorded FROM that class (tests/golden/make_golden.py
+make_cartpole_vector_entry_point).  Here: the oracle behind the product's host class, on the CPU; tests/test_gpu_parity.py runs the same
+function on the HIP engine.  No tolerance: array_equal, and the generator state after every segment."""
+import numpy as np
+import pytest
+
+import gymnasium_amd
+from conftest import golden
+from gymnasium_amd import _native
+
+SEGMENTS = {"abc": dict(num_envs=8), "d": dict(num_envs=300, max_episode_steps=17), "e": dict(num_envs=5, sutton_barto_reward=True)}
+RESETS = {"a": dict(seed=123), "b": dict(seed=7, options={"low": -0.1, "high": 0.08}), "c": dict(), "d": dict(seed=2**40 + 5), "e": dict(seed=0)}
+
+
+def check_shared_rng_segments(make_env, via_rollout=False):
+    g = golden("cartpole_vector_entry_point.npz")
+    for tags, kw in SEGMENTS.items():
+        env = make_env(**kw)
+        assert env.metadata["autoreset_mode"] == gymnasium_amd.AutoresetMode.NEXT_STEP
+        for tag in tags:
+            obs0, info = env.reset(**RESETS[tag])
+            obs0 = np.asarray(obs0.cpu()) if hasattr(obs0, "cpu") else obs0
+            assert info == {} and obs0.dtype == np.float32 and np.array_equal(obs0, g[f"{tag}_reset_obs"]), tag
+            acts = g[f"{tag}_actions"]
+            if via_rollout:  # the fused entry point, teacher-forced (device tensors)
+                import torch
+
+                out = env.rollout(len(acts), actions=torch.from_numpy(acts))
+                o, r, te, tr = (out[k].cpu().numpy() for k in ("obs", "rewards", "terminations", "truncations"))
+                assert np.array_equal(o, g[f"{tag}_obs"]) and np.array_equal(r, g[f"{tag}_rewards"]), tag
+                assert np.array_equal(te, g[f"{tag}_terminated"]) and np.array_equal(tr, g[f"{tag}_truncated"]), tag
+            else:
+                for t, a in enumerate(acts):
+                    o, r, te, tr, info = env.step(a if not hasattr(obs0, "cpu") else a)
+                    o, r, te, tr = (np.asarray(x.cpu()) if hasattr(x, "cpu") else x for x in (o, r, te, tr))
+                    assert info == {} and r.dtype == np.float32, (tag, t)
+                    assert np.array_equal(o, g[f"{tag}_obs"][t]), (tag, t)
+                    assert np.array_equal(r, g[f"{tag}_rewards"][t]) and np.array_equal(te, g[f"{tag}_terminated"][t]) and np.array_equal(tr, g[f"{tag}_truncated"][t]), (tag, t)
+                    if tag == "e":  # `-np.array(terminated, dtype=np.float32)`: a surviving pole is rewarded -0.0
+                        assert np.array_equal(np.signbit(r), g["e_reward_signbit"][t]), (tag, t)
+            # env.np_random IS the generator the sub-environments drew from: the host object follows the device's draws
+            assert np.array_equal(_native.pcg_words(env.np_random), g[f"{tag}_rng_after"]), tag
+        env.close()
+
+
+def test_oracle_equals_the_reference_vector_env(oracle_factory):
+    check_shared_rng_segments(lambda **kw: gymnasium_amd.make_vec("CartPole-v1", rng="shared", _engine_factory=oracle_factory, **kw))
+
+
+def test_stock_creator_defaults_to_the_shared_generator(oracle_factory):
+    from gymnasium_amd.envs.classic_control import StockCartPoleVectorEnv
+
+    check_shared_rng_segments(lambda **kw: StockCartPoleVectorEnv(_engine_factory=oracle_factory, **kw))
+
+
+def test_shared_rng_refusals(oracle_factory):
+    from gymnasium_amd.gym_api import error
+
+    with pytest.raises(error.Error, match="NEXT_STEP"):
+        gymnasium_amd.make_vec("CartPole-v1", num_envs=2, rng="shared", autoreset_mode="SameStep", _engine_factory=oracle_factory)
+    with pytest.raises(error.Error, match="shard"):
+        gymnasium_amd.make_vec("CartPole-v1", num_envs=2, rng="shared", env_index_offset=2, _engine_factory=oracle_factory)
+    with pytest.raises(ValueError, match="rng must be"):
+        gymnasium_amd.make_vec("CartPole-v1", num_envs=2, rng="global", _engine_factory=oracle_factory)
+    env = gymnasium_amd.make_vec("CartPole-v1", num_envs=4, rng="shared", _engine_factory=oracle_factory)
+    with pytest.raises(error.Error):
+        env.reset(seed=[1, 2, 3, 4])  # one generator: a seed per sub-environment has no meaning (the reference raises there too)
+    # a reset_mask is ignored like the reference's class ignores it: every sub-environment resets
+    env.reset(seed=3)
+    first = env.step(np.zeros(4, np.int64))[0].copy()
+    env.reset(seed=3, options={"reset_mask": np.array([True, False, False, False])})
+    assert np.array_equal(env.step(np.zeros(4, np.int64))[0], first)
+    # assigning a generator re-bases the device's stream on it
+    env.np_random = np.random.default_rng(99)
+    expect = np.random.default_rng(99).uniform(-0.05, 0.05, size=(4, 4)).T.astype(np.float32)
+    assert np.array_equal(env.reset()[0], expect)
+    env.close()

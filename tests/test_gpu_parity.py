@@ -365,6 +365,37 @@ def test_toytext_fused_rollout_and_full_size(key):
     a.close(), b.close()
 
 
+def test_frozenlake_one_map_per_sub_environment(oracle_factory):
+    """Per-sub-environment transition tables (mi_tabular_table.env_table): the reference's SyncVectorEnv over FrozenLake envs with their own maps, bit for
+    bit; then 4 096 sub-environments with 4 096 random maps, step() and the fused rollout against the oracle."""
+    import torch
+    from test_oracle_golden import check_frozenlake_per_env_maps
+    from gymnasium_amd.envs.toy_text import generate_random_map
+
+    check_frozenlake_per_env_maps(lambda **kw: gymnasium_amd.make_vec("FrozenLake-v1", device=0, **kw))
+    n = 4096
+    maps = [generate_random_map(8, 0.8, seed=i) for i in range(n)]
+    gpu = gymnasium_amd.make_vec("FrozenLake-v1", num_envs=n, desc=maps, device=0, output="torch")
+    cpu = gymnasium_amd.make_vec("FrozenLake-v1", num_envs=n, desc=maps, _engine_factory=oracle_factory)
+    assert gpu._tab["csprob"].shape[0] > 4000
+    assert np.array_equal(gpu.reset(seed=1)[0].cpu().numpy(), cpu.reset(seed=1)[0])
+    gpu.action_space.seed(2), cpu.action_space.seed(2)
+    for t in range(40):
+        a = cpu.action_space.sample()
+        g, c = gpu.step(torch.from_numpy(a).cuda()), cpu.step(a)
+        for k in range(4):
+            assert np.array_equal(g[k].cpu().numpy(), c[k]), (t, k)
+        assert np.array_equal(np.asarray(g[4]["prob"], dtype=np.float64), np.asarray(c[4]["prob"], dtype=np.float64)), t
+    out = gpu.rollout(64)
+    for t in range(64):
+        a = cpu.action_space.sample()
+        o, r, te, tr, _ = cpu.step(a)
+        assert np.array_equal(out["actions"][t].cpu().numpy(), a) and np.array_equal(out["obs"][t].cpu().numpy(), o), t
+        assert np.array_equal(out["rewards"][t].cpu().numpy(), r) and np.array_equal(out["terminations"][t].cpu().numpy(), te), t
+    assert np.array_equal(gpu.get_rng_state(), cpu.get_rng_state())
+    gpu.close(), cpu.close()
+
+
 @pytest.mark.parametrize("mode", ["NextStep", "SameStep"])
 def test_taxi_fickle_passenger_vs_oracle(mode, oracle_factory):
     """taxi.py:436-451 in the kernel: 4096 sub-environments x 700 steps against the oracle (itself pinned on the reference recording,

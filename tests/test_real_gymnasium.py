@@ -271,3 +271,35 @@ def test_gymnasium_vector_wrappers_compose(oracle_factory):
             assert data_equivalence(s1[4]["episode"]["l"], s2[4]["episode"]["l"], exact=True)
     assert seen
     ours.close(), ref.close()
+
+
+@needs_gymnasium
+def test_stock_id_override_is_a_drop_in_for_cartpole_vector_env(oracle_factory):
+    """`register_envs(override_stock_ids=True)` puts the engine behind the STOCK id.  gymnasium's CartPole-v1 already has a vector_entry_point (the NumPy
+    CartPoleVectorEnv, cartpole.py:353-505), so plain `gymnasium.make_vec("CartPole-v1", n)` must keep returning exactly that class's numbers: one shared
+    generator, float32 rewards.  Strict data_equivalence against the reference class itself, then the registry is put back."""
+    import gymnasium_amd
+    from gymnasium.envs.classic_control.cartpole import CartPoleVectorEnv as RefVec
+
+    n, T = 64, 300
+    ref = RefVec(num_envs=n, max_episode_steps=40)
+    stock = {k: spec.vector_entry_point for k, spec in gym.registry.items()}
+    try:
+        gymnasium_amd.register_envs(override_stock_ids=True)
+        ours = gym.make_vec("CartPole-v1", num_envs=n, max_episode_steps=40, _engine_factory=oracle_factory)
+        assert type(ours).__name__ == "StockCartPoleVectorEnv" and isinstance(ours, gym.vector.VectorEnv)
+    finally:
+        for k, vep in stock.items():
+            gym.registry[k].vector_entry_point = vep
+    for seed, options in ((11, None), (None, {"low": -0.2, "high": 0.2}), (5, {"high": 0.01})):
+        assert data_equivalence(ours.reset(seed=seed, options=options), ref.reset(seed=seed, options=options), exact=True) or seed is None
+        if seed is None:  # both continue their own stream from the same state: equal again
+            assert data_equivalence(ours.reset(options=options), ref.reset(options=options), exact=True)
+        ours.action_space.seed(seed or 0)
+        for t in range(T):
+            a = ours.action_space.sample()
+            s1, s2 = ours.step(a), ref.step(a)
+            for k, what in enumerate(("obs", "reward", "terminated", "truncated", "infos")):
+                assert data_equivalence(s1[k], s2[k], exact=True), f"{what} t={t}: {s1[k]!r} vs {s2[k]!r}"
+        assert ours.np_random.bit_generator.state == ref.np_random.bit_generator.state
+    ours.close(), ref.close()
