@@ -287,9 +287,13 @@ def main():
         if only and env_id not in only:
             continue
         c2 = Config(env_id, n2, inner2, 0, 0)
+        # the known-answer launch of this configuration (as bench.py's first timed launch: reset(seed=0), policy stream seeded 0): its digest is what
+        # tests/golden/bench_digest_configs2.json holds FROM THE REFERENCE for the classic kinds (tests/test_gpu_bench_contract.py compares)
+        c2.launch(c2.first)
+        sha = bench.trajectory_digest(c2.host_trajectory())
         v2, k2, ks2, el2 = steady(c2)
         line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "seconds": el2, "unit": "env-steps/s",
-                "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "roofline": c2.roofline(ks2, live=args.pmc == "full")}
+                "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "output_sha256": sha, "roofline": c2.roofline(ks2, live=args.pmc == "full")}
         head[f"{env_id}@{n2}"] = float(f"{v2:.4g}")
         if env_id not in MJ_COOP:
             head.setdefault("hbm_frac", {})[env_id] = round(line["roofline"]["frac"], 4)

@@ -13,7 +13,7 @@ cd /tmp
 if [ "${PROF_STEPS:-20}" = default ]; then STEPS=""; else STEPS="--steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-3}"; fi
 # PROF_API=1: keep the per-launch step() API section of bench.py in the profiled command (step_kernel durations)
 if [ "${PROF_API:-0}" = 1 ]; then NOAPI=""; else NOAPI="--no-api"; fi
-CMD="python $ROOT/bench.py $STEPS $NOAPI --no-cpu-baseline $*"
+CMD="python $ROOT/bench.py $STEPS $NOAPI --no-cpu-baseline --no-extras --no-verify $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -- $CMD > "$OUT/${TAG}_stats.log" 2>&1
 PMC=()
 for C in FETCH_SIZE WRITE_SIZE; do

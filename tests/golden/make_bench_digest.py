@@ -8,7 +8,12 @@ CartPoleEnv objects behind TimeLimit in one SyncVectorEnv (vector/sync_vector_en
 step(action_space.sample()).  Writes bench_digest.json: the sha256 over the bytes of (actions int64 [T,N], observations float32 [T,N,4],
 rewards float64 [T,N], terminated bool [T,N], truncated bool [T,N]) -- what bench.trajectory_digest() computes over the trajectory the rollout
 kernel writes to HBM -- plus digests of strided slices for debugging.  tests/test_bench_digest.py requires the oracle to reproduce it on the CPU and
-tests/test_gpu_bench_contract.py requires `output_sha256` of the bench line to equal it."""
+tests/test_gpu_bench_contract.py requires `output_sha256` of the bench line to equal it.
+
+    python tests/golden/make_bench_digest.py Pendulum-v1      (then Acrobot-v1, MountainCarContinuous-v0; ONE AT A TIME: they share the output file)
+
+adds BASELINE.json configs[2] at ITS exact shape (65 536 sub-environments, 128 steps, the same seeds) to bench_digest_configs2.json: the secondary lines of
+the bench (scripts/bench_extras.py) report the digest of the same known-answer rollout."""
 import hashlib
 import json
 import os
@@ -34,7 +39,7 @@ def digest(arrays):
     return h.hexdigest()
 
 
-def main(env_id="CartPole-v1", N=65536, T=128):
+def main(env_id="CartPole-v1", N=65536, T=128, out_name="bench_digest.json"):
     t0 = time.time()
     env = gym.make_vec(env_id, num_envs=N, vectorization_mode="sync")
     print(f"{N} scalar envs built in {time.time() - t0:.0f} s", flush=True)
@@ -48,17 +53,28 @@ def main(env_id="CartPole-v1", N=65536, T=128):
         if t % 16 == 0:
             print(f"step {t} at {time.time() - t0:.0f} s", flush=True)
     traj = tuple(np.stack(x) for x in (acts, obs, rew, te, tr))
-    assert traj[0].dtype == np.int64 and traj[1].dtype == np.float32 and traj[2].dtype == np.float64 and traj[3].dtype == np.bool_ and traj[4].dtype == np.bool_
+    assert traj[0].dtype in (np.int64, np.float32) and traj[1].dtype == np.float32 and traj[2].dtype == np.float64 and traj[3].dtype == np.bool_ and traj[4].dtype == np.bool_
     out = {"what": f"gymnasium {gym.__version__} make_vec({env_id!r}, {N}, 'sync'), reset(seed=0), action_space.seed(0), {T} x step(sample()); "
                    "sha256 over (actions, obs, rewards, terminated, truncated) bytes, time-major",
            "numpy": np.__version__, f"{env_id}:{N}:{T}:rank0": digest(traj),
            f"{env_id}:{N}:{T}:rank0:first_1024_envs": digest(tuple(np.ascontiguousarray(x[:, :1024]) for x in traj)),
            f"{env_id}:{N}:{T}:rank0:every_64th_env": digest(tuple(np.ascontiguousarray(x[:, ::64]) for x in traj)),
            "episodes_finished": int((traj[3] | traj[4]).sum()), "reward_sum": float(traj[2].sum())}
-    with open(os.path.join(OUT, "bench_digest.json"), "w") as f:
+    path = os.path.join(OUT, out_name)
+    if out_name != "bench_digest.json":  # BASELINE.json configs[2]: one shared file, one entry set per env id
+        prev = json.load(open(path)) if os.path.exists(path) else {}
+        prev.update({k: v for k, v in out.items() if k.startswith(env_id)})
+        prev[env_id + ":what"], prev["numpy"] = out["what"], out["numpy"]
+        prev[env_id + ":episodes_finished"], prev[env_id + ":reward_sum"] = out["episodes_finished"], out["reward_sum"]
+        out = prev
+    with open(path + f".{os.getpid()}.tmp", "w") as f:
         json.dump(out, f, indent=1)
+    os.replace(path + f".{os.getpid()}.tmp", path)
     print(json.dumps(out, indent=1), f"\n{time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # python make_bench_digest.py Pendulum-v1 -> bench_digest_configs2.json (BASELINE.json configs[2]: ~5-10 minutes per id, one at a time)
+        main(sys.argv[1], out_name="bench_digest_configs2.json")
+    else:
+        main()

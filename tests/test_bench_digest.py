@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 import bench
 from conftest import GOLDEN
@@ -26,6 +27,20 @@ def test_oracle_reproduces_the_reference_digest_at_configs1_shape():
     assert bench.trajectory_digest(tuple(np.ascontiguousarray(x[:, :1024]) for x in traj)) == g[KEY + ":first_1024_envs"]
     assert bench.trajectory_digest(tuple(np.ascontiguousarray(x[:, ::64]) for x in traj)) == g[KEY + ":every_64th_env"]
     assert bench.trajectory_digest(traj) == g[KEY]
+
+
+@pytest.mark.parametrize("env_id", ["Pendulum-v1", "Acrobot-v1", "MountainCarContinuous-v0"])
+def test_oracle_reproduces_the_reference_digest_at_configs2_shape(env_id):
+    """BASELINE.json configs[2] at its exact shape (65 536 sub-environments, 128 steps): the digest of the reference's own SyncVectorEnv rollout
+    (tests/golden/make_bench_digest.py <id>) from the oracle -- whole episodes of Pendulum (200-step TimeLimit not reached: 128 steps), the chaotic Acrobot
+    and MountainCarContinuous's float32 / float64 mixed arithmetic, every byte of 8.4 M env-steps each."""
+    g = json.load(open(os.path.join(GOLDEN, "bench_digest_configs2.json")))
+    key = f"{env_id}:65536:128:rank0"
+    if key not in g:
+        pytest.skip(f"{key} not generated yet (tests/golden/make_bench_digest.py {env_id})")
+    traj = bench.oracle_trajectory(env_id, 65536, 128, offset=0, policy_seed=0)
+    assert bench.trajectory_digest(tuple(np.ascontiguousarray(x[:, ::64]) for x in traj)) == g[key + ":every_64th_env"]
+    assert bench.trajectory_digest(traj) == g[key]
 
 
 def test_teacher_forced_subset_equals_the_policy_rollout():

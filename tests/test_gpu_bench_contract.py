@@ -68,3 +68,12 @@ def test_the_drivers_own_command_line():
         assert sec[key] > 1e5, (key, sec)
     full = json.load(open(os.path.join(ROOT, r["full"])))
     assert full["primary"]["output_sha256"] == GOLDEN_DIGEST and len(full["secondary"]) >= 6 and "api_step_device" in full
+    # BASELINE.json configs[2]: the secondaries' known-answer launches against the digests the REFERENCE produced at the same shape
+    ref2 = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_digest_configs2.json")))
+    seen = 0
+    for line in full["secondary"]:
+        key = f"{line['env']}:{line['num_envs']}:{line['vector_steps_per_launch']}:rank0"
+        if key in ref2 and "regime" not in line:
+            assert line["output_sha256"] == ref2[key], line["env"]
+            seen += 1
+    assert seen == 3
