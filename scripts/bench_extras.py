@@ -8,6 +8,8 @@
                     share and the executed-fp64 rate; then the on-the-ground regime of the two headline robots
   primary_counters  issue-slot ceiling of the primary kernel (SQ_INSTS_VALU / SALU per env-step)
   api_step_*        the per-launch step() API: device tensors, one HIP graph, NumPy over PCIe, the three fused wrappers -- never `value`
+  api_benchmark_vector_step   the metric by the reference's own protocol (utils/performance.py:57-103): NumPy API, host-side sampling in the loop
+  shared_rng        rng="shared" (the reference's NumPy CartPoleVectorEnv semantics): step() and rollout() throughput of the compatibility mode
   opt_in            fast_math / Newton-solver configurations next to the default (reference-faithful) ones
   cpu_reference     Gymnasium's own AsyncVectorEnv / SyncVectorEnv / NumPy CartPoleVectorEnv where `import gymnasium` works (GYM_REFERENCE or an
                     installed package); elsewhere (the GPU box) the AsyncVectorEnv ARCHITECTURE restated (oracle/async_baseline.py, pinned on the
@@ -239,6 +241,67 @@ def api_legs(env_id, N, local_rank=0):
     return out
 
 
+def api_faithful_leg(env_id, N, seconds=2.0, local_rank=0):
+    """the metric as the reference's own `benchmark_vector_step` measures it (utils/performance.py:57-103) -- NumPy batches through the
+    public API, the policy `action_space.sample()` drawn on the HOST inside the timed loop, NEXT_STEP reset steps not counted, wall clock.  This is what a
+    user's unchanged Gymnasium script gets; bench.py's `value` is the fused, device-resident rollout."""
+    import gymnasium_amd
+
+    env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, copy=False)
+    env.action_space.seed(0)
+    env.reset(seed=0)
+    env.step(env.action_space.sample())
+    env.reset(seed=0)
+    counted, prev_done, t0 = 0, np.zeros(N, dtype=np.bool_), time.time()
+    while True:
+        _, _, te, tr, _ = env.step(env.action_space.sample())
+        counted += N - int(np.count_nonzero(prev_done))
+        prev_done = np.logical_or(te, tr)
+        t1 = time.time()
+        if t1 - t0 > seconds:
+            break
+    env.close()
+    return {"value": counted / (t1 - t0), "unit": "env-steps/s", "how": f"benchmark_vector_step's protocol, target_duration={seconds} s, NumPy in / out, host-side action_space.sample()"}
+
+
+def shared_rng_leg(N=65536, local_rank=0):
+    """rng="shared" (the reference's NumPy CartPoleVectorEnv semantics, MI_CFG_SHARED_RNG): a compatibility mode, two launches per step -- what it costs next to
+    the per-sub-environment streams, and next to the class it replaces (13.7 M env-steps/s for the NumPy class at 65 536 on one core)."""
+    import torch
+
+    import gymnasium_amd
+
+    env = gymnasium_amd.make_vec("CartPole-v1", num_envs=N, rng="shared", device=local_rank, output="torch", copy=False)
+    env.reset(seed=0)
+    env.action_space.seed(0)
+    a = torch.randint(0, 2, (N,), device=torch.device("cuda", local_rank))
+    for _ in range(20):
+        env.step(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    env.reset_statistics()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(300):
+        env.step(a)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = env.statistics()["env_steps"]
+    out = {"step_value": steps / dt, "unit": "env-steps/s", "us_per_step_wall": dt / 300 * 1e6, "us_per_step_gpu": e0.elapsed_time(e1) * 1e3 / 300, "launches_per_step": 2}
+    env.rollout(128)
+    torch.cuda.synchronize()
+    env.reset_statistics()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        env.rollout(128)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out.update({"rollout_value": env.statistics()["env_steps"] / dt, "rollout": "4 x rollout(128): 128 x [policy sample, scan, step] launches each"})
+    env.close()
+    return out
+
+
 def steady(c, seconds=0.7):
     """~`seconds` of back-to-back launches after a tenth of that as warm-up: (env-steps/s, launches, avg kernel s, elapsed)"""
     import torch
@@ -339,6 +402,20 @@ def main():
                 head["step_graph_us_gpu"] = round(full["api_step_graph"]["us_per_step_gpu"], 2)
         except Exception as e:
             full["api_error"] = f"{type(e).__name__}: {e}"
+        flush()
+    if not args.no_api and not only and young():
+        try:
+            full["api_benchmark_vector_step"] = api_faithful_leg(env_id, N)
+            head["api_faithful"] = float(f"{full['api_benchmark_vector_step']['value']:.4g}")
+        except Exception as e:
+            full["api_benchmark_vector_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        flush()
+    if env_id == "CartPole-v1" and not args.no_api and not only and young():
+        try:
+            full["shared_rng"] = shared_rng_leg(N)
+            head["shared_rng_step"] = float(f"{full['shared_rng']['step_value']:.4g}")
+        except Exception as e:
+            full["shared_rng"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         flush()
     if env_id in STEP_BYTES and not prim.get("env_kwargs") and not only and young():
         c_opt = Config(env_id, N, inner, 0, 0, {"fast_math": True})
