@@ -73,6 +73,21 @@
                          // the isolated factorisation is 23 % faster (profiles/r03_mfma_humanoid.txt): two extra blackboard round trips and the
                          // four dependent MFMAs sit on the critical path of a kernel that one wavefront per SIMD cannot overlap.  Off.
 #endif
+#ifndef MJX_PGS_PIPELINE
+#define MJX_PGS_PIPELINE 0  // Software pipelining of the PGS sweeps over contacts (round 5; A/B with scripts/build_variant.py, results in docs/mujoco_design.md):
+                            // 0: sequential (rounds 2-4): column, three group reductions J_c a, owner relaxes the rows, a += M^-1 J_c^T dl.
+                            // 1: contact c + 1's column AND reductions are issued before the owner relaxes contact c (on the `a` that lacks c's step); the owner
+                            //    of c + 1 then adds W dl with the 3 x 3 coupling block W = J_{c+1} M^-1 J_c^T: J_{c+1} (a + M^-1 J_c^T dl) = J_{c+1} a + W dl.
+                            //    Same Gauss-Seidel iterate, rounded differently in the last bits.  MEASURED: correct (GPU parity suite green) and 9 - 17 % SLOWER:
+                            //    nine more reductions per contact and pass to form W, 18 more live doubles (465 -> 512 registers, 14 spilled).
+                            // 2: only the next contact's Jacobian column (independent of the iterate) is requested early; bit-identical to 0.
+#endif
+#ifndef MJX_PGS_EDGE_CHAIN
+#define MJX_PGS_EDGE_CHAIN 0  // 1: the four edge rows of a pyramidal contact are relaxed in EDGE space: the residuals u_e = (E v)_e - aref_e are formed once per visit and kept
+                              // current through the 4 x 4 block E A E^T (one multiply-add per later edge) instead of updating the 3-vector v and re-forming each row from
+                              // it: the dependent chain from one edge's step to the next edge's residual drops from ~8 fp64 operations to 4.  Same iterate, rounded
+                              // differently in the last bits.
+#endif
 #ifndef MJX_PGS_QS_BY_INVERSE
 #define MJX_PGS_QS_BY_INVERSE 0  // 1: PGS forms qacc_smooth = M^-1 qfrc_smooth as a row product once M^-1 exists instead of by the triangular solves.  MEASURED (r03, profiles/r03_pgs_qs_by_inverse.txt): same results to 1e-15, but the changed control flow takes the 32-lane kernel from 4 to 999 spilled VGPRs and doubles its time -- off
 #endif
@@ -276,6 +291,9 @@ struct Lane {
     // (A00 A01 A02 A11 A12 A22), the reciprocals 1 / (E A E^T + R) of its rows, J_c qacc_smooth, and where contacts beyond the LDS
     // capacity keep their M^-1 J_c^T block (global memory, per environment)
     double p_lf[2], p_lari[2], p_f[KC][4], p_A[KC][6], p_ari[KC][4], p_js[KC][3];
+#if MJX_PGS_PIPELINE == 1
+    double p_W[KC][9];  // owner of contact c: W = J_c M^-1 J_{c-1}^T (row-major 3 x 3), the coupling with its predecessor in the sweep order
+#endif
     int grp;  // which of the wavefront's sub-environments this lane belongs to (its blackboard is boards[grp]; the MFMA tile packs all of them)
 };
 
@@ -1828,6 +1846,41 @@ struct Sim {
             r.p_f[kc][0] = nw, impr -= dd * (0.5 * dd * (A[0] + Rr) + res);
             v[0] += A[0] * dd, v[1] += A[1] * dd, v[2] += A[2] * dd, dl[0] = dd;
         } else {
+#if MJX_PGS_EDGE_CHAIN
+            // edge space: E_e = e_0 + sg_e e_t (sg = +mu, -mu, +mu, -mu; t = 1, 1, 2, 2).  g_e = E_e A (a 3-vector), AR[e][e'] = g_e . E_e'.
+            // Everything that does not depend on an earlier edge's step is formed up front (independent instructions: the owner's chain is latency-bound);
+            // the chain itself per edge: nw = f k1 - u ari, max, dd = nw - f, u' += AR[e'][e] dd.
+            const double mu = r.c_mu[kc];
+            double u[4], g[4][3], fe[4], ari[4], fk[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const double sg = (e & 1) ? -mu : mu;
+                const int t = 1 + e / 2;
+                g[e][0] = A[0] + sg * (t == 1 ? A[1] : A[2]);
+                g[e][1] = A[1] + sg * (t == 1 ? A[3] : A[4]);
+                g[e][2] = A[2] + sg * (t == 1 ? A[4] : A[5]);
+                u[e] = (v[0] + sg * v[t]) - edge_aref(r, kc, sg, t);
+                fe[e] = r.p_f[kc][e], ari[e] = r.p_ari[kc][e];
+                fk[e] = fe[e] - (Rr * fe[e]) * ari[e];  // f - (u + R f) ari = (f - R f ari) - u ari
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const double sg = (e & 1) ? -mu : mu;
+                const int t = 1 + e / 2;
+                double nw = fk[e] - u[e] * ari[e];
+                nw = nw < 0 ? 0.0 : nw;
+                const double dd = nw - fe[e];
+#pragma unroll
+                for (int e2 = e + 1; e2 < 4; e2++) {
+                    const double sg2 = (e2 & 1) ? -mu : mu;
+                    const int t2 = 1 + e2 / 2;
+                    u[e2] += (g[e][0] + sg2 * g[e][t2]) * dd;  // AR[e2][e] = AR[e][e2] (A is symmetric)
+                }
+                const double res = u[e] + Rr * fe[e];
+                r.p_f[kc][e] = nw, impr -= dd * (0.5 * dd * ((g[e][0] + sg * g[e][t]) + Rr) + res);
+                dl[0] += dd, dl[t] += sg * dd;
+            }
+#else
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const double sg = (e & 1) ? -r.c_mu[kc] : r.c_mu[kc];
@@ -1845,6 +1898,7 @@ struct Sim {
                 v[3 - t] += ((t == 1 ? A[2] : A[1]) + sg * Aot) * dd;
                 dl[0] += dd, dl[t] += sg * dd;
             }
+#endif
         }
     }
     // limit rows of dof I (static: column I of M^-1 is entry I of every lane's register row), lower side then upper side
@@ -1983,6 +2037,13 @@ struct Sim {
             r.p_lf[0] = r.p_lf[1] = 0, r.p_lari[0] = r.p_lari[1] = 0;
         }
         double w = 0, qf = 0, dummy = 0;  // (M^-1 J^T f)_lane and (J^T f)_lane of the warm-start forces
+#if MJX_PGS_PIPELINE == 1
+        double bprev[3] = {0, 0, 0};
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+            for (int k = 0; k < 9; k++) r.p_W[kc][k] = 0;
+#endif
         pgs_limits<0, true>(bb, r, lane, lm0, lm1, w, qf, dummy);
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
@@ -2030,6 +2091,20 @@ struct Sim {
                 const double a00 = group_sum<G>(jcol[0] * b[0], MJX_RED(bb), lane), a01 = group_sum<G>(jcol[0] * b[1], MJX_RED(bb), lane),
                              a02 = group_sum<G>(jcol[0] * b[2], MJX_RED(bb), lane), a11 = group_sum<G>(jcol[1] * b[1], MJX_RED(bb), lane),
                              a12 = group_sum<G>(jcol[1] * b[2], MJX_RED(bb), lane), a22 = group_sum<G>(jcol[2] * b[2], MJX_RED(bb), lane);
+#if MJX_PGS_PIPELINE == 1
+                {  // W = J_c (M^-1 J_{c-1}^T): nine reductions against the previous contact's block (zero for the first contact: never used)
+                    double Wc[9];
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) Wc[3 * i + j] = group_sum<G>(jcol[i] * bprev[j], MJX_RED(bb), lane);
+                    if (lane == owner) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) r.p_W[kc][k] = Wc[k];
+                    }
+                    bprev[0] = b[0], bprev[1] = b[1], bprev[2] = b[2];
+                }
+#endif
                 if (lane == owner) {
                     double *A = r.p_A[kc];
                     A[0] = a00, A[1] = a01, A[2] = a02, A[3] = a11, A[4] = a12, A[5] = a22;
@@ -2068,6 +2143,71 @@ struct Sim {
         for (int it = 0; it < M::ITERATIONS; it++) {
             double impr = 0, unused = 0;
             pgs_limits<0, false>(bb, r, lane, lm0, lm1, a, unused, impr);
+#if MJX_PGS_PIPELINE == 2
+            // only the NEXT contact's Jacobian column (blackboard loads + a cross and three dot products, independent of the iterate) is requested before the
+            // owner relaxes the current contact's rows; the reductions wait for the updated `a` as in the sequential form: the same bits as mode 0
+            double jn[3] = {0, 0, 0};
+            if (ncon > 0 && isdof) jac_col(bb, r, 0, lane, jn);
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+#pragma unroll 1
+                for (int owner = 0; owner < G; owner++) {
+                    const int c = kc * G + owner;
+                    if (c >= ncon) break;
+                    const double jcol[3] = {jn[0], jn[1], jn[2]};
+                    double v[3], dl[3] = {0, 0, 0};
+                    v[0] = group_sum<G>(jcol[0] * a, MJX_RED(bb), lane), v[1] = group_sum<G>(jcol[1] * a, MJX_RED(bb), lane),
+                    v[2] = group_sum<G>(jcol[2] * a, MJX_RED(bb), lane);
+                    if (c + 1 < ncon) {
+                        jn[0] = jn[1] = jn[2] = 0;
+                        if (isdof) jac_col(bb, r, c + 1, lane, jn);
+                    }
+                    if (lane == owner) pgs_contact(r, kc, v, dl, impr);
+                    const double step[3] = {bcast_from(dl[0], owner, bb, lane), bcast_from(dl[1], owner, bb, lane), bcast_from(dl[2], owner, bb, lane)};
+                    a += apply_b(bb, r, c, lane, jcol, step);
+                }
+            }
+#elif MJX_PGS_PIPELINE == 1
+            // contact c + 1's column and reductions are issued BEFORE contact c's rows are relaxed (on the `a` that lacks c's step), its owner adds W dl
+            double jn[3] = {0, 0, 0}, vn[3] = {0, 0, 0};
+            if (ncon > 0) {
+                if (isdof) jac_col(bb, r, 0, lane, jn);
+                vn[0] = group_sum<G>(jn[0] * a, MJX_RED(bb), lane), vn[1] = group_sum<G>(jn[1] * a, MJX_RED(bb), lane),
+                vn[2] = group_sum<G>(jn[2] * a, MJX_RED(bb), lane);
+            }
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+#pragma unroll 1
+                for (int owner = 0; owner < G; owner++) {
+                    const int c = kc * G + owner;
+                    if (c >= ncon) break;
+                    const double jcol[3] = {jn[0], jn[1], jn[2]};
+                    double v[3] = {vn[0], vn[1], vn[2]}, dl[3] = {0, 0, 0};
+                    const bool more = c + 1 < ncon;  // group-uniform
+                    if (more) {
+                        jn[0] = jn[1] = jn[2] = 0;
+                        if (isdof) jac_col(bb, r, c + 1, lane, jn);
+                        vn[0] = group_sum<G>(jn[0] * a, MJX_RED(bb), lane), vn[1] = group_sum<G>(jn[1] * a, MJX_RED(bb), lane),
+                        vn[2] = group_sum<G>(jn[2] * a, MJX_RED(bb), lane);
+                    }
+                    if (lane == owner) pgs_contact(r, kc, v, dl, impr);
+                    // the owner's frame-space force step to every lane of the group: a cross-lane read, not an LDS exchange
+                    const double step[3] = {bcast_from(dl[0], owner, bb, lane), bcast_from(dl[1], owner, bb, lane), bcast_from(dl[2], owner, bb, lane)};
+                    a += apply_b(bb, r, c, lane, jcol, step);
+                    if (more) {
+                        // J_{c+1} (a + M^-1 J_c^T dl) = J_{c+1} a + W dl: meaningful on the owner of c + 1 (every lane evaluates its own registers: no branch)
+                        const int kn = kc + 1 < KC ? kc + 1 : kc;
+                        const bool nextrow = owner == G - 1;  // c + 1 is the first contact of the next register slot
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const double w0 = nextrow ? r.p_W[kn][3 * i] : r.p_W[kc][3 * i], w1 = nextrow ? r.p_W[kn][3 * i + 1] : r.p_W[kc][3 * i + 1],
+                                         w2 = nextrow ? r.p_W[kn][3 * i + 2] : r.p_W[kc][3 * i + 2];
+                            vn[i] += w0 * step[0] + w1 * step[1] + w2 * step[2];
+                        }
+                    }
+                }
+            }
+#else
 #pragma unroll
             for (int kc = 0; kc < KC; kc++) {
 #pragma unroll 1
@@ -2085,6 +2225,7 @@ struct Sim {
                     a += apply_b(bb, r, c, lane, jcol, step);
                 }
             }
+#endif
             const double imp = group_sum<G>(impr, MJX_RED(bb), lane);
 #if defined(MJX_HOST_EMU)
             if (lane == 0) g_stat[3]++;

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="MI355ENV_MJ_SERIAL=1")
     ap.add_argument("--env-kwargs", default="{}")
     ap.add_argument("--seconds", type=float, default=1.0)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed launches before the timed region (e.g. 40 with terminate_when_unhealthy=false: robots on the ground)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     libs = [x.split("=", 1) for x in args.libs]
@@ -38,6 +39,8 @@ def main():
                     env["MI355ENV_MJ_SERIAL"] = "1"
                 cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--env", env_id, "--num-envs", n, "--inner", inner, "--no-api", "--no-cpu-baseline",
                        "--no-secondary", "--pmc", "off", "--sustained", "0", "--pilot-seconds", str(args.seconds), "--env-kwargs", args.env_kwargs]
+                if args.warmup is not None:
+                    cmd += ["--warmup", str(args.warmup)]
                 p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
                 try:
                     r = json.loads(p.stdout.strip().splitlines()[-1])

@@ -55,7 +55,11 @@ def build_emu(name, flags=()):
 def lib(legacy=False):
     key = "legacy" if legacy else "product"
     if key not in _LIBS:
-        _LIBS[key] = build_emu("libcoop_emu_legacy.so", LEGACY_FLAGS) if legacy else build_emu("libcoop_emu.so")
+        extra = os.environ.get("MJX_EMU_EXTRA_FLAGS", "").split()  # e.g. "-DMJX_PGS_EDGE_CHAIN=1": the same tests over an A/B variant of the kernels
+        if legacy:
+            _LIBS[key] = build_emu("libcoop_emu_legacy.so", LEGACY_FLAGS)
+        else:
+            _LIBS[key] = build_emu("libcoop_emu_variant.so" if extra else "libcoop_emu.so", extra)
     return _LIBS[key]
 
 
@@ -283,3 +287,20 @@ def test_no_cross_lane_dependency_inside_a_sync_interval(model):
     finally:
         set_order(0, 1)
     assert contacts > 0
+
+
+def test_pgs_sweep_variants_stay_correct():
+    """The measured-and-not-adopted forms of the PGS sweep (mjx_coop.h MJX_PGS_PIPELINE = 1 / 2, MJX_PGS_EDGE_CHAIN = 1; profiles/r05_pgs_sweep_variants.txt) stay
+    behind their macros for A/B runs: the Humanoid forward-pass test of this file, in a child interpreter, over a build with all of them switched on (mode 1
+    includes the early column of mode 2), so that the code does not rot."""
+    import sys
+
+    for flags in ("-DMJX_PGS_PIPELINE=1 -DMJX_PGS_EDGE_CHAIN=1", "-DMJX_PGS_PIPELINE=2"):
+        env = dict(os.environ, MJX_EMU_EXTRA_FLAGS=flags)
+        so = os.path.join(EMU_DIR, "libcoop_emu_variant.so")
+        if os.path.exists(so):
+            os.remove(so)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k", "test_forward_matches_oracle and umanoid-PGS"],
+                           env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.join(HERE, ".."))
+        assert r.returncode == 0 and " passed" in r.stdout, flags + "\n" + (r.stdout + r.stderr)[-3000:]
+        os.remove(so)
