@@ -44,6 +44,25 @@ def check_shared_rng_segments(make_env, via_rollout=False):
         env.close()
 
 
+def check_seed_sequence_entry_point(make_env):
+    """The C ABI's own seeding entry point in this mode (mi_seed_sequence: SeedSequence(seed) -> PCG64 evaluated by the library; the host class hands over
+    generator words instead): the one stream must be NumPy's default_rng(seed)."""
+    for seed in (0, 42, 2**40 + 5, 2**63 + 11):
+        env = make_env(num_envs=6)
+        env._engine.seed_sequence(seed, 0, None)
+        env._seeded = True
+        obs, _ = env.reset()
+        obs = np.asarray(obs.cpu()) if hasattr(obs, "cpu") else obs
+        assert np.array_equal(obs, np.random.default_rng(seed).uniform(-0.05, 0.05, size=(4, 6)).T.astype(np.float32)), seed
+        with pytest.raises(_native.NativeError):
+            env._engine.seed_sequence(seed, 3, None)  # one generator: no shard offset
+        env.close()
+
+
+def test_oracle_seed_sequence_entry_point(oracle_factory):
+    check_seed_sequence_entry_point(lambda **kw: gymnasium_amd.make_vec("CartPole-v1", rng="shared", _engine_factory=oracle_factory, **kw))
+
+
 def test_oracle_equals_the_reference_vector_env(oracle_factory):
     check_shared_rng_segments(lambda **kw: gymnasium_amd.make_vec("CartPole-v1", rng="shared", _engine_factory=oracle_factory, **kw))
 

@@ -5,13 +5,17 @@ import numpy as np
 import pytest
 
 import gymnasium_amd
-from test_cartpole_shared_rng import check_shared_rng_segments
+from test_cartpole_shared_rng import check_seed_sequence_entry_point, check_shared_rng_segments
 
 pytestmark = pytest.mark.gpu
 
 
 def test_numpy_batches_equal_the_reference_vector_env():
     check_shared_rng_segments(lambda **kw: gymnasium_amd.make_vec("CartPole-v1", rng="shared", device=0, **kw))
+
+
+def test_seed_sequence_entry_point():
+    check_seed_sequence_entry_point(lambda **kw: gymnasium_amd.make_vec("CartPole-v1", rng="shared", device=0, **kw))
 
 
 def test_device_tensors_equal_the_reference_vector_env():
@@ -63,4 +67,28 @@ def test_many_workgroups_against_the_oracle(oracle_factory, fast_math):
         o, r, te, tr, _ = cpu.step(a)
         assert np.array_equal(out["actions"][t].cpu().numpy(), a) and np.array_equal(out["obs"][t].cpu().numpy(), o), t
         assert np.array_equal(out["terminations"][t].cpu().numpy(), te) and np.array_equal(out["rewards"][t].cpu().numpy(), r.astype(np.float64)), t
+    gpu.close(), cpu.close()
+
+
+def test_set_state_recounts_the_pending_resets(oracle_factory):
+    """mi_set_state may change which sub-environments are pending an autoreset: the per-workgroup counts the next step's scan reads must follow the new flags."""
+    n = 1000
+    gpu = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", device=0)
+    cpu = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", _engine_factory=oracle_factory)
+    gpu.reset(seed=4), cpu.reset(seed=4)
+    gpu.action_space.seed(0)
+    for _ in range(3):
+        a = gpu.action_space.sample()
+        gpu.step(a), cpu.step(a)
+    st, el, fl = cpu.get_state()
+    fl = fl.copy()
+    fl[::7] |= 1  # MI_FLAG_NEEDS_RESET on every seventh sub-environment
+    fl[5::11] &= 0xFE
+    gpu.set_state(st, el, fl), cpu.set_state(st, el, fl)
+    for t in range(6):
+        a = gpu.action_space.sample()
+        g, c = gpu.step(a), cpu.step(a)
+        for k in range(4):
+            assert np.array_equal(g[k], c[k]), (t, k)
+    assert np.array_equal(gpu.get_rng_state()[0], cpu.get_rng_state()[0])
     gpu.close(), cpu.close()
