@@ -303,3 +303,79 @@ def test_stock_id_override_is_a_drop_in_for_cartpole_vector_env(oracle_factory):
                 assert data_equivalence(s1[k], s2[k], exact=True), f"{what} t={t}: {s1[k]!r} vs {s2[k]!r}"
         assert ours.np_random.bit_generator.state == ref.np_random.bit_generator.state
     ours.close(), ref.close()
+
+
+@needs_gymnasium
+def test_shared_generator_mode_property_based(oracle_factory):
+    """Random batch sizes, TimeLimits (down to 1: every sub-environment finishes on every step it takes), seeds, reset bounds and action sequences:
+    rng="shared" against the reference's NumPy CartPoleVectorEnv under strict data_equivalence, generator state included (hypothesis)."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    import gymnasium_amd
+    from gymnasium.envs.classic_control.cartpole import CartPoleVectorEnv as RefVec
+
+    @settings(max_examples=120, deadline=None, derandomize=True)
+    @given(n=st.integers(1, 130), max_steps=st.integers(1, 25), seed=st.integers(0, 2**63 - 1), steps=st.integers(1, 60), sb=st.booleans(),
+           bounds=st.one_of(st.none(), st.tuples(st.floats(-0.2, 0.0), st.floats(0.0, 0.2))), aseed=st.integers(0, 2**32 - 1))
+    def run(n, max_steps, seed, steps, sb, bounds, aseed):
+        ours = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", max_episode_steps=max_steps, sutton_barto_reward=sb, _engine_factory=oracle_factory)
+        ref = RefVec(num_envs=n, max_episode_steps=max_steps, sutton_barto_reward=sb)
+        options = None if bounds is None else {"low": bounds[0], "high": bounds[1]}
+        assert data_equivalence(ours.reset(seed=seed, options=options), ref.reset(seed=seed, options=options), exact=True)
+        arng = np.random.default_rng(aseed)
+        for t in range(steps):
+            a = arng.integers(0, 2, n)
+            s1, s2 = ours.step(a), ref.step(a)
+            for k in range(5):
+                assert data_equivalence(s1[k], s2[k], exact=True), (t, k, s1[k], s2[k])
+            if sb:
+                assert np.array_equal(np.signbit(s1[1]), np.signbit(s2[1])), t
+        assert ours.np_random.bit_generator.state == ref.np_random.bit_generator.state
+        ours.close(), ref.close()
+
+    run()
+
+
+@needs_gymnasium
+def test_sync_semantics_property_based(oracle_factory):
+    """The per-sub-environment mode against gymnasium's SyncVectorEnv with everything drawn by hypothesis: env id, autoreset mode, batch size, TimeLimit (down
+    to 1), integer seeds and seed lists with holes, and partial resets (`reset_mask`) thrown in at random steps -- strict data_equivalence throughout."""
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    import gymnasium_amd  # noqa: F401
+
+    @settings(max_examples=120, deadline=None, derandomize=True)
+    @given(env_id=st.sampled_from(CLASSIC), mode=st.sampled_from(MODES), n=st.integers(1, 9), max_steps=st.integers(1, 30), seed=st.integers(0, 2**62),
+           steps=st.integers(1, 50), data=st.data())
+    def run(env_id, mode, n, max_steps, seed, steps, data):
+        ours = gym.make_vec(f"MI355X/{env_id}", num_envs=n, autoreset_mode=mode, max_episode_steps=max_steps, _engine_factory=oracle_factory)
+        ref = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync", vector_kwargs={"autoreset_mode": mode}, max_episode_steps=max_steps)
+        if data.draw(st.booleans()):  # a seed list with holes: the un-seeded sub-environments need a first full seeding to be comparable
+            assert _same(ours.reset(seed=seed)[0], ref.reset(seed=seed)[0], env_id)
+            seeds = [data.draw(st.one_of(st.none(), st.integers(0, 2**40))) for _ in range(n)]
+            r1, r2 = ours.reset(seed=seeds), ref.reset(seed=seeds)
+        else:
+            r1, r2 = ours.reset(seed=seed), ref.reset(seed=seed)
+        assert _same(r1[0], r2[0], env_id) and data_equivalence(r1[1], r2[1], exact=True)
+        ref.action_space.seed(seed % 2**32)
+        pending = np.zeros(n, bool)
+        for t in range(steps):
+            a = ref.action_space.sample()
+            s1, s2 = ours.step(a), ref.step(a)
+            done = s2[2] | s2[3]
+            after_reset = pending if mode == "NextStep" else (done if mode == "SameStep" else np.zeros(n, bool))
+            assert _same(s1[0], s2[0], env_id, after_reset), (t, s1[0], s2[0])
+            for k in (1, 2, 3):
+                assert data_equivalence(s1[k], s2[k], exact=True), (t, k)
+            assert data_equivalence(dict(s1[4]), dict(s2[4]), exact=True), t
+            pending = done if mode == "NextStep" else np.zeros(n, bool)
+            mask = done.copy() if mode == "Disabled" else (np.array(data.draw(st.lists(st.booleans(), min_size=n, max_size=n))) if data.draw(st.integers(0, 9)) == 0 else np.zeros(n, bool))
+            if mask.any():
+                m1, m2 = ours.reset(options={"reset_mask": mask}), ref.reset(options={"reset_mask": mask})
+                assert _same(m1[0], m2[0], env_id, mask) and data_equivalence(m1[1], m2[1], exact=True), t
+                pending = pending & ~mask
+        ours.close(), ref.close()
+
+    run()
