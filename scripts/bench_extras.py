@@ -35,6 +35,8 @@ STEP_BYTES = {"CartPole-v1": 108, "Pendulum-v1": 68, "Acrobot-v1": 116, "Mountai
 # (env, num_envs per GPU, vector steps per launch) of the secondary lines: BASELINE.json configs[2..4] + the north_star's Ant @65536
 SECONDARY = [("Pendulum-v1", 65536, 128), ("Acrobot-v1", 65536, 128), ("MountainCarContinuous-v0", 65536, 128),
              ("Ant-v5", 32768, 4), ("Ant-v5", 65536, 4), ("Humanoid-v5", 32768, 4)]
+# the ToyText kinds (bit-exact integer kernels), measured last and only while the run is young
+TOYTEXT = [("FrozenLake-v1", 65536, 128), ("Taxi-v4", 65536, 128), ("Blackjack-v1", 65536, 128)]
 # The other contact regime of the two headline robots: the random policy with `terminate_when_unhealthy` ends a Humanoid episode after ~22 steps, so
 # the batch above is mostly robots still upright; with termination off and a warm-up of GROUND_WARM launches every robot lies on the ground (many
 # contacts, the PGS sweeps dominate).  A learner that keeps the robot alive lives between the two lines.
@@ -431,6 +433,21 @@ def main():
         c1.close()
         if full["primary_counters"]["issue_bound"]:
             head["issue_frac"] = round(full["primary_counters"]["issue_bound"]["frac_of_issue_ceiling"], 3)
+        flush()
+    for env_id2, n2, inner2 in TOYTEXT:
+        if only or not young():
+            break
+        try:
+            c2 = Config(env_id2, n2, inner2, 0, 0)
+            c2.launch(c2.first)
+            sha = bench.trajectory_digest(c2.host_trajectory())
+            v2, k2, ks2, el2 = steady(c2, 0.4)
+            full["secondary"].append({"env": env_id2, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "seconds": el2, "unit": "env-steps/s",
+                                      "ms_per_launch": el2 / k2 * 1e3, "dtype": "i64", "output_sha256": sha, "roofline": c2.roofline(ks2)})
+            head[f"{env_id2}@{n2}"] = float(f"{v2:.4g}")
+            c2.close()
+        except Exception as e:
+            full["secondary"].append({"env": env_id2, "error": f"{type(e).__name__}: {e}"[:300]})
         flush()
     if not args.no_cpu_baseline and not only and young():
         ref = cpu_reference()

@@ -49,11 +49,13 @@ def main(env_id="CartPole-v1", N=65536, T=128, out_name="bench_digest.json"):
     for t in range(T):
         a = env.action_space.sample()
         o, r, d, u, _ = env.step(a)
+        if isinstance(o, tuple):  # Blackjack: Tuple(Discrete, Discrete, Discrete) batches to a tuple of arrays; the engine's observation row is the three int64
+            o = np.stack([np.asarray(x, dtype=np.int64) for x in o], axis=-1)
         acts.append(a.copy()), obs.append(o.copy()), rew.append(r.copy()), te.append(d.copy()), tr.append(u.copy())
         if t % 16 == 0:
             print(f"step {t} at {time.time() - t0:.0f} s", flush=True)
     traj = tuple(np.stack(x) for x in (acts, obs, rew, te, tr))
-    assert traj[0].dtype in (np.int64, np.float32) and traj[1].dtype == np.float32 and traj[2].dtype == np.float64 and traj[3].dtype == np.bool_ and traj[4].dtype == np.bool_
+    assert traj[0].dtype in (np.int64, np.float32) and traj[1].dtype in (np.float32, np.int64) and traj[2].dtype == np.float64 and traj[3].dtype == np.bool_ and traj[4].dtype == np.bool_
     out = {"what": f"gymnasium {gym.__version__} make_vec({env_id!r}, {N}, 'sync'), reset(seed=0), action_space.seed(0), {T} x step(sample()); "
                    "sha256 over (actions, obs, rewards, terminated, truncated) bytes, time-major",
            "numpy": np.__version__, f"{env_id}:{N}:{T}:rank0": digest(traj),
