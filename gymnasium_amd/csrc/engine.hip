@@ -1066,38 +1066,61 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
 // MI_CFG_SHARED_RNG: the reference's NumPy vector environment CartPoleVectorEnv (cartpole.py:353-505) -- one generator for all sub-environments,
 // drawn component-major over the sub-environments that reset (see include/mi355env.h).  Same dynamics (E::step), other bookkeeping.
 // ---------------------------------------------------------------------------------------------------------
-MI_DEV double shared_draw(const SharedRng &sr, uint64_t n) {  // draw number n (0-based) of the stream that starts at the base state
-    Pcg64 g;
-    g.state = make_u128(sr.words[0], sr.words[1]), g.inc = make_u128(sr.words[2], sr.words[3]);
+MI_DEV u128 shared_advance(const SharedRng &sr, u128 state, uint64_t n) {  // `state` n steps further along the base generator's sequence
     for (int j = 0; n; j++, n >>= 1)
-        if (n & 1ull) g.state = sr.pow2[j].mult * g.state + sr.pow2[j].plus;
+        if (n & 1ull) state = sr.pow2[j].mult * state + sr.pow2[j].plus;
+    return state;
+}
+// The draws of one workgroup start at a position every lane shares (the call's first draw + the component's stride + the workgroup's prefix) and differ by
+// less than the workgroup size: threads 0..3 skip ahead to the four shared positions (tens of 128-bit multiply-adds, once per workgroup, through LDS) and a
+// lane adds its own offset < 256 (at most eight).  Call from every thread, before a __syncthreads(); `stride` = draws between two components.
+MI_DEV void shared_block_bases(const SharedRng &sr, uint64_t first, uint64_t stride, uint64_t (*sh)[2]) {
+    if (threadIdx.x < 4) {
+        const u128 s = shared_advance(sr, make_u128(sr.words[0], sr.words[1]), first + (uint64_t)threadIdx.x * stride);
+        sh[threadIdx.x][0] = (uint64_t)(s >> 64), sh[threadIdx.x][1] = (uint64_t)s;
+    }
+}
+MI_DEV double shared_draw_from(const SharedRng &sr, const uint64_t (*sh)[2], int c, uint32_t offset) {  // draw `offset` after the workgroup's base of component c
+    Pcg64 g;
+    g.state = shared_advance(sr, make_u128(sh[c][0], sh[c][1]), offset), g.inc = make_u128(sr.words[2], sr.words[3]);
     return g.next_double();
 }
 
 // One workgroup, before every reset (fixed_draws = 4 N) / step (fixed_draws = 0: 4 k, k = the sub-environments that finished in the previous step):
 // exclusive scan of the per-workgroup counts, and the stream bookkeeping -- the call in flight draws from pos_base, the next one after it.
 __global__ __launch_bounds__(kBlock) void shared_scan_kernel(SharedRng sr, int grid, uint64_t fixed_draws) {
-    __shared__ uint32_t part[kBlock];
+    __shared__ uint32_t wave_total[kBlock / 64];
     const int per = (grid + kBlock - 1) / kBlock, lo = threadIdx.x * per, hi = min(grid, lo + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t sum = 0;
     if (!fixed_draws)
         for (int b = lo; b < hi; b++) sum += sr.blk_done[b];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < kBlock; t++) {
-            const uint32_t c = part[t];
-            part[t] = run, run += c;
-        }
-        const uint64_t consumed = sr.words[4];
-        sr.words[5] = consumed, sr.words[6] = run;
-        sr.words[4] = consumed + (fixed_draws ? fixed_draws : 4ull * run);
+    // inclusive scan of the threads' chunk totals: Hillis-Steele inside each wavefront (cross-lane reads, no LDS round trips), the four wavefront totals through LDS
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
     }
+    if (lane == 63) wave_total[wave] = incl;
     __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+        before += w < wave ? wave_total[w] : 0u;
+        total += wave_total[w];
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t consumed = sr.words[4];
+        sr.words[5] = consumed, sr.words[6] = total;
+        sr.words[4] = consumed + (fixed_draws ? fixed_draws : 4ull * total);
+    }
     if (!fixed_draws) {
-        uint32_t run = part[threadIdx.x];
-        for (int b = lo; b < hi; b++) sr.blk_prefix[b] = run, run += sr.blk_done[b];
+        uint32_t run = before + incl - sum;  // exclusive prefix of this thread's chunk
+        for (int b = lo; b < hi; b++) {
+            const uint32_t c = sr.blk_done[b];
+            sr.blk_prefix[b] = run, run += c;
+        }
     }
 }
 
@@ -1122,14 +1145,18 @@ __global__ __launch_bounds__(kBlock) void shared_count_kernel(DevEnv d, SharedRn
 // reset(): state[c][i] = uniform(low, high) from draw c * N + i (cartpole.py:493-500: size=(4, N))
 template <class E>
 __global__ __launch_bounds__(kBlock) void shared_reset_kernel(DevEnv d, SharedRng sr, float *obs) {
+    __shared__ uint64_t sh_base[4][2];
+    static_assert(E::NDRAWS == 4, "four state components: threads 0..3 prepare their bases");
     tables_init<E>();
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    shared_block_bases(sr, sr.words[5] + (uint64_t)blockIdx.x * kBlock, (uint64_t)d.N, sh_base);
+    __syncthreads();
     if (i < d.N) {
         Lane<E> L;
         load_lane<E>(d, i, L);
         double u[E::NDRAWS];
 #pragma unroll
-        for (int c = 0; c < E::NDRAWS; c++) u[c] = shared_draw(sr, sr.words[5] + (uint64_t)c * (uint64_t)d.N + (uint64_t)i);
+        for (int c = 0; c < E::NDRAWS; c++) u[c] = shared_draw_from(sr, sh_base, c, threadIdx.x);
         L.flags = 0;
         E::reset_u(u, L.s, L.flags, sr.low, sr.high);
         L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
@@ -1149,8 +1176,11 @@ __global__ __launch_bounds__(kBlock) void shared_reset_kernel(DevEnv d, SharedRn
 template <class E>
 __global__ __launch_bounds__(kBlock) void shared_step_kernel(DevEnv d, StepPtrs io, SharedRng sr) {
     __shared__ uint32_t sh_wave[kBlock / 64];
+    __shared__ uint64_t sh_base[4][2];
+    static_assert(E::NDRAWS == 4, "four state components: threads 0..3 prepare their bases");
     tables_init<E>();
     const int i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (sr.blk_done[blockIdx.x]) shared_block_bases(sr, sr.words[5] + (uint64_t)sr.blk_prefix[blockIdx.x], sr.words[6], sh_base);  // (workgroup-uniform test)
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     Lane<E> L;
     const bool active = i < d.N;
@@ -1167,10 +1197,9 @@ __global__ __launch_bounds__(kBlock) void shared_step_kernel(DevEnv d, StepPtrs 
         int32_t ep_len = 0;
         bool te = false, tr = false, untouched = false;
         if (resetting) {
-            const uint64_t k = sr.words[6], first = sr.words[5] + (uint64_t)sr.blk_prefix[blockIdx.x] + (uint64_t)rank;
             double u[E::NDRAWS];
 #pragma unroll
-            for (int c = 0; c < E::NDRAWS; c++) u[c] = shared_draw(sr, first + (uint64_t)c * k);
+            for (int c = 0; c < E::NDRAWS; c++) u[c] = shared_draw_from(sr, sh_base, c, rank);  // draw c * k + (workgroup prefix + rank) of this call
             L.flags = 0;
             E::reset_u(u, L.s, L.flags, sr.low, sr.high);
             L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;

@@ -76,4 +76,4 @@ def test_the_drivers_own_command_line():
         if key in ref2 and "regime" not in line:
             assert line["output_sha256"] == ref2[key], line["env"]
             seen += 1
-    assert seen == 3
+    assert seen >= 3  # configs[2]; plus the ToyText lines when the run was young enough to measure them
