@@ -521,3 +521,29 @@ def test_ragged_batch_sizes_fused_rollout(n):
     """the fused rollout (on-device policy, whole trajectory in HBM) equals the stepped env for partly filled wavefronts / workgroups too"""
     for key in ("cartpole", "pendulum", "mountaincar_continuous"):
         ps.check_rollout_fused(key, None, n=n, T=24)
+
+
+def test_four_million_sub_environments_subset_vs_oracle():
+    """A batch sized for the card, not for the benchmark: 4 194 304 CartPoles (16 384 workgroups, 16 wavefronts per SIMD) through the fused rollout with the
+    on-device policy; 2 048 strided sub-environments -- seeded by GLOBAL index like every other one -- must equal the oracle bit for bit, the action stream
+    must be the host policy's, and the totals must add up."""
+    import bench
+
+    n, T = 1 << 22, 16
+    env = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, device=0, output="torch")
+    env.reset(seed=0)
+    env.action_space.seed(5)
+    out = env.rollout(T)
+    idx = np.arange(0, n, n // 2048)
+    acts = out["actions"][:, idx].cpu().numpy()
+    _, o2, r2, te2, tr2 = bench.oracle_trajectory("CartPole-v1", n, T, offset=0, actions=np.ascontiguousarray(acts), env_indices=idx)
+    assert np.array_equal(out["obs"][:, idx].cpu().numpy(), o2) and np.array_equal(out["rewards"][:, idx].cpu().numpy(), r2)
+    assert np.array_equal(out["terminations"][:, idx].cpu().numpy(), te2) and np.array_equal(out["truncations"][:, idx].cpu().numpy(), tr2)
+    # the policy: draw t * n + i of MultiDiscrete([2] * n).sample() == (random(n) * 2).astype(int64) of the stream seeded 5
+    gen = np.random.default_rng(5)
+    for t in range(2):
+        assert np.array_equal(out["actions"][t].cpu().numpy(), (gen.random(n) * 2).astype(np.int64)), t
+    st = env.statistics()
+    done = int((out["terminations"] | out["truncations"]).sum().item())
+    assert st["env_steps"] + st["reset_steps"] == n * T and st["episodes"] == done
+    env.close()
