@@ -36,7 +36,7 @@ STEP_BYTES = {"CartPole-v1": 108, "Pendulum-v1": 68, "Acrobot-v1": 116, "Mountai
 SECONDARY = [("Pendulum-v1", 65536, 128), ("Acrobot-v1", 65536, 128), ("MountainCarContinuous-v0", 65536, 128),
              ("Ant-v5", 32768, 4), ("Ant-v5", 65536, 4), ("Humanoid-v5", 32768, 4)]
 # the ToyText kinds (bit-exact integer kernels), measured last and only while the run is young
-TOYTEXT = [("FrozenLake-v1", 65536, 128), ("Taxi-v4", 65536, 128), ("Blackjack-v1", 65536, 128)]
+TOYTEXT = [("FrozenLake-v1", 65536, 128), ("Taxi-v4", 65536, 128), ("Blackjack-v1", 65536, 128), ("MountainCar-v0", 65536, 128)]  # (+ the fifth classic id)
 # The other contact regime of the two headline robots: the random policy with `terminate_when_unhealthy` ends a Humanoid episode after ~22 steps, so
 # the batch above is mostly robots still upright; with termination off and a warm-up of GROUND_WARM launches every robot lies on the ground (many
 # contacts, the PGS sweeps dominate).  A learner that keeps the robot alive lives between the two lines.

@@ -29,7 +29,7 @@ def test_oracle_reproduces_the_reference_digest_at_configs1_shape():
     assert bench.trajectory_digest(traj) == g[KEY]
 
 
-@pytest.mark.parametrize("env_id", ["Pendulum-v1", "Acrobot-v1", "MountainCarContinuous-v0", "FrozenLake-v1", "Blackjack-v1"])
+@pytest.mark.parametrize("env_id", ["Pendulum-v1", "Acrobot-v1", "MountainCarContinuous-v0", "MountainCar-v0", "FrozenLake-v1", "FrozenLake8x8-v1", "CliffWalking-v1", "Blackjack-v1"])
 def test_oracle_reproduces_the_reference_digest_at_configs2_shape(env_id):
     """BASELINE.json configs[2] at its exact shape (65 536 sub-environments, 128 steps): the digest of the reference's own SyncVectorEnv rollout
     (tests/golden/make_bench_digest.py <id>) from the oracle -- whole episodes of Pendulum (200-step TimeLimit not reached: 128 steps), the chaotic Acrobot
