@@ -547,3 +547,35 @@ def test_four_million_sub_environments_subset_vs_oracle():
     done = int((out["terminations"] | out["truncations"]).sum().item())
     assert st["env_steps"] + st["reset_steps"] == n * T and st["episodes"] == done
     env.close()
+
+
+def _reference_digests():
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    out = {}
+    for name in ("bench_digest.json", "bench_digest_configs2.json"):
+        out.update({k: v for k, v in json.load(open(os.path.join(GOLDEN, name))).items() if k.endswith(":65536:128:rank0")})
+    return out
+
+
+_DIGESTS = _reference_digests()
+
+
+@pytest.mark.parametrize("key", sorted(_DIGESTS))
+def test_fused_rollout_reproduces_the_reference_digest_at_full_size(key):
+    """BASELINE.json configs[1] / [2] (and the ToyText kinds) at their exact shape, straight through the fused rollout entry point: the sha256 of the trajectory
+    bytes the kernels write equals the one gymnasium's own SyncVectorEnv over 65 536 scalar envs produced (tests/golden/make_bench_digest.py) -- for CartPole,
+    MountainCar and MountainCarContinuous that is the two-role kernel, for Pendulum / Acrobot the one-role kernel, for the rest the tabular kernels."""
+    import bench
+
+    env_id = key.split(":")[0]
+    env = gymnasium_amd.make_vec(env_id, num_envs=65536, device=0, output="torch")
+    env.reset(seed=0)
+    env.action_space.seed(0)
+    out = env.rollout(128)
+    traj = tuple(out[k].cpu().numpy() for k in ("actions", "obs", "rewards", "terminations", "truncations"))
+    assert bench.trajectory_digest(traj) == _DIGESTS[key]
+    env.close()
