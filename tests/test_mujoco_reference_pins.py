@@ -99,6 +99,19 @@ def test_reacher_doctest_known_answer_oracle(oracle_factory):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/gymnasium"), reason="needs the reference tree")
+def test_hopper_reset_state_recorded_in_the_reference_tests(oracle_factory):
+    """tests/envs/mujoco/test_mujoco_v5.py:380-385 (`test_set_state`) feeds Hopper twelve literals that are, to the printed 8 decimals, Hopper-v5's own
+    `reset(seed=0)` state: init_qpos / init_qvel plus `uniform(-5e-3, 5e-3)` noise on both (hopper_v5.py reset_model).  Not physics -- but a state the
+    reference wrote down: model defaults (qpos0 = [0, 1.25, 0, 0, 0, 0]), the noise scale, the draw order qpos then qvel, the stream of seed 0."""
+    new_qpos = np.array([0.00136962, 1.24769787, -0.00459026, -0.00483472, 0.0031327, 0.00412756])
+    new_qvel = np.array([0.00106636, 0.00229497, 0.00043625, 0.00435072, 0.00315854, -0.00497261])
+    env = gymnasium_amd.make_vec("Hopper-v5", num_envs=3, _engine_factory=oracle_factory)
+    env.reset(seed=0)
+    st, _, _ = env.get_state()
+    assert np.array_equal(np.round(st[0][:6], 8), new_qpos) and np.array_equal(np.round(st[0][6:12], 8), new_qvel)
+    env.close()
+
+
 def test_bin_centres_equal_the_reference_wrapper():
     """The action the discretised Reacher pin feeds is the reference wrapper's own (the wrapper is pure NumPy: run here over a stub env)."""
     import subprocess
