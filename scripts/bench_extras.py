@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     ap.add_argument("--only", default=None, help="comma-separated env ids: restrict the secondary lines")
+    ap.add_argument("--api-only", action="store_true", help="only the per-launch step() API legs (for a kernel trace of step_kernel)")
     args = ap.parse_args()
     t_ref = args.started if args.started else time.time()
     young = lambda: args.pmc == "full" or (time.time() - t_ref) < args.budget  # noqa: E731
@@ -348,6 +349,11 @@ def main():
         os.replace(args.out + ".tmp", args.out)
 
     only = set(args.only.split(",")) if args.only else None
+    if args.api_only:
+        full.update(api_legs("CartPole-v1", 65536))
+        flush()
+        print(json.dumps({"step_api_us_gpu": round(full["api_step_device"]["us_per_step_gpu"], 2)}))
+        return
     for env_id, n2, inner2 in SECONDARY:
         if only and env_id not in only:
             continue
