@@ -379,3 +379,48 @@ def test_sync_semantics_property_based(oracle_factory):
         ours.close(), ref.close()
 
     run()
+
+
+@needs_gymnasium
+def test_toytext_property_based(oracle_factory):
+    """The ToyText kinds against gymnasium's SyncVectorEnv with constructor kwargs drawn by hypothesis: FrozenLake on random boards (sizes 3-6, slippery or not,
+    success rates), CliffWalking slippery or not, Taxi rainy / fickle, Blackjack natural / sab -- every autoreset mode, strict data_equivalence of observations
+    (Blackjack's tuples included), rewards, flags and the info dicts with their dtype quirks."""
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    import gymnasium_amd  # noqa: F401
+    from gymnasium.envs.toy_text.frozen_lake import generate_random_map
+
+    kinds = st.one_of(
+        st.tuples(st.just("FrozenLake-v1"), st.fixed_dictionaries({"size": st.integers(3, 6), "mapseed": st.integers(0, 1000), "is_slippery": st.booleans(),
+                                                                  "success_rate": st.sampled_from([1.0 / 3.0, 0.5, 0.8])})),
+        st.tuples(st.just("CliffWalking-v1"), st.fixed_dictionaries({"is_slippery": st.booleans()})),
+        st.tuples(st.just("Taxi-v4"), st.fixed_dictionaries({"is_rainy": st.booleans(), "fickle_passenger": st.booleans()})),
+        st.tuples(st.just("Blackjack-v1"), st.fixed_dictionaries({"natural": st.booleans(), "sab": st.booleans()})))
+
+    @settings(max_examples=60, deadline=None, derandomize=True)
+    @given(kind=kinds, mode=st.sampled_from(MODES), n=st.integers(1, 6), max_steps=st.integers(2, 40), seed=st.integers(0, 2**40), steps=st.integers(1, 60))
+    def run(kind, mode, n, max_steps, seed, steps):
+        env_id, kw = kind
+        kw = dict(kw)
+        if env_id == "FrozenLake-v1":
+            kw["desc"] = generate_random_map(size=kw.pop("size"), p=0.8, seed=kw.pop("mapseed"))
+        ours = gym.make_vec(f"MI355X/{env_id}", num_envs=n, autoreset_mode=mode, max_episode_steps=max_steps, _engine_factory=oracle_factory, **kw)
+        ref = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync", vector_kwargs={"autoreset_mode": mode}, max_episode_steps=max_steps, **kw)
+        r1, r2 = ours.reset(seed=seed), ref.reset(seed=seed)
+        assert data_equivalence(r1[0], r2[0], exact=True) and data_equivalence(r1[1], r2[1], exact=True), (r1, r2)
+        ref.action_space.seed(seed % 2**32)
+        for t in range(steps):
+            a = ref.action_space.sample()
+            s1, s2 = ours.step(a), ref.step(a)
+            for k in range(4):
+                assert data_equivalence(s1[k], s2[k], exact=True), (env_id, kw, t, k, s1[k], s2[k])
+            assert data_equivalence(dict(s1[4]), dict(s2[4]), exact=True), (env_id, kw, t, s1[4], s2[4])
+            done = s2[2] | s2[3]
+            if mode == "Disabled" and done.any():
+                m1, m2 = ours.reset(options={"reset_mask": done}), ref.reset(options={"reset_mask": done})
+                assert data_equivalence(m1[0], m2[0], exact=True) and data_equivalence(m1[1], m2[1], exact=True), t
+        ours.close(), ref.close()
+
+    run()
