@@ -303,3 +303,38 @@ def test_device_resident_infos_equal_the_numpy_infos(mode):
 
     compare_device_infos("Ant-v5", None, mode, steps=45)
     compare_device_infos("Hopper-v5", None, mode, steps=80)
+
+
+def _kwargs_cases():
+    from mujoco_kwargs_cases import CASES
+
+    return [(env_id, k) for env_id, cases in CASES.items() for k in range(len(cases))]
+
+
+@pytest.mark.parametrize("env_id,k", _kwargs_cases())
+def test_non_default_constructor_kwargs_vs_oracle(env_id, k, oracle_factory):
+    """The constructor keywords of the v5 classes at non-default values (tests/mujoco_kwargs_cases.py; the CPU suite pins the same cases on the reference's env
+    classes): HIP engine vs oracle -- observation shapes, reset bit for bit, 12 steps within the windowed tolerance, flags and info columns."""
+    from mujoco_kwargs_cases import CASES
+
+    kw = CASES[env_id][k]
+    n = 64
+    gpu = gymnasium_amd.make_vec(env_id, num_envs=n, max_episode_steps=20, **kw)
+    cpu = gymnasium_amd.make_vec(env_id, num_envs=n, max_episode_steps=20, _engine_factory=oracle_factory, **kw)
+    assert gpu.single_observation_space == cpu.single_observation_space
+    og, oc = gpu.reset(seed=8)[0], cpu.reset(seed=8)[0]
+    np.testing.assert_allclose(og, oc, rtol=1e-9, atol=1e-9)
+    gpu.action_space.seed(4)
+    for t in range(12):
+        a = gpu.action_space.sample()
+        g, c = gpu.step(a), cpu.step(a)
+        np.testing.assert_allclose(g[0], c[0], rtol=0, atol=2e-8, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(g[1], c[1], rtol=0, atol=2e-8, err_msg=f"reward t={t}")
+        assert np.array_equal(g[2], c[2]) and np.array_equal(g[3], c[3]), t
+        assert sorted(g[4]) == sorted(c[4])
+        for key in g[4]:
+            if not key.startswith("_") and isinstance(g[4][key], np.ndarray) and g[4][key].dtype.kind == "f":
+                np.testing.assert_allclose(g[4][key], c[4][key], rtol=0, atol=2e-8, err_msg=f"info {key} t={t}")
+        if t % 4 == 3:  # re-synchronise (contact dynamics amplify last-bit differences, like the windowed parity test does)
+            gpu.set_state(*cpu.get_state())
+    gpu.close(), cpu.close()
