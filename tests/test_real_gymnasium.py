@@ -350,8 +350,12 @@ def test_sync_semantics_property_based(oracle_factory):
     @given(env_id=st.sampled_from(CLASSIC), mode=st.sampled_from(MODES), n=st.integers(1, 9), max_steps=st.integers(1, 30), seed=st.integers(0, 2**62),
            steps=st.integers(1, 50), data=st.data())
     def run(env_id, mode, n, max_steps, seed, steps, data):
-        ours = gym.make_vec(f"MI355X/{env_id}", num_envs=n, autoreset_mode=mode, max_episode_steps=max_steps, _engine_factory=oracle_factory)
-        ref = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync", vector_kwargs={"autoreset_mode": mode}, max_episode_steps=max_steps)
+        # the scalar envs' own constructor keywords, forwarded verbatim by make_vec on both sides
+        kw = {"CartPole-v1": {"sutton_barto_reward": data.draw(st.booleans())}, "Pendulum-v1": {"g": data.draw(st.sampled_from([10.0, 9.81, 3.7]))},
+              "MountainCar-v0": {"goal_velocity": data.draw(st.sampled_from([0, 0.02]))},
+              "MountainCarContinuous-v0": {"goal_velocity": data.draw(st.sampled_from([0, 0.03]))}}.get(env_id, {})
+        ours = gym.make_vec(f"MI355X/{env_id}", num_envs=n, autoreset_mode=mode, max_episode_steps=max_steps, _engine_factory=oracle_factory, **kw)
+        ref = gym.make_vec(env_id, num_envs=n, vectorization_mode="sync", vector_kwargs={"autoreset_mode": mode}, max_episode_steps=max_steps, **kw)
         if data.draw(st.booleans()):  # a seed list with holes: the un-seeded sub-environments need a first full seeding to be comparable
             assert _same(ours.reset(seed=seed)[0], ref.reset(seed=seed)[0], env_id)
             seeds = [data.draw(st.one_of(st.none(), st.integers(0, 2**40))) for _ in range(n)]
