@@ -39,7 +39,9 @@ def test_benchmark_loop_counts_like_the_reference():
     env = ab.AsyncCartPoleVectorEnv(2)
     try:
         v = ab.benchmark_vector_step(env, target_duration=0.5, seed=0)
-        assert 1e3 < v < 1e6
+        # a rate, finite and positive, below what two Python processes could possibly step (no lower bound on the speed: under a loaded host -- the
+        # suite runs four workers wide -- two forked sub-processes have been seen at 2e2 env-steps/s; the COUNTING rule is pinned by the next test)
+        assert 0 < v < 1e6
     finally:
         env.close()
 
