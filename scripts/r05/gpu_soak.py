@@ -11,6 +11,23 @@ sys.path.insert(0, __file__.rsplit("/scripts/", 1)[0])
 import gymnasium_amd  # noqa: E402
 from oracle import oracle  # noqa: E402
 
+def same_info(x, y, ignore=("t",)):
+    """Recursive equality of info dicts: same keys, same dtypes / shapes / values (object arrays element by element); the episode clock `t` is wall time."""
+    if isinstance(x, dict) or isinstance(y, dict):
+        if not (isinstance(x, dict) and isinstance(y, dict)) or set(x) != set(y):
+            return False
+        return all(k in ignore or same_info(x[k], y[k], ignore) for k in x)
+    if hasattr(x, "cpu"):
+        x = x.cpu().numpy()
+    x, y = np.asarray(x), np.asarray(y)
+    if x.dtype != y.dtype or x.shape != y.shape:
+        return False
+    if x.dtype == object:
+        return all((a is None and b is None) or (a is not None and b is not None and np.array_equal(np.asarray(a.cpu() if hasattr(a, "cpu") else a), np.asarray(b)))
+                   for a, b in zip(x.ravel(), y.ravel()))
+    return bool(np.array_equal(x, y))
+
+
 IDS = ["CartPole-v1", "Pendulum-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0", "FrozenLake-v1", "FrozenLake8x8-v1", "CliffWalking-v1", "Taxi-v4", "Blackjack-v1"]
 
 
@@ -25,8 +42,9 @@ def main(budget_s=150.0, seed=0):
         n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, int(rng.integers(1, 5000))]))
         max_steps = int(rng.choice([1, 2, 3, 7, 20, 50]))
         use_torch = bool(rng.integers(2))
-        kw = dict(num_envs=n, autoreset_mode=mode, max_episode_steps=max_steps)
-        cfg = (env_id, mode, n, max_steps, use_torch)
+        stats = bool(rng.integers(2))
+        kw = dict(num_envs=n, autoreset_mode=mode, max_episode_steps=max_steps, record_episode_statistics=stats)
+        cfg = (env_id, mode, n, max_steps, use_torch, stats)
         gpu = gymnasium_amd.make_vec(env_id, device=0, output="torch" if use_torch else "numpy", **kw)
         cpu = gymnasium_amd.make_vec(env_id, _engine_factory=oracle.engine_factory, **kw)
         def host(x):  # device tensors (or Blackjack's tuple of them) -> NumPy
@@ -64,6 +82,8 @@ def main(budget_s=150.0, seed=0):
             g, c = gpu.step(torch.from_numpy(a).cuda() if use_torch else a), cpu.step(a)
             for j in range(4):
                 assert same(host(g[j]), c[j]), (cfg, t, j)
+            if not use_torch:  # (device-resident infos have a STATIC key set by design -- `episode` every step with its mask, batched `final_obs`: hip_vector_env.py
+                assert same_info(g[4], c[4]), (cfg, t, "infos", sorted(g[4]), sorted(c[4]))  # _build_infos_device; the NumPy dict is the reference's)
             transitions += n
             done = c[2] | c[3]
             if mode == "Disabled" and done.any():
