@@ -193,6 +193,8 @@ def oracle_check(cfg, traj):
     bit-exact kinds (classic control, ToyText); <= 256 strided sub-environments within 1e-8 for the MuJoCo kinds."""
     acts, obs, rew, te, tr = traj
     T, N = cfg.inner, cfg.N
+    if (cfg.env_kwargs or {}).get("fast_math"):  # tolerance parity by design; whole-launch equality does not apply (chaotic kinds diverge within a launch)
+        return {"ok": None, "skipped": "fast_math=True: within 1 ulp per libm call of the reference, asserted with re-synchronisation by tests/test_gpu_parity.py"}
     sp = copy.deepcopy(cfg.env.action_space)
     sp.seed(cfg.rank)
     host_acts = np.stack([sp.sample() for _ in range(T)]).reshape(acts.shape)

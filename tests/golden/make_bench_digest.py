@@ -39,21 +39,54 @@ def digest(arrays):
     return h.hexdigest()
 
 
-def main(env_id="CartPole-v1", N=65536, T=128, out_name="bench_digest.json"):
+def run_in_chunks(env_id, N, T, chunk):
+    """The same rollout for ids whose 65 536 scalar envs do not fit in memory at once (Taxi: every env builds its own 500 x 6 transition dict, ~1 MB): the
+    sub-environments are independent and sub-environment g is seeded 0 + g (sync_vector_env.py:207-208), so SyncVectorEnv over `chunk` of them at a time, reset
+    with the seed LIST [lo, lo + 1, ...] and fed the columns [lo, lo + chunk) of the actions that the FULL batched space (the same `batch_space(single, N)` object
+    SyncVectorEnv builds, seeded 0) samples, gives the rows the one big SyncVectorEnv would."""
+    from gymnasium.vector.utils import batch_space
+
+    probe = gym.make(env_id)
+    space = batch_space(probe.action_space, N)
+    probe.close()
+    space.seed(0)
+    actions = [space.sample() for _ in range(T)]
+    cols = {k: [] for k in ("obs", "rew", "te", "tr")}
     t0 = time.time()
-    env = gym.make_vec(env_id, num_envs=N, vectorization_mode="sync")
-    print(f"{N} scalar envs built in {time.time() - t0:.0f} s", flush=True)
-    env.reset(seed=0)
-    env.action_space.seed(0)
-    acts, obs, rew, te, tr = [], [], [], [], []
-    for t in range(T):
-        a = env.action_space.sample()
-        o, r, d, u, _ = env.step(a)
-        if isinstance(o, tuple):  # Blackjack: Tuple(Discrete, Discrete, Discrete) batches to a tuple of arrays; the engine's observation row is the three int64
-            o = np.stack([np.asarray(x, dtype=np.int64) for x in o], axis=-1)
-        acts.append(a.copy()), obs.append(o.copy()), rew.append(r.copy()), te.append(d.copy()), tr.append(u.copy())
-        if t % 16 == 0:
-            print(f"step {t} at {time.time() - t0:.0f} s", flush=True)
+    for lo in range(0, N, chunk):
+        env = gym.make_vec(env_id, num_envs=chunk, vectorization_mode="sync")
+        env.reset(seed=list(range(lo, lo + chunk)))
+        o_, r_, d_, u_ = [], [], [], []
+        for t in range(T):
+            o, r, d, u, _ = env.step(actions[t][lo:lo + chunk])
+            if isinstance(o, tuple):
+                o = np.stack([np.asarray(x, dtype=np.int64) for x in o], axis=-1)
+            o_.append(o.copy()), r_.append(r.copy()), d_.append(d.copy()), u_.append(u.copy())
+        env.close()
+        cols["obs"].append(np.stack(o_)), cols["rew"].append(np.stack(r_)), cols["te"].append(np.stack(d_)), cols["tr"].append(np.stack(u_))
+        print(f"sub-environments {lo}..{lo + chunk - 1} at {time.time() - t0:.0f} s", flush=True)
+    return [a.copy() for a in actions], list(np.concatenate(cols["obs"], axis=1)), list(np.concatenate(cols["rew"], axis=1)), list(np.concatenate(cols["te"], axis=1)), \
+        list(np.concatenate(cols["tr"], axis=1))
+
+
+def main(env_id="CartPole-v1", N=65536, T=128, out_name="bench_digest.json", chunk=None):
+    t0 = time.time()
+    if chunk:
+        acts, obs, rew, te, tr = run_in_chunks(env_id, N, T, chunk)
+    else:
+        env = gym.make_vec(env_id, num_envs=N, vectorization_mode="sync")
+        print(f"{N} scalar envs built in {time.time() - t0:.0f} s", flush=True)
+        env.reset(seed=0)
+        env.action_space.seed(0)
+        acts, obs, rew, te, tr = [], [], [], [], []
+        for t in range(T):
+            a = env.action_space.sample()
+            o, r, d, u, _ = env.step(a)
+            if isinstance(o, tuple):  # Blackjack: Tuple(Discrete, Discrete, Discrete) batches to a tuple of arrays; the engine's observation row is the three int64
+                o = np.stack([np.asarray(x, dtype=np.int64) for x in o], axis=-1)
+            acts.append(a.copy()), obs.append(o.copy()), rew.append(r.copy()), te.append(d.copy()), tr.append(u.copy())
+            if t % 16 == 0:
+                print(f"step {t} at {time.time() - t0:.0f} s", flush=True)
     traj = tuple(np.stack(x) for x in (acts, obs, rew, te, tr))
     assert traj[0].dtype in (np.int64, np.float32) and traj[1].dtype in (np.float32, np.int64) and traj[2].dtype == np.float64 and traj[3].dtype == np.bool_ and traj[4].dtype == np.bool_
     out = {"what": f"gymnasium {gym.__version__} make_vec({env_id!r}, {N}, 'sync'), reset(seed=0), action_space.seed(0), {T} x step(sample()); "
@@ -76,7 +109,7 @@ def main(env_id="CartPole-v1", N=65536, T=128, out_name="bench_digest.json"):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:  # python make_bench_digest.py Pendulum-v1 -> bench_digest_configs2.json (BASELINE.json configs[2]: ~5-10 minutes per id, one at a time)
-        main(sys.argv[1], out_name="bench_digest_configs2.json")
+    if len(sys.argv) > 1:  # python make_bench_digest.py Pendulum-v1 [chunk] -> bench_digest_configs2.json (BASELINE.json configs[2]: ~5-10 minutes per id, one at a time)
+        main(sys.argv[1], out_name="bench_digest_configs2.json", chunk=int(sys.argv[2]) if len(sys.argv) > 2 else None)
     else:
         main()
