@@ -564,7 +564,7 @@ def main(argv=None, harness=None):
                        "parallelism": f"env-sharded x{world} (no data-path collective)"},
             "roofline": cfg.roofline(kernel_s, live=single and args.pmc != "off"),
             "cpu_baseline": None,
-            "output_sha256": digest, "verified": verified, "verified_all_ranks": (all(v is True for v in all_ok) if not args.no_verify else None),
+            "output_sha256": digest, "verified": verified, "verified_all_ranks": (None if args.no_verify else (False if any(v is False for v in all_ok) else (True if all(v is True for v in all_ok) else None))),
             "rccl_ranks": ranks_seen, "world_size_env": world, "distinct_devices": cen["distinct_devices"],
             "devices": [{k: d.get(k) for k in ("rank", "uuid", "output_sha256", "verified")} for d in cen["devices"]],
             "episodes": episodes, "mean_episode_return": (return_sum / episodes) if episodes else None,
