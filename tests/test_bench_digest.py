@@ -29,13 +29,13 @@ def test_oracle_reproduces_the_reference_digest_at_configs1_shape():
     assert bench.trajectory_digest(traj) == g[KEY]
 
 
-@pytest.mark.parametrize("env_id", ["Pendulum-v1", "Acrobot-v1", "MountainCarContinuous-v0", "MountainCar-v0", "FrozenLake-v1", "FrozenLake8x8-v1", "CliffWalking-v1", "Blackjack-v1"])
+@pytest.mark.parametrize("env_id", ["Pendulum-v1", "Acrobot-v1", "MountainCarContinuous-v0", "MountainCar-v0", "FrozenLake-v1", "FrozenLake8x8-v1", "CliffWalking-v1", "Taxi-v4", "Blackjack-v1"])
 def test_oracle_reproduces_the_reference_digest_at_configs2_shape(env_id):
     """BASELINE.json configs[2] at its exact shape (65 536 sub-environments, 128 steps): the digest of the reference's own SyncVectorEnv rollout
     (tests/golden/make_bench_digest.py <id>) from the oracle -- whole episodes of Pendulum (200-step TimeLimit not reached: 128 steps), the chaotic Acrobot
     and MountainCarContinuous's float32 / float64 mixed arithmetic, every byte of 8.4 M env-steps each -- and, at the same shape, two ToyText kinds
-    (bit-exact integer kernels; Blackjack's Tuple observation as three int64 columns; Taxi is left out: 65 536 scalar Taxi envs each
-    build their own 500 x 6 transition dict, half an hour in the reference)."""
+    (bit-exact integer kernels; Blackjack's Tuple observation as three int64 columns; Taxi's reference rollout was computed 2 048 sub-environments at a time:
+    65 536 scalar Taxi envs with their own 500 x 6 transition dicts do not fit in memory at once, tests/golden/make_bench_digest.py run_in_chunks)."""
     g = json.load(open(os.path.join(GOLDEN, "bench_digest_configs2.json")))
     key = f"{env_id}:65536:128:rank0"
     if key not in g:
