@@ -19,7 +19,7 @@ FLAG_NEEDS_RESET, FLAG_STATE_F32 = 1, 2
 CFG_SOLVER_NEWTON = 1  # MI_CFG_SOLVER_NEWTON
 CFG_FAST_MATH = 2  # MI_CFG_FAST_MATH (classic control: device sin / cos and x * x instead of the libm restatements)
 CFG_SHARED_RNG = 4  # MI_CFG_SHARED_RNG (CartPole: the reference's CartPoleVectorEnv semantics -- one generator for all sub-environments)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ENV_KINDS = {"cartpole": 0, "pendulum": 1, "acrobot": 2, "mountain_car": 3, "mountain_car_continuous": 4,
              "half_cheetah": 5, "ant": 6, "humanoid": 7, "tabular": 8,
@@ -31,7 +31,7 @@ NP_DTYPES = {MI_F32: np.float32, MI_F64: np.float64, MI_I64: np.int64}
 SYMBOLS = [
     "abi_version", "last_error", "device_count", "create", "destroy", "get_layout", "set_stream", "synchronize",
     "seed", "seed_sequence", "reset", "step", "action_seed", "rollout", "get_stats", "reset_stats", "get_state",
-    "set_state", "get_rng", "tabular_load",
+    "set_state", "get_rng", "tabular_load", "action_sample", "action_get", "action_skip",
 ]
 
 
@@ -56,7 +56,8 @@ class MiStepIO(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
                 ("truncated", C.c_void_p), ("final_obs", C.c_void_p), ("episode_return", C.c_void_p),
                 ("episode_length", C.c_void_p), ("info", C.c_void_p), ("final_info", C.c_void_p),
-                ("actions_dtype", C.c_int32), ("reserved", C.c_int32)]  # actions_dtype: MI_F32 (default) / MI_F64 rows of a Box action space
+                ("actions_dtype", C.c_int32), ("reserved", C.c_int32),  # actions_dtype: MI_F32 (default) / MI_F64 rows of a Box action space
+                ("actions_out", C.c_void_p)]  # ABI 7: with actions == NULL (the on-device policy) where the drawn actions go, or NULL
 
 
 class MiRolloutIO(C.Structure):
@@ -125,6 +126,9 @@ class NativeLib:
         self.set_state = f("set_state", [vp, vp, vp, vp], i32)
         self.get_rng = f("get_rng", [vp, vp], i32)
         self.tabular_load = f("tabular_load", [vp, C.POINTER(MiTabularTable)], i32)
+        self.action_sample = f("action_sample", [vp, i32, vp, i32], i32)
+        self.action_get = f("action_get", [vp, vp], i32)
+        self.action_skip = f("action_skip", [vp, C.c_int64], i32)
         if self.abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {self.abi_version()} != binding version {ABI_VERSION}")
         if prefix == "mi_":
@@ -255,9 +259,9 @@ class Engine:
         self.lib.check(self.lib.reset(self.handle, _ptr(mask), _ptr(b), _ptr(obs), loc))
 
     def step(self, actions, obs, reward, terminated, truncated, final_obs=None, episode_return=None,
-             episode_length=None, loc=MI_HOST, info=None, final_info=None, actions_dtype=MI_F32):
+             episode_length=None, loc=MI_HOST, info=None, final_info=None, actions_dtype=MI_F32, actions_out=None):
         io = self._step_io
-        io.final_info, io.actions_dtype = _ptr(final_info), int(actions_dtype)
+        io.final_info, io.actions_dtype, io.actions_out = _ptr(final_info), int(actions_dtype), _ptr(actions_out)
         io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
         io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
         io.episode_return, io.episode_length, io.info = _ptr(episode_return), _ptr(episode_length), _ptr(info)
@@ -272,17 +276,18 @@ class Engine:
         io.episode_return, io.episode_length, io.info, io.final_info = _ptr(episode_return), _ptr(episode_length), _ptr(info), _ptr(final_info)
         self._bound = (io, C.byref(io), int(loc), self.lib.step, self.handle)
 
-    def step_bound(self, actions: int, actions_dtype: int):
-        """mi_step into the buffers of bind_step(); `actions` is a raw address."""
+    def step_bound(self, actions: "int | None", actions_dtype: int, actions_out: "int | None" = None):
+        """mi_step into the buffers of bind_step(); `actions` is a raw address, or None: the on-device policy (the step kernel draws
+        action_space.sample() from the action stream; `actions_out`: where the drawn batch goes, or None)."""
         io, ref, loc, fn, handle = self._bound
-        io.actions, io.actions_dtype = actions, actions_dtype
+        io.actions, io.actions_dtype, io.actions_out = actions, actions_dtype, actions_out
         rc = fn(handle, ref, loc)
         if rc:
             self.lib.check(rc)
 
     def _fill_io(self, actions, obs, reward, terminated, truncated, final_obs, episode_return, episode_length, info, final_info, actions_dtype=MI_F32):
         io = self._step_io
-        io.actions_dtype = int(actions_dtype)
+        io.actions_dtype, io.actions_out = int(actions_dtype), None
         io.actions, io.obs, io.reward = _ptr(actions), _ptr(obs), _ptr(reward)
         io.terminated, io.truncated, io.final_obs = _ptr(terminated), _ptr(truncated), _ptr(final_obs)
         io.episode_return, io.episode_length, io.info, io.final_info = _ptr(episode_return), _ptr(episode_length), _ptr(info), _ptr(final_info)
@@ -325,6 +330,19 @@ class Engine:
     def action_seed(self, words):
         w = np.ascontiguousarray(words, dtype=np.uint64)
         self.lib.check(self.lib.action_seed(self.handle, _ptr(w)))
+
+    def action_sample(self, T: int, out, loc=MI_HOST):
+        """The next T batches of action_space.sample() into out[T][N][act_dim] (mi_action_sample); T = 0 prepares the per-lane stream states."""
+        self.lib.check(self.lib.action_sample(self.handle, int(T), _ptr(out), loc))
+
+    def action_get(self) -> np.ndarray:
+        """{state_hi, state_lo, inc_hi, inc_lo} of the generator that produces the action stream's next draw (mi_action_get)."""
+        w = np.empty(4, dtype=np.uint64)
+        self.lib.check(self.lib.action_get(self.handle, _ptr(w)))
+        return w
+
+    def action_skip(self, draws: int):
+        self.lib.check(self.lib.action_skip(self.handle, int(draws)))
 
     def rollout(self, T, actions_in=None, actions_out=None, obs=None, reward=None, terminated=None, truncated=None, actions_in_dtype=MI_F32):
         io = self._rollout_io

@@ -125,19 +125,24 @@ struct LaneRequest {
     uint32_t meta;
     int32_t ep_len;
     uint64_t g[4];
+    uint64_t ag[2];  // SAMPLE: the lane's state of the action stream (mi_step with actions == NULL)
     typename E::Act a;
-    MI_DEV void request(const DevEnv &d, const void *actions, int i, bool with_generator) {
+    template <bool SAMPLE>
+    MI_DEV void request(const DevEnv &d, const void *actions, const uint64_t *act_lane, int i, bool with_generator) {
 #pragma unroll
         for (int k = 0; k < E::S; k++) s[k] = d.state[(size_t)k * d.N + i];
         meta = d.meta[i], ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
-        a = static_cast<const typename E::Act *>(actions)[i];
+        if constexpr (SAMPLE)
+            ag[0] = act_lane[i], ag[1] = act_lane[(size_t)d.N + i], a = (typename E::Act)0;
+        else
+            ag[0] = ag[1] = 0, a = static_cast<const typename E::Act *>(actions)[i];
 #pragma unroll
         for (int k = 0; k < 4; k++) g[k] = with_generator ? d.rng[(size_t)k * d.N + i] : 0;
     }
     MI_DEV void arrive(Lane<E> &L, Pcg64 &gen) {
 #pragma unroll
         for (int k = 0; k < E::S; k++) hold_opaque(s[k]), L.s[k] = s[k];
-        hold_opaque(meta), hold_opaque(ep_ret), hold_opaque(ep_len), hold_opaque(a);
+        hold_opaque(meta), hold_opaque(ep_ret), hold_opaque(ep_len), hold_opaque(a), hold_opaque(ag[0]), hold_opaque(ag[1]);
 #pragma unroll
         for (int k = 0; k < 4; k++) hold_opaque(g[k]);
         L.elapsed = meta & kElapsedMask, L.flags = meta >> kFlagShift;
@@ -657,11 +662,27 @@ struct StepPtrs {
     float *final_obs;
     double *ep_ret;
     int32_t *ep_len;
+    // the on-device policy (mi_step with actions == NULL): per-lane states of the action stream [2][N] (lane i: the state whose output is draw
+    // pos + i * act_dim), where the drawn actions go (or nullptr), and the jump to the lane's slot in the next batch (N * act_dim draws on)
+    uint64_t *act_lane;
+    void *actions_out;
+    PcgJump act_jump;
 };
 }  // namespace mi_internal
 namespace {
 
-template <class E, int MODE, bool EPI = false>
+// XSL-RR output of a PCG64 state (the state AFTER its step: what the action-stream lanes hold)
+MI_DEV uint64_t pcg_output(u128 state) {
+    const uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(hi >> 58);
+    return (x >> rot) | (x << ((0u - rot) & 63u));
+}
+
+// SAMPLE: mi_step with actions == NULL -- `step(action_space.sample())` in one launch: the lane draws its own action from its state of the action
+// stream (spaces/multi_discrete.py:176-178, spaces/box.py:463-465: draw number pos + i of the batched space's generator), which rides along with the
+// lane's other loads, and leaves the state of its draw in the NEXT batch behind.  Nothing on the host changes from step to step: capturable.
+template <class E, int MODE, bool EPI = false, bool SAMPLE = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, EpiDev epi) {
     // One step is ~200 instructions per lane between trips to memory that take a microsecond each: everything the step may read -- the lane's
     // state and action, its generator (consumed only by a reset, which some lane of a 64-CartPole wavefront needs on ~95 % of the steps) and the
@@ -670,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, Epi
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     StepOut<E> o;
     LaneRequest<E> rq;
-    if (i < d.N) rq.request(d, io.actions, i, MODE != MI_AUTORESET_DISABLED);
+    if (i < d.N) rq.template request<SAMPLE>(d, io.actions, io.act_lane, i, MODE != MI_AUTORESET_DISABLED);
     BlockTotals before = block_totals_load(d);
     tables_init<E>();
     hold_opaque(before.count), hold_opaque(before.ret);
@@ -678,7 +699,15 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, Epi
         Lane<E> L;
         Pcg64 gen;
         rq.arrive(L, gen);
-        const typename E::Act a = rq.a;
+        typename E::Act a = rq.a;
+        if constexpr (SAMPLE) {
+            const u128 astate = make_u128(rq.ag[0], rq.ag[1]);
+            const uint64_t bits = pcg_output(astate);
+            a = E::SAMPLE_FROM_BITS ? E::sample_bits(bits) : E::sample((double)(bits >> 11) * (1.0 / 9007199254740992.0));
+            const u128 next = io.act_jump.mult * astate + io.act_jump.plus;
+            io.act_lane[i] = (uint64_t)(next >> 64), io.act_lane[(size_t)d.N + i] = (uint64_t)next;
+            if (io.actions_out) static_cast<typename E::Act *>(io.actions_out)[i] = a;
+        }
         lane_step<E, MODE>(d, i, L, a, o, st, nullptr, MODE != MI_AUTORESET_DISABLED ? &gen : nullptr);
         store_lane<E>(d, i, L);
         if (io.obs) store_row<E::OBS>(io.obs + (size_t)i * E::OBS, o.obs);
@@ -1677,8 +1706,11 @@ struct TabStepPtrs {
     double *ep_ret;
     int32_t *ep_len;
     double *info, *final_info;
+    uint64_t *act_lane;  // SAMPLE (mi_step with actions == NULL): as StepPtrs
+    int64_t *actions_out;
+    PcgJump act_jump;
 };
-template <int MODE>
+template <int MODE, bool SAMPLE = false>
 __global__ __launch_bounds__(kBlock) void tab_step_kernel(DevEnv d, TabStepPtrs io) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
@@ -1690,7 +1722,17 @@ __global__ __launch_bounds__(kBlock) void tab_step_kernel(DevEnv d, TabStepPtrs 
         int32_t out_len;
         bool te, tr, has_final;
         double fin_prob = 0.0;
-        tab_lane_step<MODE>(d, i, L, io.actions[i], obs, fin, has_final, reward, te, tr, out_ret, out_len, st, nullptr, &fin_prob);
+        int64_t a;
+        if constexpr (SAMPLE) {  // (random(N) * nvec).astype(int64): draw pos + i of the batched MultiDiscrete's generator (spaces/multi_discrete.py:176-178)
+            const u128 astate = make_u128(io.act_lane[i], io.act_lane[(size_t)d.N + i]);
+            a = (int64_t)((double)(pcg_output(astate) >> 11) * (1.0 / 9007199254740992.0) * (double)d.tab.nA);
+            const u128 next = io.act_jump.mult * astate + io.act_jump.plus;
+            io.act_lane[i] = (uint64_t)(next >> 64), io.act_lane[(size_t)d.N + i] = (uint64_t)next;
+            if (io.actions_out) io.actions_out[i] = a;
+        } else {
+            a = io.actions[i];
+        }
+        tab_lane_step<MODE>(d, i, L, a, obs, fin, has_final, reward, te, tr, out_ret, out_len, st, nullptr, &fin_prob);
         tab_store(d, i, L);
         if (io.obs) tab_write_obs(d, (double)obs, io.obs, (size_t)i);
         if (io.reward) io.reward[i] = reward;
@@ -1714,14 +1756,17 @@ __global__ __launch_bounds__(kBlock) void tab_reset_kernel(DevEnv d, const uint8
     tab_store(d, i, L);
     if (obs) tab_write_obs(d, L.s, obs, (size_t)i);
 }
-template <int MODE, bool SAMPLE>
+template <int MODE, bool SAMPLE, bool LDS>
 __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int lds_bytes) {
     // The transition table is read once per env-step through three levels of dependent loads (count / cumulative probabilities -> branch
     // -> successor, reward, flag); out of L2 that latency is the whole step (Taxi: 100 KB of tables).  When the launcher found that the
-    // table fits (lds_bytes > 0) the workgroup first copies it into LDS -- layout: the f64 arrays, then the i32 arrays, then the flags --
+    // table fits (LDS) the workgroup first copies it into LDS -- layout: the f64 arrays, then the i32 arrays, then the flags --
     // and every lookup of the T steps is a 64-cycle LDS read instead.
+    // LDS is a TEMPLATE parameter (round 6): chosen at run time, the table pointers were generic, the lookups FLAT loads -- 9 per env-step
+    // (profiles/r06_frozenlake_rollout.txt: SQ_INSTS_VMEM_RD 1.19e6 per launch against 5e4 LDS instructions) -- and a flat load shares the
+    // in-order vmcnt with the trajectory stores: every lookup waited for the stores before it to reach memory.
     extern __shared__ double tab_lds[];
-    if (lds_bytes > 0) {
+    if constexpr (LDS) {
         const size_t cells = (size_t)d.tab.nS * d.tab.nA, rows = cells * d.tab.K;
         double *cs = tab_lds, *pr = cs + rows, *rw = pr + rows, *isd = rw + rows;
         int32_t *nx = reinterpret_cast<int32_t *>(isd + d.tab.nS), *cnt = nx + rows;
@@ -1797,6 +1842,49 @@ __global__ void seed_sequence_kernel(DevEnv d, uint64_t first_seed, const uint8_
     if (d.tab_fickle_rows) d.state[(size_t)2 * d.N + i] = 0.0;  // fickle Taxi: likewise
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The action stream as per-lane states (mi_step with actions == NULL, mi_action_sample): `action_space.sample()` of the BATCHED space is one
+// generator drawn in sub-environment order (spaces/multi_discrete.py:176-178 `random(nvec.shape) * nvec`, spaces/box.py:463-465 `uniform(low, high,
+// size)` over (N, act_dim) row-major), so lane i owns draws pos + i * D + u of every batch.  act_lane[2][N] holds, per lane, the state whose output IS
+// its next draw; a batch later the lane is N * D draws further on (jump).  Kept on the device, the stream needs nothing from the host between
+// steps: a captured HIP graph replays sampled steps, and a loop of step(sample()) enqueues no host-to-device traffic.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void act_init_kernel(ActionStream as, uint64_t *act_lane, int N, int D) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    u128 s = make_u128(as.state_hi, as.state_lo);
+    uint64_t delta = (uint64_t)i * (uint64_t)D + 1ull;  // skip ahead: one affine map per set bit
+    for (int j = 0; delta; j++, delta >>= 1)
+        if (delta & 1ull) s = as.pow2[j].mult * s + as.pow2[j].plus;
+    act_lane[i] = (uint64_t)(s >> 64), act_lane[(size_t)N + i] = (uint64_t)s;
+}
+// what a draw becomes: Discrete (n > 0): (u * n).astype(int64); Box: uniform(low[u], high[u]).astype(float32) with the space's float32 bounds
+struct ActSpec {
+    int D;           // act_dim
+    double n;        // number of actions of a Discrete sub-space, 0 for Box
+    double lo[24], range[24];
+};
+// T batches: out[t][i][u]; one launch (a host class hands them out one batch per sample() call)
+__global__ __launch_bounds__(kBlock) void act_sample_kernel(ActSpec sp, ActionStream as, uint64_t *act_lane, void *out, int T, int N) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const u128 inc = make_u128(as.inc_hi, as.inc_lo);
+    u128 s = make_u128(act_lane[i], act_lane[(size_t)N + i]);
+    for (int t = 0; t < T; t++) {
+        const size_t row = ((size_t)t * N + i) * sp.D;
+        for (int u = 0; u < sp.D; u++) {
+            const double x = (double)(pcg_output(s) >> 11) * (1.0 / 9007199254740992.0);
+            if (sp.n > 0)
+                static_cast<int64_t *>(out)[row + u] = (int64_t)(x * sp.n);
+            else
+                static_cast<float *>(out)[row + u] = (float)(sp.lo[u] + sp.range[u] * x);
+            if (u + 1 < sp.D) s = s * pcg_mult() + inc;
+        }
+        s = as.jump_n.mult * s + as.jump_n.plus;
+    }
+    act_lane[i] = (uint64_t)(s >> 64), act_lane[(size_t)N + i] = (uint64_t)s;
+}
+
 #endif  // !MI_CLASSIC_TU
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1861,6 +1949,12 @@ struct mi_vecenv {
     Pcg64 act_rng;          // host copy of the action-space generator
     PcgJump *d_pow2;        // [64] device jump table for act_rng.inc
     PcgJump jump_n;
+    // the action stream as per-lane states on the device (act_sample_kernel): act_lane_valid = they correspond to the stream's position;
+    // act_on_device = they ARE the position (the host copy act_rng is stale until act_sync_host reads lane 0 back)
+    uint64_t *d_act_lane;   // [2][N]
+    bool act_lane_valid, act_on_device;
+    void *d_act_stage;      // mi_action_sample(MI_HOST): where the kernel writes before the copy to the caller's array
+    size_t act_stage_bytes;
     // Staging for the MI_HOST entry points (SURVEY 8(b) "Ownership"): every step output lives in ONE device block and ONE pinned host
     // block of the same layout -- [error word | obs | reward | terminated | truncated | info | episode_return | episode_length | final_obs |
     // final_info], 256-byte aligned sections -- so a host step is one H2D (actions), one launch and one D2H of the prefix in use.
@@ -2005,19 +2099,28 @@ void epilogue_swap(mi_vecenv *v) {
     if (v->epi.ret_on && v->epi.ret_update) swap(v->epi_host.return_rms);
 }
 
-template <class E, bool EPI>
+template <class E, bool EPI, bool SAMPLE = false>
 void launch_step_mode(mi_vecenv *v, const StepPtrs &p) {
     const dim3 g(v->grid), b(kBlock);
     switch (v->cfg.autoreset_mode) {
-    case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_NEXT_STEP, EPI>), g, b, 0, v->stream, v->d, p, v->epi); break;
-    case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_SAME_STEP, EPI>), g, b, 0, v->stream, v->d, p, v->epi); break;
-    default: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_DISABLED, EPI>), g, b, 0, v->stream, v->d, p, v->epi); break;
+    case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_NEXT_STEP, EPI, SAMPLE>), g, b, 0, v->stream, v->d, p, v->epi); break;
+    case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_SAME_STEP, EPI, SAMPLE>), g, b, 0, v->stream, v->d, p, v->epi); break;
+    default: hipLaunchKernelGGL((step_kernel<E, MI_AUTORESET_DISABLED, EPI, SAMPLE>), g, b, 0, v->stream, v->d, p, v->epi); break;
     }
 }
 template <class E>
 int launch_step(mi_vecenv *v, const StepPtrs &p) {
     if (!v->has_epi) {
-        launch_step_mode<E, false>(v, p);
+        // the on-device policy draws the space's own dtype (float32 rows / int64): the float64-row instantiations never sample (the caller, step_enqueue,
+        // sends a wrapped step that samples through the stand-alone sampler + this kernel with p.actions set instead)
+        if constexpr (E::ACT_KIND == MI_F32 || E::ACT_KIND == MI_I64) {
+            if (p.act_lane)
+                launch_step_mode<E, false, true>(v, p);
+            else
+                launch_step_mode<E, false>(v, p);
+        } else {
+            launch_step_mode<E, false>(v, p);
+        }
     } else {
         if (!p.obs || !p.reward || !p.terminated || !p.truncated) return fail(MI_ERR_INVALID_ARGUMENT, "a step with an epilogue needs obs, reward, terminated and truncated");
         epilogue_bind(v);
@@ -2332,6 +2435,7 @@ static int create_buffers(mi_vecenv *v, const mi_config *cfg, int device) {
     HIP_TRY(hipMalloc(&d.blk_count, sizeof(uint64_t) * 4 * v->grid));
     HIP_TRY(hipMalloc(&d.blk_ret, sizeof(double) * v->grid));
     HIP_TRY(hipMalloc(&v->d_pow2, sizeof(PcgJump) * 64));
+    HIP_TRY(hipMalloc(&v->d_act_lane, sizeof(uint64_t) * 2 * N));
     v->shared_rng = (cfg->reserved[0] & MI_CFG_SHARED_RNG) != 0;
     if (v->shared_rng) {
         HIP_TRY(hipMalloc(&v->shared.words, sizeof(uint64_t) * 8));
@@ -2398,7 +2502,7 @@ void mi_destroy(mi_vecenv *v) {
     (void)hipSetDevice(v->device);
     (void)hipStreamSynchronize(v->stream);
     void *ptrs[] = {v->d.state, v->d.meta, v->d.rng, v->d.ep_ret, v->d.ep_len, v->d.blk_count, v->d.blk_ret, v->d_out,
-                    v->d_pow2, v->d_actions, v->d_mask, v->d_words, v->d_extras, v->d_act_scratch, v->d_obs_scratch,
+                    v->d_pow2, v->d_act_lane, v->d_act_stage, v->d_actions, v->d_mask, v->d_words, v->d_extras, v->d_act_scratch, v->d_obs_scratch,
                     v->shared.words, v->d_shared_pow2, v->shared.blk_done, v->shared.blk_prefix};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -2610,13 +2714,88 @@ int mi_reset(mi_vecenv *v, const uint8_t *mask, const double *bounds, void *obs,
 // the address, as the device sees it, of the place in the page-locked block that mirrors `device_ptr` of the device block
 static void *pinned(const mi_vecenv *v, const void *device_ptr) { return v->h_out_dev + ((const char *)device_ptr - v->d_out); }
 
+// ---- the action stream's position: host copy (act_rng) <-> per-lane device states (d_act_lane) ------------------------------------------------
+static ActionStream action_stream(const mi_vecenv *v) {
+    ActionStream as;
+    memset(&as, 0, sizeof as);
+    as.state_hi = (uint64_t)(v->act_rng.state >> 64), as.state_lo = (uint64_t)v->act_rng.state;
+    as.inc_hi = (uint64_t)(v->act_rng.inc >> 64), as.inc_lo = (uint64_t)v->act_rng.inc;
+    as.pow2 = v->d_pow2, as.jump_n = v->jump_n;
+    return as;
+}
+// bring the host copy up to date: lane 0's state is the position stepped once (the state whose output is the next draw)
+static int action_sync_host(mi_vecenv *v) {
+    if (!v->act_on_device) return MI_OK;
+    uint64_t w[2];
+    HIP_TRY(hipMemcpyAsync(&w[0], v->d_act_lane, sizeof(uint64_t), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(&w[1], v->d_act_lane + (size_t)v->cfg.num_envs, sizeof(uint64_t), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    Pcg64 g;
+    g.state = make_u128(w[0], w[1]), g.inc = v->act_rng.inc;
+    g.unstep();
+    v->act_rng.state = g.state;
+    v->act_on_device = false;
+    return MI_OK;
+}
+// per-lane states for the host copy's position (skip-ahead by i * act_dim + 1 draws per lane); a no-op while they are current
+static int action_prepare_lanes(mi_vecenv *v) {
+    if (v->act_lane_valid) return MI_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (v->stream && hipStreamIsCapturing(v->stream, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    if (cap != hipStreamCaptureStatusNone)
+        return fail(MI_ERR_STATE, "the on-device policy's lane states must exist before a stream capture: call mi_action_sample(env, 0, NULL, MI_DEVICE) first");
+    hipLaunchKernelGGL(act_init_kernel, dim3(v->grid), dim3(kBlock), 0, v->stream, action_stream(v), v->d_act_lane, v->cfg.num_envs, v->lay.act_dim);
+    HIP_TRY(hipGetLastError());
+    v->act_lane_valid = true;
+    return MI_OK;
+}
+static int action_spec(const mi_vecenv *v, ActSpec *sp) {
+    memset(sp, 0, sizeof *sp);
+    sp->D = v->lay.act_dim;
+    if (sp->D > 24) return fail(MI_ERR_UNSUPPORTED, "action rows wider than 24");
+    const int kind = v->cfg.kind;
+    if (is_tab(kind))
+        sp->n = (double)v->d.tab.nA;
+    else if (kind < kClassicKinds && kNumActions[kind])
+        sp->n = (double)kNumActions[kind];
+    else if (kind == MI_ENV_PENDULUM)
+        sp->lo[0] = -2.0, sp->range[0] = 2.0 - (-2.0);  // Box(-max_torque, max_torque) (pendulum.py:112-114)
+    else if (kind == MI_ENV_MOUNTAIN_CAR_CONTINUOUS)
+        sp->lo[0] = -1.0, sp->range[0] = 1.0 - (-1.0);  // Box(min_action, max_action) (continuous_mountain_car.py:137-139)
+    else
+        return dispatch_mj(kind, [&](auto env) -> int {  // Box(low, high, (nu,), float32) from the float32 ctrlrange (mujoco_env.py:113-117)
+            using E = decltype(env);
+            for (int u = 0; u < E::NU; u++) {
+                const double lo = (double)(float)E::Model::actuator_ctrlrange[u][0], hi = (double)(float)E::Model::actuator_ctrlrange[u][1];
+                sp->lo[u] = lo, sp->range[u] = hi - lo;
+            }
+            return (int)MI_OK;
+        });
+    return MI_OK;
+}
+// T batches of action_space.sample() into `dst` (device), from the lane states
+static int action_sample_device(mi_vecenv *v, int T, void *dst) {
+    ActSpec sp;
+    if (int rc = action_spec(v, &sp)) return rc;
+    if (int rc = action_prepare_lanes(v)) return rc;
+    hipLaunchKernelGGL(act_sample_kernel, dim3(v->grid), dim3(kBlock), 0, v->stream, sp, action_stream(v), v->d_act_lane, dst, T, v->cfg.num_envs);
+    HIP_TRY(hipGetLastError());
+    v->act_on_device = true;
+    return MI_OK;
+}
+
 // Enqueue one vector step.  loc == MI_HOST: actions go through the pinned staging block (one H2D), the kernel writes the device output
 // block, and ONE D2H brings back the prefix of it that the caller asked for -- or, for the classic kinds, the kernel works on the pinned block
 // directly and there is no copy at all; nothing is synchronised here.
 static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     if (!v || !io) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     if (!v->was_reset) return fail(MI_ERR_STATE, "step before reset");
-    if (!io->actions) return fail(MI_ERR_INVALID_ARGUMENT, "actions is NULL");
+    const bool sample = io->actions == nullptr;  // the on-device policy: step(action_space.sample()) without the host
+    if (sample && loc != MI_DEVICE) return fail(MI_ERR_INVALID_ARGUMENT, "actions is NULL (the on-device policy steps device buffers: loc == MI_DEVICE; host callers draw batches with mi_action_sample)");
+    if (sample && !v->act_seeded) return fail(MI_ERR_STATE, "a step without actions needs mi_action_seed");
     if (v->has_pending) return fail(MI_ERR_STATE, "mi_step_async: the previous asynchronous step has not been waited for (mi_step_wait)");
     if (set_device(v)) return MI_ERR_HIP;
     // Device callers are asynchronous: an action outside the space (or a finished sub-environment stepped under DISABLED) is recorded by the
@@ -2628,10 +2807,14 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     const bool box = v->lay.act_dtype == MI_F32;
     if (box && io->actions_dtype != MI_F32 && io->actions_dtype != MI_F64 && io->actions_dtype != MI_F64_WEAK)
         return fail(MI_ERR_INVALID_ARGUMENT, "actions_dtype must be MI_F32, MI_F64 or MI_F64_WEAK");
-    const int act_kind = box ? io->actions_dtype : (int)MI_F32;
+    const int act_kind = (box && !sample) ? io->actions_dtype : (int)MI_F32;
     const size_t act_bytes = act_kind == MI_F32 ? v->act_bytes : v->act_bytes_max;
     StepPtrs p;
+    memset(&p, 0, sizeof p);
     bool zc = false;
+    // classic control (without a wrapper epilogue) and ToyText draw inside their step kernel; every other configuration runs the stand-alone
+    // sampler first and steps on what it wrote
+    const bool fused_sample = sample && !is_mj(v->cfg.kind) && !v->shared_rng && !v->has_epi;
     if (loc == MI_HOST) {
         // validate before anything is mutated (cartpole.py:165-167 asserts action_space.contains(action))
         const int na = is_tab(v->cfg.kind) ? v->d.tab.nA : kNumActions[v->cfg.kind];
@@ -2668,6 +2851,15 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
         p.actions = io->actions;
         p.obs = (float *)io->obs, p.reward = io->reward, p.terminated = io->terminated, p.truncated = io->truncated;
         p.final_obs = (float *)io->final_obs, p.ep_ret = io->episode_return, p.ep_len = io->episode_length;
+        if (fused_sample) {
+            if (int rc = action_prepare_lanes(v)) return rc;
+            p.act_lane = v->d_act_lane, p.actions_out = io->actions_out, p.act_jump = v->jump_n;
+            v->act_on_device = true;
+        } else if (sample) {
+            void *dst = io->actions_out ? io->actions_out : (is_mj(v->cfg.kind) ? (void *)v->d_act_scratch : v->d_actions);
+            if (int rc = action_sample_device(v, 1, dst)) return rc;
+            p.actions = dst;
+        }
     }
     double *dinfo = loc == MI_HOST ? (io->info ? v->d_info : nullptr) : io->info;
     double *dfinfo = loc == MI_HOST ? (io->final_info ? v->d_final_info : nullptr) : io->final_info;
@@ -2675,8 +2867,15 @@ static int step_enqueue(mi_vecenv *v, const mi_step_io *io, int loc) {
     int rc;
     if (is_tab(v->cfg.kind)) {
         const TabStepPtrs tp = {(const int64_t *)p.actions, (int64_t *)p.obs, p.reward, p.terminated, p.truncated, (int64_t *)p.final_obs,
-                                p.ep_ret, p.ep_len, dinfo, dfinfo};
+                                p.ep_ret, p.ep_len, dinfo, dfinfo, p.act_lane, (int64_t *)p.actions_out, p.act_jump};
         const dim3 g(v->grid), b(kBlock);
+        if (fused_sample) {
+            switch (v->cfg.autoreset_mode) {
+            case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_NEXT_STEP, true>), g, b, 0, v->stream, v->d, tp); break;
+            case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_SAME_STEP, true>), g, b, 0, v->stream, v->d, tp); break;
+            default: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_DISABLED, true>), g, b, 0, v->stream, v->d, tp); break;
+            }
+        } else
         switch (v->cfg.autoreset_mode) {
         case MI_AUTORESET_NEXT_STEP: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_NEXT_STEP>), g, b, 0, v->stream, v->d, tp); break;
         case MI_AUTORESET_SAME_STEP: hipLaunchKernelGGL((tab_step_kernel<MI_AUTORESET_SAME_STEP>), g, b, 0, v->stream, v->d, tp); break;
@@ -2788,6 +2987,7 @@ int mi_action_seed(mi_vecenv *v, const uint64_t pcg[4]) {
     const bool same_inc = v->act_seeded && v->act_rng.inc == inc;
     v->act_rng.state = make_u128(pcg[0], pcg[1]);
     v->act_rng.inc = inc;
+    v->act_lane_valid = false, v->act_on_device = false;  // the host copy IS the position again
     if (!same_inc) {
         PcgJump tab[64];
         for (int j = 0; j < 64; j++) tab[j] = pcg_jump(inc, (u128)1 << j);
@@ -2809,6 +3009,8 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
     if (sample && !v->act_seeded) return fail(MI_ERR_STATE, "rollout without actions needs mi_action_seed");
     if (T == 0) return MI_OK;
     if (set_device(v)) return MI_ERR_HIP;
+    if (sample)  // (earlier steps / samples may have left the position on the device)
+        if (int rc = action_sync_host(v)) return rc;
     RolloutPtrs p = {io->actions_in, io->actions_out, io->obs, io->reward, io->terminated, io->truncated};
     const bool box = v->lay.act_dtype == MI_F32;
     if (box && !sample && io->actions_in_dtype != MI_F32 && io->actions_in_dtype != MI_F64 && io->actions_in_dtype != MI_F64_WEAK)
@@ -2835,14 +3037,24 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
             if (lds > 150 * 1024) lds = 0;
         }
         const int lb = (int)lds;
+        auto launch = [&](auto mode, auto smp) {
+            constexpr int M = decltype(mode)::value;
+            constexpr bool S = decltype(smp)::value;
+            if (lds)
+                hipLaunchKernelGGL((tab_rollout_kernel<M, S, true>), g, b, lds, v->stream, v->d, p, as, T, lb);
+            else
+                hipLaunchKernelGGL((tab_rollout_kernel<M, S, false>), g, b, 0, v->stream, v->d, p, as, T, lb);
+        };
+        typedef std::integral_constant<int, MI_AUTORESET_NEXT_STEP> NextT;
+        typedef std::integral_constant<int, MI_AUTORESET_SAME_STEP> SameT;
         if (next && sample)
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, true>), g, b, lds, v->stream, v->d, p, as, T, lb);
+            launch(NextT(), std::true_type());
         else if (next)
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_NEXT_STEP, false>), g, b, lds, v->stream, v->d, p, as, T, lb);
+            launch(NextT(), std::false_type());
         else if (sample)
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, true>), g, b, lds, v->stream, v->d, p, as, T, lb);
+            launch(SameT(), std::true_type());
         else
-            hipLaunchKernelGGL((tab_rollout_kernel<MI_AUTORESET_SAME_STEP, false>), g, b, lds, v->stream, v->d, p, as, T, lb);
+            launch(SameT(), std::false_type());
         HIP_TRY(hipGetLastError());
         rc = MI_OK;
     } else if (is_mj(v->cfg.kind)) {
@@ -2871,7 +3083,53 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
     if (sample) {  // the host copy of the generator moves past the T*N draws the kernel consumes
         const PcgJump j = pcg_jump(v->act_rng.inc, (u128)T * (u128)v->cfg.num_envs * (u128)v->lay.act_dim);
         v->act_rng.state = j.mult * v->act_rng.state + j.plus;
+        v->act_lane_valid = false;
     }
+    return MI_OK;
+}
+
+int mi_action_sample(mi_vecenv *v, int T, void *out, int loc) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (T < 0 || (T > 0 && !out)) return fail(MI_ERR_INVALID_ARGUMENT, "mi_action_sample: T >= 0 batches into a non-null array");
+    if (!v->act_seeded) return fail(MI_ERR_STATE, "mi_action_sample needs mi_action_seed");
+    if (set_device(v)) return MI_ERR_HIP;
+    if (T == 0) return action_prepare_lanes(v);
+    if (loc == MI_DEVICE) return action_sample_device(v, T, out);
+    const size_t bytes = (size_t)T * v->act_bytes;
+    if (bytes > v->act_stage_bytes) {
+        HIP_TRY(hipStreamSynchronize(v->stream));
+        if (v->d_act_stage) (void)hipFree(v->d_act_stage);
+        v->d_act_stage = nullptr, v->act_stage_bytes = 0;
+        HIP_TRY(hipMalloc(&v->d_act_stage, bytes));
+        v->act_stage_bytes = bytes;
+    }
+    if (int rc = action_sample_device(v, T, v->d_act_stage)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, v->d_act_stage, bytes, hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    return MI_OK;
+}
+
+int mi_action_get(mi_vecenv *v, uint64_t pcg[4]) {
+    if (!v || !pcg) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (!v->act_seeded) return fail(MI_ERR_STATE, "mi_action_get needs mi_action_seed");
+    if (set_device(v)) return MI_ERR_HIP;
+    if (int rc = action_sync_host(v)) return rc;
+    pcg[0] = (uint64_t)(v->act_rng.state >> 64), pcg[1] = (uint64_t)v->act_rng.state;
+    pcg[2] = (uint64_t)(v->act_rng.inc >> 64), pcg[3] = (uint64_t)v->act_rng.inc;
+    return MI_OK;
+}
+
+int mi_action_skip(mi_vecenv *v, int64_t draws) {
+    if (!v) return fail(MI_ERR_INVALID_ARGUMENT, "null env");
+    if (!v->act_seeded) return fail(MI_ERR_STATE, "mi_action_skip needs mi_action_seed");
+    if (set_device(v)) return MI_ERR_HIP;
+    if (int rc = action_sync_host(v)) return rc;
+    if (draws == 0) return MI_OK;
+    // backwards = forwards by 2^128 - n: the generator's period
+    const u128 delta = draws > 0 ? (u128)(uint64_t)draws : (u128)0 - (u128)((uint64_t)0 - (uint64_t)draws);
+    const PcgJump j = pcg_jump(v->act_rng.inc, delta);
+    v->act_rng.state = j.mult * v->act_rng.state + j.plus;
+    v->act_lane_valid = false;
     return MI_OK;
 }
 

@@ -26,6 +26,7 @@ import numpy as np
 
 from .. import _native
 from ..gym_api import AutoresetMode, VectorEnv, batch_space, error, logger, seeding
+from . import device_policy
 
 _U64 = (1 << 64) - 1
 
@@ -151,7 +152,8 @@ class HipVectorEnv(VectorEnv):
     # --------------------------------------------------------------------------------------------------
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, autoreset_mode=AutoresetMode.NEXT_STEP,
                  render_mode: str | None = None, device=None, output: str = "numpy", copy: bool = True,
-                 env_index_offset: int = 0, record_episode_statistics: bool = False, strict_actions: bool = False, _engine_factory=None):
+                 env_index_offset: int = 0, record_episode_statistics: bool = False, strict_actions: bool = False, sample_output: str | None = None,
+                 _engine_factory=None):
         if render_mode is not None:
             raise error.Error("gymnasium_amd sub-environments live on the GPU and cannot render; use render_mode=None")
         if output not in ("numpy", "torch"):
@@ -171,6 +173,14 @@ class HipVectorEnv(VectorEnv):
         # of the asynchrony (debugging aid).  NumPy input is always validated on the host before anything is mutated.
         self.strict_actions = bool(strict_actions)
         self.output = output
+        # What `action_space.sample()` hands out (vector/device_policy.py).  Either way the batch is drawn by the engine from the space's own
+        # stream, bit-equal to the NumPy sampler.  "numpy" (default): NumPy arrays like the reference's, whatever `output` is -- scripts that
+        # treat a sample as an ndarray keep working.  "torch" (needs output="torch"): device tensors, so that the metric's own loop
+        # `env.step(env.action_space.sample())` (utils/performance.py:82-97) enqueues nothing but step kernels.
+        sample_output = "numpy" if sample_output is None else sample_output
+        if sample_output not in ("numpy", "torch") or (sample_output == "torch" and output != "torch"):
+            raise ValueError(f"sample_output must be 'numpy' or (with output='torch') 'torch', got {sample_output!r} with output={output!r}")
+        self.sample_output = sample_output
         self.max_episode_steps = self.DEFAULT_MAX_EPISODE_STEPS if max_episode_steps is None else max_episode_steps
         self.env_index_offset = int(env_index_offset)
         self.record_episode_statistics = bool(record_episode_statistics)
@@ -191,6 +201,10 @@ class HipVectorEnv(VectorEnv):
         eng = self._engine
         self._discrete = eng.act_dtype is np.int64
         self._act_shape = (self.num_envs,) if self._discrete else (self.num_envs, eng.act_dim)
+        # action_space.sample() from the engine's action stream (vector/device_policy.py): same draws as the NumPy sampler, no host sampling
+        self._device_policy = hasattr(getattr(eng, "lib", None), "action_sample") and not getattr(self, "_host_policy_only", False)
+        self.action_space = device_policy.attach(self.action_space, self, eng.act_dim)
+        self.last_sampled_actions = None  # step(None): the batch the on-device policy drew in the last such step
         self._seeded = False
         self._has_reset = False
         self._was_done = np.zeros(self.num_envs, dtype=np.bool_)  # mirror of the device's needs-reset flags (SyncVectorEnv._autoreset_envs)
@@ -214,6 +228,10 @@ class HipVectorEnv(VectorEnv):
         if output not in ("numpy", "torch"):
             raise ValueError(f"output must be 'numpy' or 'torch', got {output!r}")
         if output != self.output:
+            if hasattr(self.action_space, "_hip_to_host"):
+                self.action_space._hip_to_host()  # (batches drawn ahead have the old mode's array type)
+            if output == "numpy":
+                self.sample_output = "numpy"
             self.output = output
             self._alloc_buffers()
             self._has_reset = False
@@ -465,13 +483,25 @@ class HipVectorEnv(VectorEnv):
         self._check_not_pending("step")
         if not self._has_reset:
             raise AssertionError("Call reset before using step method.")
-        keep, aptr, adt = self._coerce_actions(actions)
+        aout = None
+        if actions is None:
+            # the on-device policy: `step(action_space.sample())` in ONE launch -- the step kernel draws the batch from the action stream itself
+            # (mi_step with actions == NULL).  Device tensors only; with NumPy batches it is the two calls it stands for.
+            eng_stream = self.action_space.hip_use_stream() if (self.output == "torch" and hasattr(self.action_space, "hip_use_stream")) else None
+            if eng_stream is None:
+                return self.step(self.action_space.sample())
+            if self.last_sampled_actions is None:
+                t = self._torch
+                self.last_sampled_actions = t.zeros(self._act_shape, dtype=t.int64 if self._discrete else t.float32, device=self._tdev)
+            keep, aptr, adt, aout = None, None, _native.MI_F32, self.last_sampled_actions.data_ptr()
+        else:
+            keep, aptr, adt = self._coerce_actions(actions)
         self._act_f64 = adt != _native.MI_F32
         self._bind_stream()
         self._sync_epilogue()
         try:
             if self.output == "torch":
-                self._engine.step_bound(aptr, adt)
+                self._engine.step_bound(aptr, adt, aout)
                 if self.strict_actions:
                     self._engine.synchronize()  # raises the device error word of this very step
             else:
@@ -665,6 +695,32 @@ class HipVectorEnv(VectorEnv):
                     self._episode_start[dones] = now
         return infos
 
+    # -- the policy `action_space.sample()` on the engine's action stream (vector/device_policy.py) -----------------------------------
+    def _draw_action_batches(self, K: int):
+        """The next K batches of ``action_space.sample()`` in one engine call (mi_action_sample); a tuple of K arrays / device tensors,
+        views of ONE freshly allocated block (nothing a caller holds is ever overwritten)."""
+        eng = self._engine
+        if self.sample_output == "torch" and self.output == "torch":
+            t = self._torch
+            self._bind_stream()
+            block = t.empty((K,) + self._act_shape, dtype=t.int64 if self._discrete else t.float32, device=self._tdev)
+            eng.action_sample(K, block.data_ptr(), _native.MI_DEVICE)
+            return block.unbind(0)
+        dtype = np.int64 if self._discrete else np.float32
+        block = None
+        if self._engine_factory is None:  # page-locked, so that the device-to-host copy of the block runs at PCIe speed
+            try:
+                import torch
+
+                block = torch.empty((K,) + self._act_shape, dtype=torch.int64 if self._discrete else torch.float32, pin_memory=True).numpy()
+            except Exception:
+                block = None
+        if block is None:
+            block = np.empty((K,) + self._act_shape, dtype=dtype)
+        self._bind_stream()
+        eng.action_sample(K, block, _native.MI_HOST)
+        return tuple(block)
+
     # -- fused rollouts ---------------------------------------------------------------------------------
     def rollout(self, num_steps: int, actions=None, *, return_actions: bool = True):
         """``num_steps`` consecutive ``step()`` calls in ONE kernel launch; trajectories are time-major tensors in HBM.
@@ -695,7 +751,9 @@ class HipVectorEnv(VectorEnv):
             if tuple(a_in.shape) != act_shape:
                 raise ValueError(f"actions must have shape {act_shape}, got {tuple(a_in.shape)}")
         else:
-            eng.action_seed(_native.pcg_words(self.action_space.np_random))
+            on_stream = self.action_space.hip_use_stream() if hasattr(self.action_space, "hip_use_stream") else None
+            if on_stream is None:  # a space without the device sampler: its NumPy generator is the position
+                eng.action_seed(_native.pcg_words(self.action_space.np_random))
             if return_actions:
                 a_out = t.empty(act_shape, dtype=act_dtype, device=dev)
         obs = t.empty((T,) + tuple(self._obs_shape), dtype=self._obs_tdtype, device=dev)
@@ -705,7 +763,7 @@ class HipVectorEnv(VectorEnv):
         eng.rollout(T, None if a_in is None else a_in.data_ptr(), None if a_out is None else a_out.data_ptr(),
                     obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), actions_in_dtype=in_dtype)
         self._act_f64 = in_dtype == _native.MI_F64
-        if actions is None:
+        if actions is None and on_stream is None:
             self.action_space.np_random.bit_generator.advance(T * N * eng.act_dim)
         out = {"obs": obs, "rewards": rew, "terminations": term, "truncations": trunc}
         if a_out is not None:
@@ -730,7 +788,8 @@ class HipVectorEnv(VectorEnv):
 
         ``actions``: a device tensor the captured steps READ at replay time (write the next actions into it with ``copy_`` before
         ``replay()``); or ``policy``: a callable ``obs -> actions`` of torch ops, captured with the steps (its first input is the current
-        observation buffer).  Capturing executes nothing: the sub-environments advance only when the graph is replayed.  What a replay does not
+        observation buffer), or the string ``"random"``: every captured step is ``step(action_space.sample())`` with the batch drawn inside the
+        step kernel from the action stream, whose position lives on the device and moves with every replay (``step(None)``).  Capturing executes nothing: the sub-environments advance only when the graph is replayed.  What a replay does not
         do: the host-side checks of step() (an invalid action raises at the next eager call or ``synchronize()``), and the wall-clock ``t`` of
         the episode statistics (a host value, frozen at capture).  Requires output="torch" and one eager step()/reset() before (kernels load
         on first use, which a capture must not trigger).  The reference has no counterpart: its step is a Python loop (sync_vector_env.py:253-323)."""
@@ -749,7 +808,9 @@ class HipVectorEnv(VectorEnv):
             raise error.Error("vector wrappers are fused into this env's step kernel (their running statistics double-buffer on the host side): "
                               "its step() cannot be captured")
         if (actions is None) == (policy is None):
-            raise ValueError("capture_steps() takes either `actions` (a device tensor read at replay time) or `policy`")
+            raise ValueError("capture_steps() takes either `actions` (a device tensor read at replay time) or `policy` (a callable, or \"random\")")
+        if policy == "random" and not hasattr(self.action_space, "hip_use_stream"):
+            raise error.Error("policy=\"random\" needs the device-sampled action space")
         return GraphedSteps(self, actions, int(steps), policy)
 
     # -- bookkeeping -----------------------------------------------------------------------------------
@@ -791,6 +852,11 @@ class HipVectorEnv(VectorEnv):
     def close_extras(self, **kwargs):
         eng = getattr(self, "_engine", None)
         if eng is not None:
+            if hasattr(self.action_space, "_hip_to_host"):  # the action space outlives the env: its NumPy generator takes the stream's position back
+                try:
+                    self.action_space._hip_to_host()
+                except Exception:
+                    pass
             if getattr(self, "_async_pending", None) is not None and self._async_pending[0] == "engine":
                 try:  # a step is in flight on the pinned block: collect it before the block goes away
                     eng.step_wait()
@@ -829,12 +895,15 @@ class GraphedSteps:
         self.env, self.steps, self.actions = env, steps, actions
         self.graph = t.cuda.CUDAGraph()
         self.results = []
+        if policy == "random":  # the per-lane states of the action stream must exist before the capture opens (mi_action_sample with T = 0)
+            env._bind_stream()
+            env.action_space.hip_use_stream().action_sample(0, None, _native.MI_DEVICE)
         env.synchronize()
         try:
             with t.cuda.graph(self.graph):
                 obs = env._obs
                 for _ in range(steps):
-                    out = env.step(actions if policy is None else policy(obs))
+                    out = env.step(actions if policy is None else (None if policy == "random" else policy(obs)))
                     obs = out[0]
                     self.results.append(out)
         finally:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355ENV_ABI_VERSION 6
+#define MI355ENV_ABI_VERSION 7
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -165,7 +165,12 @@ typedef struct mi_layout {
  * (mi_mem_location).  Nullable members are skipped.
  *   actions          in   [N][act_dim] act_dtype     (i64 for Discrete -- what iterate(MultiDiscrete) yields); Box kinds: float32
  *                                               rows (layout.act_dtype, the dtype of the space and of its sampler) or, with
- *                                               actions_dtype = MI_F64, float64 rows taken UN-ROUNDED
+ *                                               actions_dtype = MI_F64, float64 rows taken UN-ROUNDED.
+ *                                               NULL (ABI 7, loc == MI_DEVICE): the ON-DEVICE POLICY -- the step kernel itself draws
+ *                                               `action_space.sample()` from the action stream (mi_action_seed), i.e. the call is
+ *                                               `step(action_space.sample())` (utils/performance.py:82-97, the metric's own loop) in one
+ *                                               launch with no host-to-device traffic; the stream advances by N * act_dim draws
+ *   actions_out      out  [N][act_dim] act_dtype     with actions == NULL: the actions that were drawn (NULL to skip)
  *   obs              out  [N][obs_dim] obs_dtype
  *   reward           out  [N] f64                     (sync_vector_env.py:171)
  *   terminated       out  [N] u8 0/1                  (np.bool_ compatible)
@@ -198,6 +203,7 @@ typedef struct mi_step_io {
      * reproduces that; the pinned action array of mi_host_buffers is sized for either type.  Ignored by the Discrete kinds (MI_I64). */
     int32_t actions_dtype;
     int32_t reserved;
+    void *actions_out; /* ABI 7: see above (only read when actions == NULL) */
 } mi_step_io;
 
 /* Buffers of one fused rollout() call: T consecutive step()s in one launch, time-major [T][N][dim].
@@ -307,6 +313,18 @@ int mi_tabular_load(mi_vecenv *env, const mi_tabular_table *table);
  * bit-for-bit in a single launch. */
 int mi_action_seed(mi_vecenv *env, const uint64_t pcg[4]);
 int mi_rollout(mi_vecenv *env, int T, const mi_rollout_io *io);
+/* The action stream as a sampler of its own (ABI 7).  All three keep ONE position: whatever draws mi_rollout / mi_step(actions == NULL) /
+ * mi_action_sample consume, the next consumer continues where the last one stopped, exactly like successive `action_space.sample()` calls on
+ * the reference's seeded space (spaces/space.py:112-122 seed(), spaces/multi_discrete.py:176-178, spaces/box.py:463-465 sample()).
+ *   mi_action_sample: out[T][N][act_dim] (layout.act_dtype) <- the next T batches of `action_space.sample()`; loc == MI_DEVICE only enqueues
+ *                     (a host class hands them out one batch per sample() call: T launches' worth of policy in one), MI_HOST synchronises.
+ *                     T == 0 just prepares the per-lane stream states (before a stream capture: mi_step(actions == NULL) is capturable).
+ *   mi_action_get:    the generator that would produce the NEXT draw, as {state_hi, state_lo, inc_hi, inc_lo} (synchronises when the position
+ *                     lives on the device, i.e. after mi_step(actions == NULL) / mi_action_sample): hand it to np.random.PCG64 to continue on the host.
+ *   mi_action_skip:   move the position by `draws` (negative: backwards -- a host class that sampled ahead returns what it did not hand out). */
+int mi_action_sample(mi_vecenv *env, int T, void *out, int loc);
+int mi_action_get(mi_vecenv *env, uint64_t pcg[4]);
+int mi_action_skip(mi_vecenv *env, int64_t draws);
 
 /* Bookkeeping ------------------------------------------------------------------------------------------ */
 int mi_get_stats(mi_vecenv *env, mi_stats *out);     /* synchronises */

@@ -246,7 +246,8 @@ def api_legs(env_id, N, local_rank=0):
 def api_faithful_leg(env_id, N, seconds=2.0, local_rank=0):
     """the metric as the reference's own `benchmark_vector_step` measures it (utils/performance.py:57-103) -- NumPy batches through the
     public API, the policy `action_space.sample()` drawn on the HOST inside the timed loop, NEXT_STEP reset steps not counted, wall clock.  This is what a
-    user's unchanged Gymnasium script gets; bench.py's `value` is the fused, device-resident rollout."""
+    user's unchanged Gymnasium script gets; bench.py's `value` is the fused, device-resident rollout.  Since round 6 `action_space.sample()` of a
+    HipVectorEnv is served by the engine (one device launch + one pinned copy per block of batches, vector/device_policy.py) instead of NumPy on the host."""
     import gymnasium_amd
 
     env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, copy=False)
@@ -263,7 +264,56 @@ def api_faithful_leg(env_id, N, seconds=2.0, local_rank=0):
         if t1 - t0 > seconds:
             break
     env.close()
-    return {"value": counted / (t1 - t0), "unit": "env-steps/s", "how": f"benchmark_vector_step's protocol, target_duration={seconds} s, NumPy in / out, host-side action_space.sample()"}
+    return {"value": counted / (t1 - t0), "unit": "env-steps/s", "how": f"benchmark_vector_step's protocol, target_duration={seconds} s, NumPy in / out, action_space.sample() NumPy batches drawn by the engine"}
+
+
+def api_faithful_device_leg(env_id, N, seconds=2.0, local_rank=0):
+    """The same protocol with the policy on the device (round 6): `output="torch", sample_output="torch"` -- `action_space.sample()` hands out device
+    tensors the engine drew ahead from the space's own stream (mi_action_sample; bit-equal to the NumPy sampler, tests/test_gpu_device_policy.py), `step()`
+    returns device tensors, and the loop `env.step(env.action_space.sample())` of utils/performance.py:82-97 enqueues nothing but step kernels.  The count is
+    the engine's own `env_steps` (NEXT_STEP reset steps not counted, like the reference's `num_envs - count_nonzero(previous_done)`), read once after the
+    loop instead of from the flags on the host after every step -- the one change to the protocol, and what keeps the host out of the loop.  Also: the same
+    loop as `env.step(None)` (the step kernel draws the batch itself: one launch per step, mi_step with actions == NULL) and as one HIP graph of 32 such steps."""
+    import torch
+
+    import gymnasium_amd
+
+    out = {}
+
+    def protocol(step_fn, label, per_call=1):
+        env = gymnasium_amd.make_vec(env_id, num_envs=N, device=local_rank, output="torch", sample_output="torch", copy=False)
+        env.action_space.seed(0)
+        env.reset(seed=0)
+        env.step(env.action_space.sample())
+        env.reset(seed=0)
+        fn = step_fn(env)
+        for _ in range(3):
+            fn()
+        env.synchronize()
+        env.reset_statistics()
+        calls, t0 = 0, time.time()
+        while True:
+            fn()
+            calls += 1
+            if (calls & 63) == 0 and time.time() - t0 > seconds:  # (the clock is read every 64 calls: time.time() costs what a step costs)
+                break
+        env.synchronize()
+        t1 = time.time()
+        st = env.statistics()
+        out[label] = {"value": st["env_steps"] / (t1 - t0), "unit": "env-steps/s", "us_per_step_wall": (t1 - t0) / (calls * per_call) * 1e6,
+                      "vector_steps": calls * per_call, "counted_env_steps": st["env_steps"], "reset_steps_not_counted": st["reset_steps"]}
+        env.close()
+
+    protocol(lambda env: (lambda: env.step(env.action_space.sample())), "step_of_a_device_sample")
+    protocol(lambda env: (lambda: env.step(None)), "step_none")
+    try:
+        protocol(lambda env: env.capture_steps(policy="random", steps=32).replay, "graph_of_32_sampled_steps", per_call=32)
+    except Exception as e:
+        out["graph_of_32_sampled_steps"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
+    out["how"] = ("benchmark_vector_step's loop (utils/performance.py:82-97) with output='torch', sample_output='torch'; env-steps counted by the engine's own "
+                  f"counter after the loop; target_duration={seconds} s")
+    out["value"] = out["step_of_a_device_sample"]["value"]
+    return out
 
 
 def shared_rng_leg(N=65536, local_rank=0):
@@ -333,6 +383,7 @@ def main():
     ap.add_argument("--no-api", action="store_true")
     ap.add_argument("--only", default=None, help="comma-separated env ids: restrict the secondary lines")
     ap.add_argument("--api-only", action="store_true", help="only the per-launch step() API legs (for a kernel trace of step_kernel)")
+    ap.add_argument("--policy-only", action="store_true", help="only the benchmark_vector_step protocol legs (NumPy and device policy)")
     args = ap.parse_args()
     t_ref = args.started if args.started else time.time()
     young = lambda: args.pmc == "full" or (time.time() - t_ref) < args.budget  # noqa: E731
@@ -349,6 +400,12 @@ def main():
         os.replace(args.out + ".tmp", args.out)
 
     only = set(args.only.split(",")) if args.only else None
+    if args.policy_only:
+        full["api_benchmark_vector_step"] = api_faithful_leg("CartPole-v1", 65536)
+        full["api_benchmark_vector_step_device_policy"] = api_faithful_device_leg("CartPole-v1", 65536)
+        flush()
+        print(json.dumps({"numpy": full["api_benchmark_vector_step"]["value"], **{k: v.get("value", v) for k, v in full["api_benchmark_vector_step_device_policy"].items() if isinstance(v, dict)}}))
+        return
     if args.api_only:
         full.update(api_legs("CartPole-v1", 65536))
         flush()
@@ -416,9 +473,15 @@ def main():
     if not args.no_api and not only and young():
         try:
             full["api_benchmark_vector_step"] = api_faithful_leg(env_id, N)
-            head["api_faithful"] = float(f"{full['api_benchmark_vector_step']['value']:.4g}")
+            head["api_faithful_numpy"] = float(f"{full['api_benchmark_vector_step']['value']:.4g}")
         except Exception as e:
             full["api_benchmark_vector_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            full["api_benchmark_vector_step_device_policy"] = api_faithful_device_leg(env_id, N)
+            head["api_faithful"] = float(f"{full['api_benchmark_vector_step_device_policy']['value']:.4g}")
+            head["api_step_none"] = float(f"{full['api_benchmark_vector_step_device_policy']['step_none']['value']:.4g}")
+        except Exception as e:
+            full["api_benchmark_vector_step_device_policy"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         flush()
     if env_id == "CartPole-v1" and not args.no_api and not only and young():
         try:

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header(tmp_path):
 
     assert ctypes.sizeof(n.MiConfig) == 8 * 4 + 16 * 8
     assert ctypes.sizeof(n.MiLayout) == 8 * 4
-    assert ctypes.sizeof(n.MiStepIO) == 10 * 8 + 2 * 4  # ten pointers, actions_dtype, reserved
+    assert ctypes.sizeof(n.MiStepIO) == 11 * 8 + 2 * 4  # ten pointers, actions_dtype, reserved, actions_out (ABI 7)
     assert ctypes.sizeof(n.MiRolloutIO) == 6 * 8 + 2 * 4
     assert ctypes.sizeof(n.MiStats) == 5 * 8
     assert (n.MI_F32, n.MI_F64, n.MI_I64, n.MI_F64_WEAK) == (0, 1, 2, 3)
