@@ -679,6 +679,16 @@ MI_DEV uint64_t pcg_output(u128 state) {
     return (x >> rot) | (x << ((0u - rot) & 63u));
 }
 
+// action_space.sample() of one lane from the state of the action stream whose output is the lane's draw
+template <class E>
+MI_DEV typename E::Act action_of_state(u128 astate) {
+    if constexpr (E::SAMPLE_FROM_BITS) {
+        return E::sample_state((uint64_t)(astate >> 64), (uint64_t)astate);
+    } else {
+        return E::sample((double)(pcg_output(astate) >> 11) * (1.0 / 9007199254740992.0));
+    }
+}
+
 // SAMPLE: mi_step with actions == NULL -- `step(action_space.sample())` in one launch: the lane draws its own action from its state of the action
 // stream (spaces/multi_discrete.py:176-178, spaces/box.py:463-465: draw number pos + i of the batched space's generator), which rides along with the
 // lane's other loads, and leaves the state of its draw in the NEXT batch behind.  Nothing on the host changes from step to step: capturable.
@@ -702,8 +712,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevEnv d, StepPtrs io, Epi
         typename E::Act a = rq.a;
         if constexpr (SAMPLE) {
             const u128 astate = make_u128(rq.ag[0], rq.ag[1]);
-            const uint64_t bits = pcg_output(astate);
-            a = E::SAMPLE_FROM_BITS ? E::sample_bits(bits) : E::sample((double)(bits >> 11) * (1.0 / 9007199254740992.0));
+            a = action_of_state<E>(astate);
             const u128 next = io.act_jump.mult * astate + io.act_jump.plus;
             io.act_lane[i] = (uint64_t)(next >> 64), io.act_lane[(size_t)d.N + i] = (uint64_t)next;
             if (io.actions_out) static_cast<typename E::Act *>(io.actions_out)[i] = a;
@@ -824,11 +833,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
             if ((t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
             typename E::Act a;
             if (SAMPLE) {
-                const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate;
-                const uint64_t x = hi ^ lo;
-                const unsigned rot = (unsigned)(hi >> 58);
-                const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
-                a = E::SAMPLE_FROM_BITS ? E::sample_bits(out) : E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
+                a = action_of_state<E>(astate);
                 astate = as.jump_n.mult * astate + as.jump_n.plus;
                 if (FULL || io.actions_out) static_cast<typename E::Act *>(io.actions_out)[t * N + i] = a;
             } else {
@@ -943,14 +948,20 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     // aux role
     u128 astate = 0;
     double ep_ret = 0.0;
-    int32_t ep_len = 0;
+    int32_t ep_len = 0, ep_len_start = 0;  // (ep_len_start: 0 for a sub-environment whose first step is its autoreset step -- that episode was counted when it finished)
+    uint32_t n_term = 0;
+    bool last_done = false, last_te = false;
     if (active) {
         if (is_env) {
             load_lane<E>(d, i, L);
             q.have = false;
             q.rng = load_rng(d, i);
         }
-        if (is_book) ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
+        if (is_book) {
+            ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
+            last_done = ((d.meta[i] >> kFlagShift) & kNeedsReset) != 0;  // (as if the step before the launch had finished the episode: right for T = 0 as well)
+            ep_len_start = last_done ? 0 : ep_len;
+        }
         if (is_policy) {
             astate = make_u128(as.state_hi, as.state_lo);  // skip ahead by (i + 1) draws: one affine map per set bit of (i + 1)
             uint32_t delta = (uint32_t)i + 1u;
@@ -971,10 +982,13 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                     const int buf = c & 1;
                     // (rolled: with a partner wavefront on the SIMD the LDS read of the action at the top of a step is covered, and four copies
                     //  of the step body -- libm slow paths included -- are 30 KB of instruction cache: measured +5 % against the unrolled form)
+                    // (the queue's periodic refill, rollout_kernel's `t % kRefillPeriod == 0`: with chunks that divide the period the test leaves the step loop)
+                    constexpr bool REFILL_PER_CHUNK = kRefillPeriod % C == 0;
+                    if (REFILL_PER_CHUNK && ((c * C) & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
 #pragma unroll 1
                     for (int k = 0; k < C; k++) {
                         const int t = c * C + k;
-                        if ((t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
+                        if (!REFILL_PER_CHUNK && (t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
                         float o[E::OBS];
                         double rew;
                         uint32_t bits;
@@ -998,21 +1012,28 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                         const uint32_t bits = sh_bits[buf][k][slot];
                         const bool resetting = (bits & 4u) != 0, te = (bits & 1u) != 0, tr = (bits & 2u) != 0;
                         double rew;
+                        const bool done = te || tr;
                         if constexpr (E::REWARD_FROM_TERMINATED) {
+                            // the reward is a function of the flags, so every total follows from three counters and the episode length (finish_totals,
+                            // below): no float64 accumulation per step
                             rew = resetting ? 0.0 : E::reward_from_terminated(te, d.P);
+                            ep_len = resetting ? 0 : ep_len + 1;
+                            st.reset_steps += resetting ? 1u : 0u;
+                            st.episodes += done ? 1u : 0u;
+                            n_term += te ? 1u : 0u;
+                            last_done = done, last_te = te;
                         } else {
                             rew = sh_rew[buf][k][slot];
+                            const double ret = ep_ret + rew;
+                            const int32_t len = ep_len + 1;
+                            ep_ret = resetting ? 0.0 : ret;
+                            ep_len = resetting ? 0 : len;
+                            st.reset_steps += resetting ? 1u : 0u;
+                            st.env_steps += resetting ? 0u : 1u;
+                            st.episodes += done ? 1u : 0u;
+                            st.return_sum += done ? ret : 0.0;
+                            st.length_sum += done ? (uint64_t)len : 0ull;
                         }
-                        const bool done = te || tr;
-                        const double ret = ep_ret + rew;
-                        const int32_t len = ep_len + 1;
-                        ep_ret = resetting ? 0.0 : ret;
-                        ep_len = resetting ? 0 : len;
-                        st.reset_steps += resetting ? 1u : 0u;
-                        st.env_steps += resetting ? 0u : 1u;
-                        st.episodes += done ? 1u : 0u;
-                        st.return_sum += done ? ret : 0.0;
-                        st.length_sum += done ? (uint64_t)len : 0ull;
                         store_row<E::OBS>(static_cast<float *>(io.obs) + (t * N + i) * E::OBS, o);
                         io.reward[t * N + i] = rew;
                         io.terminated[t * N + i] = te;
@@ -1024,11 +1045,7 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
 #pragma unroll
                     for (int k = 0; k < C; k++) {
                         const size_t t = (size_t)p * C + k;
-                        const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate;
-                        const uint64_t x = hi ^ lo;
-                        const unsigned rot = (unsigned)(hi >> 58);
-                        const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
-                        const Act a = E::SAMPLE_FROM_BITS ? E::sample_bits(out) : E::sample((double)(out >> 11) * (1.0 / 9007199254740992.0));
+                        const Act a = action_of_state<E>(astate);
                         astate = as.jump_n.mult * astate + as.jump_n.plus;
                         sh_act[buf][k][slot] = a;
                         static_cast<Act *>(io.actions_out)[t * N + i] = a;
@@ -1066,6 +1083,21 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
             }
             store_rng_state(d, i, q.rng);
         } else if (is_book) {
+            if constexpr (E::REWARD_FROM_TERMINATED) {
+                // The totals of the launch from the counters.  Every env-step lengthens exactly one episode by one, so the lengths of the episodes
+                // that FINISHED add up to the env-steps taken plus what the running episode had at the start minus what it has now; and with a
+                // reward that is r_T on the terminating step and r_N on every other one (E::reward_from_terminated: +-1 / 0 -- sums of such values are
+                // exact in float64 in any order) the finished episodes' returns are r_N (lengths - terminations) + r_T terminations, the running
+                // episode's return r_N x its length.  Same numbers as the step-by-step accumulation of rollout_kernel, bit for bit.
+                const double r_n = E::reward_from_terminated(false, d.P), r_t = E::reward_from_terminated(true, d.P);
+                st.env_steps = (uint32_t)(chunks * C) - st.reset_steps;
+                // (an episode that finished in the very last step still sits in ep_len, waiting for its autoreset step: it IS among the finished ones)
+                st.length_sum = (uint64_t)((int64_t)st.env_steps + (int64_t)ep_len_start - (last_done ? (int64_t)0 : (int64_t)ep_len));
+                st.return_sum = r_n * (double)((int64_t)st.length_sum - (int64_t)n_term) + r_t * (double)n_term;
+                st.return_sum = st.episodes ? st.return_sum : 0.0;  // (no finished episode: +0.0 like the accumulation, whatever the signs of r_n, r_t)
+                ep_ret = (last_done && last_te) ? r_n * (double)(ep_len - 1) + r_t : r_n * (double)ep_len;
+                if (chunks == 0) ep_ret = d.ep_ret[i];
+            }
             d.ep_ret[i] = ep_ret, d.ep_len[i] = ep_len;
         }
     }
@@ -1276,10 +1308,7 @@ __global__ __launch_bounds__(kBlock) void shared_sample_kernel(DevEnv d, ActionS
     uint64_t n = (uint64_t)t * (uint64_t)d.N + (uint64_t)i + 1ull;
     for (int j = 0; n; j++, n >>= 1)
         if (n & 1ull) s = as.pow2[j].mult * s + as.pow2[j].plus;
-    const uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s, x = hi ^ lo;
-    const unsigned rot = (unsigned)(hi >> 58);
-    const uint64_t bits = (x >> rot) | (x << ((0u - rot) & 63u));
-    out[i] = E::SAMPLE_FROM_BITS ? E::sample_bits(bits) : E::sample((double)(bits >> 11) * (1.0 / 9007199254740992.0));
+    out[i] = action_of_state<E>(s);
 }
 
 #ifndef MI_CLASSIC_TU

@@ -61,6 +61,10 @@ struct ExactMathT {
     static MI_DEV double sin(double x) { return mi_sincos::sin_bf<false, KASM>(g_trig6, x); }
     static MI_DEV double cos(double x) { return mi_sincos::cos_bf<false, KASM>(g_trig6, x); }
     static MI_DEV void sincos(double x, double &s, double &c) { mi_sincos::sincos_bf<false, true, KASM>(g_trig6, x, s, c); }
+    // the two halves of sincos() for a caller that defers the rare case: the short routine of |x| < 0.855469 evaluated unconditionally (its result
+    // is only meaningful when in_main_range(x); an index outside the table reads zeros from LDS, no fault), and the test
+    static MI_DEV void sincos_main_unchecked(double x, double &s, double &c) { mi_sincos::sincos_main<KASM>(g_trig6, x, s, c); }
+    static MI_DEV bool in_main_range(double x) { return ((uint32_t)(mi_sincos::bits(x) >> 32) & 0x7fffffffu) < 0x3feb6000u; }
     static MI_DEV void sincos_spread(double x, double &s, double &c) { mi_sincos::sincos_bf<false, false, KASM>(g_trig6, x, s, c); }  // any range, no small-angle short cut
     // for angles the environment wraps or clips (|x| far below 1e8): no hand-over to the platform's huge-argument routine, and lanes
     // spread over all ranges (no wavefront-uniform short cut)
@@ -127,6 +131,18 @@ MI_DEV double div_by_constant(double x, C) {
     const double ax = fabs(x);
     if (__builtin_expect(!(ax <= 1e300 && ax >= 1e-300), 0)) return x / c;
     return q2;
+}
+
+// the two halves of div_by_constant for a caller that tests several operands with ONE branch (CartPole's step: three divisions by total_mass)
+template <class C>
+MI_DEV double div_by_constant_unchecked(double x, C) {
+    constexpr double c = C::value, r = 1.0 / C::value;
+    const double q = x * r;
+    return fma(fma(-q, c, x), r, q);
+}
+MI_DEV bool div_by_constant_in_range(double x) {
+    const double ax = fabs(x);
+    return (ax <= 1e300) & (ax >= 1e-300);
 }
 
 struct EnvParams {
@@ -214,6 +230,12 @@ struct CartPoleT {
     // floor(u * 2) is the top bit
     static constexpr bool SAMPLE_FROM_BITS = true;
     static MI_DEV Act sample_bits(uint64_t bits) { return (Act)(bits >> 63); }
+    // ... and straight from the generator's state words: the output is rotr64(hi ^ lo, hi >> 58), whose top bit is bit (63 + rot) mod 64 of hi ^ lo --
+    // one 64-bit shift instead of the rotation's two and their merge
+    static MI_DEV Act sample_state(uint64_t hi, uint64_t lo) {
+        const unsigned rot = (unsigned)(hi >> 58);
+        return (Act)(((hi ^ lo) >> ((rot + 63u) & 63u)) & 1ull);
+    }
 
     // cartpole.py:164-226: explicit Euler with the OLD velocities, all float64.
     static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &) {
@@ -224,11 +246,38 @@ struct CartPoleT {
         double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
         const double force = action == 1 ? force_mag : -force_mag;
         double costheta, sintheta;  // cartpole.py:180-181 np.cos / np.sin
-        M::sincos(theta, sintheta, costheta);
-        const double temp = div_by_constant(force + polemass_length * (theta_dot * theta_dot) * sintheta, TotalMass());
-        const double thetaacc = (gravity * sintheta - costheta * temp) /
-                                (length * (4.0 / 3.0 - div_by_constant(masspole * (costheta * costheta), TotalMass())));
-        const double xacc = temp - div_by_constant(polemass_length * thetaacc * costheta, TotalMass());
+        double temp, thetaacc, xacc;
+        if constexpr (M::EXACT) {
+            // Round 6: ONE rare branch per step instead of four.  The step has four places where a lane may leave the common case -- an angle
+            // outside the short sin / cos routine's range and the three operands of the constant divisions outside the range in which three
+            // FMAs give the IEEE quotient -- and each cost a compare pair, two exec-mask instructions and a branch on a wavefront that issues one
+            // instruction at a time.  The common case is now evaluated unconditionally (same operations on the same operands: same bits) and the
+            // lanes that left it redo the step through the general routines.  (masspole * cos^2 needs no test of its own: inside the short
+            // routine's range cos >= 0.65.)
+            const bool main_range = M::in_main_range(theta);
+            M::sincos_main_unchecked(theta, sintheta, costheta);
+            const double t1 = force + polemass_length * (theta_dot * theta_dot) * sintheta;
+            temp = div_by_constant_unchecked(t1, TotalMass());
+            thetaacc = (gravity * sintheta - costheta * temp) /
+                       (length * (4.0 / 3.0 - div_by_constant_unchecked(masspole * (costheta * costheta), TotalMass())));
+            const double t3 = polemass_length * thetaacc * costheta;
+            xacc = temp - div_by_constant_unchecked(t3, TotalMass());
+            // (`&`, not `&&`: three flags combined by scalar instructions, no control flow of their own)
+            const bool common = main_range & div_by_constant_in_range(t1) & div_by_constant_in_range(t3);
+            if (__builtin_expect(!common, 0)) {
+                M::sincos(theta, sintheta, costheta);
+                temp = div_by_constant(force + polemass_length * (theta_dot * theta_dot) * sintheta, TotalMass());
+                thetaacc = (gravity * sintheta - costheta * temp) /
+                           (length * (4.0 / 3.0 - div_by_constant(masspole * (costheta * costheta), TotalMass())));
+                xacc = temp - div_by_constant(polemass_length * thetaacc * costheta, TotalMass());
+            }
+        } else {
+            M::sincos(theta, sintheta, costheta);
+            temp = div_by_constant(force + polemass_length * (theta_dot * theta_dot) * sintheta, TotalMass());
+            thetaacc = (gravity * sintheta - costheta * temp) /
+                       (length * (4.0 / 3.0 - div_by_constant(masspole * (costheta * costheta), TotalMass())));
+            xacc = temp - div_by_constant(polemass_length * thetaacc * costheta, TotalMass());
+        }
         x = x + tau * x_dot;
         x_dot = x_dot + tau * xacc;
         theta = theta + tau * theta_dot;
@@ -276,6 +325,7 @@ struct PendulumT {
     static MI_DEV Act sample(double u) { return (Act)(-2.0 + (2.0 - (-2.0)) * u); }  // Box.sample: uniform(low, high).astype(f32)
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
+    static MI_DEV Act sample_state(uint64_t, uint64_t) { return 0; }
 
     static MI_DEV Act clip_torque(Act u) {  // np.clip(u, -2, 2)[0] stays np.float32 for a float32 row; a float64 row (or a list's) makes it an np.float64
         const double max_torque = 2.0;
@@ -371,6 +421,7 @@ struct AcrobotT {
     static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }  // u * 3.0 rounds: not reducible to integer arithmetic
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
+    static MI_DEV Act sample_state(uint64_t, uint64_t) { return 0; }
 
     // acrobot.py:244-279, "book" dynamics; y = (theta1, theta2, dtheta1, dtheta2), a = torque.  The `** 2` on Python floats (lc1**2 = 0.25, ...)
     // are exact; the ones on np.float64 state components go through libm pow (M::sq).
@@ -470,6 +521,7 @@ struct MountainCarT {
     static MI_DEV Act sample(double u) { return (Act)(u * 3.0); }  // u * 3.0 rounds: not reducible to integer arithmetic
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
+    static MI_DEV Act sample_state(uint64_t, uint64_t) { return 0; }
 
     static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &) {
         const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5;
@@ -521,6 +573,7 @@ struct MountainCarContinuousT {
     static MI_DEV Act sample(double u) { return (Act)(float)(-1.0 + (1.0 - (-1.0)) * u); }
     static constexpr bool SAMPLE_FROM_BITS = false;
     static MI_DEV Act sample_bits(uint64_t) { return 0; }
+    static MI_DEV Act sample_state(uint64_t, uint64_t) { return 0; }
 
     static MI_DEV void step(double s[S], uint32_t &flags, Act a0, const EnvParams &P, double &reward, bool &terminated, Trig &t) {
         if constexpr (ACT_KIND == MI_F32)

@@ -20,7 +20,7 @@ import numpy as np
 from .. import _native
 from ..gym_api import AutoresetMode, error, spaces
 from ..gym_api import VectorEnv as VectorEnvBase
-from ..vector.hip_vector_env import HipVectorEnv, _verify_number_and_cast, parse_low_high
+from ..vector.hip_vector_env import _SHORT_STEP_OWNERS, HipVectorEnv, _verify_number_and_cast, parse_low_high
 
 DEFAULT_X = np.pi  # pendulum.py:14-15
 DEFAULT_Y = 1.0
@@ -76,6 +76,9 @@ class CartPoleVectorEnv(_ClassicControlVectorEnv):
     def _engine_options(self) -> int:
         return super()._engine_options() | (_native.CFG_SHARED_RNG if self._shared_rng else 0)
 
+    def _short_step_allowed(self) -> bool:
+        return not self._shared_rng  # (the shared-generator mode returns float32 rewards: step() below converts)
+
     # -- rng="shared": VectorEnv.np_random IS the generator the sub-environments draw from (cartpole.py:475, 497) ------------------------
     def _seed_engines(self, seed, mask):
         if not self._shared_rng:
@@ -115,9 +118,9 @@ class CartPoleVectorEnv(_ClassicControlVectorEnv):
         return super().reset(seed=seed, options=options)
 
     def step(self, actions):
+        if not self._shared_rng:  # (nothing to add: HipVectorEnv.step's short path stays reachable, see _SHORT_STEP_OWNERS)
+            return HipVectorEnv.step(self, actions)
         out = super().step(actions)
-        if not self._shared_rng:
-            return out
         rew = out[1]
         rew = rew.to(self._torch.float32) if self.output == "torch" else rew.astype(np.float32)  # reward arrays of cartpole.py:466-468 are float32
         return (out[0], rew) + tuple(out[2:])
@@ -133,6 +136,9 @@ class CartPoleVectorEnv(_ClassicControlVectorEnv):
 
     def _parse_reset_options(self, options):
         return parse_low_high(options, -0.05, 0.05)
+
+
+_SHORT_STEP_OWNERS.add(CartPoleVectorEnv.step)  # (it only adds to the result with rng="shared", and then _short_step_allowed() says no)
 
 
 class PendulumVectorEnv(_ClassicControlVectorEnv):

@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..gym_api import error, spaces
+from ..gym_api import error, logger, spaces
 from ..vector.hip_vector_env import HipVectorEnv
 
 
@@ -122,6 +122,39 @@ def _board(desc) -> list:
     return rows
 
 
+def _is_tile(x) -> bool:
+    return isinstance(x, (str, bytes, np.str_, np.bytes_)) and len(x) == 1
+
+
+def _is_list_of_boards(desc) -> bool:
+    """One board is 2-D in tiles: a sequence of rows, each a string or a sequence of single characters (FrozenLakeEnv.desc is an (nrow, ncol) array of
+    bytes).  A list of boards has one more level: its elements are themselves boards.  Decided by dimensionality, not by how the rows are spelled:
+    `[env.desc for env in envs]`, lists of lists of characters and lists of lists of row strings are all lists of boards."""
+    if isinstance(desc, np.ndarray):
+        return desc.ndim == 3 or (desc.ndim == 2 and desc.size > 0 and not _is_tile(desc.flat[0]))  # (a 2-D array of ROW STRINGS: one board per row of the array)
+    if len(desc) == 0:
+        return False
+    first = desc[0]
+    if isinstance(first, (str, bytes, np.str_, np.bytes_)):
+        return False  # rows spelled as strings: one board
+    if isinstance(first, np.ndarray):
+        return first.ndim == 2 or (first.ndim == 1 and first.size > 0 and not _is_tile(first.flat[0]))
+    if len(first) == 0:
+        return False
+    return not _is_tile(first[0])  # a row of single tiles: one board; anything longer / nested: a board of its own
+
+
+def _check_board(rows):
+    """Rows of equal length made of the four tile letters (frozen_lake.py:98-106): anything else would silently build a different MDP."""
+    if not rows or any(len(r) != len(rows[0]) for r in rows) or len(rows[0]) == 0:
+        raise ValueError(f"a FrozenLake board needs rows of equal, non-zero length, got {rows!r}")
+    bad = sorted({c for r in rows for c in r} - set("SFHG"))
+    if bad:
+        raise ValueError(f"a FrozenLake board is made of the tiles S, F, H, G; found {bad!r} in {rows!r}")
+    if not any("S" in r for r in rows):
+        raise ValueError(f"a FrozenLake board needs a start tile S: {rows!r}")
+
+
 def _goal_reachable(board, size: int) -> bool:
     """frozen_lake.py:34-53 is_valid: is "G" reachable from (0, 0) over non-hole tiles (4-neighbourhood)?  (Any graph search gives the same answer.)"""
     seen, stack = {(0, 0)}, [(0, 0)]
@@ -161,14 +194,19 @@ class FrozenLakeVectorEnv(TabularVectorEnv):
         # `desc` may also be a list of num_envs boards -- one map per sub-environment, reproducibly: [generate_random_map(8, 0.8, seed + i) for i in ...].
         self.descs = None
         if desc is None and map_name is None:
+            if int(num_envs) > 4096:
+                logger.warn(f"FrozenLake with map_name=None draws one random map per sub-environment like SyncVectorEnv's scalar envs do: {num_envs} maps are "
+                            "generated in a Python loop and every distinct board gets its own transition table on the device (8x8: ~22 KB each, no LDS "
+                            "staging in rollouts); pass `desc=` (one board, or a list of a few boards repeated) to avoid that cost")
             self.descs = [generate_random_map() for _ in range(int(num_envs))]
-        elif desc is not None and len(desc) > 0 and not isinstance(desc[0], (str, bytes, np.str_, np.bytes_)) and not np.isscalar(desc[0]) \
-                and isinstance(desc[0][0], (str, bytes, np.str_, np.bytes_)) and len(desc[0][0]) > 1:
+        elif desc is not None and _is_list_of_boards(desc):
             self.descs = [_board(b) for b in desc]
             if len(self.descs) != int(num_envs):
                 raise ValueError(f"a list of boards must have one board per sub-environment: got {len(self.descs)} for num_envs={num_envs}")
             if len({(len(b), len(b[0])) for b in self.descs}) != 1:
                 raise ValueError("the boards of one vector environment must have the same shape (one observation space)")
+        for b in (self.descs if self.descs is not None else ([_board(desc)] if desc is not None else [])):
+            _check_board(b)
         self.desc = self.descs[0] if self.descs is not None else _board(desc if desc is not None else FROZEN_LAKE_MAPS[map_name])
         self.is_slippery, self.success_rate, self.reward_schedule = bool(is_slippery), success_rate, tuple(reward_schedule)
         super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, render_mode=render_mode, **kwargs)

@@ -91,6 +91,12 @@ class _DevicePolicyMixin:
         return super().seed(seed)
 
     def sample(self, mask=None, probability=None):
+        d = self.__dict__
+        if mask is None and probability is None:  # the common call: the next batch of the block drawn ahead (a non-empty block implies an attached engine)
+            pos, ring = d.get("_hip_pos", 0), d.get("_hip_ring", ())
+            if pos < len(ring):
+                d["_hip_pos"] = pos + 1
+                return ring[pos]
         env, eng = self._hip_engine()
         if eng is None or mask is not None or probability is not None:
             return super().sample(mask, probability)
