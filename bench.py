@@ -52,7 +52,7 @@ STATE_BYTES = {"CartPole-v1": 96, "Pendulum-v1": 64, "Acrobot-v1": 96, "Mountain
 MJ_COOP = ("Ant-v5", "Humanoid-v5", "HumanoidStandup-v5", "HalfCheetah-v5", "Walker2d-v5")
 MJ_IDS = MJ_COOP + ("Hopper-v5", "InvertedPendulum-v5", "InvertedDoublePendulum-v5", "Reacher-v5", "Swimmer-v5", "Pusher-v5")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-DUO_CHUNK = {"CartPole-v1": 4, "MountainCar-v0": 8, "MountainCarContinuous-v0": 8}  # envs_classic.h DUO_ROLLOUT / DUO_CHUNK
+DUO_CHUNK = {"CartPole-v1": 8, "MountainCar-v0": 8, "MountainCarContinuous-v0": 8}  # envs_classic.h DUO_ROLLOUT / DUO_CHUNK
 
 
 # ---- CPU legs: the oracle as the timed baseline and as the checker of the first timed launch ----------------------------------------
@@ -190,7 +190,8 @@ def oracle_check(cfg, traj):
     """`traj` = the first timed launch of this rank, on the host.  (1) its actions are the host policy's: `action_space.seed(rank)` + T x
     `sample()` of the batched space (spaces/multi_discrete.py:176-178, spaces/box.py:463-465); (2) the oracle, reset with the same seeds and
     teacher-forced with those actions, produces the same observations / rewards / flags: every sub-environment, bit for bit, for the
-    bit-exact kinds (classic control, ToyText); <= 256 strided sub-environments within 1e-8 for the MuJoCo kinds."""
+    bit-exact kinds (classic control, ToyText); <= 1 024 strided sub-environments within 1e-8 for the MuJoCo kinds, whose
+    later steps mujoco_window_check covers."""
     acts, obs, rew, te, tr = traj
     T, N = cfg.inner, cfg.N
     if (cfg.env_kwargs or {}).get("fast_math"):  # tolerance parity by design; whole-launch equality does not apply (chaotic kinds diverge within a launch)
@@ -200,7 +201,7 @@ def oracle_check(cfg, traj):
     host_acts = np.stack([sp.sample() for _ in range(T)]).reshape(acts.shape)
     policy_ok = bool(np.array_equal(host_acts.astype(acts.dtype), acts))
     exact = cfg.env_id not in MJ_IDS
-    stride = 1 if exact else max(1, N // 256)
+    stride = 1 if exact else max(1, N // 1024)
     idx = None if stride == 1 else np.arange(0, N, stride)
     sel = (lambda a: a) if idx is None else (lambda a: np.ascontiguousarray(a[:, idx]))
     _, o2, r2, te2, tr2 = oracle_trajectory(cfg.env_id, N, T, offset=cfg.rank * N, env_kwargs=cfg.env_kwargs, actions=sel(acts), env_indices=idx)
@@ -213,6 +214,54 @@ def oracle_check(cfg, traj):
         vals_ok = worst <= 1e-8
     return {"ok": policy_ok and flags_ok and vals_ok, "against": "oracle/ (C restatement), same seeds, in this run", "envs": N if idx is None else len(idx),
             "steps": T, "compare": "array_equal" if exact else "atol 1e-8", "max_abs_diff": worst, "policy_equals_host_sample": policy_ok}
+
+
+def mujoco_window_check(cfg, robots=1024, windows=10, threads=None):
+    """The MuJoCo kinds beyond their first launch: `windows` further launches of `cfg.inner` vector steps from WHEREVER the
+    sub-environments are now -- after the timed region, i.e. late in their episodes, or lying on the ground when the configuration switched termination
+    off and warmed up -- each compared on `robots` strided sub-environments with the oracle started from the engine's own state, generator words and
+    TimeLimit counters at the window's start and teacher-forced with the engine's actions: observations and rewards within 1e-8, flags equal.  (The
+    oracle is re-synchronised per window because articulated bodies in contact amplify a 1e-12 difference past any tolerance within tens of steps; inside a
+    window of `inner` steps the agreement is what DESIGN.md section 4 states.)  The oracle's robots are stepped by `threads` host threads (ctypes drops the GIL)."""
+    import concurrent.futures as cf
+
+    import gymnasium_amd
+    from oracle import oracle
+
+    env, eng, N, T = cfg.env, cfg.eng, cfg.N, cfg.inner
+    idx = np.arange(0, N, max(1, N // robots))[:robots]
+    threads = threads or max(1, min(usable_cpus()[0], len(idx) // 16 or 1))
+    slices = [s for s in np.array_split(np.arange(len(idx)), threads) if len(s)]
+    kw = {k: v for k, v in (cfg.env_kwargs or {}).items()}
+    checkers = [gymnasium_amd.make_vec(cfg.env_id, num_envs=len(s), _engine_factory=oracle.engine_factory, **kw) for s in slices]
+    for c in checkers:
+        c.reset(seed=0)
+    worst, flags_ok, finished = 0.0, True, 0
+    bufs = cfg.alloc_trajectory()
+    for _ in range(windows):
+        state, elapsed, flags = env.get_state()
+        words = env.get_rng_state()
+        cfg.launch(bufs)
+        acts, obs, rew, te, tr = tuple(b.cpu().numpy() for b in bufs[0])
+
+        def one(k):
+            sl, c = idx[slices[k]], checkers[k]
+            c._engine.seed(np.ascontiguousarray(words[sl]), None)
+            c.set_state(state[sl], elapsed[sl], flags[sl])
+            o2, r2 = np.zeros((T, len(sl), eng.obs_dim)), np.zeros((T, len(sl)))
+            te2, tr2 = np.zeros((T, len(sl)), np.bool_), np.zeros((T, len(sl)), np.bool_)
+            c._engine.rollout(T, np.ascontiguousarray(acts[:, sl]), None, o2, r2, te2, tr2)
+            d = max(float(np.max(np.abs(obs[:, sl] - o2))), float(np.max(np.abs(rew[:, sl] - r2))))
+            return d, bool(np.array_equal(te[:, sl], te2) and np.array_equal(tr[:, sl], tr2)), int(np.count_nonzero(te2 | tr2))
+
+        with cf.ThreadPoolExecutor(len(slices)) as pool:
+            for d, ok, fin in pool.map(one, range(len(slices))):
+                worst, flags_ok, finished = max(worst, d), flags_ok and ok, finished + fin
+    for c in checkers:
+        c.close()
+    return {"ok": bool(flags_ok and worst <= 1e-8), "envs": int(len(idx)), "steps": int(windows * T), "window_steps": int(T), "max_abs_diff": worst,
+            "episodes_finished_inside": finished, "compare": "atol 1e-8 per window, oracle re-synchronised to the engine's state at every window start",
+            "host_threads": len(slices)}
 
 
 # ---- live PMC passes (rocprofv3 on a short child invocation of this file) --------------------------------------------------------
@@ -255,6 +304,75 @@ def live_traffic(env_id, N, inner, kernel, env_kwargs=None, warm=1, timeout_s=15
     if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
         return 1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0]), f"live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run ({f['FETCH_SIZE'][1]} dispatches)"
     return None, None
+
+
+def kernel_tag(env_id, kernel):
+    """A fragment of the dominant kernel's demangled name that tells this env's instantiation from every other env's (one rocprofv3 pass can then
+    serve several configurations: live_traffic_batch)."""
+    classic = {"CartPole-v1": "CartPoleT<", "Pendulum-v1": "PendulumT<", "Acrobot-v1": "AcrobotT<", "MountainCar-v0": "MountainCarT<",
+               "MountainCarContinuous-v0": "MountainCarContinuousT<"}
+    if env_id in classic:
+        return f"{kernel}<mi::{classic[env_id]}"
+    if kernel in ("mj_physics_kernel", "mj_rollout_kernel"):
+        return f"{kernel}<mjx::MjEnv<mjx::{env_id.split('-')[0]}Model,"
+    return kernel  # the tabular kernels are one instantiation for every table: such configurations get a pass of their own
+
+
+def live_traffic_batch(configs, timeout_s=240):
+    """live_traffic for several configurations with TWO rocprofv3 passes per group instead of two per configuration: a child process runs the
+    configurations of a group one after the other (`--child-list`), and each one's dispatches are told apart by kernel_tag.  configs: dicts with
+    env_id, N, inner, env_kwargs, warm, kernel, key.  Returns {key: (HBM bytes per dispatch, provenance)}; configurations whose tag another member of
+    the group shares (the tabular kernels; one robot at two sizes or in two regimes) go into further groups."""
+    groups = []
+    for c in configs:
+        tag = kernel_tag(c["env_id"], c["kernel"])
+        for g in groups:
+            if all(tag not in t and t not in tag for t in g["tags"]):
+                g["tags"].append(tag), g["members"].append((c, tag))
+                break
+        else:
+            groups.append({"tags": [tag], "members": [(c, tag)]})
+    out = {}
+    for g in groups:
+        spec = json.dumps([[c["env_id"], c["N"], c["inner"], c.get("env_kwargs") or {}, c.get("warm", 1)] for c, _ in g["members"]])
+        # one pass per counter; every member's rows are read from the same database
+        res = {counter: _rocprof_counters_multi(["--child-list", spec], [counter], [tag for _, tag in g["members"]], timeout_s) for counter in ("FETCH_SIZE", "WRITE_SIZE")}
+        for c, tag in g["members"]:
+            f, w = (res["FETCH_SIZE"] or {}).get(tag), (res["WRITE_SIZE"] or {}).get(tag)
+            if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
+                out[c["key"]] = (1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0]),
+                                 f"live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run ({f['FETCH_SIZE'][1]} dispatches; one child process for {len(g['members'])} configurations)")
+            else:
+                out[c["key"]] = (None, None)
+    return out
+
+
+def _rocprof_counters_multi(args, counters, kernel_likes, timeout_s):
+    """_rocprof_counters for several kernel-name fragments out of ONE profiled run: {fragment: {counter: (avg per dispatch, dispatches)}}."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--child", *args]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        dbs = sorted(glob.glob(tmp + "/**/*.db", recursive=True))
+        if not dbs:
+            return None
+        db = sqlite3.connect(dbs[-1])
+        out = {}
+        for like in kernel_likes:
+            rows = db.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by counter_name",
+                              (f"%{like}%",)).fetchall()
+            out[like] = {c: (float(v), int(n)) for c, v, n in rows} or None
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def recorded_traffic(env_id, N, inner):
@@ -360,7 +478,11 @@ class Config:
             return "tab_rollout_kernel"
         return "mj_physics_kernel" if self.env_id in MJ_COOP else "mj_rollout_kernel"
 
-    def roofline(self, kernel_s, live=False, warm=1):
+    def traffic_request(self, key, warm=1):
+        """This configuration as live_traffic_batch wants it."""
+        return {"env_id": self.env_id, "N": self.N, "inner": self.inner, "env_kwargs": self.env_kwargs, "warm": warm, "kernel": self.dominant_kernel(), "key": key}
+
+    def roofline(self, kernel_s, live=False, warm=1, traffic=None):
         """The contract's roofline object for the dominant kernel.  achieved = algorithmic bytes per launch / the average launch duration the
         HIP events measured; traffic = HBM bytes per launch from the PMC counters (live passes on a child invocation when `live`, else the
         recorded profile, else null).  The cooperative MuJoCo kernels are VALU / latency bound: `bound` says so, the
@@ -369,13 +491,18 @@ class Config:
         achieved = algo / kernel_s / 1e9
         kernel = self.dominant_kernel()
         per = self.inner if self.env_id in MJ_COOP else 1  # dispatches of the dominant kernel per rollout launch
-        traffic, src = live_traffic(self.env_id, self.N, self.inner, kernel, self.env_kwargs, warm) if live else (None, None)
+        if traffic is not None:  # (bytes per dispatch, provenance) measured by the caller: live_traffic_batch
+            traffic, src = traffic
+        else:
+            traffic, src = live_traffic(self.env_id, self.N, self.inner, kernel, self.env_kwargs, warm) if live else (None, None)
+        stale = False
         if traffic is not None:
             traffic *= per
         else:
             traffic, src = recorded_traffic(self.env_id, self.N, self.inner)
+            stale = traffic is not None
         return {"bound": "valu" if self.env_id in MJ_COOP else "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": algo,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, **({"stale": True} if stale else {}), "algorithmic_bytes_per_launch": algo,
                 "avg_kernel_ms": kernel_s * 1e3, "traffic_over_algorithmic": (traffic / algo) if traffic else None}
 
     def close(self):
@@ -448,6 +575,7 @@ def main(argv=None, harness=None):
     ap.add_argument("--extras-budget", type=float, default=150.0, help="extras: seconds after which no further optional measurement is started")
     ap.add_argument("--env-kwargs", default="{}", help='JSON constructor kwargs of the env, e.g. \'{"solver": "Newton"}\' (Humanoid: opt-in solver)')
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
+    ap.add_argument("--child-list", default=None, help=argparse.SUPPRESS)  # ... for several configurations one after the other: JSON [[env, N, inner, kwargs, warm], ...]
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--pilot-seconds", type=float, default=1.0, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -484,6 +612,14 @@ def main(argv=None, harness=None):
             dist.barrier()
         sync_local()
 
+    if args.child and args.child_list:  # the profiled child of live_traffic_batch: each configuration's warm-up and three launches, nothing printed
+        for c_env, c_n, c_inner, c_kw, c_warm in json.loads(args.child_list):
+            c = make_config(c_env, int(c_n), int(c_inner), local_rank, rank, c_kw or None)
+            for _ in range(int(c_warm) + 3):
+                c.launch()
+            sync_local()
+            c.close()
+        return 0
     env_kwargs = json.loads(args.env_kwargs)
     cfg = make_config(args.env, N, inner, local_rank, rank, env_kwargs)
     if K is None:  # ~1 s of timed launches: a 50-launch burst is 5 ms, over before the clocks have ramped (round 1: the driver's sampler saw 0 % busy)
@@ -537,6 +673,13 @@ def main(argv=None, harness=None):
         except Exception as e:
             verified = {"ok": None, "error": f"{type(e).__name__}: {e}"[:200]}
     del traj
+    if verified is not None and verified.get("ok") is not None and args.env in MJ_IDS and gpu:
+        try:  # ... and ten more launches from where the timed region left the robots (contacts, resets, TimeLimit), window by window
+            later = mujoco_window_check(cfg)
+            verified.update({"later_windows": later, "ok": bool(verified["ok"] and later["ok"]), "steps": verified["steps"] + later["steps"],
+                             "max_abs_diff": max(verified["max_abs_diff"], later["max_abs_diff"])})
+        except Exception as e:
+            verified["later_windows"] = {"ok": None, "error": f"{type(e).__name__}: {e}"[:200]}
     # ---- sustained: the same launch back to back for >= args.sustained seconds (all ranks, same barrier discipline) ----------------
     sustained = None
     if args.sustained > 0 and elapsed >= 0.8:  # (elapsed is the all-reduced maximum: every rank takes the same branch)
@@ -588,8 +731,9 @@ def main(argv=None, harness=None):
         dist.destroy_process_group()
     if rank == 0:
         print(fit_line(result), flush=True)
-        if verified is not None and verified.get("ok") is False:
-            print("bench.py: the first timed launch does NOT equal the oracle's trajectory -- the number above is not a measurement", file=sys.stderr)
+        if (verified is not None and verified.get("ok") is False) or result.get("verified_all_ranks") is False:
+            print("bench.py: the first timed launch of " + ("this rank" if (verified or {}).get("ok") is False else "another rank") +
+                  " does NOT equal the oracle's trajectory -- the number above is not a measurement", file=sys.stderr)
             return 1
     return 0
 

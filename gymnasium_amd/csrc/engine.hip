@@ -182,7 +182,9 @@ template <class E>
 struct ResetQueue {
     double u[E::NDRAWS];
     double rs[E::S];  // the reset state those draws give under the default bounds (autoreset has no options): computed once per refill
-    bool have;
+    // (an integer, not a bool: a bool that lives across the role branches of rollout_duo_kernel is a lane mask in scalar registers, which the
+    //  compiler merges with three scalar instructions at every join of every phase -- ~9 instructions per phase and flag, on every wavefront)
+    uint32_t have;
     Pcg64 rng;
     MI_DEV void refill() {
 #pragma unroll
@@ -191,7 +193,7 @@ struct ResetQueue {
         uint32_t f = 0;
         E::default_bounds(b0, b1);
         E::reset_u(u, rs, f, b0, b1);
-        have = true;
+        have = 1u;
     }
     // what reset_u does to the flag word does not depend on the draws: it sets or clears kStateF32 (envs_classic.h)
     static MI_DEV uint32_t reset_flags(uint32_t flags) {
@@ -220,7 +222,7 @@ MI_DEV void lane_autoreset(const DevEnv &d, int i, Lane<E> &L, ResetQueue<E> *q,
         if (!q->have) q->refill();  // rare: two episode ends within one refill period
 #pragma unroll
         for (int k = 0; k < E::NDRAWS; k++) u[k] = q->u[k];
-        q->have = false;
+        q->have = 0u;
     } else {
         draw_reset_values<E>(d, i, u, preloaded);
     }
@@ -361,7 +363,7 @@ MI_DEV void lane_step_fused(const DevEnv &d, Lane<E> &L, typename E::Act a, Step
     L.elapsed = resetting ? 0u : elapsed;
     L.ep_ret = resetting ? 0.0 : ep_ret;
     L.ep_len = resetting ? 0 : ep_len;
-    q.have = q.have && !resetting;
+    q.have = resetting ? 0u : q.have;
     st.reset_steps += resetting ? 1u : 0u;
     st.env_steps += resetting ? 0u : moved;
     st.episodes += done ? 1u : 0u;
@@ -780,7 +782,8 @@ struct RolloutPtrs {
 // the number of draws taken since: draw number n of the stream is the output after skipping n steps ahead of the base (Brown's O(log n) jump through
 // the pow2 table), so every lane finds its own draws without a serial pass and nothing but two counters ever changes.
 struct SharedRng {
-    uint64_t *words;       // [8] device: base {state_hi, state_lo, inc_hi, inc_lo}, [4] consumed, [5] pos_base = first draw of the call in flight, [6] k = sub-envs it re-draws
+    uint64_t *words;       // [8] device: base {state_hi, state_lo, inc_hi, inc_lo}, [4] consumed, [5] pos_base = first draw of the call in flight, [6] k = sub-envs it re-draws,
+                           // [7] != 0: a batch with an action outside the space was refused (shared_validate_kernel) -- every later step is a no-op until the host has raised it
     const PcgJump *pow2;   // [64] device: jump by 2^j steps of the base generator's increment
     uint32_t *blk_done;    // [grid] sub-environments of each step workgroup that finished an episode in the previous step
     uint32_t *blk_prefix;  // [grid] exclusive scan of blk_done (shared_scan_kernel)
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
         (void)ainc;
         const size_t N = (size_t)d.N;
         ResetQueue<E> q;
-        q.have = false;
+        q.have = 0u;
         q.rng = load_rng(d, i);
         // (per-kind unroll factor: 2 for Acrobot -- its long loop body schedules better as two steps, +4.6 %; 1 = none for the others, where 2 and 4
         //  measured +-0.1 %; Acrobot x4: -6 %.  profiles/r04_maxilp_classic.txt)
@@ -879,7 +882,11 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(DevEnv d, RolloutPtrs i
 constexpr int kDuoBlock = 2 * kBlock;
 template <class E>
 struct DuoTraits {
+#ifdef MI_DUO_CHUNK_OVERRIDE  // (A/B builds: scripts/build_variant.py ... -DMI_DUO_CHUNK_OVERRIDE=8)
+    static constexpr int CHUNK = MI_DUO_CHUNK_OVERRIDE;
+#else
     static constexpr int CHUNK = E::DUO_CHUNK;  // steps per phase (envs_classic.h: measured per environment; 2 costs 10 .. 14 % in barriers)
+#endif
 };
 
 // env role: lane_step_fused<E, false> without the episode statistics; `bits`: 1 terminated, 2 truncated, 4 this was the autoreset step
@@ -910,10 +917,34 @@ MI_DEV void duo_env_step(const DevEnv &d, Lane<E> &L, typename E::Act a, ResetQu
     }
     L.flags = resetting ? rflags : (done ? (sflags | kNeedsReset) : sflags);
     L.elapsed = resetting ? 0u : elapsed;
-    q.have = q.have && !resetting;
+    q.have = resetting ? 0u : q.have;
     if constexpr (!E::SPLIT_TERMINAL) E::obs(L.s, L.flags, obs, L.trig);
     reward = resetting ? 0.0 : rew;
     bits = (resetting ? 4u : 0u) | ((!resetting && te) ? 1u : 0u) | ((!resetting && tr) ? 2u : 0u);
+}
+
+// ... and the env role of an environment whose aux role derives the observation row and the flags from the state (E::AUX_DERIVES_FLAGS): the same
+// step and autoreset select, then only the state words go over (E::aux_pack) -- no observation conversion, no flag word
+template <class E>
+MI_DEV void duo_env_step_state(const DevEnv &d, Lane<E> &L, typename E::Act a, ResetQueue<E> &q, double *w64, float *w32) {
+    static_assert(!E::SPLIT_TERMINAL, "the split terminal test belongs to the observation, which this role does not take");
+    const bool resetting = (L.flags & kNeedsReset) != 0;
+    if (__builtin_expect(resetting && !q.have, 0)) q.refill();  // rare: two episode ends within one refill period
+    const double (&rs)[E::S] = q.rs;
+    const uint32_t rflags = ResetQueue<E>::reset_flags(L.flags & ~kNeedsReset);
+    double rew;
+    bool te;
+    uint32_t sflags = L.flags;
+    E::step(L.s, sflags, a, d.P, rew, te, L.trig);
+    const uint32_t elapsed = L.elapsed + 1u;  // TimeLimit.step (wrappers/common.py:129-133)
+    const bool tr = d.max_steps > 0 && (int)elapsed >= d.max_steps;
+    const bool done = !resetting && (te || tr);
+#pragma unroll
+    for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
+    L.flags = resetting ? rflags : (done ? (sflags | kNeedsReset) : sflags);
+    L.elapsed = resetting ? 0u : elapsed;
+    q.have = resetting ? 0u : q.have;
+    E::aux_pack(L.s, w64, w32);
 }
 
 // (Measured and not kept: the aux role split once more into "policy" and "book" wavefronts for three per SIMD: CartPole 78.9 us against 76.4 us --
@@ -924,14 +955,21 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     constexpr int ROLES = 2;
     constexpr int C = DuoTraits<E>::CHUNK;
     __shared__ Act sh_act[2][C][kBlock];
-    __shared__ float sh_obs[2][C][kBlock][E::OBS];
+    // what goes from the env role to the aux role: the observation row and a flag word -- or, for the environments whose aux role derives both from
+    // the state (E::AUX_DERIVES_FLAGS, envs_classic.h), the state words
+    constexpr bool DERIVE = E::AUX_DERIVES_FLAGS;
+    static_assert(!DERIVE || E::REWARD_FROM_TERMINATED, "an aux role that derives the flags also derives the reward from them");
+    constexpr int NF64 = E::AUX_F64 > 0 ? E::AUX_F64 : 1, NF32 = E::AUX_F32 > 0 ? E::AUX_F32 : 1;
+    __shared__ double sh_w64[DERIVE ? 2 : 1][DERIVE ? C : 1][DERIVE ? kBlock : 1][NF64];
+    __shared__ float sh_w32[(DERIVE && E::AUX_F32 > 0) ? 2 : 1][(DERIVE && E::AUX_F32 > 0) ? C : 1][(DERIVE && E::AUX_F32 > 0) ? kBlock : 1][NF32];
+    __shared__ float sh_obs[DERIVE ? 1 : 2][DERIVE ? 1 : C][DERIVE ? 1 : kBlock][E::OBS];
     // (Measured and not kept: Pendulum with its reward -- three exact pow and an fmod, none of which feeds the next state -- evaluated by the aux role from
     //  the pre-step state passed through LDS: bit-identical, 168.7 us against 168.7 us for the one-role kernel.  Its instruction count is the limit.)
     constexpr bool PASS_REWARD = !E::REWARD_FROM_TERMINATED;  // (not transferred when the aux role can recompute it)
     __shared__ double sh_rew[PASS_REWARD ? 2 : 1][PASS_REWARD ? C : 1][kBlock];
     // (the flag word's width is tuning, measured per environment at T = 128: CartPole +2.3 % with a dword, MountainCarContinuous +2.9 % with a byte)
     typedef typename std::conditional<E::REWARD_FROM_TERMINATED && E::OBS == 4, uint32_t, uint8_t>::type MI_DUO_FLAG_T;
-    __shared__ MI_DUO_FLAG_T sh_bits[2][C][kBlock];
+    __shared__ MI_DUO_FLAG_T sh_bits[DERIVE ? 1 : 2][DERIVE ? 1 : C][DERIVE ? 1 : kBlock];
     __shared__ uint64_t sh_c[4][kBlock / 64];
     __shared__ double sh_r[kBlock / 64];
     tables_init<E>();
@@ -950,17 +988,20 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     double ep_ret = 0.0;
     int32_t ep_len = 0, ep_len_start = 0;  // (ep_len_start: 0 for a sub-environment whose first step is its autoreset step -- that episode was counted when it finished)
     uint32_t n_term = 0;
-    bool last_done = false, last_te = false;
+    uint32_t start_flags = 0;
+    uint32_t aux_elapsed = 0, aux_needs_reset = 0;  // DERIVE: the aux role's own copy of the TimeLimit counter and of the pending-autoreset flag
     if (active) {
         if (is_env) {
             load_lane<E>(d, i, L);
-            q.have = false;
+            q.have = 0u;
             q.rng = load_rng(d, i);
         }
         if (is_book) {
             ep_ret = d.ep_ret[i], ep_len = d.ep_len[i];
-            last_done = ((d.meta[i] >> kFlagShift) & kNeedsReset) != 0;  // (as if the step before the launch had finished the episode: right for T = 0 as well)
-            ep_len_start = last_done ? 0 : ep_len;
+            const uint32_t meta0 = d.meta[i];
+            start_flags = meta0 >> kFlagShift;
+            aux_elapsed = meta0 & kElapsedMask, aux_needs_reset = start_flags & kNeedsReset;
+            ep_len_start = (start_flags & kNeedsReset) ? 0 : ep_len;
         }
         if (is_policy) {
             astate = make_u128(as.state_hi, as.state_lo);  // skip ahead by (i + 1) draws: one affine map per set bit of (i + 1)
@@ -989,14 +1030,24 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                     for (int k = 0; k < C; k++) {
                         const int t = c * C + k;
                         if (!REFILL_PER_CHUNK && (t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
-                        float o[E::OBS];
-                        double rew;
-                        uint32_t bits;
-                        duo_env_step<E>(d, L, sh_act[buf][k][slot], q, o, rew, bits);
+                        if constexpr (DERIVE) {
+                            double w64[NF64];
+                            float w32[NF32];
+                            duo_env_step_state<E>(d, L, sh_act[buf][k][slot], q, w64, w32);
 #pragma unroll
-                        for (int j = 0; j < E::OBS; j++) sh_obs[buf][k][slot][j] = o[j];
-                        if constexpr (PASS_REWARD) sh_rew[buf][k][slot] = rew;
-                        sh_bits[buf][k][slot] = (MI_DUO_FLAG_T)bits;
+                            for (int j = 0; j < E::AUX_F64; j++) sh_w64[buf][k][slot][j] = w64[j];
+#pragma unroll
+                            for (int j = 0; j < E::AUX_F32; j++) sh_w32[buf][k][slot][j] = w32[j];
+                        } else {
+                            float o[E::OBS];
+                            double rew;
+                            uint32_t bits;
+                            duo_env_step<E>(d, L, sh_act[buf][k][slot], q, o, rew, bits);
+#pragma unroll
+                            for (int j = 0; j < E::OBS; j++) sh_obs[buf][k][slot][j] = o[j];
+                            if constexpr (PASS_REWARD) sh_rew[buf][k][slot] = rew;
+                            sh_bits[buf][k][slot] = (MI_DUO_FLAG_T)bits;
+                        }
                     }
                 }
             } else {
@@ -1007,10 +1058,30 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                     for (int k = 0; k < C; k++) {
                         const size_t t = (size_t)c * C + k;
                         float o[E::OBS];
+                        bool resetting, te, tr;
+                        if constexpr (DERIVE) {
+                            double w64[NF64];
+                            float w32[NF32];
 #pragma unroll
-                        for (int j = 0; j < E::OBS; j++) o[j] = sh_obs[buf][k][slot][j];
-                        const uint32_t bits = sh_bits[buf][k][slot];
-                        const bool resetting = (bits & 4u) != 0, te = (bits & 1u) != 0, tr = (bits & 2u) != 0;
+                            for (int j = 0; j < E::AUX_F64; j++) w64[j] = sh_w64[buf][k][slot][j];
+#pragma unroll
+                            for (int j = 0; j < E::AUX_F32; j++) w32[j] = sh_w32[buf][k][slot][j];
+                            bool t0;
+                            E::aux_unpack(w64, w32, d.P, o, t0);
+                            // the vectoriser's state machine once more, on this role's own counters (sync_vector_env.py:277-329, wrappers/common.py:129-133):
+                            // the same integers the env role holds, so the same flags
+                            resetting = aux_needs_reset != 0;
+                            const uint32_t el = aux_elapsed + 1u;
+                            te = !resetting && t0;
+                            tr = !resetting && d.max_steps > 0 && (int)el >= d.max_steps;
+                            aux_elapsed = resetting ? 0u : el;
+                            aux_needs_reset = (te || tr) ? 1u : 0u;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < E::OBS; j++) o[j] = sh_obs[buf][k][slot][j];
+                            const uint32_t bits = sh_bits[buf][k][slot];
+                            resetting = (bits & 4u) != 0, te = (bits & 1u) != 0, tr = (bits & 2u) != 0;
+                        }
                         double rew;
                         const bool done = te || tr;
                         if constexpr (E::REWARD_FROM_TERMINATED) {
@@ -1021,7 +1092,6 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                             st.reset_steps += resetting ? 1u : 0u;
                             st.episodes += done ? 1u : 0u;
                             n_term += te ? 1u : 0u;
-                            last_done = done, last_te = te;
                         } else {
                             rew = sh_rew[buf][k][slot];
                             const double ret = ep_ret + rew;
@@ -1090,6 +1160,22 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                 // exact in float64 in any order) the finished episodes' returns are r_N (lengths - terminations) + r_T terminations, the running
                 // episode's return r_N x its length.  Same numbers as the step-by-step accumulation of rollout_kernel, bit for bit.
                 const double r_n = E::reward_from_terminated(false, d.P), r_t = E::reward_from_terminated(true, d.P);
+                // how the LAST step ended: its flags are still in the ring (nothing is carried through the phases for this)
+                bool last_done, last_te;
+                if constexpr (DERIVE) {  // (this role's own flag; whether the finishing step terminated: the last state is still in the ring)
+                    double w64[NF64];
+                    float w32[NF32], o[E::OBS];
+#pragma unroll
+                    for (int j = 0; j < E::AUX_F64; j++) w64[j] = sh_w64[((chunks > 0 ? chunks : 1) - 1) & 1][C - 1][slot][j];
+#pragma unroll
+                    for (int j = 0; j < E::AUX_F32; j++) w32[j] = sh_w32[((chunks > 0 ? chunks : 1) - 1) & 1][C - 1][slot][j];
+                    bool t0;
+                    E::aux_unpack(w64, w32, d.P, o, t0);
+                    last_done = aux_needs_reset != 0, last_te = last_done && t0;
+                } else {
+                    const uint32_t last_bits = chunks > 0 ? (uint32_t)sh_bits[(chunks - 1) & 1][C - 1][slot] : ((start_flags & kNeedsReset) ? 2u : 0u);
+                    last_done = (last_bits & 3u) != 0, last_te = (last_bits & 1u) != 0;
+                }
                 st.env_steps = (uint32_t)(chunks * C) - st.reset_steps;
                 // (an episode that finished in the very last step still sits in ep_len, waiting for its autoreset step: it IS among the finished ones)
                 st.length_sum = (uint64_t)((int64_t)st.env_steps + (int64_t)ep_len_start - (last_done ? (int64_t)0 : (int64_t)ep_len));
@@ -1149,8 +1235,21 @@ MI_DEV double shared_draw_from(const SharedRng &sr, const uint64_t (*sh)[2], int
 
 // One workgroup, before every reset (fixed_draws = 4 N) / step (fixed_draws = 0: 4 k, k = the sub-environments that finished in the previous step):
 // exclusive scan of the per-workgroup counts, and the stream bookkeeping -- the call in flight draws from pos_base, the next one after it.
+// CartPoleVectorEnv.step asserts `self.action_space.contains(action)` for the WHOLE batch before it touches a sub-environment or the generator
+// (cartpole.py:424-426).  A device caller's batch is checked by this pre-pass: one bad action marks the batch refused, and the scan / step kernels
+// of this and of every later call return at once (no draw consumed, no sub-environment stepped) until the host has raised the error (raise_device_error).
+template <class E>
+__global__ __launch_bounds__(kBlock) void shared_validate_kernel(DevEnv d, const typename E::Act *actions, SharedRng sr) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < d.N && !E::valid(actions[i])) {
+        *d.error = kErrInvalidAction;
+        sr.words[7] = 1;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void shared_scan_kernel(SharedRng sr, int grid, uint64_t fixed_draws) {
     __shared__ uint32_t wave_total[kBlock / 64];
+    if (!fixed_draws && sr.words[7]) return;  // a refused batch (uniform)
     const int per = (grid + kBlock - 1) / kBlock, lo = threadIdx.x * per, hi = min(grid, lo + per);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t sum = 0;
@@ -1239,6 +1338,7 @@ __global__ __launch_bounds__(kBlock) void shared_step_kernel(DevEnv d, StepPtrs 
     __shared__ uint32_t sh_wave[kBlock / 64];
     __shared__ uint64_t sh_base[4][2];
     static_assert(E::NDRAWS == 4, "four state components: threads 0..3 prepare their bases");
+    if (sr.words[7]) return;  // a refused batch (shared_validate_kernel): nothing is touched, blk_done keeps the previous step's counts
     tables_init<E>();
     const int i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (sr.blk_done[blockIdx.x]) shared_block_bases(sr, sr.words[5] + (uint64_t)sr.blk_prefix[blockIdx.x], sr.words[6], sh_base);  // (workgroup-uniform test)
@@ -2099,6 +2199,10 @@ int raise_device_error(mi_vecenv *v) {  // precondition: the stream is idle (a k
     const int err = *v->h_err;
     if (!err) return MI_OK;
     *v->h_err = 0;
+    if (v->shared_rng && v->shared.words) {  // the shared-generator mode refuses every step after a bad batch until it has been raised: lift that
+        (void)hipMemsetAsync(v->shared.words + 7, 0, sizeof(uint64_t), v->stream);
+        (void)hipStreamSynchronize(v->stream);
+    }
     if (err == kErrInvalidAction) return fail(MI_ERR_INVALID_ARGUMENT, "action outside the action space");
     return fail(MI_ERR_STATE, "DISABLED autoreset: a finished sub-environment was stepped without reset");
 }
@@ -2235,6 +2339,11 @@ int shared_reset(mi_vecenv *v, float *dobs) {
     });
 }
 int shared_step(mi_vecenv *v, const StepPtrs &p) {
+    dispatch_shared(v, [&](auto env) -> int {
+        using E = decltype(env);
+        hipLaunchKernelGGL((shared_validate_kernel<E>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, static_cast<const typename E::Act *>(p.actions), v->shared);
+        return (int)MI_OK;
+    });
     hipLaunchKernelGGL(shared_scan_kernel, dim3(1), dim3(kBlock), 0, v->stream, v->shared, v->grid, (uint64_t)0);
     return dispatch_shared(v, [&](auto env) -> int {
         hipLaunchKernelGGL((shared_step_kernel<decltype(env)>), dim3(v->grid), dim3(kBlock), 0, v->stream, v->d, p, v->shared);

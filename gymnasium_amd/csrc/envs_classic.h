@@ -200,12 +200,26 @@ struct CartPoleT {
     static constexpr int ACT_KIND = MI_I64;
     static constexpr int ROLLOUT_UNROLL = 1;  // engine.hip rollout_kernel: steps per unrolled loop body
     static constexpr bool DUO_ROLLOUT = true;  // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments): measured +13 %
-    static constexpr int DUO_CHUNK = 4;  // steps per phase of the two-role kernel (8: -2.4 %)
+    static constexpr int DUO_CHUNK = 8;  // steps per phase of the two-role kernel (round 6, after the phase overhead left the wavefronts: +3.0 % over 4; round 4 measured -2.4 %)
     // the reward of a (non-reset) step is a function of its terminated flag (step(), below): the aux role recomputes it instead of receiving it
     static constexpr bool REWARD_FROM_TERMINATED = true;
     static MI_DEV double reward_from_terminated(bool terminated, const EnvParams &P) {
         const bool sutton_barto = P.p[0] != 0.0;
         return terminated ? (sutton_barto ? -1.0 : 1.0) : (sutton_barto ? 0.0 : 1.0);
+    }
+    // Two-role rollout, round 6: the aux role derives the observation row AND the flags of a step from the state itself, so the env role hands over
+    // the state -- the two components the termination test reads (x, theta: cartpole.py:200-205) as the float64 they are, the two velocities as the
+    // float32 the observation holds -- and neither converts an observation nor packs a flag word.  aux_unpack's test is step()'s, on the same doubles.
+    static constexpr bool AUX_DERIVES_FLAGS = true;
+    static constexpr int AUX_F64 = 2, AUX_F32 = 2;
+    static MI_DEV void aux_pack(const double s[S], double w64[AUX_F64], float w32[AUX_F32]) {
+        w64[0] = s[0], w64[1] = s[2], w32[0] = (float)s[1], w32[1] = (float)s[3];
+    }
+    static MI_DEV void aux_unpack(const double w64[AUX_F64], const float w32[AUX_F32], const EnvParams &, float o[OBS], bool &terminated) {
+        const double theta_threshold = 12 * 2 * kPi / 360, x_threshold = 2.4;
+        const double x = w64[0], theta = w64[1];
+        o[0] = (float)x, o[1] = w32[0], o[2] = (float)theta, o[3] = w32[1];
+        terminated = x < -x_threshold || x > x_threshold || theta < -theta_threshold || theta > theta_threshold;
     }
     typedef int64_t Act;
 
@@ -506,6 +520,15 @@ struct MountainCarT {
     static constexpr int DUO_CHUNK = 8;  // steps per phase of the two-role kernel (+2.6 % over 4)
     static constexpr bool REWARD_FROM_TERMINATED = true;  // -1.0 every step (step(), below)
     static MI_DEV double reward_from_terminated(bool, const EnvParams &) { return -1.0; }
+    // (see CartPoleT: the aux role of the two-role rollout derives observation and flags from the float64 state, mountain_car.py:139-142)
+    static constexpr bool AUX_DERIVES_FLAGS = true;
+    static constexpr int AUX_F64 = 2, AUX_F32 = 0;
+    static MI_DEV void aux_pack(const double s[S], double w64[AUX_F64], float *) { w64[0] = s[0], w64[1] = s[1]; }
+    static MI_DEV void aux_unpack(const double w64[AUX_F64], const float *, const EnvParams &P, float o[OBS], bool &terminated) {
+        const double goal_position = 0.5;
+        o[0] = (float)w64[0], o[1] = (float)w64[1];
+        terminated = w64[0] >= goal_position && w64[1] >= P.p[0];
+    }
     typedef int64_t Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
@@ -558,6 +581,11 @@ struct MountainCarContinuousT {
     static constexpr int DUO_CHUNK = 8;  // steps per phase of the two-role kernel (+4.2 % over 4)
     static constexpr bool REWARD_FROM_TERMINATED = false;
     static MI_DEV double reward_from_terminated(bool, const EnvParams &) { return 0.0; }
+    // (the state's float32 / float64 phases and the reward's dependence on the action keep observation, reward and flags on the env role here)
+    static constexpr bool AUX_DERIVES_FLAGS = false;
+    static constexpr int AUX_F64 = 1, AUX_F32 = 0;
+    static MI_DEV void aux_pack(const double *, double *, float *) {}
+    static MI_DEV void aux_unpack(const double *, const float *, const EnvParams &, float *, bool &) {}
     typedef typename AK::T Act;
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }

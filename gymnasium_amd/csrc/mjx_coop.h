@@ -33,67 +33,6 @@
 #else
 #define MJX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#ifndef MJX_CHOL_LDS_FOR_16
-#define MJX_CHOL_LDS_FOR_16 0  // diagnostic switch: 16-lane groups on the LDS-exchange Cholesky as well (costs LDS: 3 instead of 4 wavefronts per CU)
-#endif
-#ifndef MJX_KIN_LOCAL_JOINTS
-#define MJX_KIN_LOCAL_JOINTS 1  // kinematics: a body's joint chain is evaluated once, in the body's static frame, before the level loop (0: inside it, rounds 1-2)
-#endif
-#ifndef MJX_FLAT_JOINTS
-#define MJX_FLAT_JOINTS 1  // the phases that walk a body's joints read one flat static record per body instead of chained model tables
-#endif
-#ifndef MJX_RK4_INLINE
-#define MJX_RK4_INLINE 0  // 1: the RK4 stage update inlined into the stage loop -- DO NOT: see rk4_stage
-#endif
-#ifndef MJX_PGS_MORE_BLOCKS
-#define MJX_PGS_MORE_BLOCKS 1  // PGS: M^-1 J_c^T of up to 15 contacts (not 7) stays on the blackboard (Sim::bblock)
-#endif
-#ifndef MJX_CRB_BLEND_ALL
-#define MJX_CRB_BLEND_ALL 1  // the blended mass-matrix rows for every robot (see Sim::CRB_BLEND)
-#endif
-#ifndef MJX_CRB_BRANCHFREE
-#define MJX_CRB_BRANCHFREE 1  // mass-matrix rows: both candidate dot products and a select instead of two divergent branches per entry
-#endif
-#ifndef MJX_COLLIDE_TABLES
-#define MJX_COLLIDE_TABLES 1  // collision of the many-slot robots (Sim::COLLIDE_TABLES): geom poses once per pass on the blackboard + one flat descriptor per candidate slot
-#endif
-#ifndef MJX_CHOL_PIPELINED
-#define MJX_CHOL_PIPELINED 1  // Cholesky sweeps: no selects for the unused upper entries; LDS variant: the next pivot column is published before the row update
-#endif
-#ifndef MJX_VEL_PREFIX
-#define MJX_VEL_PREFIX 1  // com velocities / RNE accelerations: prefix sums over the body tree by pointer jumping instead of one pass per tree level
-#endif
-#ifndef MJX_KIN_PREFIX
-#define MJX_KIN_PREFIX 1  // kinematics: world poses by pointer jumping over the body tree (ceil(log2(depth)) rounds) instead of one pass per tree level
-#endif
-#ifndef MJX_CHOL_MFMA
-#define MJX_CHOL_MFMA 0  // 1: 32-lane PGS kernels factor M in block-16 form with the Schur update on v_mfma_f64_16x16x4_f64 (chol_factor_blocked).
-                         // MEASURED in the product (round 3, profiles/r03_mfma_cholesky_in_product.txt): correct (GPU suite green, states equal to
-                         // 1e-15) but 1.9 % SLOWER end to end (Humanoid-v5 1.047 M vs 1.067 M env-steps/s, factor phase 24.9 k vs 24.5 k cycles) although
-                         // the isolated factorisation is 23 % faster (profiles/r03_mfma_humanoid.txt): two extra blackboard round trips and the
-                         // four dependent MFMAs sit on the critical path of a kernel that one wavefront per SIMD cannot overlap.  Off.
-#endif
-#ifndef MJX_PGS_PIPELINE
-#define MJX_PGS_PIPELINE 0  // Software pipelining of the PGS sweeps over contacts (round 5; A/B with scripts/build_variant.py, results in docs/mujoco_design.md):
-                            // 0: sequential (rounds 2-4): column, three group reductions J_c a, owner relaxes the rows, a += M^-1 J_c^T dl.
-                            // 1: contact c + 1's column AND reductions are issued before the owner relaxes contact c (on the `a` that lacks c's step); the owner
-                            //    of c + 1 then adds W dl with the 3 x 3 coupling block W = J_{c+1} M^-1 J_c^T: J_{c+1} (a + M^-1 J_c^T dl) = J_{c+1} a + W dl.
-                            //    Same Gauss-Seidel iterate, rounded differently in the last bits.  MEASURED: correct (GPU parity suite green) and 9 - 17 % SLOWER:
-                            //    nine more reductions per contact and pass to form W, 18 more live doubles (465 -> 512 registers, 14 spilled).
-                            // 2: only the next contact's Jacobian column (independent of the iterate) is requested early; bit-identical to 0.
-#endif
-#ifndef MJX_PGS_EDGE_CHAIN
-#define MJX_PGS_EDGE_CHAIN 0  // 1: the four edge rows of a pyramidal contact are relaxed in EDGE space: the residuals u_e = (E v)_e - aref_e are formed once per visit and kept
-                              // current through the 4 x 4 block E A E^T (one multiply-add per later edge) instead of updating the 3-vector v and re-forming each row from
-                              // it: the dependent chain from one edge's step to the next edge's residual drops from ~8 fp64 operations to 4.  Same iterate, rounded
-                              // differently in the last bits.
-#endif
-#ifndef MJX_PGS_QS_BY_INVERSE
-#define MJX_PGS_QS_BY_INVERSE 0  // 1: PGS forms qacc_smooth = M^-1 qfrc_smooth as a row product once M^-1 exists instead of by the triangular solves.  MEASURED (r03, profiles/r03_pgs_qs_by_inverse.txt): same results to 1e-15, but the changed control flow takes the 32-lane kernel from 4 to 999 spilled VGPRs and doubles its time -- off
-#endif
-#ifndef MJX_GROUP_SUM_SHFL
-#define MJX_GROUP_SUM_SHFL 0   // diagnostic switch: group reductions as __shfl_xor butterflies instead of DPP rotations
-#endif
 
 namespace mjx {
 namespace coop {
@@ -155,10 +94,6 @@ MJX_DEV void row_pair(double v, double &even_rows, double &odd_rows) {
 }
 template <int G>
 MJX_DEV double group_sum(double v, decltype(nullptr), int) {
-#if MJX_GROUP_SUM_SHFL
-    for (int off = G / 2; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
-#endif
     if (G == 32) {
         double a, b;
         row_pair(v, a, b);
@@ -214,7 +149,7 @@ struct Board {
         } kin;
         struct {
             double L[NTRI];                                   // packed lower Cholesky factor (column access in back substitution)
-            double col[2][(G_ == 16 && !MJX_CHOL_LDS_FOR_16) ? 1 : NV];                 // pivot column / substitution exchange of the 32-lane variant (double buffered)
+            double col[2][(G_ == 16 && !0) ? 1 : NV];                 // pivot column / substitution exchange of the 32-lane variant (double buffered)
             double vdir[NV];                                  // solution of the last solve (qacc_smooth, then the search directions)
         } sol;
     } A;
@@ -223,7 +158,7 @@ struct Board {
             double cacc[NB][6], cfrc[NB][6];
         } rne;
         double cinert[NB][10];
-        double geo[(MJX_COLLIDE_TABLES && M::NSLOT > 2 * G_) ? M::NGEOM : 1][6];  // collision (Sim::COLLIDE_TABLES): world position and axis of every geom (dead before the RNE pass starts)
+        double geo[(M::NSLOT > 2 * G_) ? M::NGEOM : 1][6];  // collision (Sim::COLLIDE_TABLES): world position and axis of every geom (dead before the RNE pass starts)
     } Bu;
     union {
         struct {
@@ -244,15 +179,14 @@ struct Board {
     // consecutive addresses), which is what keeps that kernel from spilling.
     static constexpr bool M_IN_LDS = NV > 16;
     double Mt[M_IN_LDS ? NV : 1][M_IN_LDS ? NV : 1];
-    // blocked Cholesky (Sim::chol_factor_blocked): this environment's block of the 16 x 16 MFMA tile L21 L21^T (rows / columns 16 .. NV - 1)
-    static constexpr bool CHOL_BLOCKED = G_ == 32 && NV > 16 && NV <= 24 && MJX_CHOL_MFMA;
     // PGS (Sim::bblock): M^-1 J_c^T blocks beyond the ones that fit the dead storage of M, of the Cholesky factor and of union Bu -- as many as keep
     // the 32-lane robots at four wavefronts' worth of LDS per CU (2 x 20 064 B per wavefront for the Humanoid)
-    static constexpr int NBX = (M_IN_LDS && MJX_PGS_MORE_BLOCKS) ? 2 : 0;
-    double schur[CHOL_BLOCKED ? 8 : 1][CHOL_BLOCKED ? 8 : 1];
-    // (zero-length -- a GNU / clang extension -- for the robots without it: a Board that grows by a single double re-lays every LDS offset, and these
-    //  kernels' code generation is sensitive to that: measured Ant 5.02 -> 4.83 M env-steps/s for one unused word, and the Humanoid 1.26 -> 1.23 M when
-    //  the word was folded into a union with `schur` instead; scripts/r03/gpu_call37.sh, gpu_call38.sh)
+    static constexpr int NBX = M_IN_LDS ? 2 : 0;
+    // One word that nothing reads: until round 6 the (switched-off) blocked MFMA Cholesky kept its 8 x 8 Schur tile here, one double for every robot
+    // without it.  The word stays because a Board that grows or shrinks by a single double re-lays every LDS offset behind it, and these kernels'
+    // code generation is sensitive to that (measured in round 3: Ant 5.02 -> 4.83 M env-steps/s for one word more, Humanoid 1.26 -> 1.23 M when the
+    // word was folded into a union; scripts/r03/gpu_call37.sh, gpu_call38.sh): removing the dead code must not move the shipped kernels.
+    double layout_word[1][1];
     double bx[NBX][NBX ? 3 * NV : 1];  // live from the row assembly to the end of the sweeps
     int con_pair[MAXCON];             // geom pair of the contact | body of its first geom << 16 | body of its second geom << 24 (the bodies
                                       // ride along because pair -> geom -> body is two dependent table loads from global memory per use;
@@ -291,10 +225,7 @@ struct Lane {
     // (A00 A01 A02 A11 A12 A22), the reciprocals 1 / (E A E^T + R) of its rows, J_c qacc_smooth, and where contacts beyond the LDS
     // capacity keep their M^-1 J_c^T block (global memory, per environment)
     double p_lf[2], p_lari[2], p_f[KC][4], p_A[KC][6], p_ari[KC][4], p_js[KC][3];
-#if MJX_PGS_PIPELINE == 1
-    double p_W[KC][9];  // owner of contact c: W = J_c M^-1 J_{c-1}^T (row-major 3 x 3), the coupling with its predecessor in the sweep order
-#endif
-    int grp;  // which of the wavefront's sub-environments this lane belongs to (its blackboard is boards[grp]; the MFMA tile packs all of them)
+    int grp;  // which of the wavefront's sub-environments this lane belongs to (its blackboard is boards[grp])
 };
 
 template <class M, int G, bool PGS = (M::SOLVER == 1)>
@@ -372,14 +303,14 @@ struct Sim {
         return t;
     }
     static constexpr DofTab kDof = make_dofs();
-    // joint jj of body b (MJX_FLAT_JOINTS = 0: through the model tables, for A/B runs)
-    static MJX_DEV int jnum(int b) { return MJX_FLAT_JOINTS ? kBody.b[b].jn : M::body_jntnum[b]; }
-    static MJX_DEV int jtype(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].jtype[jj] : M::jnt_type[M::body_jntadr[b] + jj]; }
-    static MJX_DEV int jqadr(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].qadr[jj] : M::jnt_qposadr[M::body_jntadr[b] + jj]; }
-    static MJX_DEV int jdadr(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].dadr[jj] : M::jnt_dofadr[M::body_jntadr[b] + jj]; }
-    static MJX_DEV double jq0(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].q0[jj] : M::qpos0[M::jnt_qposadr[M::body_jntadr[b] + jj]]; }
-    static MJX_DEV const double *jpos(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].jpos[jj] : M::jnt_pos[M::body_jntadr[b] + jj]; }
-    static MJX_DEV const double *jaxis(int b, int jj) { return MJX_FLAT_JOINTS ? kBody.b[b].jaxis[jj] : M::jnt_axis[M::body_jntadr[b] + jj]; }
+    // joint jj of body b (1 = 0: through the model tables, for A/B runs)
+    static MJX_DEV int jnum(int b) { return 1 ? kBody.b[b].jn : M::body_jntnum[b]; }
+    static MJX_DEV int jtype(int b, int jj) { return 1 ? kBody.b[b].jtype[jj] : M::jnt_type[M::body_jntadr[b] + jj]; }
+    static MJX_DEV int jqadr(int b, int jj) { return 1 ? kBody.b[b].qadr[jj] : M::jnt_qposadr[M::body_jntadr[b] + jj]; }
+    static MJX_DEV int jdadr(int b, int jj) { return 1 ? kBody.b[b].dadr[jj] : M::jnt_dofadr[M::body_jntadr[b] + jj]; }
+    static MJX_DEV double jq0(int b, int jj) { return 1 ? kBody.b[b].q0[jj] : M::qpos0[M::jnt_qposadr[M::body_jntadr[b] + jj]]; }
+    static MJX_DEV const double *jpos(int b, int jj) { return 1 ? kBody.b[b].jpos[jj] : M::jnt_pos[M::body_jntadr[b] + jj]; }
+    static MJX_DEV const double *jaxis(int b, int jj) { return 1 ? kBody.b[b].jaxis[jj] : M::jnt_axis[M::body_jntadr[b] + jj]; }
 
     // ancestors at distance 1, 2, 4, ... of every body (0 = the world: nothing left to compose), for the pointer-jumping kinematics
     struct AncTab {
@@ -409,7 +340,6 @@ struct Sim {
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
         const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = jnum(bi);
-#if MJX_KIN_LOCAL_JOINTS
         // (round 3) The joints of a body act in the body's own static frame F0 (parent pose o body_pos / body_quat): with pose = F0 o (pl, ql),
         //   anchor_j = F0 (pl + R(ql) jnt_pos_j),  axis_j = F0 R(ql) jnt_axis_j,  hinge: ql <- ql o q(axis_j, theta_j), pl <- anchor_j^loc - R(ql) jnt_pos_j,
         //   slide: pl += axis_j^loc theta_j
@@ -444,7 +374,6 @@ struct Sim {
             }
         }
         MJX_PHASE_X(r, 4, 12);
-#if MJX_KIN_PREFIX
         // World poses by pointer jumping.  T_b starts as the body's pose in its parent's frame (static frame o joint chain; the free root: its
         // qpos) and a_b as the parent; a round replaces T_b by T_{a_b} o T_b and a_b by a_{a_b}, so after ceil(log2(MAXDEPTH)) rounds every T_b
         // is a world pose -- 3 rounds of one pose product for the Humanoid's 6 levels (2 for Ant's 4) instead of one pass over the whole
@@ -521,118 +450,6 @@ struct Sim {
             for (int k = 0; k < 9; k++) bb.A.kin.xmat[b][k] = r.xmat[k];
         }
         coop_sync();
-#else
-#pragma unroll 1
-        for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
-            if (isbody && depth == lev) {
-                double pos[3], quat[4];
-                if (free_root) {
-                    const int qa = M::jnt_qposadr[ja];
-                    pos[0] = bb.qpos[qa], pos[1] = bb.qpos[qa + 1], pos[2] = bb.qpos[qa + 2];
-                    quat[0] = bb.qpos[qa + 3], quat[1] = bb.qpos[qa + 4], quat[2] = bb.qpos[qa + 5], quat[3] = bb.qpos[qa + 6];
-                    quat_normalize(quat);
-                    r.anchor[0][0] = pos[0], r.anchor[0][1] = pos[1], r.anchor[0][2] = pos[2];
-                    r.axis[0][0] = 0, r.axis[0][1] = 0, r.axis[0][2] = 1;
-                } else {
-                    double t[3], posS[3], quatS[4], RS[9];
-                    if (p == 0) {  // the world frame is the identity (its rows of the blackboard are not kept)
-#pragma unroll
-                        for (int k = 0; k < 3; k++) posS[k] = M::body_pos[bi][k];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) quatS[k] = M::body_quat[bi][k];
-                    } else {
-                        rot_vec(t, bb.A.kin.xmat[p], M::body_pos[bi]);
-                        posS[0] = bb.xpos[p][0] + t[0], posS[1] = bb.xpos[p][1] + t[1], posS[2] = bb.xpos[p][2] + t[2];
-                        quat_mul(quatS, bb.A.kin.xquat[p], M::body_quat[bi]);
-                    }
-                    quat_to_mat(RS, quatS);
-#pragma unroll
-                    for (int jj = 0; jj < M::MAXJPB; jj++) {
-                        if (jj < jn) {
-                            rot_vec(t, RS, r.anchor[jj]);
-                            r.anchor[jj][0] = posS[0] + t[0], r.anchor[jj][1] = posS[1] + t[1], r.anchor[jj][2] = posS[2] + t[2];
-                            rot_vec(t, RS, r.axis[jj]);
-                            r.axis[jj][0] = t[0], r.axis[jj][1] = t[1], r.axis[jj][2] = t[2];
-                        }
-                    }
-                    rot_vec(t, RS, pl);
-                    pos[0] = posS[0] + t[0], pos[1] = posS[1] + t[1], pos[2] = posS[2] + t[2];
-                    quat_mul(quat, quatS, ql);
-                }
-                quat_normalize(quat);
-                double t[3];
-                quat_to_mat(r.xmat, quat);
-                rot_vec(t, r.xmat, M::body_ipos[bi]);
-#pragma unroll
-                for (int k = 0; k < 3; k++) bb.xpos[b][k] = pos[k], bb.xipos[b][k] = pos[k] + t[k];
-#pragma unroll
-                for (int k = 0; k < 4; k++) bb.A.kin.xquat[b][k] = quat[k];
-#pragma unroll
-                for (int k = 0; k < 9; k++) bb.A.kin.xmat[b][k] = r.xmat[k];
-            }
-            coop_sync();
-        }
-#endif
-#else
-#pragma unroll 1
-        for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
-            if (isbody && depth == lev) {
-                double pos[3], quat[4];
-                if (jn == 1 && M::jnt_type[ja] == FREE) {
-                    const int qa = M::jnt_qposadr[ja];
-                    pos[0] = bb.qpos[qa], pos[1] = bb.qpos[qa + 1], pos[2] = bb.qpos[qa + 2];
-                    quat[0] = bb.qpos[qa + 3], quat[1] = bb.qpos[qa + 4], quat[2] = bb.qpos[qa + 5], quat[3] = bb.qpos[qa + 6];
-                    quat_normalize(quat);
-                    r.anchor[0][0] = pos[0], r.anchor[0][1] = pos[1], r.anchor[0][2] = pos[2];
-                    r.axis[0][0] = 0, r.axis[0][1] = 0, r.axis[0][2] = 1;
-                } else {
-                    double t[3];
-                    if (p == 0) {  // the world frame is the identity (its rows of the blackboard are not kept)
-#pragma unroll
-                        for (int k = 0; k < 3; k++) pos[k] = M::body_pos[bi][k];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) quat[k] = M::body_quat[bi][k];
-                    } else {
-                        rot_vec(t, bb.A.kin.xmat[p], M::body_pos[bi]);
-                        pos[0] = bb.xpos[p][0] + t[0], pos[1] = bb.xpos[p][1] + t[1], pos[2] = bb.xpos[p][2] + t[2];
-                        quat_mul(quat, bb.A.kin.xquat[p], M::body_quat[bi]);
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < M::MAXJPB; jj++) {
-                        if (jj < jn) {
-                            const int j = ja + jj;
-                            double Rm[9], ql[4];
-                            quat_to_mat(Rm, quat);
-                            rot_vec(t, Rm, M::jnt_pos[j]);
-                            r.anchor[jj][0] = pos[0] + t[0], r.anchor[jj][1] = pos[1] + t[1], r.anchor[jj][2] = pos[2] + t[2];
-                            rot_vec(r.axis[jj], Rm, M::jnt_axis[j]);
-                            const double q = bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]];
-                            if (M::jnt_type[j] == HINGE) {
-                                axis_angle_quat(ql, M::jnt_axis[j], q);
-                                quat_mul(quat, quat, ql);
-                                quat_to_mat(Rm, quat);
-                                rot_vec(t, Rm, M::jnt_pos[j]);
-                                pos[0] = r.anchor[jj][0] - t[0], pos[1] = r.anchor[jj][1] - t[1], pos[2] = r.anchor[jj][2] - t[2];
-                            } else {
-                                pos[0] += r.axis[jj][0] * q, pos[1] += r.axis[jj][1] * q, pos[2] += r.axis[jj][2] * q;
-                            }
-                        }
-                    }
-                }
-                quat_normalize(quat);
-                double t[3];
-                quat_to_mat(r.xmat, quat);
-                rot_vec(t, r.xmat, M::body_ipos[bi]);
-#pragma unroll
-                for (int k = 0; k < 3; k++) bb.xpos[b][k] = pos[k], bb.xipos[b][k] = pos[k] + t[k];
-#pragma unroll
-                for (int k = 0; k < 4; k++) bb.A.kin.xquat[b][k] = quat[k];
-#pragma unroll
-                for (int k = 0; k < 9; k++) bb.A.kin.xmat[b][k] = r.xmat[k];
-            }
-            coop_sync();
-        }
-    #endif
     }
 
     // subtree centre of mass of the tree (every lane computes it: same summation order as the one-lane code), the body's
@@ -707,7 +524,6 @@ struct Sim {
         const bool isbody = b < NB;
         const int bi = isbody ? b : 1;
         const int depth = M::body_depth[bi], p = M::body_parentid[bi], ja = M::body_jntadr[bi], jn = jnum(bi);
-#if MJX_VEL_PREFIX
         // cvel and cacc live in ONE frame (the com-based world frame), so a body's value is its parent's plus the contributions of its own
         // joints: two prefix sums over the tree, done by pointer jumping (see kinematics()) -- first the velocities (a joint's cdof_dot needs the
         // velocity just before it), then the accelerations.  Each body walks its own joint chain ONCE instead of the wavefront walking the
@@ -805,52 +621,6 @@ struct Sim {
         }
         coop_sync();
         MJX_PHASE_X(r, 3, 13);
-#else
-#pragma unroll 1
-        for (int lev = 1; lev <= M::MAXDEPTH; lev++) {
-            if (isbody && depth == lev) {
-                double v[6], a[6];
-                if (p == 0) {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) v[k] = 0, a[k] = 0;
-                    a[3] = -M::gravity[0], a[4] = -M::gravity[1], a[5] = -M::gravity[2];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) v[k] = bb.cvel[p][k], a[k] = bb.Bu.rne.cacc[p][k];
-                }
-#pragma unroll
-                for (int jj = 0; jj < M::MAXJPB; jj++) {
-                    if (jj < jn) {
-                        const int j = ja + jj, da = M::jnt_dofadr[j];
-                        if (M::jnt_type[j] == FREE) {
-#pragma unroll
-                            for (int k = 0; k < 3; k++)
-#pragma unroll
-                                for (int c = 0; c < 6; c++) v[c] += bb.cdof[da + k][c] * bb.qvel[da + k];
-                            double dd[3][6];
-#pragma unroll
-                            for (int k = 0; k < 3; k++) cross_motion(dd[k], v, bb.cdof[da + 3 + k]);
-#pragma unroll
-                            for (int k = 0; k < 3; k++)
-#pragma unroll
-                                for (int c = 0; c < 6; c++)
-                                    v[c] += bb.cdof[da + 3 + k][c] * bb.qvel[da + 3 + k], a[c] += dd[k][c] * bb.qvel[da + 3 + k];
-                        } else {
-                            double dd[6];
-                            cross_motion(dd, v, bb.cdof[da]);
-#pragma unroll
-                            for (int c = 0; c < 6; c++) v[c] += bb.cdof[da][c] * bb.qvel[da], a[c] += dd[c] * bb.qvel[da];
-                        }
-                    }
-                }
-                double Ia[6], Iv[6], x[6];
-                inert_mul(Ia, r.cinert, a), inert_mul(Iv, r.cinert, v), cross_force(x, v, Iv);
-#pragma unroll
-                for (int k = 0; k < 6; k++) bb.cvel[b][k] = v[k], bb.Bu.rne.cacc[b][k] = a[k], bb.Bu.rne.cfrc[b][k] = Ia[k] + x[k];
-            }
-            coop_sync();
-        }
-#endif
         // bias force of dof i: its motion subspace against the summed body forces of the subtree it moves
         if (lane < NV) {
             const unsigned desc = (unsigned)M::dof_descbodies[lane];
@@ -873,7 +643,7 @@ struct Sim {
     // The blended form of the row loop lets the scheduler overlap the entries (Humanoid rows 8.3 k -> 6.4 k cycles, +2.1 % end to end; HalfCheetah,
     // Walker2d, Hopper +1 %).  The overlap costs registers: while physics16.hip was built with MachineLICM off, the 14-dof Ant kernel went from 21 to
     // 71 spilled VGPRs with it and lost 2.8 %; on the sink flag set (build.py) it has no spills either way and gains 0.6 %.  profiles/r03_collision_tables.txt
-    static constexpr bool CRB_BLEND = MJX_CRB_BLEND_ALL || B::M_IN_LDS || NV <= 12;  // (MJX_CRB_BLEND_ALL = 0: the select form for the Ant, for A/B runs)
+    static constexpr bool CRB_BLEND = true;  // (every robot; until round 6 a switch kept the select form for the Ant's A/B runs)
     static MJX_DEV void crb(B &bb, R &r, int lane) {
         const int b = lane + 1;
         if (b < NB) {
@@ -909,7 +679,6 @@ struct Sim {
             const unsigned anc = (unsigned)M::dof_ancmask[lane];
 #pragma unroll
             for (int j = 0; j < NV; j++) {
-#if MJX_CRB_BRANCHFREE
                 // both candidates, then a select: as two branches per entry (2 NV exec-mask regions, each waiting out its own LDS reads before a
                 // chain of six multiply-adds) this loop cost a lone wavefront ~9 k cycles for the Humanoid; the selected sum is the same, bit for bit
                 double s1 = 0, s2 = 0;
@@ -927,32 +696,16 @@ struct Sim {
                 } else {
                     s = ((anc >> j) & 1u) ? s1 : ((((unsigned)M::dof_ancmask[j] >> lane) & 1u) ? s2 : 0.0);
                 }
-#else
-                double s = 0;
-                if ((anc >> j) & 1u) {  // j is lane itself or one of its ancestors
-#pragma unroll
-                    for (int k = 0; k < 6; k++) s += bb.cdof[j][k] * mybuf[k];
-                } else if (((unsigned)M::dof_ancmask[j] >> lane) & 1u) {  // lane is an ancestor of j
-#pragma unroll
-                    for (int k = 0; k < 6; k++) s += r.cdof[k] * bb.C.crb.buf[j][k];
-                }
-#endif
                 if (j == lane) s += M::dof_armature[j];
-#if MJX_CRB_BRANCHFREE
                 if (B::M_IN_LDS)
                     r.Hrow[j] = s;  // stored below, all at once: a store into the blackboard between two entries pins the next entry's reads behind it
                 else
                     set_mrow(bb, r, lane, j, s);
-#else
-                set_mrow(bb, r, lane, j, s);
-#endif
             }
-#if MJX_CRB_BRANCHFREE
             if (B::M_IN_LDS) {
 #pragma unroll
                 for (int j = 0; j < NV; j++) set_mrow(bb, r, lane, j, r.Hrow[j]);
             }
-#endif
         } else if (!B::M_IN_LDS) {
 #pragma unroll
             for (int j = 0; j < NV; j++) set_mrow(bb, r, lane, j, 0.0);
@@ -998,11 +751,7 @@ struct Sim {
     template <int K, int J>
     static MJX_DEV void chol_update(B &bb, double *A, double ak, double t, int lane) {
         const double cj = bcast<J>(ak, bb, lane);  // A'[J][K], held by lane J
-#if MJX_CHOL_PIPELINED
         A[J] -= t * cj;  // entries J > lane are never used: unmasked, they carry a finite, meaningless mirror image of the elimination
-#else
-        A[J] -= (J <= lane ? t : 0.0) * cj;        // entries J > lane are never used
-#endif
         if constexpr (J + 1 < NV) chol_update<K, J + 1>(bb, A, ak, t, lane);
     }
     template <int K>
@@ -1060,7 +809,6 @@ struct Sim {
     // in flight per column and made the Humanoid kernel spill (335 VGPRs against 71 this way).
     // A: row `lane` (entries j <= lane are used) -> L in place; idiag = 1 / L[lane][lane]; L also stored packed in bb.A.sol.L
     static MJX_DEV void chol_factor_lds(B &bb, double *A, double &idiag, int lane) {
-#if MJX_CHOL_PIPELINED
         // The entry that becomes the NEXT pivot column is updated and published first, the rest of the row afterwards: the LDS round trip of
         // the exchange overlaps the row update instead of following it.  Entries j > lane are never used, so nothing is masked: they carry
         // the (finite, meaningless) mirror image of the elimination and cost no selects.
@@ -1087,106 +835,6 @@ struct Sim {
             }
             coop_sync();
         }
-#else
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-            double (&col)[NV] = bb.A.sol.col[k & 1];
-            if (lane >= k && lane < NV) col[lane] = A[k];
-            coop_sync();
-            if (lane >= k && lane < NV) {
-                double piv = col[k];
-                piv = piv < kMinVal ? kMinVal : piv;
-                const double inv = rsq(piv);
-                const double lik = A[k] * inv;
-                A[k] = lik;
-                if (lane == k) idiag = inv;
-                const double t = lik * inv;
-#pragma unroll
-                for (int j = k + 1; j < NV; j++) A[j] -= (j <= lane ? t : 0.0) * col[j];  // entries j > lane are never used
-            }
-        }
-#endif
-        if (lane < NV) {
-#pragma unroll
-            for (int j = 0; j < NV; j++)
-                if (j <= lane) bb.A.sol.L[tri(lane, 0) + j] = A[j];
-        }
-        coop_sync();
-    }
-    // Block-16 right-looking form of the same factorisation for the 32-lane PGS kernels (NV = 23): columns 0..15 by the row sweep WITHOUT touching
-    // A22 (rows / columns 16..NV-1), then A22 -= L21 L21^T as ONE 16 x 16 x 16 product on the matrix cores -- four v_mfma_f64_16x16x4_f64,
-    // the (NV - 16)-row blocks of the wavefront's two sub-environments packed block-diagonally into the tile (rows 0..7 / 8..15; the cross
-    // blocks are computed and dropped) -- and the last columns by the row sweep.  Measured (scripts/mfma/humanoid_bench.hip,
-    // profiles/r03_mfma_humanoid.txt): 16.8 k -> 13.0 k cycles per factorisation; the tile is bit-identical to fused multiply-add chains over
-    // k = 0..15 (the same benchmark), which is what the host emulation computes.
-    // Operand map (cdna_hip_programming.md section 3): A[i][k] on lane i + 16 k, B[k][j] on lane j + 16 k, D[row][col]: col = lane & 15,
-    // row = (lane >> 4) + 4 reg.  B = A^T here, so every lane supplies ONE value per instruction as both operands.
-    // REQUIRES the whole wavefront at this point: the kernel keeps a sub-environment that does not step this call alive on a dummy state
-    // (mjx_physics.h) instead of retiring its lanes.
-    template <int K0, int K1, int JMAX>
-    static MJX_DEV void chol_sweep(B &bb, double *A, double &idiag, int lane) {
-#pragma unroll
-        for (int k = K0; k < K1; k++) {
-            double (&col)[NV] = bb.A.sol.col[k & 1];
-            if (lane >= k && lane < NV) col[lane] = A[k];
-            coop_sync();
-            if (lane >= k && lane < NV) {
-                double piv = col[k];
-                piv = piv < kMinVal ? kMinVal : piv;
-                const double inv = rsq(piv);
-                const double lik = A[k] * inv;
-                A[k] = lik;
-                if (lane == k) idiag = inv;
-                const double t = lik * inv;
-#pragma unroll
-                for (int j = k + 1; j < JMAX; j++) A[j] -= (j <= lane ? t : 0.0) * col[j];
-            }
-        }
-    }
-    static MJX_DEV void chol_factor_blocked(B &bb, double *A, double &idiag, int lane, int grp) {
-        constexpr int KB = 16, NR = NV - KB;  // block size, rows of the trailing block
-        static_assert(NR >= 1 && NR <= 8, "the trailing blocks of two sub-environments share one 16 x 16 tile");
-        chol_sweep<0, KB, KB>(bb, A, idiag, lane);
-        if (lane >= KB && lane < NV) {  // L21 is final: into the packed factor (where the substitutions read it), from where the tile is gathered
-#pragma unroll
-            for (int k = 0; k < KB; k++) bb.A.sol.L[tri(lane, 0) + k] = A[k];
-        }
-        coop_sync();
-#if defined(MJX_HOST_EMU)
-        (void)grp;
-        if (lane >= KB && lane < NV) {
-#pragma unroll
-            for (int j = KB; j < NV; j++) {
-                double acc = 0;
-#pragma unroll
-                for (int k = 0; k < KB; k++) acc = fma(bb.A.sol.L[tri(lane, 0) + k], bb.A.sol.L[tri(j, 0) + k], acc);
-                bb.schur[lane - KB][j - KB] = acc;
-            }
-        }
-#else
-        {
-            typedef double v4d __attribute__((ext_vector_type(4)));
-            B *wb = &bb - grp;  // the wavefront's blackboards
-            const int wl = (int)(threadIdx.x & 63u), i = wl & 15, kk = wl >> 4, e = i >> 3, p = i & 7;
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int t = 0; t < KB / 4; t++) {
-                const double a = p < NR ? wb[e].A.sol.L[tri(KB + (p < NR ? p : 0), 0) + 4 * t + kk] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                const int row = kk + 4 * rg;
-                if ((row >> 3) == e && (row & 7) < NR && p < NR) wb[e].schur[row & 7][p] = acc[rg];
-            }
-        }
-#endif
-        coop_sync();
-        if (lane >= KB && lane < NV) {
-#pragma unroll
-            for (int j = KB; j < NV; j++) A[j] -= (j <= lane) ? bb.schur[lane - KB][j - KB] : 0.0;
-        }
-        chol_sweep<KB, NV, NV>(bb, A, idiag, lane);
         if (lane < NV) {
 #pragma unroll
             for (int j = 0; j < NV; j++)
@@ -1215,20 +863,14 @@ struct Sim {
         return y;
     }
 
-#ifndef MJX_CHOL_LDS_FOR_32
-#define MJX_CHOL_LDS_FOR_32 1  // measured: the broadcast variant makes the 23-row Humanoid kernel spill 350 VGPRs (71 this way)
-#endif
     static MJX_DEV void chol_factor(B &bb, double *A, double &idiag, int lane) {
-        if constexpr ((G == 16 && !MJX_CHOL_LDS_FOR_16) || (G == 32 && !MJX_CHOL_LDS_FOR_32))
+        if constexpr ((G == 16 && !0) || (G == 32 && !1))
             chol_factor_bcast(bb, A, idiag, lane);
         else
             chol_factor_lds(bb, A, idiag, lane);
     }
-#ifndef MJX_SOLVE_BCAST_FOR_32
-#define MJX_SOLVE_BCAST_FOR_32 1  // the triangular solves of a 32-lane group broadcast by v_permlane16_swap + DPP (a handful of live values: no spills) instead of LDS
-#endif
     static MJX_DEV double chol_solve(B &bb, const double *Lrow, double idiag, double rhs, int lane) {
-        if constexpr ((G == 16 && !MJX_CHOL_LDS_FOR_16) || (G == 32 && (!MJX_CHOL_LDS_FOR_32 || MJX_SOLVE_BCAST_FOR_32)))
+        if constexpr ((G == 16 && !0) || (G == 32 && (!1 || 1)))
             return chol_solve_bcast(bb, Lrow, idiag, rhs, lane);
         else
             return chol_solve_lds(bb, Lrow, idiag, rhs, lane);
@@ -1322,7 +964,7 @@ struct Sim {
     }
     // Measured (profiles/r03_collision_tables.txt): Humanoid (140 slots, five rounds + the second pass) 18.6 k -> 11.8 k cycles per forward pass;
     // the robots with one or two rounds lose 1 - 3 % to the extra pass and fence, so they keep the direct form.
-    static constexpr bool COLLIDE_TABLES = MJX_COLLIDE_TABLES && M::NSLOT > 2 * G;
+    static constexpr bool COLLIDE_TABLES = M::NSLOT > 2 * G;
     static MJX_DEV void detect(const B &bb, int slot, Cand &c) {
         int g1, g2, t1, t2, p, sub;
         bool flip = false;
@@ -1553,16 +1195,10 @@ struct Sim {
         bool any = false;
         r.lim_on[0] = r.lim_on[1] = false;
         if (lane < NV) {
-#if MJX_FLAT_JOINTS
             const typename DofTab::Rec &dr = kDof.d[lane];
             const int j = dr.jnt;
             const bool limited = dr.limited;
             const double value = bb.qpos[dr.qadr], rng[2] = {dr.range[0], dr.range[1]}, invw = dr.invweight0;
-#else
-            const int j = M::dof_jntid[lane];
-            const bool limited = M::jnt_limited[j] && (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE);
-            const double value = bb.qpos[M::jnt_qposadr[j]], rng[2] = {M::jnt_range[j][0], M::jnt_range[j][1]}, invw = M::dof_invweight0[lane];
-#endif
             if (limited) {
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
@@ -1759,11 +1395,11 @@ struct Sim {
     //   * M^-1 J_c^T (3 x NV per contact) is computed once per pass; the first BCAP contacts keep it in the LDS storage of M (dead after
     //     the factorisation), for later ones the sweeps apply M^-1 (register rows) to J_c^T dl directly (apply_b).
     // Warm start = mj's dual warmstart: the forces implied by qacc_warmstart (r.warm), dropped for zero if their dual cost is positive.
-    // Where the blocks live (all of it storage that is dead while the sweeps run): the NV x NV words of M (NV / 3 blocks), then -- MJX_PGS_MORE_BLOCKS --
+    // Where the blocks live (all of it storage that is dead while the sweeps run): the NV x NV words of M (NV / 3 blocks), then -- 1 --
     // the packed Cholesky factor (dead once M^-1 is formed: NTRI / (3 NV) blocks), the RNE / CRB scratch of union Bu, and B::NBX blocks of their own.
     typedef decltype(B::Bu) bb_union_b_t;
     static constexpr int BCAP0 = B::M_IN_LDS ? NV / 3 : 0;
-    static constexpr bool MORE_BLOCKS = MJX_PGS_MORE_BLOCKS && B::M_IN_LDS && PGS;
+    static constexpr bool MORE_BLOCKS = B::M_IN_LDS && PGS;
     static constexpr int BCAP1 = BCAP0 + (MORE_BLOCKS ? B::NTRI / (3 * NV) : 0);
     static constexpr int BCAP2 = BCAP1 + (MORE_BLOCKS ? (int)(sizeof(bb_union_b_t) / sizeof(double)) / (3 * NV) : 0);
     static constexpr int BCAP = BCAP2 + (MORE_BLOCKS ? B::NBX : 0);
@@ -1846,41 +1482,6 @@ struct Sim {
             r.p_f[kc][0] = nw, impr -= dd * (0.5 * dd * (A[0] + Rr) + res);
             v[0] += A[0] * dd, v[1] += A[1] * dd, v[2] += A[2] * dd, dl[0] = dd;
         } else {
-#if MJX_PGS_EDGE_CHAIN
-            // edge space: E_e = e_0 + sg_e e_t (sg = +mu, -mu, +mu, -mu; t = 1, 1, 2, 2).  g_e = E_e A (a 3-vector), AR[e][e'] = g_e . E_e'.
-            // Everything that does not depend on an earlier edge's step is formed up front (independent instructions: the owner's chain is latency-bound);
-            // the chain itself per edge: nw = f k1 - u ari, max, dd = nw - f, u' += AR[e'][e] dd.
-            const double mu = r.c_mu[kc];
-            double u[4], g[4][3], fe[4], ari[4], fk[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const double sg = (e & 1) ? -mu : mu;
-                const int t = 1 + e / 2;
-                g[e][0] = A[0] + sg * (t == 1 ? A[1] : A[2]);
-                g[e][1] = A[1] + sg * (t == 1 ? A[3] : A[4]);
-                g[e][2] = A[2] + sg * (t == 1 ? A[4] : A[5]);
-                u[e] = (v[0] + sg * v[t]) - edge_aref(r, kc, sg, t);
-                fe[e] = r.p_f[kc][e], ari[e] = r.p_ari[kc][e];
-                fk[e] = fe[e] - (Rr * fe[e]) * ari[e];  // f - (u + R f) ari = (f - R f ari) - u ari
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const double sg = (e & 1) ? -mu : mu;
-                const int t = 1 + e / 2;
-                double nw = fk[e] - u[e] * ari[e];
-                nw = nw < 0 ? 0.0 : nw;
-                const double dd = nw - fe[e];
-#pragma unroll
-                for (int e2 = e + 1; e2 < 4; e2++) {
-                    const double sg2 = (e2 & 1) ? -mu : mu;
-                    const int t2 = 1 + e2 / 2;
-                    u[e2] += (g[e][0] + sg2 * g[e][t2]) * dd;  // AR[e2][e] = AR[e][e2] (A is symmetric)
-                }
-                const double res = u[e] + Rr * fe[e];
-                r.p_f[kc][e] = nw, impr -= dd * (0.5 * dd * ((g[e][0] + sg * g[e][t]) + Rr) + res);
-                dl[0] += dd, dl[t] += sg * dd;
-            }
-#else
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const double sg = (e & 1) ? -r.c_mu[kc] : r.c_mu[kc];
@@ -1898,7 +1499,6 @@ struct Sim {
                 v[3 - t] += ((t == 1 ? A[2] : A[1]) + sg * Aot) * dd;
                 dl[0] += dd, dl[t] += sg * dd;
             }
-#endif
         }
     }
     // limit rows of dof I (static: column I of M^-1 is entry I of every lane's register row), lower side then upper side
@@ -1935,49 +1535,8 @@ struct Sim {
 #pragma unroll
         for (int j = 0; j < NV; j++) r.Hrow[j] = mrow(bb, r, lane, j);
         MJX_PHASE_X(r, 1, 12);
-        if constexpr (B::CHOL_BLOCKED)
-            chol_factor_blocked(bb, r.Hrow, r.idiag, lane, r.grp);
-        else
-            chol_factor(bb, r.Hrow, r.idiag, lane);
+        chol_factor(bb, r.Hrow, r.idiag, lane);
         MJX_PHASE_X(r, 1, 13);
-#if MJX_PGS_QS_BY_INVERSE
-        // With constraint rows the sweeps need M^-1 explicitly anyway: the unconstrained acceleration is then one row-times-vector product
-        // (one exchange of qfrc_smooth through the blackboard) instead of the 2 NV dependent steps of the triangular solves.
-        double qs;
-#if MJX_PGS_QS_BY_INVERSE == 1
-        if (!anyrow) {
-            qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
-            r.qacc_smooth = qs, r.qfrc_constraint = 0, r.qacc = qs;
-            MJX_PHASE(r, 8);
-            return;
-        }
-#endif
-        MJX_PHASE(r, 8);
-        {
-            double minv[NV];
-            invert(bb, r.idiag, lane, minv);
-#pragma unroll
-            for (int j = 0; j < NV; j++) r.Hrow[j] = minv[j];  // r.Hrow = row `lane` of M^-1
-        }
-        if (isdof) bb.A.sol.vdir[lane] = r.qfrc_smooth;
-        coop_sync();
-        qs = 0;
-        if (isdof) {
-#pragma unroll
-            for (int j = 0; j < NV; j++) qs += r.Hrow[j] * bb.A.sol.vdir[j];
-        }
-        coop_sync();
-        if (isdof) bb.A.sol.vdir[lane] = qs;  // (what the solve used to leave there: qacc_smooth for the twist pass below)
-        coop_sync();
-        r.qacc_smooth = qs, r.qfrc_constraint = 0;
-        MJX_PHASE(r, 7);
-#if MJX_PGS_QS_BY_INVERSE == 2  // no triangular solves in the kernel at all: environments without constraint rows pay the inversion instead
-        if (!anyrow) {
-            r.qacc = qs;
-            return;
-        }
-#endif
-#else
         const double qs = chol_solve(bb, r.Hrow, r.idiag, isdof ? r.qfrc_smooth : 0.0, lane);
         r.qacc_smooth = qs, r.qfrc_constraint = 0;
         MJX_PHASE(r, 8);
@@ -1985,7 +1544,6 @@ struct Sim {
             r.qacc = qs;
             return;
         }
-#endif
         // contact-frame images of qacc_smooth (vdir, left there by the solve) and of the warm start
         double jw[KC][3];
         twist(bb, bb.A.sol.vdir, lane);
@@ -2005,7 +1563,6 @@ struct Sim {
         }
         coop_sync();
         MJX_PHASE(r, 9);
-#if !MJX_PGS_QS_BY_INVERSE
         {
             double minv[NV];
             invert(bb, r.idiag, lane, minv);
@@ -2013,7 +1570,6 @@ struct Sim {
             for (int j = 0; j < NV; j++) r.Hrow[j] = minv[j];  // r.Hrow = row `lane` of M^-1
         }
         MJX_PHASE(r, 7);
-#endif
         const unsigned lm0 = bb.limmask[0], lm1 = bb.limmask[1];
         const int ncon = bb.ncon;
         // ---- rows: diagonal, warm-start force, dual cost pieces --------------------------------------------------------------------
@@ -2037,13 +1593,6 @@ struct Sim {
             r.p_lf[0] = r.p_lf[1] = 0, r.p_lari[0] = r.p_lari[1] = 0;
         }
         double w = 0, qf = 0, dummy = 0;  // (M^-1 J^T f)_lane and (J^T f)_lane of the warm-start forces
-#if MJX_PGS_PIPELINE == 1
-        double bprev[3] = {0, 0, 0};
-#pragma unroll
-        for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-            for (int k = 0; k < 9; k++) r.p_W[kc][k] = 0;
-#endif
         pgs_limits<0, true>(bb, r, lane, lm0, lm1, w, qf, dummy);
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
@@ -2091,20 +1640,6 @@ struct Sim {
                 const double a00 = group_sum<G>(jcol[0] * b[0], MJX_RED(bb), lane), a01 = group_sum<G>(jcol[0] * b[1], MJX_RED(bb), lane),
                              a02 = group_sum<G>(jcol[0] * b[2], MJX_RED(bb), lane), a11 = group_sum<G>(jcol[1] * b[1], MJX_RED(bb), lane),
                              a12 = group_sum<G>(jcol[1] * b[2], MJX_RED(bb), lane), a22 = group_sum<G>(jcol[2] * b[2], MJX_RED(bb), lane);
-#if MJX_PGS_PIPELINE == 1
-                {  // W = J_c (M^-1 J_{c-1}^T): nine reductions against the previous contact's block (zero for the first contact: never used)
-                    double Wc[9];
-#pragma unroll
-                    for (int i = 0; i < 3; i++)
-#pragma unroll
-                        for (int j = 0; j < 3; j++) Wc[3 * i + j] = group_sum<G>(jcol[i] * bprev[j], MJX_RED(bb), lane);
-                    if (lane == owner) {
-#pragma unroll
-                        for (int k = 0; k < 9; k++) r.p_W[kc][k] = Wc[k];
-                    }
-                    bprev[0] = b[0], bprev[1] = b[1], bprev[2] = b[2];
-                }
-#endif
                 if (lane == owner) {
                     double *A = r.p_A[kc];
                     A[0] = a00, A[1] = a01, A[2] = a02, A[3] = a11, A[4] = a12, A[5] = a22;
@@ -2143,71 +1678,6 @@ struct Sim {
         for (int it = 0; it < M::ITERATIONS; it++) {
             double impr = 0, unused = 0;
             pgs_limits<0, false>(bb, r, lane, lm0, lm1, a, unused, impr);
-#if MJX_PGS_PIPELINE == 2
-            // only the NEXT contact's Jacobian column (blackboard loads + a cross and three dot products, independent of the iterate) is requested before the
-            // owner relaxes the current contact's rows; the reductions wait for the updated `a` as in the sequential form: the same bits as mode 0
-            double jn[3] = {0, 0, 0};
-            if (ncon > 0 && isdof) jac_col(bb, r, 0, lane, jn);
-#pragma unroll
-            for (int kc = 0; kc < KC; kc++) {
-#pragma unroll 1
-                for (int owner = 0; owner < G; owner++) {
-                    const int c = kc * G + owner;
-                    if (c >= ncon) break;
-                    const double jcol[3] = {jn[0], jn[1], jn[2]};
-                    double v[3], dl[3] = {0, 0, 0};
-                    v[0] = group_sum<G>(jcol[0] * a, MJX_RED(bb), lane), v[1] = group_sum<G>(jcol[1] * a, MJX_RED(bb), lane),
-                    v[2] = group_sum<G>(jcol[2] * a, MJX_RED(bb), lane);
-                    if (c + 1 < ncon) {
-                        jn[0] = jn[1] = jn[2] = 0;
-                        if (isdof) jac_col(bb, r, c + 1, lane, jn);
-                    }
-                    if (lane == owner) pgs_contact(r, kc, v, dl, impr);
-                    const double step[3] = {bcast_from(dl[0], owner, bb, lane), bcast_from(dl[1], owner, bb, lane), bcast_from(dl[2], owner, bb, lane)};
-                    a += apply_b(bb, r, c, lane, jcol, step);
-                }
-            }
-#elif MJX_PGS_PIPELINE == 1
-            // contact c + 1's column and reductions are issued BEFORE contact c's rows are relaxed (on the `a` that lacks c's step), its owner adds W dl
-            double jn[3] = {0, 0, 0}, vn[3] = {0, 0, 0};
-            if (ncon > 0) {
-                if (isdof) jac_col(bb, r, 0, lane, jn);
-                vn[0] = group_sum<G>(jn[0] * a, MJX_RED(bb), lane), vn[1] = group_sum<G>(jn[1] * a, MJX_RED(bb), lane),
-                vn[2] = group_sum<G>(jn[2] * a, MJX_RED(bb), lane);
-            }
-#pragma unroll
-            for (int kc = 0; kc < KC; kc++) {
-#pragma unroll 1
-                for (int owner = 0; owner < G; owner++) {
-                    const int c = kc * G + owner;
-                    if (c >= ncon) break;
-                    const double jcol[3] = {jn[0], jn[1], jn[2]};
-                    double v[3] = {vn[0], vn[1], vn[2]}, dl[3] = {0, 0, 0};
-                    const bool more = c + 1 < ncon;  // group-uniform
-                    if (more) {
-                        jn[0] = jn[1] = jn[2] = 0;
-                        if (isdof) jac_col(bb, r, c + 1, lane, jn);
-                        vn[0] = group_sum<G>(jn[0] * a, MJX_RED(bb), lane), vn[1] = group_sum<G>(jn[1] * a, MJX_RED(bb), lane),
-                        vn[2] = group_sum<G>(jn[2] * a, MJX_RED(bb), lane);
-                    }
-                    if (lane == owner) pgs_contact(r, kc, v, dl, impr);
-                    // the owner's frame-space force step to every lane of the group: a cross-lane read, not an LDS exchange
-                    const double step[3] = {bcast_from(dl[0], owner, bb, lane), bcast_from(dl[1], owner, bb, lane), bcast_from(dl[2], owner, bb, lane)};
-                    a += apply_b(bb, r, c, lane, jcol, step);
-                    if (more) {
-                        // J_{c+1} (a + M^-1 J_c^T dl) = J_{c+1} a + W dl: meaningful on the owner of c + 1 (every lane evaluates its own registers: no branch)
-                        const int kn = kc + 1 < KC ? kc + 1 : kc;
-                        const bool nextrow = owner == G - 1;  // c + 1 is the first contact of the next register slot
-#pragma unroll
-                        for (int i = 0; i < 3; i++) {
-                            const double w0 = nextrow ? r.p_W[kn][3 * i] : r.p_W[kc][3 * i], w1 = nextrow ? r.p_W[kn][3 * i + 1] : r.p_W[kc][3 * i + 1],
-                                         w2 = nextrow ? r.p_W[kn][3 * i + 2] : r.p_W[kc][3 * i + 2];
-                            vn[i] += w0 * step[0] + w1 * step[1] + w2 * step[2];
-                        }
-                    }
-                }
-            }
-#else
 #pragma unroll
             for (int kc = 0; kc < KC; kc++) {
 #pragma unroll 1
@@ -2225,7 +1695,6 @@ struct Sim {
                     a += apply_b(bb, r, c, lane, jcol, step);
                 }
             }
-#endif
             const double imp = group_sum<G>(impr, MJX_RED(bb), lane);
 #if defined(MJX_HOST_EMU)
             if (lane == 0) g_stat[3]++;
@@ -2287,7 +1756,6 @@ struct Sim {
         MJX_PHASE(r, 6);
         if (isdof) {
             double act = 0.0, passive;
-#if MJX_FLAT_JOINTS
             const typename DofTab::Rec &dr = kDof.d[lane];
             if (dr.act >= 0) {
                 double c = bb.ctrl[dr.act];
@@ -2296,18 +1764,6 @@ struct Sim {
             }
             passive = -dr.damping * bb.qvel[lane];
             if (dr.scalar_joint) passive -= dr.stiffness * (bb.qpos[dr.qadr] - dr.q0);
-#else
-            const int u = M::dof_actuator[lane];
-            if (u >= 0) {
-                double c = bb.ctrl[u];
-                c = c < M::actuator_ctrlrange[u][0] ? M::actuator_ctrlrange[u][0] : (c > M::actuator_ctrlrange[u][1] ? M::actuator_ctrlrange[u][1] : c);
-                act = M::actuator_gear[u] * c;
-            }
-            passive = -M::dof_damping[lane] * bb.qvel[lane];
-            const int j = M::dof_jntid[lane];
-            if (M::jnt_type[j] == HINGE || M::jnt_type[j] == SLIDE)
-                passive -= M::jnt_stiffness[j] * (bb.qpos[M::jnt_qposadr[j]] - M::qpos0[M::jnt_qposadr[j]]);
-#endif
             r.qfrc_actuator = act;
             r.qfrc_smooth = passive - r.bias + act;
         } else {
@@ -2556,7 +2012,7 @@ struct Sim {
     // As a function of its own the kernel is bit-identical across schedulers; four calls per sub-step cost ~1 % next to four forward passes.
 #if defined(MJX_HOST_EMU)
     static inline void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {
-#elif MJX_RK4_INLINE
+#elif 0
     static MJX_DEV void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {
 #else
     static __device__ __attribute__((noinline)) void rk4_stage(B &bb, double qacc, int lane, int i, double &v0, double &sumv, double &suma) {

@@ -47,37 +47,25 @@ __global__ __launch_bounds__(64, MJX_MIN_WAVES_PER_EU) void mj_physics_kernel(Ar
     __shared__ typename S::B boards[EPW];
     const int grp = threadIdx.x / G, lane = threadIdx.x % G;
     const int env = blockIdx.x * EPW + grp;
-    // A sub-environment that does not step in this call (past the end of the batch, or in its NEXT_STEP autoreset step) ...
+    // A sub-environment that does not step in this call (past the end of the batch, or in its NEXT_STEP autoreset step) retires its lanes.
     const bool steps = env < d.N && !(SKIP_RESETTING && (d.meta[env < d.N ? env : 0] & d.needs_reset_mask));
-    // ... retires its lanes -- except in the kernels whose factorisation runs on the matrix cores (mjx_coop.h chol_factor_blocked): an MFMA
-    // instruction spans the whole wavefront, so there the idle group keeps running on a harmless dummy state (the model's initial pose, no
-    // controls) and simply stores nothing.  It costs nothing in time: the wavefront runs at the pace of its other sub-environment anyway.
-    constexpr bool KEEP_WAVE = S::B::CHOL_BLOCKED && PGS;
-    if (!KEEP_WAVE && !steps) return;
+    if (!steps) return;
     typename S::B &bb = boards[grp];
     typename S::R r;
     r.grp = grp;
     S::init(bb, lane);
     const size_t N = (size_t)d.N;
-    if (steps) {
-        for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
-        for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
-        if (d.act_f64) {  // (grid-uniform)
-            for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = static_cast<const double *>(actions)[(size_t)env * M::NU + k];
-        } else {
-            for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)static_cast<const float *>(actions)[(size_t)env * M::NU + k];
-        }
-        r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
+    for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = d.state[(size_t)k * N + env];
+    for (int k = lane; k < M::NV; k += G) bb.qvel[k] = d.state[(size_t)(M::NQ + k) * N + env];
+    if (d.act_f64) {  // (grid-uniform)
+        for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = static_cast<const double *>(actions)[(size_t)env * M::NU + k];
     } else {
-        for (int k = lane; k < M::NQ; k += G) bb.qpos[k] = M::qpos0[k];
-        for (int k = lane; k < M::NV; k += G) bb.qvel[k] = 0.0;
-        for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = 0.0;
-        r.warm = 0.0;
+        for (int k = lane; k < M::NU; k += G) bb.ctrl[k] = (double)static_cast<const float *>(actions)[(size_t)env * M::NU + k];
     }
+    r.warm = lane < M::NV ? d.state[(size_t)(M::NQ + M::NV + lane) * N + env] : 0.0;  // qacc_warmstart slot of the state row
     mjx::coop::coop_sync();
     for (int f = 0; f < d.frame_skip; f++) S::step(bb, r, lane);
     mjx::coop::coop_sync();
-    if (!steps) return;
     for (int k = lane; k < M::NQ; k += G) d.state[(size_t)k * N + env] = bb.qpos[k];
     for (int k = lane; k < M::NV; k += G) d.state[(size_t)(M::NQ + k) * N + env] = bb.qvel[k];
     if (lane < M::NV) d.state[(size_t)(M::NQ + M::NV + lane) * N + env] = r.warm;

@@ -99,10 +99,14 @@ class CartPoleVectorEnv(_ClassicControlVectorEnv):
     @property
     def np_random(self):
         """The generator of ``reset`` / the autoresets.  With rng="shared" the draws happen on the device: reading this property brings the
-        host object up to date with them (one small device-to-host copy; synchronises)."""
+        host object up to date with them (one small device-to-host copy; synchronises).  In the reference this object IS the generator the
+        sub-environments draw from, so a draw the caller takes from it moves the stream for the next reset / autoreset too: once the object has
+        been handed out, every engine call of this env first takes over what the caller drew (_shared_push) and afterwards brings the object up to
+        date again (_shared_pull) -- the price is one synchronisation per call, paid only by callers that touch ``np_random``."""
         gen = VectorEnvBase.np_random.fget(self)
         if getattr(self, "_shared_rng", False) and getattr(self, "_seeded", False) and getattr(self, "_engine", None) is not None:
-            _native.set_pcg_words(gen, self._engine.get_rng()[0])
+            self._shared_pull(gen)
+            self._shared_handed_out = True
         return gen
 
     @np_random.setter
@@ -111,16 +115,52 @@ class CartPoleVectorEnv(_ClassicControlVectorEnv):
         if getattr(self, "_shared_rng", False) and getattr(self, "_engine", None) is not None:
             self._engine.seed(np.tile(_native.pcg_words(value), (self.num_envs, 1)), None)
             self._seeded = True
+            self._shared_words = _native.pcg_words(value)
+
+    def _shared_pull(self, gen=None):
+        """host generator <- the device's position"""
+        gen = VectorEnvBase.np_random.fget(self) if gen is None else gen
+        words = self._engine.get_rng()[0]
+        _native.set_pcg_words(gen, words)
+        self._shared_words = np.array(words, dtype=np.uint64)
+
+    def _shared_push(self):
+        """device <- the host generator, if the caller has drawn from it since the last pull"""
+        if not getattr(self, "_shared_handed_out", False):
+            return
+        words = _native.pcg_words(VectorEnvBase.np_random.fget(self))
+        if self.__dict__.get("_shared_words") is None or not np.array_equal(words, self._shared_words):
+            self._engine.seed(np.tile(words, (self.num_envs, 1)), None)
+            self._shared_words = words
 
     def reset(self, *, seed=None, options=None):
         if self._shared_rng and options is not None and "reset_mask" in options:
             options = {k: v for k, v in options.items() if k != "reset_mask"}  # CartPoleVectorEnv.reset knows no reset_mask: every sub-environment resets
-        return super().reset(seed=seed, options=options)
+        if not self._shared_rng:
+            return super().reset(seed=seed, options=options)
+        if seed is None:
+            self._shared_push()
+        out = super().reset(seed=seed, options=options)
+        if getattr(self, "_shared_handed_out", False):
+            self._shared_pull()
+        return out
+
+    def rollout(self, *args, **kwargs):
+        if not self._shared_rng:
+            return super().rollout(*args, **kwargs)
+        self._shared_push()
+        out = super().rollout(*args, **kwargs)
+        if getattr(self, "_shared_handed_out", False):
+            self._shared_pull()
+        return out
 
     def step(self, actions):
         if not self._shared_rng:  # (nothing to add: HipVectorEnv.step's short path stays reachable, see _SHORT_STEP_OWNERS)
             return HipVectorEnv.step(self, actions)
+        self._shared_push()
         out = super().step(actions)
+        if getattr(self, "_shared_handed_out", False):
+            self._shared_pull()
         rew = out[1]
         rew = rew.to(self._torch.float32) if self.output == "torch" else rew.astype(np.float32)  # reward arrays of cartpole.py:466-468 are float32
         return (out[0], rew) + tuple(out[2:])

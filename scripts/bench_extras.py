@@ -40,6 +40,11 @@ TOYTEXT = [("FrozenLake-v1", 65536, 128), ("Taxi-v4", 65536, 128), ("Blackjack-v
 # The other contact regime of the two headline robots: the random policy with `terminate_when_unhealthy` ends a Humanoid episode after ~22 steps, so
 # the batch above is mostly robots still upright; with termination off and a warm-up of GROUND_WARM launches every robot lies on the ground (many
 # contacts, the PGS sweeps dominate).  A learner that keeps the robot alive lives between the two lines.
+# what the counters say bounds the tabular rollouts (profiles/r06_{frozenlake,taxi,blackjack}_rollout*.txt): not memory
+TOYTEXT_BOUND = {e: ("one wavefront per SIMD: ~380 (FrozenLake) / ~780 (Blackjack) instructions per env-step issued one per ~5 cycles (two 128-bit PCG64 steps -- the env's "
+                     "transition draw and the policy's --, the categorical search, five stores) plus dependent LDS table lookups: half the wave cycles issue, the other "
+                     "half wait; HBM traffic is the algorithmic bytes.  4x the sub-environments (4 wavefronts per SIMD) runs 2.6x (FrozenLake) / 2.0x (Blackjack) faster")
+                 for e in ("FrozenLake-v1", "Taxi-v4", "Blackjack-v1")}
 GROUND_WARM = 40
 SECONDARY_GROUND = [("Ant-v5", 32768, 4), ("Humanoid-v5", 32768, 4)]
 F64_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz
@@ -57,6 +62,16 @@ CPU_REFERENCE_RECORDED = {
     "single env gym.make": {"CartPole-v1": 82e3, "MountainCar-v0": 70e3, "MountainCarContinuous-v0": 35e3, "Pendulum-v1": 20e3, "Acrobot-v1": 16e3, "cores": 1},
     "MuJoCo ids": "unavailable: `mujoco` is not installed in the build container either",
 }
+
+
+def dominant_kernel_of(env_id, inner):
+    """bench.Config.dominant_kernel without constructing the env."""
+    if env_id in bench.ROLLOUT_BYTES:
+        chunk = bench.DUO_CHUNK.get(env_id)
+        return "rollout_duo_kernel" if (chunk and inner % chunk == 0 and os.environ.get("MI355ENV_ROLLOUT_DUO", "1")[:1] != "0") else "rollout_kernel"
+    if env_id in MJ_COOP:
+        return "mj_physics_kernel"
+    return "tab_rollout_kernel" if env_id.split("-")[0] in ("FrozenLake", "FrozenLake8x8", "Taxi", "Blackjack", "CliffWalking") else "mj_rollout_kernel"
 
 
 # ---- counters -------------------------------------------------------------------------------------------------------------------------
@@ -381,6 +396,7 @@ def main():
     ap.add_argument("--started", type=float, default=None, help="time.time() at which the parent command started (budget reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the MuJoCo lines (bench.mujoco_window_check)")
     ap.add_argument("--only", default=None, help="comma-separated env ids: restrict the secondary lines")
     ap.add_argument("--api-only", action="store_true", help="only the per-launch step() API legs (for a kernel trace of step_kernel)")
     ap.add_argument("--policy-only", action="store_true", help="only the benchmark_vector_step protocol legs (NumPy and device policy)")
@@ -400,6 +416,23 @@ def main():
         os.replace(args.out + ".tmp", args.out)
 
     only = set(args.only.split(",")) if args.only else None
+    # Live HBM traffic for EVERY line of this file (no recorded round-3 numbers): the FETCH_SIZE / WRITE_SIZE passes of all
+    # configurations run up front in a handful of child processes (bench.live_traffic_batch), a line then finds its bytes under its key.
+    traffic = {}
+    if args.pmc != "off" and not args.policy_only and not args.api_only:
+        reqs = []
+        for env_id, n2, inner2 in SECONDARY + TOYTEXT:
+            if only and env_id not in only:
+                continue
+            reqs.append({"env_id": env_id, "N": n2, "inner": inner2, "env_kwargs": None, "warm": 1, "kernel": dominant_kernel_of(env_id, inner2), "key": f"{env_id}:{n2}"})
+        for env_id, n2, inner2 in SECONDARY_GROUND:
+            if only and env_id not in only:
+                continue
+            reqs.append({"env_id": env_id, "N": n2, "inner": inner2, "env_kwargs": {"terminate_when_unhealthy": False}, "warm": GROUND_WARM,
+                         "kernel": dominant_kernel_of(env_id, inner2), "key": f"{env_id}:{n2}:ground"})
+        t_tr = time.time()
+        traffic = bench.live_traffic_batch(reqs)
+        full["traffic_passes"] = {"seconds": round(time.time() - t_tr, 1), "configurations": len(reqs), "measured": sum(1 for v in traffic.values() if v[0] is not None)}
     if args.policy_only:
         full["api_benchmark_vector_step"] = api_faithful_leg("CartPole-v1", 65536)
         full["api_benchmark_vector_step_device_policy"] = api_faithful_device_leg("CartPole-v1", 65536)
@@ -421,7 +454,7 @@ def main():
         sha = bench.trajectory_digest(c2.host_trajectory())
         v2, k2, ks2, el2 = steady(c2)
         line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "seconds": el2, "unit": "env-steps/s",
-                "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "output_sha256": sha, "roofline": c2.roofline(ks2, live=args.pmc == "full")}
+                "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "output_sha256": sha, "roofline": c2.roofline(ks2, traffic=traffic.get(f"{env_id}:{n2}"))}
         head[f"{env_id}@{n2}"] = float(f"{v2:.4g}")
         if env_id not in MJ_COOP:
             head.setdefault("hbm_frac", {})[env_id] = round(line["roofline"]["frac"], 4)
@@ -429,6 +462,12 @@ def main():
         flush()
         if env_id in MJ_COOP and args.pmc != "off" and young():
             line["roofline"].update(coop_counters(c2, ks2, v2))
+        if env_id in MJ_COOP and not args.no_verify:  # >= 1 024 robots x 40 steps against the oracle, from where the timed launches left them
+            try:
+                line["verified"] = bench.mujoco_window_check(c2)
+            except Exception as e:
+                line["verified"] = {"ok": None, "error": f"{type(e).__name__}: {e}"[:200]}
+            head.setdefault("verified", {})[f"{env_id}@{n2}"] = line["verified"].get("ok")
         c2.close()
         opt = {"fast_math": True} if env_id in STEP_BYTES else ({"solver": "Newton"} if env_id in ("Humanoid-v5", "HumanoidStandup-v5") else None)
         if opt and young():  # the opt-in, faster configuration next to the default (reference-faithful) one
@@ -452,10 +491,16 @@ def main():
         line = {"env": env_id, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "seconds": el2, "unit": "env-steps/s",
                 "ms_per_launch": el2 / k2 * 1e3, "dtype": "f64", "env_kwargs": kw,
                 "regime": f"robots on the ground: terminate_when_unhealthy=False, {GROUND_WARM} launches ({GROUND_WARM * inner2} vector steps) of warm-up before the timed region",
-                "roofline": c2.roofline(ks2)}
+                "roofline": c2.roofline(ks2, traffic=traffic.get(f"{env_id}:{n2}:ground"))}
         head[f"{env_id}@{n2} on the ground"] = float(f"{v2:.4g}")
         if args.pmc != "off" and young():
             line["roofline"].update(coop_counters(c2, ks2, v2, warm=GROUND_WARM))
+        if not args.no_verify:  # the regime that matters: robots on the ground, many contacts, PGS at its sweep cap
+            try:
+                line["verified"] = bench.mujoco_window_check(c2)
+            except Exception as e:
+                line["verified"] = {"ok": None, "error": f"{type(e).__name__}: {e}"[:200]}
+            head.setdefault("verified", {})[f"{env_id}@{n2} on the ground"] = line["verified"].get("ok")
         c2.close()
         full["secondary"].append(line)
         flush()
@@ -514,7 +559,8 @@ def main():
             sha = bench.trajectory_digest(c2.host_trajectory())
             v2, k2, ks2, el2 = steady(c2, 0.4)
             full["secondary"].append({"env": env_id2, "num_envs": n2, "vector_steps_per_launch": inner2, "launches": k2, "value": v2, "seconds": el2, "unit": "env-steps/s",
-                                      "ms_per_launch": el2 / k2 * 1e3, "dtype": "i64", "output_sha256": sha, "roofline": c2.roofline(ks2)})
+                                      "ms_per_launch": el2 / k2 * 1e3, "dtype": "i64", "output_sha256": sha, "roofline": c2.roofline(ks2, traffic=traffic.get(f"{env_id2}:{n2}")),
+                                      "bound_note": TOYTEXT_BOUND.get(env_id2)})
             head[f"{env_id2}@{n2}"] = float(f"{v2:.4g}")
             c2.close()
         except Exception as e:

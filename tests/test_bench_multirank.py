@@ -85,6 +85,19 @@ def test_baseline_config4_command_line_humanoid_sharded():
     assert r["cpu_baseline"]["value"] > 0 and "Humanoid-v5" in r["cpu_baseline"]["sample"]
 
 
+def test_baseline_config4_at_its_real_world_size():
+    """BASELINE.json configs[4] as the driver will launch it -- `torchrun --nproc-per-node 8 bench.py --gpus 8 --env Humanoid-v5 --num-envs 32768 --inner 4` -- at
+    world size 8, with a tiny shard per rank: eight ranks in the collective, eight distinct digests (every rank owns its own global
+    env indices), every rank's first timed launch verified against the oracle, one line under 4 KB."""
+    r = _run(8, ["--env", "Humanoid-v5", "--steps", "2", "--warmup", "1", "--sustained", "0"], num_envs=2, inner=4)
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["world_size_env"] == 8 and r["distinct_devices"] == 8
+    assert sorted(d["rank"] for d in r["devices"]) == list(range(8)) and len({d["output_sha256"] for d in r["devices"]}) == 8
+    assert r["verified_all_ranks"] is True and all(d["verified"] is True for d in r["devices"])
+    assert r["config"]["env"] == "Humanoid-v5" and r["config"]["vector_steps_per_launch"] == 4 and r["config"]["parallelism"] == "env-sharded x8 (no data-path collective)"
+    assert 0 < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= 8 * 2 * 4 * r["steps"] * (1 + 1e-9)
+    assert len(json.dumps(r, separators=(",", ":"))) < 4096
+
+
 def test_bench_py_cannot_be_pointed_at_the_checker():
     """The product script has no --engine / --backend switch any more: the metric line can only come from the HIP engine."""
     src = open(os.path.join(ROOT, "bench.py")).read()

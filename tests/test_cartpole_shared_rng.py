@@ -95,3 +95,60 @@ def test_shared_rng_refusals(oracle_factory):
     expect = np.random.default_rng(99).uniform(-0.05, 0.05, size=(4, 4)).T.astype(np.float32)
     assert np.array_equal(env.reset()[0], expect)
     env.close()
+
+
+def test_a_draw_from_np_random_moves_the_stream_of_the_sub_environments(oracle_factory):
+    """in the reference `env.np_random` IS the generator the resets draw from (cartpole.py:475, 497), so a value the caller takes from it
+    shifts every later reset / autoreset.  Also through a reference to the generator object that the caller kept across steps."""
+    n = 5
+    env = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", _engine_factory=oracle_factory)
+    env.reset(seed=11)
+    ref = np.random.default_rng(11)
+    ref.uniform(-0.05, 0.05, size=(4, n))          # the reset's draws
+    g = env.np_random
+    assert g.random() == ref.random()               # the caller's own draw continues the stream ...
+    got, _ = env.reset()                            # ... and the next reset continues after it
+    assert np.array_equal(got, ref.uniform(-0.05, 0.05, size=(4, n)).T.astype(np.float32))
+    assert g.random() == ref.random()               # the kept object is up to date after the engine call
+    # steps with autoresets in between: the kept object follows the device's draws
+    env.action_space.seed(0)
+    for t in range(80):
+        env.step(env.action_space.sample())
+    # (the real class is compared in the next test; here: the kept object equals the device's position, and a twin that does the same calls agrees)
+    assert np.array_equal(_native.pcg_words(g), env._engine.get_rng()[0])
+    v = g.random()
+    env2 = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", _engine_factory=oracle_factory)
+    env2.reset(seed=11)
+    g2 = env2.np_random
+    g2.random(), env2.reset(), g2.random()
+    env2.action_space.seed(0)
+    for t in range(80):
+        env2.step(env2.action_space.sample())
+    assert env2.np_random.random() == v
+    assert np.array_equal(env.reset()[0], env2.reset()[0])
+    env.close(), env2.close()
+
+
+def test_a_draw_from_np_random_against_the_reference_class(oracle_factory):
+    from gymnasium_amd.gym_api import HAVE_GYMNASIUM
+
+    if not HAVE_GYMNASIUM:
+        pytest.skip("needs gymnasium itself")
+    from gymnasium.envs.classic_control.cartpole import CartPoleVectorEnv as Ref
+
+    n = 7
+    ref, env = Ref(num_envs=n), gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", _engine_factory=oracle_factory)
+    assert np.array_equal(ref.reset(seed=3)[0], env.reset(seed=3)[0])
+    rng_a = np.random.default_rng(1)
+    gr, ge = ref.np_random, env.np_random
+    for t in range(200):
+        if t % 13 == 5:  # the caller draws from the env's generator now and then (through the property and through the kept object)
+            assert ref.np_random.random() == env.np_random.random()
+        if t % 17 == 9:
+            assert gr.random() == ge.random()
+        a = (rng_a.random(n) * 2).astype(np.int64)
+        r, e = ref.step(a), env.step(a)
+        for k in range(4):
+            assert np.array_equal(r[k], e[k]), (t, k)
+    assert np.array_equal(ref.reset()[0], env.reset()[0])
+    env.close()

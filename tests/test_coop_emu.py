@@ -30,9 +30,8 @@ def oracle_model(model):
     return om.OracleModel(cp.compile_model(name, faithful_solver=(solver != "Newton")))
 
 
-# the round-3 rewrites of the forward pass keep their predecessors behind these switches (A/B runs on the GPU, scripts/build_variant.py)
-LEGACY_FLAGS = ["-DMJX_KIN_LOCAL_JOINTS=0", "-DMJX_KIN_PREFIX=0", "-DMJX_VEL_PREFIX=0", "-DMJX_CHOL_PIPELINED=0", "-DMJX_COLLIDE_TABLES=0",
-                "-DMJX_CRB_BRANCHFREE=0", "-DMJX_FLAT_JOINTS=0", "-DMJX_PGS_MORE_BLOCKS=0"]
+# (until round 6 the header kept the predecessors of the round-3 rewrites and the rejected PGS sweeps behind A/B switches, and this file compared builds
+#  with them on and off; the switches and their dead branches are gone -- docs/rejected_experiments.md has the measurements, the git history the code)
 _LIBS = {}
 
 
@@ -52,19 +51,15 @@ def build_emu(name, flags=()):
     return L
 
 
-def lib(legacy=False):
-    key = "legacy" if legacy else "product"
-    if key not in _LIBS:
-        extra = os.environ.get("MJX_EMU_EXTRA_FLAGS", "").split()  # e.g. "-DMJX_PGS_EDGE_CHAIN=1": the same tests over an A/B variant of the kernels
-        if legacy:
-            _LIBS[key] = build_emu("libcoop_emu_legacy.so", LEGACY_FLAGS)
-        else:
-            _LIBS[key] = build_emu("libcoop_emu_variant.so" if extra else "libcoop_emu.so", extra)
-    return _LIBS[key]
+def lib():
+    if "product" not in _LIBS:
+        extra = os.environ.get("MJX_EMU_EXTRA_FLAGS", "").split()  # the same tests over an A/B build of the kernels (scripts/build_variant.py's host-side twin)
+        _LIBS["product"] = build_emu("libcoop_emu_variant.so" if extra else "libcoop_emu.so", extra)
+    return _LIBS["product"]
 
 
-def emu(model, m, qpos, qvel, ctrl, nsub, warm=None, legacy=False):
-    L = lib(legacy)
+def emu(model, m, qpos, qvel, ctrl, nsub, warm=None):
+    L = lib()
     qo, vo = np.zeros(m.nq), np.zeros(m.nv)
     ex, dbg = np.zeros(L.coop_emu_extras_dim(model % 10)), np.zeros(4 * m.nv + m.nv * m.nv)
     p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)
@@ -98,35 +93,6 @@ def test_forward_matches_oracle(model):
         np.testing.assert_allclose(dbg[:nv], d.get("qacc"), rtol=0, atol=1e-11 * scale)
         if not pgs:
             np.testing.assert_allclose(dbg[3 * nv:4 * nv], d.get("qfrc_constraint"), rtol=0, atol=1e-9 * scale)
-
-
-@pytest.mark.parametrize("model", [1, 2, 12], ids=["ant", "humanoid-PGS", "humanoid-Newton"])
-def test_rewritten_forward_pass_equals_its_predecessor(model):
-    """Round 3 re-cut the forward pass (pointer-jumping kinematics and RNE prefix sums, pipelined Cholesky, collision tables, branch-free mass-matrix
-    rows, flat static records); the previous forms stay in the header behind switches for A/B runs.  Both must give the same physics: one env step
-    with contacts, the rewritten build against the build with every switch off, far below the tolerances against the oracle."""
-    om_ = oracle_model(model)
-    m, d = om_.m, om_.make_data()
-    amp = 0.4 if model >= 2 else 1.0
-    rng = np.random.default_rng(7 + model)
-    qpos = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
-    qpos[3:7] /= np.linalg.norm(qpos[3:7])
-    d.reset(), d.set_state(qpos, 0.1 * rng.normal(size=m.nv), np.zeros(m.nu))
-    for t in range(400):  # a random policy until the robot stands on something after the 40th step
-        d.set_state(None, None, amp * rng.uniform(-1, 1, m.nu)), d.step(5)
-        if t >= 40 and d.get("ncon") > 0:
-            break
-    q, v, warm = d.get("qpos"), d.get("qvel"), d.get("qacc_warmstart").copy()
-    ctrl = amp * rng.uniform(-1, 1, m.nu)
-    qa, va, exa, _, na = emu(model, m, q, v, ctrl, 5, warm.copy())
-    qb, vb, exb, _, nb_ = emu(model, m, q, v, ctrl, 5, warm.copy(), legacy=True)
-    assert na == nb_ and na > 0
-    np.testing.assert_allclose(qa, qb, rtol=0, atol=1e-13)
-    np.testing.assert_allclose(va, vb, rtol=0, atol=1e-11)
-    np.testing.assert_allclose(exa, exb, rtol=0, atol=1e-9 * max(1.0, np.abs(exb).max()))
-    _, _, _, da, _ = emu(model, m, q, v, ctrl, 0)
-    _, _, _, db, _ = emu(model, m, q, v, ctrl, 0, legacy=True)
-    np.testing.assert_allclose(da[:m.nv], db[:m.nv], rtol=0, atol=1e-10 * max(1.0, np.abs(db[:m.nv]).max()))  # qacc of one forward pass
 
 
 @pytest.mark.parametrize("model", list(VARIANTS), ids=[f"{n}-{s}" if s else n for n, s in VARIANTS.values()])
@@ -164,11 +130,10 @@ def test_env_steps_match_oracle_with_contacts(model):
     assert seen_contacts > 0 and most_contacts > 0
 
 
-@pytest.mark.parametrize("legacy", [False, True], ids=["15-block store", "7-block store"])
-def test_pgs_more_contacts_than_the_lds_store_holds(legacy):
-    """The cooperative PGS keeps M^-1 J_c^T of the first contacts on the blackboard (15 blocks: the storage of M, of the Cholesky factor, of the RNE
-    pass and two of their own; 7 in the build with the switches off) and applies M^-1 directly for the rest: a humanoid pressed flat into the floor
-    (>= 10 contacts: beyond the 7-block store, inside the 15-block one) must equal the oracle either way, forward pass and sub-steps."""
+def test_pgs_with_ten_and_more_contacts():
+    """The cooperative PGS keeps M^-1 J_c^T of the first 15 contacts on the blackboard (the storage of M, of the Cholesky factor, of the RNE pass and two
+    blocks of their own) and applies M^-1 directly for the rest: a humanoid pressed flat into the floor (>= 10 contacts) must equal the oracle, forward
+    pass and sub-steps."""
     om_ = oracle_model(8)
     m, d = om_.m, om_.make_data()
     rng = np.random.default_rng(5)
@@ -179,11 +144,11 @@ def test_pgs_more_contacts_than_the_lds_store_holds(legacy):
         qvel, ctrl = 0.3 * rng.normal(size=m.nv), 0.4 * rng.uniform(-1, 1, m.nu)
         d.reset(), d.set_state(qpos, qvel, ctrl), d.forward()
         assert d.get("ncon") >= 10, d.get("ncon")
-        _, _, _, dbg, ncon = emu(8, m, qpos, qvel, ctrl, 0, legacy=legacy)
+        _, _, _, dbg, ncon = emu(8, m, qpos, qvel, ctrl, 0)
         assert ncon == d.get("ncon")
         np.testing.assert_allclose(dbg[:m.nv], d.get("qacc"), rtol=0, atol=1e-10 * max(1.0, np.abs(d.get("qacc")).max()))
         d.reset(), d.set_state(qpos, qvel, ctrl), d.step(2), d.rne_post_constraint()
-        qo, vo, ex, _, _ = emu(8, m, qpos, qvel, ctrl, 2, np.zeros(m.nv), legacy=legacy)
+        qo, vo, ex, _, _ = emu(8, m, qpos, qvel, ctrl, 2, np.zeros(m.nv))
         np.testing.assert_allclose(qo, d.get("qpos"), rtol=0, atol=1e-10)
         np.testing.assert_allclose(vo, d.get("qvel"), rtol=0, atol=1e-8 * max(1.0, np.abs(vo).max()))
         cf = ex[4:4 + 6 * m.nbody].reshape(m.nbody, 6)
@@ -287,20 +252,3 @@ def test_no_cross_lane_dependency_inside_a_sync_interval(model):
     finally:
         set_order(0, 1)
     assert contacts > 0
-
-
-def test_pgs_sweep_variants_stay_correct():
-    """The measured-and-not-adopted forms of the PGS sweep (mjx_coop.h MJX_PGS_PIPELINE = 1 / 2, MJX_PGS_EDGE_CHAIN = 1; profiles/r05_pgs_sweep_variants.txt) stay
-    behind their macros for A/B runs: the Humanoid forward-pass test of this file, in a child interpreter, over a build with all of them switched on (mode 1
-    includes the early column of mode 2), so that the code does not rot."""
-    import sys
-
-    for flags in ("-DMJX_PGS_PIPELINE=1 -DMJX_PGS_EDGE_CHAIN=1", "-DMJX_PGS_PIPELINE=2"):
-        env = dict(os.environ, MJX_EMU_EXTRA_FLAGS=flags)
-        so = os.path.join(EMU_DIR, "libcoop_emu_variant.so")
-        if os.path.exists(so):
-            os.remove(so)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k", "test_forward_matches_oracle and umanoid-PGS"],
-                           env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.join(HERE, ".."))
-        assert r.returncode == 0 and " passed" in r.stdout, flags + "\n" + (r.stdout + r.stderr)[-3000:]
-        os.remove(so)

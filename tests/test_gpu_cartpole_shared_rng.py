@@ -92,3 +92,30 @@ def test_set_state_recounts_the_pending_resets(oracle_factory):
             assert np.array_equal(g[k], c[k]), (t, k)
     assert np.array_equal(gpu.get_rng_state()[0], cpu.get_rng_state()[0])
     gpu.close(), cpu.close()
+
+
+def test_a_batch_with_an_invalid_action_is_refused_whole():
+    """cartpole.py:424-426: `assert self.action_space.contains(action)` before anything is touched.  A device caller's bad batch steps no
+    sub-environment and consumes no draw: after the error has been raised the env continues exactly like a twin that never saw the batch."""
+    import torch
+
+    n = 3000
+    a = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", device=0, output="torch", max_episode_steps=9)
+    b = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, rng="shared", device=0, output="torch", max_episode_steps=9)
+    a.reset(seed=2), b.reset(seed=2)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    acts = [torch.randint(0, 2, (n,), generator=gen).cuda() for _ in range(40)]
+    for t in range(20):
+        a.step(acts[t]), b.step(acts[t])
+    bad = acts[20].clone()
+    bad[1234] = 7
+    a.step(bad)  # enqueued; the error word is raised by the next call that looks
+    with pytest.raises(AssertionError, match="action"):
+        a.step(acts[20])
+        a.synchronize()
+    for t in range(20, 40):
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        for k in range(4):
+            assert torch.equal(ra[k], rb[k]), (t, k)
+    assert np.array_equal(a.get_rng_state()[0], b.get_rng_state()[0]) and a.statistics() == b.statistics()
+    a.close(), b.close()
