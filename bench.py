@@ -52,7 +52,7 @@ STATE_BYTES = {"CartPole-v1": 96, "Pendulum-v1": 64, "Acrobot-v1": 96, "Mountain
 MJ_COOP = ("Ant-v5", "Humanoid-v5", "HumanoidStandup-v5", "HalfCheetah-v5", "Walker2d-v5")
 MJ_IDS = MJ_COOP + ("Hopper-v5", "InvertedPendulum-v5", "InvertedDoublePendulum-v5", "Reacher-v5", "Swimmer-v5", "Pusher-v5")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-DUO_CHUNK = {"CartPole-v1": 8, "MountainCar-v0": 8, "MountainCarContinuous-v0": 8}  # envs_classic.h DUO_ROLLOUT / DUO_CHUNK
+DUO_CHUNK = {"CartPole-v1": 8, "Pendulum-v1": 8, "MountainCar-v0": 8, "MountainCarContinuous-v0": 8}  # envs_classic.h DUO_ROLLOUT / DUO_CHUNK
 
 
 # ---- CPU legs: the oracle as the timed baseline and as the checker of the first timed launch ----------------------------------------
@@ -318,11 +318,13 @@ def kernel_tag(env_id, kernel):
     return kernel  # the tabular kernels are one instantiation for every table: such configurations get a pass of their own
 
 
-def live_traffic_batch(configs, timeout_s=240):
-    """live_traffic for several configurations with TWO rocprofv3 passes per group instead of two per configuration: a child process runs the
-    configurations of a group one after the other (`--child-list`), and each one's dispatches are told apart by kernel_tag.  configs: dicts with
-    env_id, N, inner, env_kwargs, warm, kernel, key.  Returns {key: (HBM bytes per dispatch, provenance)}; configurations whose tag another member of
-    the group shares (the tabular kernels; one robot at two sizes or in two regimes) go into further groups."""
+def live_counters_batch(configs, extra_sets=None, timeout_s=240):
+    """rocprofv3 counter passes for several configurations with a handful of child processes instead of several per configuration: a child runs the
+    configurations of a group one after the other (`--child-list`), each one's dispatches are told apart by kernel_tag, and every counter SET is one pass
+    over the group (FETCH_SIZE and WRITE_SIZE each on their own, as MI355X_MICROARCH.md prescribes for the HBM bytes; `extra_sets`: name -> counters, e.g.
+    the SQ activity and the fp64 instruction mix of the cooperative MuJoCo kernels).  configs: dicts with env_id, N, inner, env_kwargs, warm, kernel, key.
+    Returns ({key: (HBM bytes per dispatch, provenance)}, {key: {set name: {counter: (avg per dispatch, dispatches)}}}).  Configurations whose tag another
+    member of a group shares (the tabular kernels; one robot at two sizes or in two regimes) go into further groups."""
     groups = []
     for c in configs:
         tag = kernel_tag(c["env_id"], c["kernel"])
@@ -332,19 +334,27 @@ def live_traffic_batch(configs, timeout_s=240):
                 break
         else:
             groups.append({"tags": [tag], "members": [(c, tag)]})
-    out = {}
+    traffic, extra = {}, {}
     for g in groups:
         spec = json.dumps([[c["env_id"], c["N"], c["inner"], c.get("env_kwargs") or {}, c.get("warm", 1)] for c, _ in g["members"]])
-        # one pass per counter; every member's rows are read from the same database
-        res = {counter: _rocprof_counters_multi(["--child-list", spec], [counter], [tag for _, tag in g["members"]], timeout_s) for counter in ("FETCH_SIZE", "WRITE_SIZE")}
+        tags = [tag for _, tag in g["members"]]
+        res = {counter: _rocprof_counters_multi(["--child-list", spec], [counter], tags, timeout_s) for counter in ("FETCH_SIZE", "WRITE_SIZE")}
+        wanted = {name: ctrs for name, ctrs in (extra_sets or {}).items() if any(c.get("extra") for c, _ in g["members"])}
+        more = {name: _rocprof_counters_multi(["--child-list", spec], ctrs, tags, timeout_s) for name, ctrs in wanted.items()}
         for c, tag in g["members"]:
             f, w = (res["FETCH_SIZE"] or {}).get(tag), (res["WRITE_SIZE"] or {}).get(tag)
             if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
-                out[c["key"]] = (1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0]),
-                                 f"live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run ({f['FETCH_SIZE'][1]} dispatches; one child process for {len(g['members'])} configurations)")
+                traffic[c["key"]] = (1024.0 * (w["WRITE_SIZE"][0] + 2.0 * f["FETCH_SIZE"][0]),
+                                     f"live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run ({f['FETCH_SIZE'][1]} dispatches; one child process for {len(g['members'])} configurations)")
             else:
-                out[c["key"]] = (None, None)
-    return out
+                traffic[c["key"]] = (None, None)
+            if c.get("extra"):
+                extra[c["key"]] = {name: (r or {}).get(tag) for name, r in more.items()}
+    return traffic, extra
+
+
+def live_traffic_batch(configs, timeout_s=240):
+    return live_counters_batch(configs, None, timeout_s)[0]
 
 
 def _rocprof_counters_multi(args, counters, kernel_likes, timeout_s):
@@ -572,7 +582,7 @@ def main(argv=None, harness=None):
     ap.add_argument("--no-api", action="store_true", help="extras: skip the per-launch step() API measurements")
     ap.add_argument("--no-secondary", "--no-extras", dest="no_secondary", action="store_true", help="skip scripts/bench_extras.py (BASELINE.json configs[2..4], API, opt-in lines)")
     ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"), help="sidecar file with everything the line leaves out")
-    ap.add_argument("--extras-budget", type=float, default=150.0, help="extras: seconds after which no further optional measurement is started")
+    ap.add_argument("--extras-budget", type=float, default=210.0, help="extras: seconds after which no further optional measurement is started")
     ap.add_argument("--env-kwargs", default="{}", help='JSON constructor kwargs of the env, e.g. \'{"solver": "Newton"}\' (Humanoid: opt-in solver)')
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
     ap.add_argument("--child-list", default=None, help=argparse.SUPPRESS)  # ... for several configurations one after the other: JSON [[env, N, inner, kwargs, warm], ...]

@@ -905,6 +905,9 @@ MI_DEV void duo_env_step(const DevEnv &d, Lane<E> &L, typename E::Act a, ResetQu
         for (int k = 0; k < E::S; k++) L.s[k] = resetting ? rs[k] : L.s[k];
         E::obs(L.s, sflags, obs, L.trig);
         E::terminal_after_obs(L.s, L.trig, rew, te);
+    } else if constexpr (E::AUX_REWARD) {  // the aux role evaluates the reward (from E::aux_pre of the state before this step): the dynamics alone
+        E::advance(L.s, a, d.P, L.trig);
+        rew = 0.0, te = false;
     } else {
         E::step(L.s, sflags, a, d.P, rew, te, L.trig);
     }
@@ -954,7 +957,8 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     typedef typename E::Act Act;
     constexpr int ROLES = 2;
     constexpr int C = DuoTraits<E>::CHUNK;
-    __shared__ Act sh_act[2][C][kBlock];
+    typedef Act ActLds;  // (a byte per Discrete action would save 28 KB of LDS at chunk 8 and costs 1 %: the widening on the env role)
+    __shared__ ActLds sh_act[2][C][kBlock];
     // what goes from the env role to the aux role: the observation row and a flag word -- or, for the environments whose aux role derives both from
     // the state (E::AUX_DERIVES_FLAGS, envs_classic.h), the state words
     constexpr bool DERIVE = E::AUX_DERIVES_FLAGS;
@@ -965,7 +969,9 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     __shared__ float sh_obs[DERIVE ? 1 : 2][DERIVE ? 1 : C][DERIVE ? 1 : kBlock][E::OBS];
     // (Measured and not kept: Pendulum with its reward -- three exact pow and an fmod, none of which feeds the next state -- evaluated by the aux role from
     //  the pre-step state passed through LDS: bit-identical, 168.7 us against 168.7 us for the one-role kernel.  Its instruction count is the limit.)
-    constexpr bool PASS_REWARD = !E::REWARD_FROM_TERMINATED;  // (not transferred when the aux role can recompute it)
+    constexpr bool AUXREW = E::AUX_REWARD;  // the aux role evaluates the reward from words about the state before the step (Pendulum)
+    constexpr bool PASS_REWARD = !E::REWARD_FROM_TERMINATED && !AUXREW;  // (not transferred when the aux role can compute it)
+    __shared__ double sh_pre[AUXREW ? 2 : 1][AUXREW ? C : 1][AUXREW ? kBlock : 1][E::AUX_PRE];
     __shared__ double sh_rew[PASS_REWARD ? 2 : 1][PASS_REWARD ? C : 1][kBlock];
     // (the flag word's width is tuning, measured per environment at T = 128: CartPole +2.3 % with a dword, MountainCarContinuous +2.9 % with a byte)
     typedef typename std::conditional<E::REWARD_FROM_TERMINATED && E::OBS == 4, uint32_t, uint8_t>::type MI_DUO_FLAG_T;
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                         if constexpr (DERIVE) {
                             double w64[NF64];
                             float w32[NF32];
-                            duo_env_step_state<E>(d, L, sh_act[buf][k][slot], q, w64, w32);
+                            duo_env_step_state<E>(d, L, (Act)sh_act[buf][k][slot], q, w64, w32);
 #pragma unroll
                             for (int j = 0; j < E::AUX_F64; j++) sh_w64[buf][k][slot][j] = w64[j];
 #pragma unroll
@@ -1042,7 +1048,13 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                             float o[E::OBS];
                             double rew;
                             uint32_t bits;
-                            duo_env_step<E>(d, L, sh_act[buf][k][slot], q, o, rew, bits);
+                            if constexpr (AUXREW) {  // (of a sub-environment in its autoreset step too: the aux role discards that reward)
+                                double pre[E::AUX_PRE];
+                                E::aux_pre(L.s, pre);
+#pragma unroll
+                                for (int j = 0; j < E::AUX_PRE; j++) sh_pre[buf][k][slot][j] = pre[j];
+                            }
+                            duo_env_step<E>(d, L, (Act)sh_act[buf][k][slot], q, o, rew, bits);
 #pragma unroll
                             for (int j = 0; j < E::OBS; j++) sh_obs[buf][k][slot][j] = o[j];
                             if constexpr (PASS_REWARD) sh_rew[buf][k][slot] = rew;
@@ -1093,7 +1105,15 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                             st.episodes += done ? 1u : 0u;
                             n_term += te ? 1u : 0u;
                         } else {
-                            rew = sh_rew[buf][k][slot];
+                            if constexpr (AUXREW) {
+                                double pre[E::AUX_PRE];
+#pragma unroll
+                                for (int j = 0; j < E::AUX_PRE; j++) pre[j] = sh_pre[buf][k][slot][j];
+                                // (the action of this very step: chunk c was drawn two phases ago into the ring half the policy refills only AFTER this loop)
+                                rew = resetting ? 0.0 : E::aux_reward(pre, (Act)sh_act[buf][k][slot]);
+                            } else {
+                                rew = sh_rew[buf][k][slot];
+                            }
                             const double ret = ep_ret + rew;
                             const int32_t len = ep_len + 1;
                             ep_ret = resetting ? 0.0 : ret;
@@ -1117,7 +1137,7 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                         const size_t t = (size_t)p * C + k;
                         const Act a = action_of_state<E>(astate);
                         astate = as.jump_n.mult * astate + as.jump_n.plus;
-                        sh_act[buf][k][slot] = a;
+                        sh_act[buf][k][slot] = (ActLds)a;
                         static_cast<Act *>(io.actions_out)[t * N + i] = a;
                     }
                 }
@@ -1653,16 +1673,24 @@ struct TabLane {
 };
 // Taxi's fickle passenger (taxi.py:436-451, :462-464): params[2] != 0 switches the rule on, params[3] = fickle_probability
 MI_DEV bool tab_fickle(const DevEnv &d) { return d.tab_fickle_rows != 0; }
+// The tabular kernels serve three kinds of environment (a plain transition table, Taxi with the fickle passenger, Blackjack) behind run-time tests; the
+// fused rollout is instantiated per kind (TK: kTabPlain / kTabFickle / kTabBlackjack; kTabAny = decide at run time, the per-step kernels), so that a
+// FrozenLake rollout carries neither Blackjack's dealer loop nor Taxi's re-draw (round 6: the kernel issues one instruction per ~5 cycles, profiles/r06_acrobot_toytext_root_cause.txt).
+enum { kTabAny = -1, kTabPlain = 0, kTabFickle = 1, kTabBlackjack = 2 };
+template <int TK>
+MI_DEV bool tab_is_fickle(const DevEnv &d) { return TK == kTabAny ? d.tab_fickle_rows != 0 : TK == kTabFickle; }
+template <int TK = kTabAny>
 MI_DEV void tab_load(const DevEnv &d, int i, TabLane &L) {
     L.s = d.state[i], L.prob = d.state[(size_t)d.N + i];
-    L.aux = tab_fickle(d) ? d.state[(size_t)2 * d.N + i] : 0.0;
+    L.aux = tab_is_fickle<TK>(d) ? d.state[(size_t)2 * d.N + i] : 0.0;
     const uint32_t m = d.meta[i];
     L.elapsed = m & kElapsedMask, L.flags = m >> kFlagShift;
     L.ep_ret = d.ep_ret[i], L.ep_len = d.ep_len[i];
 }
+template <int TK = kTabAny>
 MI_DEV void tab_store(const DevEnv &d, int i, const TabLane &L) {
     d.state[i] = L.s, d.state[(size_t)d.N + i] = L.prob;
-    if (tab_fickle(d)) d.state[(size_t)2 * d.N + i] = L.aux;
+    if (tab_is_fickle<TK>(d)) d.state[(size_t)2 * d.N + i] = L.aux;
     d.meta[i] = (L.elapsed & kElapsedMask) | (L.flags << kFlagShift);
     d.ep_ret[i] = L.ep_ret, d.ep_len[i] = L.ep_len;
 }
@@ -1671,6 +1699,8 @@ MI_DEV void tab_store(const DevEnv &d, int i, const TabLane &L) {
 // second word = the generator's buffered 32-bit half (1 << 32 | value; 0 = empty): draw_card is np_random.choice(deck) =
 // Lemire's bounded uint32 on next_uint32, and PCG64's next_uint32 hands out the low, then the high half of one 64-bit output.
 MI_DEV bool is_blackjack(const DevEnv &d) { return d.tab.nS < 0; }
+template <int TK>
+MI_DEV bool tab_is_blackjack(const DevEnv &d) { return TK == kTabAny ? d.tab.nS < 0 : TK == kTabBlackjack; }
 MI_DEV uint32_t bj_next32(Pcg64 &rng, double &aux_slot) {
     const uint64_t aux = (uint64_t)aux_slot;
     if (aux >> 32) {
@@ -1736,16 +1766,17 @@ MI_DEV void bj_step(Pcg64 &rng, double &s, double &aux, int64_t action, bool nat
 
 // `held`: the lane's generator kept in registers by a fused rollout (loaded before its loop, stored after it); nullptr = the per-step
 // kernels, which load and store the stream around every use.
+template <int TK = kTabAny>
 MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L, Pcg64 *held = nullptr) {
     Pcg64 local;
     if (!held) local = load_rng(d, i);
     Pcg64 &rng = held ? *held : local;
-    if (is_blackjack(d)) {
+    if (tab_is_blackjack<TK>(d)) {
         bj_reset(rng, L.s, L.prob);
     } else {
         const size_t tb = d.tab.env_table ? (size_t)d.tab.env_table[i] : 0;  // the sub-environment's own table (its own random map, ...)
         L.s = (double)tab_categorical(d.tab.isd + tb * d.tab.nS, d.tab.nS, rng), L.prob = 1.0;
-        if (tab_fickle(d)) {  // taxi.py:462-464: fickle_step = fickle_passenger and np_random.random() < fickle_probability -- one more draw
+        if (tab_is_fickle<TK>(d)) {  // taxi.py:462-464: fickle_step = fickle_passenger and np_random.random() < fickle_probability -- one more draw
             const double flag = rng.next_double() < d.P.p[3] ? 1.0 : 0.0;
             L.aux = floor(L.aux * 0.5) * 2.0 + flag;
         }
@@ -1754,18 +1785,19 @@ MI_DEV void tab_autoreset(const DevEnv &d, int i, TabLane &L, Pcg64 *held = null
     L.elapsed = 0, L.ep_ret = 0.0, L.ep_len = 0;
 }
 // observation row of a tabular lane: the state index, or Blackjack's three integers
+template <int TK = kTabAny>
 MI_DEV void tab_write_obs(const DevEnv &d, double s, int64_t *base, size_t row) {
-    if (is_blackjack(d))
+    if (tab_is_blackjack<TK>(d))
         bj_obs(s, base + 3 * row);
     else
         base[row] = (int64_t)s;
 }
-template <int MODE>
+template <int MODE, int TK = kTabAny>
 MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t &obs, int64_t &final_obs, bool &has_final, double &reward,
                           bool &te, bool &tr, double &out_ret, int32_t &out_len, LaneStats &st, Pcg64 *held = nullptr, double *final_prob = nullptr) {
     te = tr = false, reward = 0.0, has_final = false;
     if (MODE == MI_AUTORESET_NEXT_STEP && (L.flags & kNeedsReset)) {
-        tab_autoreset(d, i, L, held);
+        tab_autoreset<TK>(d, i, L, held);
         st.reset_steps++;
     } else if (MODE == MI_AUTORESET_DISABLED && (L.flags & kNeedsReset)) {
         *d.error = kErrDisabledStepped;
@@ -1780,7 +1812,7 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
         Pcg64 local;
         if (!held) local = load_rng(d, i);
         Pcg64 &rng = held ? *held : local;
-        if (is_blackjack(d)) {
+        if (tab_is_blackjack<TK>(d)) {
             bj_step(rng, L.s, L.prob, a, d.P.p[0] != 0.0, d.P.p[1] != 0.0, reward, te);
             if (!held) store_rng_state(d, i, rng);
         } else {
@@ -1788,7 +1820,7 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
             const size_t cell = (tb * d.tab.nS + (size_t)L.s) * d.tab.nA + (size_t)a, row = cell * d.tab.K;
             const int k = tab_categorical(d.tab.csprob + row, d.tab.count[cell], rng);
             int next = d.tab.next[row + k];
-            if (tab_fickle(d) && ((int64_t)L.aux & 1)) {
+            if (tab_is_fickle<TK>(d) && ((int64_t)L.aux & 1)) {
                 // taxi.py:436-451: the passenger was in the taxi before this step (shadow pass_loc == 4) and the step moved the taxi: once per episode
                 // the destination is re-drawn among the other three -- Generator.choice = a Lemire-bounded 32-bit draw on the buffered halves (bj_bounded)
                 const int old = (int)L.s;
@@ -1817,7 +1849,7 @@ MI_DEV void tab_lane_step(const DevEnv &d, int i, TabLane &L, int64_t a, int64_t
     if (MODE == MI_AUTORESET_SAME_STEP && done) {
         final_obs = (int64_t)L.s, has_final = true;
         if (final_prob) *final_prob = L.prob;  // info["prob"] of the finishing transition ("final_info"); the reset then reports prob = 1
-        tab_autoreset(d, i, L, held);
+        tab_autoreset<TK>(d, i, L, held);
     }
     obs = (int64_t)L.s;
     if (done && MODE != MI_AUTORESET_SAME_STEP)
@@ -1885,7 +1917,7 @@ __global__ __launch_bounds__(kBlock) void tab_reset_kernel(DevEnv d, const uint8
     tab_store(d, i, L);
     if (obs) tab_write_obs(d, L.s, obs, (size_t)i);
 }
-template <int MODE, bool SAMPLE, bool LDS>
+template <int MODE, bool SAMPLE, bool LDS, int TK>
 __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int lds_bytes) {
     // The transition table is read once per env-step through three levels of dependent loads (count / cumulative probabilities -> branch
     // -> successor, reward, flag); out of L2 that latency is the whole step (Taxi: 100 KB of tables).  When the launcher found that the
@@ -1911,7 +1943,7 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
     LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
     if (i < d.N) {
         TabLane L;
-        tab_load(d, i, L);
+        tab_load<TK>(d, i, L);
         Pcg64 rng = load_rng(d, i);  // the lane's own stream stays in registers for the whole rollout
         u128 astate = 0;
         if (SAMPLE) {
@@ -1937,13 +1969,13 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
             double reward, out_ret;
             int32_t out_len;
             bool te, tr, has_final;
-            tab_lane_step<MODE>(d, i, L, a, obs, fin, has_final, reward, te, tr, out_ret, out_len, st, &rng);
-            if (io.obs) tab_write_obs(d, (double)obs, static_cast<int64_t *>(io.obs), t * N + i);
+            tab_lane_step<MODE, TK>(d, i, L, a, obs, fin, has_final, reward, te, tr, out_ret, out_len, st, &rng);
+            if (io.obs) tab_write_obs<TK>(d, (double)obs, static_cast<int64_t *>(io.obs), t * N + i);
             if (io.reward) io.reward[t * N + i] = reward;
             if (io.terminated) io.terminated[t * N + i] = te;
             if (io.truncated) io.truncated[t * N + i] = tr;
         }
-        tab_store(d, i, L);
+        tab_store<TK>(d, i, L);
         store_rng_state(d, i, rng);
     }
     block_accumulate(d, st);
@@ -3175,13 +3207,20 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
             if (lds > 150 * 1024) lds = 0;
         }
         const int lb = (int)lds;
+        const int tk = v->d.tab.nS < 0 ? kTabBlackjack : (v->d.tab_fickle_rows ? kTabFickle : kTabPlain);
         auto launch = [&](auto mode, auto smp) {
             constexpr int M = decltype(mode)::value;
             constexpr bool S = decltype(smp)::value;
-            if (lds)
-                hipLaunchKernelGGL((tab_rollout_kernel<M, S, true>), g, b, lds, v->stream, v->d, p, as, T, lb);
+            if (tk == kTabBlackjack)  // (no table)
+                hipLaunchKernelGGL((tab_rollout_kernel<M, S, false, kTabBlackjack>), g, b, 0, v->stream, v->d, p, as, T, lb);
+            else if (tk == kTabFickle && lds)
+                hipLaunchKernelGGL((tab_rollout_kernel<M, S, true, kTabFickle>), g, b, lds, v->stream, v->d, p, as, T, lb);
+            else if (tk == kTabFickle)
+                hipLaunchKernelGGL((tab_rollout_kernel<M, S, false, kTabFickle>), g, b, 0, v->stream, v->d, p, as, T, lb);
+            else if (lds)
+                hipLaunchKernelGGL((tab_rollout_kernel<M, S, true, kTabPlain>), g, b, lds, v->stream, v->d, p, as, T, lb);
             else
-                hipLaunchKernelGGL((tab_rollout_kernel<M, S, false>), g, b, 0, v->stream, v->d, p, as, T, lb);
+                hipLaunchKernelGGL((tab_rollout_kernel<M, S, false, kTabPlain>), g, b, 0, v->stream, v->d, p, as, T, lb);
         };
         typedef std::integral_constant<int, MI_AUTORESET_NEXT_STEP> NextT;
         typedef std::integral_constant<int, MI_AUTORESET_SAME_STEP> SameT;

@@ -207,10 +207,16 @@ struct CartPoleT {
         const bool sutton_barto = P.p[0] != 0.0;
         return terminated ? (sutton_barto ? -1.0 : 1.0) : (sutton_barto ? 0.0 : 1.0);
     }
-    // Two-role rollout, round 6: the aux role derives the observation row AND the flags of a step from the state itself, so the env role hands over
-    // the state -- the two components the termination test reads (x, theta: cartpole.py:200-205) as the float64 they are, the two velocities as the
-    // float32 the observation holds -- and neither converts an observation nor packs a flag word.  aux_unpack's test is step()'s, on the same doubles.
-    static constexpr bool AUX_DERIVES_FLAGS = true;
+    // Two-role rollout, round 6: the aux role CAN derive the observation row and the flags of a step from the state itself -- the env role then hands
+    // over the two components the termination test reads (x, theta: cartpole.py:200-205) as the float64 they are and the two velocities as the float32
+    // the observation holds, and neither converts an observation nor packs a flag word.  aux_unpack's test is step()'s, on the same doubles.
+    // Measured (profiles/r06_duo_diet_ab.txt): what bounds the pair of wavefronts is the SUM of their instructions, and for CartPole the hand-over costs
+    // the aux role what it saves the env role: 127.2 G against 128.3 G env-steps/s -- off here; MountainCar, whose state is the whole observation, gains 1.9 %.
+    static constexpr bool AUX_DERIVES_FLAGS = false;
+    static constexpr bool AUX_REWARD = false;  // (the reward comes from the flags here: REWARD_FROM_TERMINATED)
+    static constexpr int AUX_PRE = 1;
+    static MI_DEV void aux_pre(const double *, double *) {}
+    static MI_DEV double aux_reward(const double *, int64_t) { return 0.0; }
     static constexpr int AUX_F64 = 2, AUX_F32 = 2;
     static MI_DEV void aux_pack(const double s[S], double w64[AUX_F64], float w32[AUX_F32]) {
         w64[0] = s[0], w64[1] = s[2], w32[0] = (float)s[1], w32[1] = (float)s[3];
@@ -315,8 +321,24 @@ struct PendulumT {
     static constexpr int S = 2, OBS = 3;
     static constexpr bool DISCRETE = false;
     static constexpr int ROLLOUT_UNROLL = 1;
-    static constexpr bool DUO_ROLLOUT = false;  // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments): measured -0.5 % (215 registers), and +-0 with the reward evaluated by the aux role: the instruction count is the limit
+    // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments).  Round 4 measured -0.5 % (and +-0 with the reward on the aux role) and
+    // concluded that the instruction count is the limit; it was the kernel's own phase overhead (round 6: lane masks carried through the role branches).
+    // Now the step is cut in two balanced halves: the env role advances the state and takes the observation (one exact sincos) plus ONE of the reward's
+    // three exact pow() calls, the aux role evaluates the rest of the reward -- fmod, two pow, the sums, from the pre-step angle and the action it drew
+    // itself -- next to the policy, the episode statistics and the stores.  Same operations on the same operands (reward_of == aux_reward o aux_pre).
+    static constexpr bool DUO_ROLLOUT = true && ACT_KIND == MI_F32;  // (the float64-row instantiations never sample: one role; MI355ENV_ROLLOUT_DUO=0 is the A/B switch)
+    static constexpr int DUO_CHUNK = 8;
+    static constexpr bool REWARD_FROM_TERMINATED = false;
+    static MI_DEV double reward_from_terminated(bool, const EnvParams &) { return 0.0; }
+    static constexpr bool AUX_DERIVES_FLAGS = false;
+    static constexpr int AUX_F64 = 1, AUX_F32 = 0;
+    static MI_DEV void aux_pack(const double *, double *, float *) {}
+    static MI_DEV void aux_unpack(const double *, const float *, const EnvParams &, float *, bool &) {}
+    static constexpr bool AUX_REWARD = true;
+    static constexpr int AUX_PRE = 2;
     typedef typename AK::T Act;
+    // pendulum.py:131 in two halves: what the env role hands over about the state BEFORE the step ...
+    static MI_DEV void aux_pre(const double s[S], double pre[AUX_PRE]) { pre[0] = s[0], pre[1] = 0.1 * M::sq(s[1]); }
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
 
@@ -364,6 +386,24 @@ struct PendulumT {
         else
             cu = 0.001 * M::sq(u);  // all float64
         const double costs = M::sq(an) + 0.1 * M::sq(thdot) + cu;
+        return -costs;
+    }
+    // ... and the reward from it on the aux role: reward_of with 0.1 * thdot ** 2 already evaluated (the sums in the reference's order)
+    static MI_DEV double aux_reward(const double pre[AUX_PRE], Act action) {
+        const Act u = clip_torque(action);
+        double md = M::fmod_2pi(pre[0] + kPi);
+        if (md != 0.0) {
+            if (md < 0.0) md += 2 * kPi;
+        } else {
+            md = 0.0;
+        }
+        const double an = md - kPi;
+        double cu;
+        if constexpr (ACT_KIND == MI_F32)
+            cu = (double)(0.001f * M::sqf(u));
+        else
+            cu = 0.001 * M::sq(u);
+        const double costs = M::sq(an) + pre[1] + cu;
         return -costs;
     }
     // pendulum.py:133-141 the dynamics alone
@@ -522,6 +562,10 @@ struct MountainCarT {
     static MI_DEV double reward_from_terminated(bool, const EnvParams &) { return -1.0; }
     // (see CartPoleT: the aux role of the two-role rollout derives observation and flags from the float64 state, mountain_car.py:139-142)
     static constexpr bool AUX_DERIVES_FLAGS = true;
+    static constexpr bool AUX_REWARD = false;
+    static constexpr int AUX_PRE = 1;
+    static MI_DEV void aux_pre(const double *, double *) {}
+    static MI_DEV double aux_reward(const double *, int64_t) { return 0.0; }
     static constexpr int AUX_F64 = 2, AUX_F32 = 0;
     static MI_DEV void aux_pack(const double s[S], double w64[AUX_F64], float *) { w64[0] = s[0], w64[1] = s[1]; }
     static MI_DEV void aux_unpack(const double w64[AUX_F64], const float *, const EnvParams &P, float o[OBS], bool &terminated) {
@@ -586,7 +630,11 @@ struct MountainCarContinuousT {
     static constexpr int AUX_F64 = 1, AUX_F32 = 0;
     static MI_DEV void aux_pack(const double *, double *, float *) {}
     static MI_DEV void aux_unpack(const double *, const float *, const EnvParams &, float *, bool &) {}
+    static constexpr bool AUX_REWARD = false;  // (the reward reads the unclipped action AND the terminated flag: it stays with the step)
+    static constexpr int AUX_PRE = 1;
+    static MI_DEV void aux_pre(const double *, double *) {}
     typedef typename AK::T Act;
+    static MI_DEV double aux_reward(const double *, Act) { return 0.0; }
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = -0.6, b1 = -0.4; }
     static constexpr int NDRAWS = 1;

@@ -585,7 +585,7 @@ static void make_constraint(const mjo_model *m, mjo_data *d) {
         }
     }
     /* contacts */
-    static double jp1[MJO_MAXV][3], jr1[MJO_MAXV][3], jp2[MJO_MAXV][3], jr2[MJO_MAXV][3];
+    static __thread double jp1[MJO_MAXV][3], jr1[MJO_MAXV][3], jp2[MJO_MAXV][3], jr2[MJO_MAXV][3];
     for (int c = 0; c < d->ncon; c++) {
         mjo_contact *con = &d->contact[c];
         int b1 = m->geom_bodyid[con->geom1], b2 = m->geom_bodyid[con->geom2];
@@ -764,7 +764,7 @@ static void constraint_update(const mjo_model *m, mjo_data *d, const double *qac
 static void solve_newton(const mjo_model *m, mjo_data *d) {
     int nv = m->nv, ne = d->nefc;
     double qacc[MJO_MAXV], grad[MJO_MAXV], dir[MJO_MAXV], jar[MJO_MAXEFC], jd[MJO_MAXEFC];
-    static double H[MJO_MAXV][MJO_MAXV], HL[MJO_MAXV][MJO_MAXV];
+    static __thread double H[MJO_MAXV][MJO_MAXV], HL[MJO_MAXV][MJO_MAXV];
     /* warm start: whichever of qacc_warmstart / qacc_smooth has the lower cost */
     double cost_best = 0;
     for (int pass = 0; pass < 2; pass++) {
@@ -864,7 +864,7 @@ static void solve_newton(const mjo_model *m, mjo_data *d) {
 
 static void solve_pgs(const mjo_model *m, mjo_data *d) {
     int nv = m->nv, ne = d->nefc;
-    static double AR[MJO_MAXEFC][MJO_MAXEFC], MiJT[MJO_MAXEFC][MJO_MAXV];
+    static __thread double AR[MJO_MAXEFC][MJO_MAXEFC], MiJT[MJO_MAXEFC][MJO_MAXV];
     double b[MJO_MAXEFC], f[MJO_MAXEFC];
     for (int r = 0; r < ne; r++) {
         memcpy(MiJT[r], d->efc_J[r], sizeof(double) * nv);
@@ -992,7 +992,7 @@ static void euler(const mjo_model *m, mjo_data *d) {
     double qacc[MJO_MAXV];
     for (int i = 0; i < nv; i++) damped |= m->dof_damping[i] > 0;
     if (damped) { /* implicit in the joint damping: (M + h D) qacc = qfrc_smooth + qfrc_constraint */
-        static double A[MJO_MAXV][MJO_MAXV], L[MJO_MAXV][MJO_MAXV];
+        static __thread double A[MJO_MAXV][MJO_MAXV], L[MJO_MAXV][MJO_MAXV];
         memcpy(A, d->qM, sizeof A);
         for (int i = 0; i < nv; i++) A[i][i] += m->timestep * m->dof_damping[i], qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
         chol_factor(nv, A, L);

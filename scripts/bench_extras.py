@@ -93,15 +93,16 @@ def issue_counters(c: Config, kernel_s, timeout_s=150):
             "source": "rocprofv3 --pmc " + " ".join(ISSUE_COUNTERS) + " on a child invocation in this run"}
 
 
-def coop_counters(c: Config, kernel_s, env_steps_per_s, warm=1, timeout_s=150):
+def coop_counters(c: Config, kernel_s, env_steps_per_s, warm=1, timeout_s=150, measured=None):
     """Cooperative MuJoCo physics kernel: share of wave cycles that issue VALU work, and the fp64 flops it EXECUTES against the vector fp64 peak
-    (2 per FMA, 1 per MUL / ADD, x 64 lanes per wave-level instruction -- masked lanes are counted: the rate the vector units are driven at)."""
+    (2 per FMA, 1 per MUL / ADD, x 64 lanes per wave-level instruction -- masked lanes are counted: the rate the vector units are driven at).
+    `measured`: {"SQ": ..., "FLOP": ...} from bench.live_counters_batch (one child process for several configurations); else two passes of its own."""
     out, args, kernel = {}, child_args(c.env_id, c.N, c.inner, c.env_kwargs, warm), c.dominant_kernel()
-    sq = _rocprof_counters(args, SQ_COUNTERS, kernel, timeout_s)
+    sq = (measured or {}).get("SQ") or (None if measured is not None else _rocprof_counters(args, SQ_COUNTERS, kernel, timeout_s))
     if sq and sq.get("SQ_WAVE_CYCLES", (0, 0))[0] > 0:
         wc = sq["SQ_WAVE_CYCLES"][0]
         out["sq"] = {k[3:].lower() + "_frac": sq[k][0] / wc for k in SQ_COUNTERS[1:] if k in sq}
-    fc = _rocprof_counters(args, FLOP_COUNTERS, kernel, timeout_s)
+    fc = (measured or {}).get("FLOP") or (None if measured is not None else _rocprof_counters(args, FLOP_COUNTERS, kernel, timeout_s))
     if fc and fc.get("SQ_INSTS_VALU", (0, 0))[0] > 0:
         g = lambda k: fc.get(k, (0.0, 0))[0]  # noqa: E731
         per_dispatch = 64.0 * (2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64"))
@@ -392,7 +393,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--primary", default=None, help="JSON file with bench.py's primary result (copied into the sidecar)")
     ap.add_argument("--pmc", choices=["auto", "full", "off"], default="auto")
-    ap.add_argument("--budget", type=float, default=150.0)
+    ap.add_argument("--budget", type=float, default=210.0)
     ap.add_argument("--started", type=float, default=None, help="time.time() at which the parent command started (budget reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
@@ -418,20 +419,21 @@ def main():
     only = set(args.only.split(",")) if args.only else None
     # Live HBM traffic for EVERY line of this file (no recorded round-3 numbers): the FETCH_SIZE / WRITE_SIZE passes of all
     # configurations run up front in a handful of child processes (bench.live_traffic_batch), a line then finds its bytes under its key.
-    traffic = {}
+    traffic, coop_measured = {}, {}
     if args.pmc != "off" and not args.policy_only and not args.api_only:
         reqs = []
         for env_id, n2, inner2 in SECONDARY + TOYTEXT:
             if only and env_id not in only:
                 continue
-            reqs.append({"env_id": env_id, "N": n2, "inner": inner2, "env_kwargs": None, "warm": 1, "kernel": dominant_kernel_of(env_id, inner2), "key": f"{env_id}:{n2}"})
+            reqs.append({"env_id": env_id, "N": n2, "inner": inner2, "env_kwargs": None, "warm": 1, "kernel": dominant_kernel_of(env_id, inner2), "key": f"{env_id}:{n2}",
+                         "extra": env_id in MJ_COOP})
         for env_id, n2, inner2 in SECONDARY_GROUND:
             if only and env_id not in only:
                 continue
             reqs.append({"env_id": env_id, "N": n2, "inner": inner2, "env_kwargs": {"terminate_when_unhealthy": False}, "warm": GROUND_WARM,
-                         "kernel": dominant_kernel_of(env_id, inner2), "key": f"{env_id}:{n2}:ground"})
+                         "kernel": dominant_kernel_of(env_id, inner2), "key": f"{env_id}:{n2}:ground", "extra": True})
         t_tr = time.time()
-        traffic = bench.live_traffic_batch(reqs)
+        traffic, coop_measured = bench.live_counters_batch(reqs, {"SQ": SQ_COUNTERS, "FLOP": FLOP_COUNTERS})
         full["traffic_passes"] = {"seconds": round(time.time() - t_tr, 1), "configurations": len(reqs), "measured": sum(1 for v in traffic.values() if v[0] is not None)}
     if args.policy_only:
         full["api_benchmark_vector_step"] = api_faithful_leg("CartPole-v1", 65536)
@@ -460,8 +462,8 @@ def main():
             head.setdefault("hbm_frac", {})[env_id] = round(line["roofline"]["frac"], 4)
         full["secondary"].append(line)
         flush()
-        if env_id in MJ_COOP and args.pmc != "off" and young():
-            line["roofline"].update(coop_counters(c2, ks2, v2))
+        if env_id in MJ_COOP and args.pmc != "off":
+            line["roofline"].update(coop_counters(c2, ks2, v2, measured=coop_measured.get(f"{env_id}:{n2}", {})))
         if env_id in MJ_COOP and not args.no_verify:  # >= 1 024 robots x 40 steps against the oracle, from where the timed launches left them
             try:
                 line["verified"] = bench.mujoco_window_check(c2)
@@ -493,8 +495,8 @@ def main():
                 "regime": f"robots on the ground: terminate_when_unhealthy=False, {GROUND_WARM} launches ({GROUND_WARM * inner2} vector steps) of warm-up before the timed region",
                 "roofline": c2.roofline(ks2, traffic=traffic.get(f"{env_id}:{n2}:ground"))}
         head[f"{env_id}@{n2} on the ground"] = float(f"{v2:.4g}")
-        if args.pmc != "off" and young():
-            line["roofline"].update(coop_counters(c2, ks2, v2, warm=GROUND_WARM))
+        if args.pmc != "off":
+            line["roofline"].update(coop_counters(c2, ks2, v2, warm=GROUND_WARM, measured=coop_measured.get(f"{env_id}:{n2}:ground", {})))
         if not args.no_verify:  # the regime that matters: robots on the ground, many contacts, PGS at its sweep cap
             try:
                 line["verified"] = bench.mujoco_window_check(c2)
@@ -515,7 +517,7 @@ def main():
         except Exception as e:
             full["api_error"] = f"{type(e).__name__}: {e}"
         flush()
-    if not args.no_api and not only and young():
+    if not args.no_api and not only:  # (not subject to the budget: SURVEY 8(d)(i) asks for this number first)
         try:
             full["api_benchmark_vector_step"] = api_faithful_leg(env_id, N)
             head["api_faithful_numpy"] = float(f"{full['api_benchmark_vector_step']['value']:.4g}")
