@@ -232,6 +232,41 @@ def test_cooperative_kernel_equals_one_lane_simulator(name, monkeypatch):
     ser.close(), coop.close()
 
 
+@pytest.mark.parametrize("name,kw", [("ant", {}), ("humanoid", {}), ("humanoid", {"terminate_when_unhealthy": False})], ids=["ant", "humanoid", "humanoid-on-the-ground"])
+def test_full_batch_cooperative_equals_one_lane_at_the_benchmark_shape(name, kw, monkeypatch):
+    """the WHOLE batch of BASELINE configs[3] / [4]'s per-GPU shape -- 32 768 robots -- stepped by the cooperative kernel and by the one-lane
+    simulator from the same states, window by window (4 steps, like a bench launch), every robot compared; with termination off and a warm-up the Humanoids
+    lie on the ground (4-15 contacts, PGS at its 50-sweep cap).  The oracle covers 1 024 strided robots of the same shape inside bench.py
+    (mujoco_window_check); this is every robot, against the second HIP implementation."""
+    import torch
+
+    n, windows, T = 32768, 3, 4
+    warm = 40 if kw else 6
+    monkeypatch.setenv("MI355ENV_MJ_COOP", "1")
+    coop = gymnasium_amd.make_vec(COOP_ROBOTS[name], num_envs=n, output="torch", **kw)
+    monkeypatch.delenv("MI355ENV_MJ_COOP")
+    monkeypatch.setenv("MI355ENV_MJ_SERIAL", "1")
+    ser = gymnasium_amd.make_vec(COOP_ROBOTS[name], num_envs=n, output="torch", **kw)
+    monkeypatch.delenv("MI355ENV_MJ_SERIAL")
+    coop.reset(seed=0), ser.reset(seed=0)
+    coop.action_space.seed(0)
+    for _ in range(warm):
+        coop.rollout(T, return_actions=False)
+    worst = 0.0
+    for w in range(windows):
+        st, el, fl = coop.get_state()
+        ser.set_state(st, el, fl)
+        ser._engine.seed(coop.get_rng_state(), None)
+        out = coop.rollout(T)
+        ref = ser.rollout(T, actions=out["actions"])
+        assert torch.equal(out["terminations"], ref["terminations"]) and torch.equal(out["truncations"], ref["truncations"]), (name, w)
+        d = max(float((out["obs"] - ref["obs"]).abs().max()), float((out["rewards"] - ref["rewards"]).abs().max()))
+        worst = max(worst, d)
+        assert d <= 1e-8, (name, w, d)
+    print(f"{name} {kw}: 32768 robots, cooperative vs one-lane max diff {worst:.3e} over {windows} windows of {T} steps after {warm} warm-up launches")
+    coop.close(), ser.close()
+
+
 def test_pusher_contacts_gpu_vs_oracle(oracle_factory):
     """Pusher-v5 with the arm lowered onto the object and the table (capsule - cylinder and plane - capsule contacts active from the
     first step): HIP vs oracle from identical states, 10 steps."""
