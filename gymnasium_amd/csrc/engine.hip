@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                             // the reward is a function of the flags, so every total follows from three counters and the episode length (finish_totals,
                             // below): no float64 accumulation per step
                             rew = resetting ? 0.0 : E::reward_from_terminated(te, d.P);
-                            ep_len = resetting ? 0 : ep_len + 1;
+                            // (an aux role that keeps its own TimeLimit counter needs no episode length per step: see the totals below.  Measured for
+                            //  MountainCar: +3.8 %; for CartPole, with the counter handed over through LDS: -1 % -- profiles/r06_duo_three_changes_ab.txt)
+                            if constexpr (!DERIVE) ep_len = resetting ? 0 : ep_len + 1;
                             st.reset_steps += resetting ? 1u : 0u;
                             st.episodes += done ? 1u : 0u;
                             n_term += te ? 1u : 0u;
@@ -1196,6 +1198,9 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                     const uint32_t last_bits = chunks > 0 ? (uint32_t)sh_bits[(chunks - 1) & 1][C - 1][slot] : ((start_flags & kNeedsReset) ? 2u : 0u);
                     last_done = (last_bits & 3u) != 0, last_te = (last_bits & 1u) != 0;
                 }
+                // DERIVE: the running episode's length is the TimeLimit counter once an autoreset step has zeroed both (they advance together from
+                // there), and what it was plus the launch's steps otherwise
+                if (DERIVE && chunks > 0) ep_len = st.reset_steps ? (int32_t)aux_elapsed : ep_len + chunks * C;
                 st.env_steps = (uint32_t)(chunks * C) - st.reset_steps;
                 // (an episode that finished in the very last step still sits in ep_len, waiting for its autoreset step: it IS among the finished ones)
                 st.length_sum = (uint64_t)((int64_t)st.env_steps + (int64_t)ep_len_start - (last_done ? (int64_t)0 : (int64_t)ep_len));
