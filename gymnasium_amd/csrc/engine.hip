@@ -970,7 +970,8 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     // (Measured and not kept: Pendulum with its reward -- three exact pow and an fmod, none of which feeds the next state -- evaluated by the aux role from
     //  the pre-step state passed through LDS: bit-identical, 168.7 us against 168.7 us for the one-role kernel.  Its instruction count is the limit.)
     constexpr bool AUXREW = E::AUX_REWARD;  // the aux role evaluates the reward from words about the state before the step (Pendulum)
-    constexpr bool PASS_REWARD = !E::REWARD_FROM_TERMINATED && !AUXREW;  // (not transferred when the aux role can compute it)
+    constexpr bool REW_OF_ACT = E::AUX_REWARD_OF_ACTION;  // ... or from the action it drew and the terminated flag (MountainCarContinuous)
+    constexpr bool PASS_REWARD = !E::REWARD_FROM_TERMINATED && !AUXREW && !REW_OF_ACT;  // (not transferred when the aux role can compute it)
     __shared__ double sh_pre[AUXREW ? 2 : 1][AUXREW ? C : 1][AUXREW ? kBlock : 1][E::AUX_PRE];
     __shared__ double sh_rew[PASS_REWARD ? 2 : 1][PASS_REWARD ? C : 1][kBlock];
     // (the flag word's width is tuning, measured per environment at T = 128: CartPole +2.3 % with a dword, MountainCarContinuous +2.9 % with a byte)
@@ -1113,6 +1114,8 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                                 for (int j = 0; j < E::AUX_PRE; j++) pre[j] = sh_pre[buf][k][slot][j];
                                 // (the action of this very step: chunk c was drawn two phases ago into the ring half the policy refills only AFTER this loop)
                                 rew = resetting ? 0.0 : E::aux_reward(pre, (Act)sh_act[buf][k][slot]);
+                            } else if constexpr (REW_OF_ACT) {
+                                rew = resetting ? 0.0 : E::reward_of_action(te, (Act)sh_act[buf][k][slot]);
                             } else {
                                 rew = sh_rew[buf][k][slot];
                             }

@@ -214,6 +214,9 @@ struct CartPoleT {
     // the aux role what it saves the env role: 127.2 G against 128.3 G env-steps/s -- off here; MountainCar, whose state is the whole observation, gains 1.9 %.
     static constexpr bool AUX_DERIVES_FLAGS = false;
     static constexpr bool AUX_REWARD = false;  // (the reward comes from the flags here: REWARD_FROM_TERMINATED)
+    static constexpr bool AUX_REWARD_OF_ACTION = false;
+    template <class A>
+    static MI_DEV double reward_of_action(bool, A) { return 0.0; }
     static constexpr int AUX_PRE = 1;
     static MI_DEV void aux_pre(const double *, double *) {}
     static MI_DEV double aux_reward(const double *, int64_t) { return 0.0; }
@@ -324,8 +327,9 @@ struct PendulumT {
     // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments).  Round 4 measured -0.5 % (and +-0 with the reward on the aux role) and
     // concluded that the instruction count is the limit; it was the kernel's own phase overhead (round 6: lane masks carried through the role branches).
     // Now the step is cut in two balanced halves: the env role advances the state and takes the observation (one exact sincos) plus ONE of the reward's
-    // three exact pow() calls, the aux role evaluates the rest of the reward -- fmod, two pow, the sums, from the pre-step angle and the action it drew
-    // itself -- next to the policy, the episode statistics and the stores.  Same operations on the same operands (reward_of == aux_reward o aux_pre).
+    // three exact pow() calls and the angle's normalisation (the exact fmod), the aux role evaluates the rest of the reward -- two pow and the sums, from
+    // the normalised pre-step angle and the action it drew itself -- next to the policy, the episode statistics and the stores.  Same operations on the
+    // same operands (reward_of == aux_reward o aux_pre).
     static constexpr bool DUO_ROLLOUT = true && ACT_KIND == MI_F32;  // (the float64-row instantiations never sample: one role; MI355ENV_ROLLOUT_DUO=0 is the A/B switch)
     static constexpr int DUO_CHUNK = 8;
     static constexpr bool REWARD_FROM_TERMINATED = false;
@@ -335,10 +339,24 @@ struct PendulumT {
     static MI_DEV void aux_pack(const double *, double *, float *) {}
     static MI_DEV void aux_unpack(const double *, const float *, const EnvParams &, float *, bool &) {}
     static constexpr bool AUX_REWARD = true;
+    static constexpr bool AUX_REWARD_OF_ACTION = false;
+    template <class A>
+    static MI_DEV double reward_of_action(bool, A) { return 0.0; }
     static constexpr int AUX_PRE = 2;
     typedef typename AK::T Act;
     // pendulum.py:131 in two halves: what the env role hands over about the state BEFORE the step ...
-    static MI_DEV void aux_pre(const double s[S], double pre[AUX_PRE]) { pre[0] = s[0], pre[1] = 0.1 * M::sq(s[1]); }
+    // (round 6, second cut: with the angle handed over as it is the aux role was the longer one -- 306 k against 229 k cycles of work per launch,
+    //  profiles/r06_duo_timing.txt -- so angle_normalize moved to the env role as well)
+    static MI_DEV double angle_normalize(double th) {  // pendulum.py:281-282  ((x + pi) % (2 pi)) - pi with Python's floor-modulo
+        double md = M::fmod_2pi(th + kPi);
+        if (md != 0.0) {
+            if (md < 0.0) md += 2 * kPi;
+        } else {
+            md = 0.0;
+        }
+        return md - kPi;
+    }
+    static MI_DEV void aux_pre(const double s[S], double pre[AUX_PRE]) { pre[0] = angle_normalize(s[0]), pre[1] = 0.1 * M::sq(s[1]); }
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
 
@@ -372,14 +390,7 @@ struct PendulumT {
     // pendulum.py:131  costs = angle_normalize(th) ** 2 + 0.1 * thdot ** 2 + 0.001 * (u ** 2), of the state BEFORE the step; reward = -costs.
     static MI_DEV double reward_of(double th, double thdot, Act action) {
         const Act u = clip_torque(action);
-        // angle_normalize: ((x + pi) % (2 pi)) - pi with Python floor-modulo
-        double md = M::fmod_2pi(th + kPi);
-        if (md != 0.0) {
-            if (md < 0.0) md += 2 * kPi;
-        } else {
-            md = 0.0;
-        }
-        const double an = md - kPi;
+        const double an = angle_normalize(th);
         double cu;
         if constexpr (ACT_KIND == MI_F32)
             cu = (double)(0.001f * M::sqf(u));  // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
@@ -388,16 +399,10 @@ struct PendulumT {
         const double costs = M::sq(an) + 0.1 * M::sq(thdot) + cu;
         return -costs;
     }
-    // ... and the reward from it on the aux role: reward_of with 0.1 * thdot ** 2 already evaluated (the sums in the reference's order)
+    // ... and the reward from it on the aux role: reward_of with the normalised angle and 0.1 * thdot ** 2 already evaluated (the sums in the reference's order)
     static MI_DEV double aux_reward(const double pre[AUX_PRE], Act action) {
         const Act u = clip_torque(action);
-        double md = M::fmod_2pi(pre[0] + kPi);
-        if (md != 0.0) {
-            if (md < 0.0) md += 2 * kPi;
-        } else {
-            md = 0.0;
-        }
-        const double an = md - kPi;
+        const double an = pre[0];
         double cu;
         if constexpr (ACT_KIND == MI_F32)
             cu = (double)(0.001f * M::sqf(u));
@@ -563,6 +568,9 @@ struct MountainCarT {
     // (see CartPoleT: the aux role of the two-role rollout derives observation and flags from the float64 state, mountain_car.py:139-142)
     static constexpr bool AUX_DERIVES_FLAGS = true;
     static constexpr bool AUX_REWARD = false;
+    static constexpr bool AUX_REWARD_OF_ACTION = false;
+    template <class A>
+    static MI_DEV double reward_of_action(bool, A) { return 0.0; }
     static constexpr int AUX_PRE = 1;
     static MI_DEV void aux_pre(const double *, double *) {}
     static MI_DEV double aux_reward(const double *, int64_t) { return 0.0; }
@@ -630,7 +638,20 @@ struct MountainCarContinuousT {
     static constexpr int AUX_F64 = 1, AUX_F32 = 0;
     static MI_DEV void aux_pack(const double *, double *, float *) {}
     static MI_DEV void aux_unpack(const double *, const float *, const EnvParams &, float *, bool &) {}
-    static constexpr bool AUX_REWARD = false;  // (the reward reads the unclipped action AND the terminated flag: it stays with the step)
+    static constexpr bool AUX_REWARD = false;
+    // The reward reads the unclipped action and the terminated flag (continuous_mountain_car.py:174-176) -- both of which the aux role of the two-role
+    // rollout holds itself (it drew the action, the flag comes over with the observation): round 6 takes the reward off the env role, which bounds
+    // this kernel (150 k against 99 k cycles of work per launch, profiles/r06_duo_timing.txt), and its float64 ring out of LDS.
+    static constexpr bool AUX_REWARD_OF_ACTION = true;
+    template <class A>
+    static MI_DEV double reward_of_action(bool terminated, A a0) {
+        if constexpr (ACT_KIND == MI_F32) {
+            const double a_d = (double)a0;
+            return (terminated ? 100.0 : 0.0) - (a_d * a_d) * 0.1;  // (step_f32's last line)
+        } else {
+            return (terminated ? 100.0 : 0.0) - M::sq((double)a0) * 0.1;  // (step_f64's)
+        }
+    }
     static constexpr int AUX_PRE = 1;
     static MI_DEV void aux_pre(const double *, double *) {}
     typedef typename AK::T Act;
