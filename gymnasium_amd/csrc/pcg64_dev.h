@@ -31,11 +31,39 @@ MI_HD constexpr u128 pcg_mult_inverse() {
 }
 static_assert(pcg_mult_inverse() * (((u128)0x2360ED051FC65DA4ULL << 64) | (u128)0x4385DF649FCCF645ULL) == (u128)1, "inverse");
 
+// mult * s + plus mod 2^128, limb by limb.  Left to `unsigned __int128` the device compiler zero-extends every partial product into a fresh register pair
+// (~29 instructions for a run-time multiplier, 27 for the generator's constant); here the products accumulate in 64-bit multiply-adds whose addends
+// cannot overflow where a carry would matter, the one carry that can occur (out of the middle limbs) is the addition's overflow flag, and the top limb's
+// four cross products are 32-bit: 19 instructions.  Checked against the __int128 expression on 2e7 random and edge-pattern operands (tests/test_pcg_limbs.py).
+//   T0 = a0 m0 + p0                       <= (2^32-1)^2 + 2^32-1 < 2^64
+//   T1 = a1 m0 + (hi(T0) + p1) + a0 m1    first sum <= 2^64-1; the second may carry: c1, worth 2^96
+//   H  = a2 m0 + a1 m1 + a0 m2 + hi(T1) + (p3:p2)   mod 2^64 (bits 64..127)
+//   r3 = hi(H) + lo32(a3 m0 + a2 m1 + a1 m2 + a0 m3) + c1
+MI_HD u128 pcg_muladd(u128 s, u128 mult, u128 plus) {
+    const uint32_t a0 = (uint32_t)s, a1 = (uint32_t)(s >> 32), a2 = (uint32_t)(s >> 64), a3 = (uint32_t)(s >> 96);
+    const uint32_t m0 = (uint32_t)mult, m1 = (uint32_t)(mult >> 32), m2 = (uint32_t)(mult >> 64), m3 = (uint32_t)(mult >> 96);
+    const uint32_t p0 = (uint32_t)plus, p1 = (uint32_t)(plus >> 32);
+    const uint64_t p23 = (uint64_t)(plus >> 64);
+    const uint64_t t0 = (uint64_t)a0 * m0 + p0;
+    const uint64_t t1a = (uint64_t)a1 * m0 + ((t0 >> 32) + p1);
+    uint64_t t1;
+    const bool c1 = __builtin_add_overflow((uint64_t)a0 * m1, t1a, &t1);
+    uint64_t h = (uint64_t)a2 * m0 + ((t1 >> 32) + p23);
+    h = (uint64_t)a1 * m1 + h;
+    h = (uint64_t)a0 * m2 + h;
+    const uint32_t x = a3 * m0 + a2 * m1 + a1 * m2 + a0 * m3;
+    const uint32_t r3 = (uint32_t)(h >> 32) + x + (c1 ? 1u : 0u);
+    return ((u128)r3 << 96) | ((u128)(uint32_t)h << 64) | ((u128)(uint32_t)t1 << 32) | (u128)(uint32_t)t0;
+}
+
 struct Pcg64 {
     u128 state;
     u128 inc;
 
-    MI_HD void step() { state = state * pcg_mult() + inc; }
+#ifndef MI_PCG_LIMB_STEP  // (A/B builds: -DMI_PCG_LIMB_STEP=0)
+#define MI_PCG_LIMB_STEP 1
+#endif
+    MI_HD void step() { state = MI_PCG_LIMB_STEP ? pcg_muladd(state, pcg_mult(), inc) : state * pcg_mult() + inc; }
     MI_HD void unstep() { state = (state - inc) * pcg_mult_inverse(); }  // exact inverse of step()
     MI_HD uint64_t next64() {
         step();
