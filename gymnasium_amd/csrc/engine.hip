@@ -958,7 +958,8 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
     constexpr int ROLES = 2;
     constexpr int C = DuoTraits<E>::CHUNK;
     typedef Act ActLds;  // (a byte per Discrete action would save 28 KB of LDS at chunk 8 and costs 1 %: the widening on the env role)
-    __shared__ ActLds sh_act[2][C][kBlock];
+    constexpr bool ACT_AHEAD = E::DUO_ACT_AHEAD;  // the env role requests step k + 1's action while step k runs (measured per environment, envs_classic.h)
+    __shared__ ActLds sh_act[2][C + (ACT_AHEAD ? 1 : 0)][kBlock];  // (+ one row nobody writes: the env role's request for "the next step's action" after a chunk's last step)
     // what goes from the env role to the aux role: the observation row and a flag word -- or, for the environments whose aux role derives both from
     // the state (E::AUX_DERIVES_FLAGS, envs_classic.h), the state words
     constexpr bool DERIVE = E::AUX_DERIVES_FLAGS;
@@ -1033,14 +1034,18 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                     // (the queue's periodic refill, rollout_kernel's `t % kRefillPeriod == 0`: with chunks that divide the period the test leaves the step loop)
                     constexpr bool REFILL_PER_CHUNK = kRefillPeriod % C == 0;
                     if (REFILL_PER_CHUNK && ((c * C) & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
+                    // ACT_AHEAD: the action of step k + 1 is requested while step k runs -- the rolled loop otherwise starts every step with an LDS round trip
+                    ActLds a_next = sh_act[buf][0][slot];
 #pragma unroll 1
                     for (int k = 0; k < C; k++) {
                         const int t = c * C + k;
                         if (!REFILL_PER_CHUNK && (t & (kRefillPeriod - 1)) == 0 && !q.have) q.refill();
+                        const Act a_k = ACT_AHEAD ? (Act)a_next : (Act)sh_act[buf][k][slot];
+                        if (ACT_AHEAD) a_next = sh_act[buf][k + 1][slot];
                         if constexpr (DERIVE) {
                             double w64[NF64];
                             float w32[NF32];
-                            duo_env_step_state<E>(d, L, (Act)sh_act[buf][k][slot], q, w64, w32);
+                            duo_env_step_state<E>(d, L, a_k, q, w64, w32);
 #pragma unroll
                             for (int j = 0; j < E::AUX_F64; j++) sh_w64[buf][k][slot][j] = w64[j];
 #pragma unroll
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
 #pragma unroll
                                 for (int j = 0; j < E::AUX_PRE; j++) sh_pre[buf][k][slot][j] = pre[j];
                             }
-                            duo_env_step<E>(d, L, (Act)sh_act[buf][k][slot], q, o, rew, bits);
+                            duo_env_step<E>(d, L, a_k, q, o, rew, bits);
 #pragma unroll
                             for (int j = 0; j < E::OBS; j++) sh_obs[buf][k][slot][j] = o[j];
                             if constexpr (PASS_REWARD) sh_rew[buf][k][slot] = rew;

@@ -201,6 +201,7 @@ struct CartPoleT {
     static constexpr int ROLLOUT_UNROLL = 1;  // engine.hip rollout_kernel: steps per unrolled loop body
     static constexpr bool DUO_ROLLOUT = true;  // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments): measured +13 %
     static constexpr int DUO_CHUNK = 8;  // steps per phase of the two-role kernel (round 6, after the phase overhead left the wavefronts: +3.0 % over 4; round 4 measured -2.4 %)
+    static constexpr bool DUO_ACT_AHEAD = false;  // (profiles/r06_act_prefetch_ab.txt)
     // the reward of a (non-reset) step is a function of its terminated flag (step(), below): the aux role recomputes it instead of receiving it
     static constexpr bool REWARD_FROM_TERMINATED = true;
     static MI_DEV double reward_from_terminated(bool terminated, const EnvParams &P) {
@@ -332,6 +333,7 @@ struct PendulumT {
     // same operands (reward_of == aux_reward o aux_pre).
     static constexpr bool DUO_ROLLOUT = true && ACT_KIND == MI_F32;  // (the float64-row instantiations never sample: one role; MI355ENV_ROLLOUT_DUO=0 is the A/B switch)
     static constexpr int DUO_CHUNK = 8;
+    static constexpr bool DUO_ACT_AHEAD = false;  // (profiles/r06_act_prefetch_ab.txt)
     static constexpr bool REWARD_FROM_TERMINATED = false;
     static MI_DEV double reward_from_terminated(bool, const EnvParams &) { return 0.0; }
     static constexpr bool AUX_DERIVES_FLAGS = false;
@@ -563,6 +565,7 @@ struct MountainCarT {
     static constexpr int ROLLOUT_UNROLL = 1;  // engine.hip rollout_kernel: steps per unrolled loop body
     static constexpr bool DUO_ROLLOUT = true;  // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments): measured +15 %
     static constexpr int DUO_CHUNK = 8;  // steps per phase of the two-role kernel (+2.6 % over 4)
+    static constexpr bool DUO_ACT_AHEAD = true;   // +3.5 % here; CartPole -0.7 %, Pendulum -1 %, MountainCarContinuous -3.4 %
     static constexpr bool REWARD_FROM_TERMINATED = true;  // -1.0 every step (step(), below)
     static MI_DEV double reward_from_terminated(bool, const EnvParams &) { return -1.0; }
     // (see CartPoleT: the aux role of the two-role rollout derives observation and flags from the float64 state, mountain_car.py:139-142)
@@ -631,6 +634,7 @@ struct MountainCarContinuousT {
     static constexpr int ROLLOUT_UNROLL = 1;
     static constexpr bool DUO_ROLLOUT = true;  // engine.hip rollout_duo_kernel (env + aux wavefront per 64 sub-environments): measured +8 %
     static constexpr int DUO_CHUNK = 8;  // steps per phase of the two-role kernel (+4.2 % over 4)
+    static constexpr bool DUO_ACT_AHEAD = false;  // (profiles/r06_act_prefetch_ab.txt)
     static constexpr bool REWARD_FROM_TERMINATED = false;
     static MI_DEV double reward_from_terminated(bool, const EnvParams &) { return 0.0; }
     // (the state's float32 / float64 phases and the reward's dependence on the action keep observation, reward and flags on the env role here)
