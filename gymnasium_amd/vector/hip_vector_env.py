@@ -515,7 +515,9 @@ class HipVectorEnv(VectorEnv):
             # (mi_step with actions == NULL).  Device tensors only; with NumPy batches it is the two calls it stands for.
             eng_stream = self.action_space.hip_use_stream() if (self.output == "torch" and hasattr(self.action_space, "hip_use_stream")) else None
             if eng_stream is None:
-                return self.step(self.action_space.sample())
+                # (not `self.step(...)`: a subclass that reshapes what step() returns -- Blackjack's tuple of columns -- is already on the stack)
+                actions = self.action_space.sample()
+        if actions is None:
             if self.last_sampled_actions is None:
                 t = self._torch
                 self.last_sampled_actions = t.zeros(self._act_shape, dtype=t.int64 if self._discrete else t.float32, device=self._tdev)

@@ -23,6 +23,21 @@ def test_step_none_equals_step_of_a_sample(env_id, oracle_factory):
     ps.check_step_none_equals_step_sample(env_id, oracle_factory, n=24, steps=60)
 
 
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1", "Blackjack-v1", "Taxi-v4"])
+def test_step_none_with_numpy_batches_is_the_two_calls_it_stands_for(env_id, oracle_factory):
+    """output="numpy": step(None) == step(action_space.sample()), through whatever a subclass does to step()'s result (Blackjack's tuple of columns:
+    the fallback once went through self.step() a second time; found by scripts/r06/gpu_soak.py)."""
+    a = gymnasium_amd.make_vec(env_id, num_envs=9, _engine_factory=oracle_factory)
+    b = gymnasium_amd.make_vec(env_id, num_envs=9, _engine_factory=oracle_factory)
+    a.reset(seed=2), b.reset(seed=2)
+    a.action_space.seed(6), b.action_space.seed(6)
+    for _ in range(40):
+        ra, rb = a.step(None), b.step(b.action_space.sample())
+        for k in range(4):
+            assert ps._same(ra[k], rb[k])
+    a.close(), b.close()
+
+
 def test_sample_output_torch_needs_torch_output(oracle_factory):
     with pytest.raises(ValueError, match="sample_output"):
         gymnasium_amd.make_vec("CartPole-v1", num_envs=2, sample_output="torch", _engine_factory=oracle_factory)
