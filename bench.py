@@ -582,6 +582,7 @@ def main(argv=None, harness=None):
     ap.add_argument("--no-api", action="store_true", help="extras: skip the per-launch step() API measurements")
     ap.add_argument("--no-secondary", "--no-extras", dest="no_secondary", action="store_true", help="skip scripts/bench_extras.py (BASELINE.json configs[2..4], API, opt-in lines)")
     ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"), help="sidecar file with everything the line leaves out")
+    ap.add_argument("--cpu-baseline-at-any-n", action="store_true", help="time the CPU leg on rank 0 also when WORLD_SIZE > 1 (default: at N = 1 only)")
     ap.add_argument("--extras-budget", type=float, default=210.0, help="extras: seconds after which no further optional measurement is started")
     ap.add_argument("--env-kwargs", default="{}", help='JSON constructor kwargs of the env, e.g. \'{"solver": "Newton"}\' (Humanoid: opt-in solver)')
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child: launches only, prints nothing
@@ -726,8 +727,8 @@ def main(argv=None, harness=None):
         }
     cfg.close()
 
-    # ---- CPU leg: the oracle port on rank 0 (every N) ---------------------------------------------------------------------------------------
-    if rank == 0 and not args.no_cpu_baseline:
+    # ---- CPU leg: the oracle port on rank 0, at N = 1 only (the contract; --cpu-baseline-at-any-n for the dry runs of the N > 1 flow) ------------------
+    if rank == 0 and not args.no_cpu_baseline and (world == 1 or args.cpu_baseline_at_any_n):
         # the whole batch of one GPU on every host core (MuJoCo: a bounded sample of 64 sub-environments per core -- the oracle's per-env cost
         # does not depend on the batch size)
         n_cpu = min(N, 64 * usable_cpus()[0]) if args.env in MJ_COOP else N

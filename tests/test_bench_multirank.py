@@ -61,7 +61,7 @@ def test_default_flags_pilot_sets_k_on_every_rank(world):
     assert len({d["output_sha256"] for d in r["devices"]}) == world and r["devices"][0]["output_sha256"] == r["output_sha256"][:16]
     assert len(json.dumps(r, separators=(",", ":"))) < 4096
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["algorithmic_bytes_per_launch"] == (34 * 8 + 96) * 256
-    assert r["cpu_baseline"]["cores"] == 2 and r["cpu_baseline"]["value"] > 0
+    assert r["cpu_baseline"] is None  # (the CPU leg is timed at N = 1 only)
     assert "secondary" not in r and "api_step_device" not in r  # one-GPU extras stay out of the N > 1 line
 
 
@@ -76,7 +76,7 @@ def test_driver_style_explicit_steps_takes_the_separate_sustained_loop():
 def test_baseline_config4_command_line_humanoid_sharded():
     """BASELINE.json configs[4] -- Humanoid-v5 sharded over the ranks -- with the driver's flags (`--env Humanoid-v5 --num-envs N --inner 4`): the MuJoCo
     branch of the line (algorithmic bytes of a cooperative robot, `bound: "valu"`, the CPU leg's bounded sample) on two gloo ranks."""
-    r = _run(2, ["--env", "Humanoid-v5", "--steps", "2", "--warmup", "1", "--sustained", "0"], num_envs=6, inner=2)
+    r = _run(2, ["--env", "Humanoid-v5", "--steps", "2", "--warmup", "1", "--sustained", "0", "--cpu-baseline-at-any-n"], num_envs=6, inner=2)
     assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["config"]["env"] == "Humanoid-v5" and r["config"]["num_envs_per_gpu"] == 6
     lanes = 2 * 6 * 2 * r["steps"]
     assert 0 < r["value"] * r["ms_per_step"] * 1e-3 * r["steps"] <= lanes * (1 + 1e-9)  # (no episode ends in 4 steps: exactly `lanes` env-steps, up to rounding)
