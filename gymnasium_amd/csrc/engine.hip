@@ -1966,15 +1966,22 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
                 if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
         }
         const size_t N = (size_t)d.N;
+        // (the policy's draw does not depend on the environment: step t + 1's action is drawn while step t's chain of table lookups is in flight)
+        auto draw = [&]() {
+            const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate, x = hi ^ lo;
+            const unsigned rot = (unsigned)(hi >> 58);
+            const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+            astate = as.jump_n.mult * astate + as.jump_n.plus;
+            return (int64_t)((double)(out >> 11) * (1.0 / 9007199254740992.0) * (double)d.tab.nA);  // (random(N) * nvec).astype(int64)
+        };
+        int64_t a_next = 0;
+        if (SAMPLE && T > 0) a_next = draw();
         for (int t = 0; t < T; t++) {
             int64_t a;
             if (SAMPLE) {
-                const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate, x = hi ^ lo;
-                const unsigned rot = (unsigned)(hi >> 58);
-                const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
-                a = (int64_t)((double)(out >> 11) * (1.0 / 9007199254740992.0) * (double)d.tab.nA);  // (random(N) * nvec).astype(int64)
-                astate = as.jump_n.mult * astate + as.jump_n.plus;
+                a = a_next;
                 if (io.actions_out) static_cast<int64_t *>(io.actions_out)[t * N + i] = a;
+                a_next = draw();  // (one draw past the last step: the stream's position is kept by the host, not by this state)
             } else {
                 a = static_cast<const int64_t *>(io.actions_in)[t * N + i];
             }
