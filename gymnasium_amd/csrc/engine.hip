@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
     // LDS is a TEMPLATE parameter (round 6): chosen at run time, the table pointers were generic, the lookups FLAT loads -- 9 per env-step
     // (profiles/r06_frozenlake_rollout.txt: SQ_INSTS_VMEM_RD 1.19e6 per launch against 5e4 LDS instructions) -- and a flat load shares the
     // in-order vmcnt with the trajectory stores: every lookup waited for the stores before it to reach memory.
-    extern __shared__ double tab_lds[];
+    extern __shared__ __align__(16) double tab_lds[];
     if constexpr (LDS) {
         const size_t cells = (size_t)d.tab.nS * d.tab.nA, rows = cells * d.tab.K;
         double *cs = tab_lds, *pr = cs + rows, *rw = pr + rows, *isd = rw + rows;
@@ -1996,6 +1996,176 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
             if (io.truncated) io.truncated[t * N + i] = tr;
         }
         tab_store<TK>(d, i, L);
+        store_rng_state(d, i, rng);
+    }
+    block_accumulate(d, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The collector's rollout of a PLAIN transition table (FrozenLake, CliffWalking, Taxi without the fickle passenger): NEXT_STEP, on-device
+// policy, one table for all sub-environments, at most three outcomes per (state, action).  Round 6, after the counters
+// (profiles/r06_acrobot_toytext_root_cause.txt: 381 instructions per env-step from a lone wavefront, 39 branches in the loop body, three levels of
+// dependent LDS reads): the same values as tab_rollout_kernel<NEXT_STEP, true, true, kTabPlain> from a loop body WITHOUT data-dependent control flow.
+//   * A step and an autoreset step both take exactly ONE draw from the sub-environment's generator (utils.py:4-8 categorical_sample in
+//     frozen_lake.py:330 and :345), so the draw is unconditional and the two cases are selects on its result, not two copies of the generator.
+//   * The table is repacked into LDS as one record per (state, action) -- the cumulative probabilities with -1 behind the row's last outcome
+//     ("first k with csprob[k] > u, 0 if none" then needs no count), the rewards, and successor | terminated << 31 -- so ONE level of reads
+//     fetches every candidate and the outcome is selected in registers.
+//   * The initial-state draw (first state whose cumulative probability exceeds u) starts from a 256-entry guide table -- guide[g] = first
+//     state with isd_cs > g / 256, a lower bound of the answer for every u in [g / 256, (g + 1) / 256) because the sums are
+//     non-decreasing -- and scans forward: one read for FrozenLake / CliffWalking, ~two for Taxi's 300 start states; under one
+//     wavefront-uniform branch that only the steps with an autoreset in the wavefront take.
+//   * info["prob"] of the last transition is looked up once, after the loop.
+// KL: outcomes per record (1 or 3; a table with two outcomes uses 3).  FULL: all five trajectory arrays are present.
+// ---------------------------------------------------------------------------------------------------------
+template <int KL>
+struct TabLeanCell;
+template <>
+struct TabLeanCell<1> {
+    static constexpr int BYTES = 16;  // {reward, successor | terminated << 31, -}
+};
+template <>
+struct TabLeanCell<3> {
+    static constexpr int BYTES = 64;  // {cs0, cs1 | cs2, reward0 | reward1, reward2 | nt0, nt1, nt2, -}
+};
+constexpr int kTabGuide = 256;
+static inline size_t tab_lean_lds_bytes(int nS, int nA, int KL) {
+    return (size_t)nS * nA * (KL == 1 ? TabLeanCell<1>::BYTES : TabLeanCell<3>::BYTES) + (size_t)nS * sizeof(double) + kTabGuide * sizeof(uint32_t);
+}
+template <int KL, bool FULL>
+__global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
+    extern __shared__ __align__(16) double tab_lds[];
+    constexpr int CELL = TabLeanCell<KL>::BYTES;
+    const int nS = d.tab.nS, nA = d.tab.nA, K = d.tab.K;
+    const int cells = nS * nA;
+    char *const cell_base = reinterpret_cast<char *>(tab_lds);
+    double *const isd = reinterpret_cast<double *>(cell_base + (size_t)cells * CELL);
+    uint32_t *const guide = reinterpret_cast<uint32_t *>(isd + nS);
+    for (int c = threadIdx.x; c < cells; c += kBlock) {
+        const int n = d.tab.count[c];
+        char *rec = cell_base + (size_t)c * CELL;
+        if constexpr (KL == 1) {
+            *reinterpret_cast<double *>(rec) = d.tab.reward[(size_t)c * K];
+            *reinterpret_cast<uint32_t *>(rec + 8) = (uint32_t)d.tab.next[(size_t)c * K] | (d.tab.term[(size_t)c * K] ? 0x80000000u : 0u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const bool have = j < K && j < n;
+                const size_t r = (size_t)c * K + (j < K ? j : 0);
+                reinterpret_cast<double *>(rec)[j] = have ? d.tab.csprob[r] : -1.0;
+                reinterpret_cast<double *>(rec)[3 + j] = d.tab.reward[r];
+                reinterpret_cast<uint32_t *>(rec + 48)[j] = (uint32_t)d.tab.next[r] | (d.tab.term[r] ? 0x80000000u : 0u);
+            }
+        }
+    }
+    for (int k = threadIdx.x; k < nS; k += kBlock) isd[k] = d.tab.isd[k];
+    for (int g = threadIdx.x; g < kTabGuide; g += kBlock) {  // first state with isd_cs > g / 256 (nS when there is none): bisection in the global array
+        const double lim = (double)g * (1.0 / kTabGuide);
+        int lo = 0, hi = nS;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (d.tab.isd[mid] > lim)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        guide[g] = (uint32_t)lo;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        const size_t N = (size_t)d.N;
+        int s = (int)d.state[i];
+        double prob = d.state[N + i];
+        const uint32_t m = d.meta[i];
+        uint32_t elapsed = m & kElapsedMask;
+        const uint32_t flags0 = m >> kFlagShift;
+        uint32_t need_reset = flags0 & kNeedsReset;
+        double ep_ret = d.ep_ret[i];
+        int32_t ep_len = d.ep_len[i];
+        Pcg64 rng = load_rng(d, i);
+        u128 astate = make_u128(as.state_hi, as.state_lo);
+        {
+            uint32_t delta = (uint32_t)i + 1u;
+            for (int j = 0; delta; j++, delta >>= 1)
+                if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
+        }
+        const double dnA = (double)nA;
+        auto draw = [&]() {  // (random(N) * nvec).astype(int64), spaces/multi_discrete.py:176-178
+            const uint64_t hi = (uint64_t)(astate >> 64), lo = (uint64_t)astate, x = hi ^ lo;
+            const unsigned rot = (unsigned)(hi >> 58);
+            const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+            astate = pcg_muladd(astate, as.jump_n.mult, as.jump_n.plus);
+            return (int32_t)((double)(out >> 11) * (1.0 / 9007199254740992.0) * dnA);
+        };
+        int32_t a_next = draw();
+        int64_t *out_act = static_cast<int64_t *>(io.actions_out) + i, *out_obs = static_cast<int64_t *>(io.obs) + i;
+        double *out_rew = io.reward + i;
+        uint8_t *out_te = io.terminated + i, *out_tr = io.truncated + i;
+        uint32_t last_rec = 0xffffffffu;  // record offset | outcome of the last step (0xffffffff: it was an autoreset step, or there was none)
+#pragma unroll 2
+        for (int t = 0; t < T; t++) {
+            const int32_t a = a_next;
+            a_next = draw();  // (one draw past the last step: the stream's position is kept by the host, not by this state)
+            const bool resetting = need_reset != 0;
+            const double u = rng.next_double();
+            const uint32_t rec = (uint32_t)(s * nA + a) * (uint32_t)CELL;
+            const char *p = cell_base + rec;
+            double rew;
+            uint32_t nt;
+            uint32_t kk = 0;
+            if constexpr (KL == 1) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(p);
+                rew = __hiloint2double((int)q.y, (int)q.x);
+                nt = q.z;
+            } else {
+                double2 q0 = *reinterpret_cast<const double2 *>(p), q1 = *reinterpret_cast<const double2 *>(p + 16),
+                              q2 = *reinterpret_cast<const double2 *>(p + 32);
+                uint4 q3 = *reinterpret_cast<const uint4 *>(p + 48);
+                hold_opaque(q1.y), hold_opaque(q2.x), hold_opaque(q2.y), hold_opaque(q3.x), hold_opaque(q3.y), hold_opaque(q3.z);  // (all four reads are issued together: left alone the compiler sinks two of them behind a branch on c0)
+                const bool c0 = q0.x > u, c1 = q0.y > u, c2 = q1.x > u;
+                const bool take0 = c0 | !(c1 | c2);  // the first outcome, also when no cumulative sum exceeds u (np.argmax of all-False)
+                rew = take0 ? q1.y : (c1 ? q2.x : q2.y);
+                nt = take0 ? q3.x : (c1 ? q3.y : q3.z);
+                kk = take0 ? 0u : (c1 ? 1u : 2u);
+            }
+            int rs = 0;
+            if (resetting) {  // frozen_lake.py:345: categorical_sample(initial_state_distrib); only the steps with an autoreset in the wavefront come here
+                int idx = (int)guide[(int)(u * (double)kTabGuide)];
+                while (idx < nS && !(isd[idx] > u)) idx++;
+                rs = idx < nS ? idx : 0;
+            }
+            const int s_new = resetting ? rs : (int)(nt & 0x7fffffffu);
+            const bool te = !resetting && (nt >> 31) != 0;
+            const double reward = resetting ? 0.0 : rew;
+            const uint32_t el = elapsed + 1u;
+            const bool tr = !resetting && d.max_steps > 0 && (int)el >= d.max_steps;
+            const bool done = te || tr;
+            const double ret = ep_ret + reward;
+            const int32_t len = ep_len + 1;
+            st.reset_steps += resetting ? 1u : 0u;
+            st.episodes += done ? 1u : 0u;
+            st.return_sum += done ? ret : 0.0;
+            st.length_sum += done ? (uint64_t)len : 0ull;
+            ep_ret = resetting ? 0.0 : ret;
+            ep_len = resetting ? 0 : len;
+            elapsed = resetting ? 0u : el;
+            need_reset = done ? 1u : 0u;
+            s = s_new;
+            if (t == T - 1) last_rec = resetting ? 0xffffffffu : (rec / (uint32_t)CELL) * 4u + kk;
+            if (FULL || io.actions_out) *out_act = (int64_t)a;
+            if (FULL || io.obs) *out_obs = (int64_t)s_new;
+            if (FULL || io.reward) *out_rew = reward;
+            if (FULL || io.terminated) *out_te = te;
+            if (FULL || io.truncated) *out_tr = tr;
+            out_act += N, out_obs += N, out_rew += N, out_te += N, out_tr += N;
+        }
+        st.env_steps = (uint32_t)T - st.reset_steps;
+        if (T > 0) prob = last_rec == 0xffffffffu ? 1.0 : d.tab.prob[(size_t)(last_rec >> 2) * K + (last_rec & 3u)];
+        d.state[i] = (double)s, d.state[N + i] = prob;
+        d.meta[i] = (elapsed & kElapsedMask) | (((flags0 & ~kNeedsReset) | need_reset) << kFlagShift);
+        d.ep_ret[i] = ep_ret, d.ep_len[i] = ep_len;
         store_rng_state(d, i, rng);
     }
     block_accumulate(d, st);
@@ -3244,7 +3414,21 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
         };
         typedef std::integral_constant<int, MI_AUTORESET_NEXT_STEP> NextT;
         typedef std::integral_constant<int, MI_AUTORESET_SAME_STEP> SameT;
-        if (next && sample)
+        // the branch-free kernel for the collector's case: one plain table of <= 3 outcomes per (state, action) that fits into LDS in its packed form
+        static const bool lean_on = !(getenv("MI355ENV_TAB_LEAN") && getenv("MI355ENV_TAB_LEAN")[0] == '0');  // "0": tab_rollout_kernel (A/B, tests)
+        const int kl = v->d.tab.K == 1 ? 1 : 3;
+        const size_t lean_lds = tk == kTabPlain && v->d.tab.nS > 0 ? (tab_lean_lds_bytes(v->d.tab.nS, v->d.tab.nA, kl) + 15) & ~(size_t)15 : 0;
+        if (next && sample && lean_on && tk == kTabPlain && !v->d.tab.env_table && v->d.tab.K <= 3 && lean_lds <= 150 * 1024) {
+            const bool full = p.actions_out && p.obs && p.reward && p.terminated && p.truncated;
+            if (kl == 1 && full)
+                hipLaunchKernelGGL((tab_rollout_lean_kernel<1, true>), g, b, lean_lds, v->stream, v->d, p, as, T);
+            else if (kl == 1)
+                hipLaunchKernelGGL((tab_rollout_lean_kernel<1, false>), g, b, lean_lds, v->stream, v->d, p, as, T);
+            else if (full)
+                hipLaunchKernelGGL((tab_rollout_lean_kernel<3, true>), g, b, lean_lds, v->stream, v->d, p, as, T);
+            else
+                hipLaunchKernelGGL((tab_rollout_lean_kernel<3, false>), g, b, lean_lds, v->stream, v->d, p, as, T);
+        } else if (next && sample)
             launch(NextT(), std::true_type());
         else if (next)
             launch(NextT(), std::false_type());

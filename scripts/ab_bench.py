@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--libs", nargs="+", required=True, help="name=path pairs")
+    ap.add_argument("--libs", nargs="+", required=True, help="name=path pairs (name=path@KEY=VAL,... adds environment variables)")
     ap.add_argument("--envs", nargs="+", required=True, help="env_id:num_envs:inner")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--coop", action="store_true", help="MI355ENV_MJ_COOP=1: the cooperative physics kernel also where the one-lane kernel ships")
@@ -32,7 +32,9 @@ def main():
         for spec in args.envs:
             env_id, n, inner = spec.split(":")
             for name, path in libs:
+                path, _, extra = path.partition("@")  # name=path@KEY=VAL,KEY=VAL: the same library under other environment switches
                 env = dict(os.environ, MI355ENV_LIBRARY=os.path.abspath(os.path.join(ROOT, path)))
+                env.update(kv.split("=", 1) for kv in extra.split(",") if kv)
                 if args.coop:
                     env["MI355ENV_MJ_COOP"] = "1"
                 if args.serial:
