@@ -2017,6 +2017,8 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_kernel(DevEnv d, RolloutPt
 //     wavefront-uniform branch that only the steps with an autoreset in the wavefront take.
 //   * info["prob"] of the last transition is looked up once, after the loop.
 // KL: outcomes per record (1 or 3; a table with two outcomes uses 3).  FULL: all five trajectory arrays are present.
+// ONE_START: every episode starts in `start_state` (FrozenLake, CliffWalking: the initial distribution is one state, mi_tabular_load found it) -- the
+//   draw is taken and not looked at.  APOW2: the number of actions is a power of two -- (random() * nA).astype(int64) is the top bits of the output.
 // ---------------------------------------------------------------------------------------------------------
 template <int KL>
 struct TabLeanCell;
@@ -2032,8 +2034,8 @@ constexpr int kTabGuide = 256;
 static inline size_t tab_lean_lds_bytes(int nS, int nA, int KL) {
     return (size_t)nS * nA * (KL == 1 ? TabLeanCell<1>::BYTES : TabLeanCell<3>::BYTES) + (size_t)nS * sizeof(double) + kTabGuide * sizeof(uint32_t);
 }
-template <int KL, bool FULL>
-__global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T) {
+template <int KL, bool FULL, bool ONE_START, bool APOW2>
+__global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int start_state, int action_shift) {
     extern __shared__ __align__(16) double tab_lds[];
     constexpr int CELL = TabLeanCell<KL>::BYTES;
     const int nS = d.tab.nS, nA = d.tab.nA, K = d.tab.K;
@@ -2058,8 +2060,8 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, Roll
             }
         }
     }
-    for (int k = threadIdx.x; k < nS; k += kBlock) isd[k] = d.tab.isd[k];
-    for (int g = threadIdx.x; g < kTabGuide; g += kBlock) {  // first state with isd_cs > g / 256 (nS when there is none): bisection in the global array
+    for (int k = threadIdx.x; !ONE_START && k < nS; k += kBlock) isd[k] = d.tab.isd[k];
+    for (int g = threadIdx.x; !ONE_START && g < kTabGuide; g += kBlock) {  // first state with isd_cs > g / 256 (nS when there is none): bisection in the global array
         const double lim = (double)g * (1.0 / kTabGuide);
         int lo = 0, hi = nS;
         while (lo < hi) {
@@ -2097,6 +2099,8 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, Roll
             const unsigned rot = (unsigned)(hi >> 58);
             const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
             astate = pcg_muladd(astate, as.jump_n.mult, as.jump_n.plus);
+            // (nA a power of two: random() * nA is exact, its integer part the output's top bits)
+            if constexpr (APOW2) return (int32_t)(out >> action_shift);
             return (int32_t)((double)(out >> 11) * (1.0 / 9007199254740992.0) * dnA);
         };
         int32_t a_next = draw();
@@ -2109,6 +2113,7 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, Roll
             const int32_t a = a_next;
             a_next = draw();  // (one draw past the last step: the stream's position is kept by the host, not by this state)
             const bool resetting = need_reset != 0;
+            // (ONE_START with one outcome per record: nothing reads u -- the generator still advances, its output function is dead code)
             const double u = rng.next_double();
             const uint32_t rec = (uint32_t)(s * nA + a) * (uint32_t)CELL;
             const char *p = cell_base + rec;
@@ -2130,8 +2135,8 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, Roll
                 nt = take0 ? q3.x : (c1 ? q3.y : q3.z);
                 kk = take0 ? 0u : (c1 ? 1u : 2u);
             }
-            int rs = 0;
-            if (resetting) {  // frozen_lake.py:345: categorical_sample(initial_state_distrib); only the steps with an autoreset in the wavefront come here
+            int rs = start_state;
+            if (!ONE_START && resetting) {  // frozen_lake.py:345: categorical_sample(initial_state_distrib); only the steps with an autoreset in the wavefront come here
                 int idx = (int)guide[(int)(u * (double)kTabGuide)];
                 while (idx < nS && !(isd[idx] > u)) idx++;
                 rs = idx < nS ? idx : 0;
@@ -2328,6 +2333,7 @@ struct mi_vecenv {
     bool has_pending;
     void *tab_bufs[8];
     bool tab_loaded;
+    int tab_start_state;  // the one state every episode starts in (its cumulative initial probability is >= 1), -1 when the start is drawn among several
     // MuJoCo family: cooperative physics kernel (default) or the one-lane simulator (MI355ENV_MJ_SERIAL=1, cross-check)
     bool mj_coop;
     int extras_dim;
@@ -3336,6 +3342,12 @@ int mi_tabular_load(mi_vecenv *v, const mi_tabular_table *t) {
     tab.csprob = (const double *)v->tab_bufs[0], tab.prob = (const double *)v->tab_bufs[1], tab.reward = (const double *)v->tab_bufs[2];
     tab.isd = (const double *)v->tab_bufs[3], tab.next = (const int32_t *)v->tab_bufs[4], tab.count = (const int32_t *)v->tab_bufs[5];
     tab.term = (const uint8_t *)v->tab_bufs[6], tab.env_table = (const int32_t *)v->tab_bufs[7];
+    v->tab_start_state = -1;
+    if (M == 1) {  // "first state whose cumulative probability exceeds u" is the same state for every u < 1 when that state's sum is already >= 1
+        int first = 0;
+        while (first < t->num_states && !(t->isd_csprob[first] > 0.0)) first++;
+        if (first < t->num_states && t->isd_csprob[first] >= 1.0) v->tab_start_state = first;
+    }
     v->tab_loaded = true;
     return MI_OK;
 }
@@ -3420,14 +3432,36 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
         const size_t lean_lds = tk == kTabPlain && v->d.tab.nS > 0 ? (tab_lean_lds_bytes(v->d.tab.nS, v->d.tab.nA, kl) + 15) & ~(size_t)15 : 0;
         if (next && sample && lean_on && tk == kTabPlain && !v->d.tab.env_table && v->d.tab.K <= 3 && lean_lds <= 150 * 1024) {
             const bool full = p.actions_out && p.obs && p.reward && p.terminated && p.truncated;
-            if (kl == 1 && full)
-                hipLaunchKernelGGL((tab_rollout_lean_kernel<1, true>), g, b, lean_lds, v->stream, v->d, p, as, T);
-            else if (kl == 1)
-                hipLaunchKernelGGL((tab_rollout_lean_kernel<1, false>), g, b, lean_lds, v->stream, v->d, p, as, T);
-            else if (full)
-                hipLaunchKernelGGL((tab_rollout_lean_kernel<3, true>), g, b, lean_lds, v->stream, v->d, p, as, T);
+            const int nA = v->d.tab.nA, start = v->tab_start_state;
+            const bool apow2 = nA >= 2 && (nA & (nA - 1)) == 0;
+            int shift = 64;
+            for (int x = nA; apow2 && x > 1; x >>= 1) shift--;
+            auto lean = [&](auto kl_c, auto full_c, auto one_c, auto pow_c) {
+                hipLaunchKernelGGL((tab_rollout_lean_kernel<decltype(kl_c)::value, decltype(full_c)::value, decltype(one_c)::value, decltype(pow_c)::value>), g, b,
+                                   lean_lds, v->stream, v->d, p, as, T, start, shift);
+            };
+            auto pick_pow = [&](auto kl_c, auto full_c, auto one_c) {
+                if (apow2)
+                    lean(kl_c, full_c, one_c, std::true_type());
+                else
+                    lean(kl_c, full_c, one_c, std::false_type());
+            };
+            auto pick_one = [&](auto kl_c, auto full_c) {
+                if (start >= 0)
+                    pick_pow(kl_c, full_c, std::true_type());
+                else
+                    pick_pow(kl_c, full_c, std::false_type());
+            };
+            auto pick_full = [&](auto kl_c) {
+                if (full)
+                    pick_one(kl_c, std::true_type());
+                else
+                    pick_one(kl_c, std::false_type());
+            };
+            if (kl == 1)
+                pick_full(std::integral_constant<int, 1>());
             else
-                hipLaunchKernelGGL((tab_rollout_lean_kernel<3, false>), g, b, lean_lds, v->stream, v->d, p, as, T);
+                pick_full(std::integral_constant<int, 3>());
         } else if (next && sample)
             launch(NextT(), std::true_type());
         else if (next)
