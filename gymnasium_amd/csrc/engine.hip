@@ -2176,6 +2176,171 @@ __global__ __launch_bounds__(kBlock) void tab_rollout_lean_kernel(DevEnv d, Roll
     block_accumulate(d, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Blackjack-v1's rollout (NEXT_STEP, on-device policy) without data-dependent control flow -- the values of tab_rollout_kernel<NEXT_STEP, true, false,
+// kTabBlackjack>, which spends 784 instructions per env-step in three divergent branches (hit / stick with the dealer's loop / autoreset with its
+// five or six draws), each with its own copies of the generator step and of Lemire's rejection loop.
+//   * A step consumes a VARIABLE number of 32-bit values (np_random.choice = Lemire's bounded draw on PCG64's buffered halves): every lane produces the
+//     next three 64-bit outputs unconditionally -- with the buffered half that is six or seven values, enough for an autoreset (5 - 6), a hit (1) and
+//     a dealer who draws up to six cards -- evaluates all six as cards, and only COUNTS how many its case consumed: the generator's new state is
+//     one of the four states it already has, the new buffered half one of the three high halves.
+//   * hit, stick (the dealer's loop unrolled six times under a running `need` flag) and autoreset are evaluated side by side and selected.
+//   * What does not fit -- a rejected draw (9 / 2^32 per card), a dealer who needs a seventh card -- is flagged per lane, and the flagged lanes redo
+//     the step from the saved generator state through bj_step / bj_reset, behind one wavefront-uniform branch (`force_slow`: tests send every k-th
+//     lane-step there).
+// ---------------------------------------------------------------------------------------------------------
+MI_DEV int bj_hand(int raw, int ace) { return (ace != 0 && raw + 10 <= 21) ? raw + 10 : raw; }
+template <bool FULL>
+__global__ __launch_bounds__(kBlock) void bj_rollout_lean_kernel(DevEnv d, RolloutPtrs io, ActionStream as, int T, int force_slow) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    LaneStats st = {0u, 0u, 0u, 0ull, 0.0};
+    if (i < d.N) {
+        const size_t N = (size_t)d.N;
+        const int64_t packed0 = (int64_t)d.state[i];
+        int psum = (int)(packed0 & 63), pace = (int)((packed0 >> 6) & 1), ptwo = (int)((packed0 >> 7) & 1);
+        int d0 = (int)((packed0 >> 8) & 15), d1 = (int)((packed0 >> 12) & 15);
+        const uint64_t aux0 = (uint64_t)d.state[N + i];
+        int hh = (aux0 >> 32) ? 1 : 0;  // a buffered 32-bit half is waiting
+        uint32_t half = (uint32_t)aux0;
+        const uint32_t m0 = d.meta[i];
+        uint32_t elapsed = m0 & kElapsedMask;
+        const uint32_t flags0 = m0 >> kFlagShift;
+        uint32_t need_reset = flags0 & kNeedsReset;
+        double ep_ret = d.ep_ret[i];
+        int32_t ep_len = d.ep_len[i];
+        Pcg64 rng = load_rng(d, i);
+        const bool natural = d.P.p[0] != 0.0, sab = d.P.p[1] != 0.0;
+        u128 astate = make_u128(as.state_hi, as.state_lo);
+        {
+            uint32_t delta = (uint32_t)i + 1u;
+            for (int j = 0; delta; j++, delta >>= 1)
+                if (delta & 1u) astate = as.pow2[j].mult * astate + as.pow2[j].plus;
+        }
+        auto draw = [&]() {  // Discrete(2): (random() * 2).astype(int64) is the output's top bit
+            const int32_t a = (int32_t)(pcg_output(astate) >> 63);
+            astate = pcg_muladd(astate, as.jump_n.mult, as.jump_n.plus);
+            return a;
+        };
+        int32_t a_next = draw();
+        int64_t *out_act = static_cast<int64_t *>(io.actions_out) + i, *out_obs = static_cast<int64_t *>(io.obs) + (size_t)3 * i;
+        double *out_rew = io.reward + i;
+        uint8_t *out_te = io.terminated + i, *out_tr = io.truncated + i;
+        for (int t = 0; t < T; t++) {
+            const int32_t a = a_next;
+            a_next = draw();
+            const bool resetting = need_reset != 0;
+            // the next three outputs and the six values a step can consume
+            const u128 s0 = rng.state;
+            const u128 s1 = pcg_muladd(s0, pcg_mult(), rng.inc), s2 = pcg_muladd(s1, pcg_mult(), rng.inc), s3 = pcg_muladd(s2, pcg_mult(), rng.inc);
+            const uint64_t o1 = pcg_output(s1), o2 = pcg_output(s2), o3 = pcg_output(s3);
+            const uint32_t l1 = (uint32_t)o1, h1 = (uint32_t)(o1 >> 32), l2 = (uint32_t)o2, h2 = (uint32_t)(o2 >> 32), l3 = (uint32_t)o3, h3 = (uint32_t)(o3 >> 32);
+            uint32_t x[6];
+            x[0] = hh ? half : l1, x[1] = hh ? l1 : h1, x[2] = hh ? h1 : l2, x[3] = hh ? l2 : h2, x[4] = hh ? h2 : l3, x[5] = hh ? l3 : h3;
+            int c[6];
+            bool rej[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {  // bj_card: deck[Lemire(13)], rejected when the product's low word is below 2^32 mod 13 = 9
+                const uint32_t k = __umulhi(x[j], 13u);
+                c[j] = k < 9u ? (int)k + 1 : 10;
+                rej[j] = x[j] * 13u < 9u;
+            }
+            // autoreset (blackjack.py:181-202): dealer's hand, player's hand, the suit draw (n = 4: never rejected), the face draw when the dealer shows a ten (n = 3: rejects 0)
+            const int r_cnt = 5 + (c[0] == 10 ? 1 : 0);
+            const bool r_over = rej[0] | rej[1] | rej[2] | rej[3] | (c[0] == 10 && x[5] == 0u);
+            const int r_psum = c[2] + c[3], r_pace = (c[2] == 1 || c[3] == 1) ? 1 : 0;
+            // hit (:144-151)
+            const int h_psum = psum + c[0], h_pace = pace | (c[0] == 1 ? 1 : 0);
+            const bool h_te = bj_hand(h_psum, h_pace) > 21;
+            // stick (:152-169): the dealer draws to 17
+            int dsum = d0 + d1, dace = (d0 == 1 || d1 == 1) ? 1 : 0, dtwo = 1, s_cnt = 0;
+            bool s_over = false, alive = true;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const bool need = alive && bj_hand(dsum, dace) < 17;
+                s_cnt += need ? 1 : 0;
+                dsum += need ? c[j] : 0;
+                dace |= (need && c[j] == 1) ? 1 : 0;
+                dtwo = need ? 0 : dtwo;
+                s_over |= need && rej[j];
+                alive = need;
+            }
+            s_over |= alive && bj_hand(dsum, dace) < 17;  // a seventh card
+            const int ph = bj_hand(psum, pace), dh = bj_hand(dsum, dace);
+            const int ps = ph > 21 ? 0 : ph, ds = dh > 21 ? 0 : dh;
+            double s_rew = (double)(ps > ds) - (double)(ps < ds);
+            const bool pnat = ptwo && pace && psum == 11, dnat = dtwo && dace && dsum == 11;  // sorted(hand) == [1, 10]
+            s_rew = (sab && pnat && !dnat) ? 1.0 : ((!sab && natural && pnat && s_rew == 1.0) ? 1.5 : s_rew);
+            // the lane's case
+            const bool hit = a != 0;
+            int cnt = resetting ? r_cnt : (hit ? 1 : s_cnt);
+            bool over = resetting ? r_over : (hit ? rej[0] : s_over);
+            if (force_slow) over |= (uint32_t)(i + t) % (uint32_t)force_slow == 0u;
+            const int o_psum = psum, o_pace = pace, o_ptwo = ptwo, o_d0 = d0, o_d1 = d1;
+            double rew = resetting ? 0.0 : (hit ? (h_te ? -1.0 : 0.0) : s_rew);
+            bool te0 = !resetting && (hit ? h_te : true);
+            psum = resetting ? r_psum : (hit ? h_psum : psum);
+            pace = resetting ? r_pace : (hit ? h_pace : pace);
+            ptwo = resetting ? 1 : (hit ? 0 : ptwo);
+            d0 = resetting ? c[0] : d0, d1 = resetting ? c[1] : d1;
+            // what the case consumed: `cnt` values = the buffered half first, then halves of new outputs
+            const int m = cnt - hh, calls = (m + 1) >> 1;
+            const int o_hh = hh;
+            const uint32_t o_half = half;
+            half = calls == 0 ? half : (calls == 1 ? h1 : (calls == 2 ? h2 : h3));
+            hh = m & 1;
+            rng.state = calls == 0 ? s0 : (calls == 1 ? s1 : (calls == 2 ? s2 : s3));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(over) != 0ull, 0)) {
+                if (over) {  // the general routines from the state before the step
+                    Pcg64 r = {s0, rng.inc};
+                    double aux = o_hh ? (double)((1ull << 32) | (uint64_t)o_half) : 0.0;
+                    double sd = (double)(o_psum | (o_pace << 6) | (o_ptwo << 7) | (o_d0 << 8) | (o_d1 << 12));
+                    if (resetting) {
+                        bj_reset(r, sd, aux);
+                        rew = 0.0, te0 = false;
+                    } else {
+                        bj_step(r, sd, aux, (int64_t)a, natural, sab, rew, te0);
+                    }
+                    const int64_t q = (int64_t)sd;
+                    psum = (int)(q & 63), pace = (int)((q >> 6) & 1), ptwo = (int)((q >> 7) & 1), d0 = (int)((q >> 8) & 15), d1 = (int)((q >> 12) & 15);
+                    const uint64_t ax = (uint64_t)aux;
+                    hh = (ax >> 32) ? 1 : 0, half = (uint32_t)ax;
+                    rng.state = r.state;
+                }
+            }
+            const bool te = te0;
+            const uint32_t el = elapsed + 1u;
+            const bool tr = !resetting && d.max_steps > 0 && (int)el >= d.max_steps;
+            const bool done = te || tr;
+            const double ret = ep_ret + rew;
+            const int32_t len = ep_len + 1;
+            st.reset_steps += resetting ? 1u : 0u;
+            st.episodes += done ? 1u : 0u;
+            st.return_sum += done ? ret : 0.0;
+            st.length_sum += done ? (uint64_t)len : 0ull;
+            ep_ret = resetting ? 0.0 : ret;
+            ep_len = resetting ? 0 : len;
+            elapsed = resetting ? 0u : el;
+            need_reset = done ? 1u : 0u;
+            if (FULL || io.actions_out) *out_act = (int64_t)a;
+            if (FULL || io.obs) {  // _get_obs: (player sum with a usable ace as 11, dealer's first card, usable ace)
+                const int usable = (pace != 0 && psum + 10 <= 21) ? 1 : 0;
+                out_obs[0] = (int64_t)(usable ? psum + 10 : psum), out_obs[1] = (int64_t)d0, out_obs[2] = (int64_t)usable;
+            }
+            if (FULL || io.reward) *out_rew = rew;
+            if (FULL || io.terminated) *out_te = te;
+            if (FULL || io.truncated) *out_tr = tr;
+            out_act += N, out_obs += 3 * N, out_rew += N, out_te += N, out_tr += N;
+        }
+        st.env_steps = (uint32_t)T - st.reset_steps;
+        d.state[i] = (double)(psum | (pace << 6) | (ptwo << 7) | (d0 << 8) | (d1 << 12));
+        d.state[N + i] = hh ? (double)((1ull << 32) | (uint64_t)half) : 0.0;
+        d.meta[i] = (elapsed & kElapsedMask) | (((flags0 & ~kNeedsReset) | need_reset) << kFlagShift);
+        d.ep_ret[i] = ep_ret, d.ep_len[i] = ep_len;
+        store_rng_state(d, i, rng);
+    }
+    block_accumulate(d, st);
+}
+
 __global__ void seed_words_kernel(DevEnv d, const uint64_t *words, const uint8_t *mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N || (mask && !mask[i])) return;
@@ -3462,6 +3627,13 @@ int mi_rollout(mi_vecenv *v, int T, const mi_rollout_io *io) {
                 pick_full(std::integral_constant<int, 1>());
             else
                 pick_full(std::integral_constant<int, 3>());
+        } else if (next && sample && lean_on && tk == kTabBlackjack) {
+            const char *fs = getenv("MI355ENV_BJ_FORCE_SLOW");  // tests: every k-th lane-step through the general routines
+            const int force_slow = fs ? atoi(fs) : 0;
+            if (p.actions_out && p.obs && p.reward && p.terminated && p.truncated)
+                hipLaunchKernelGGL((bj_rollout_lean_kernel<true>), g, b, 0, v->stream, v->d, p, as, T, force_slow);
+            else
+                hipLaunchKernelGGL((bj_rollout_lean_kernel<false>), g, b, 0, v->stream, v->d, p, as, T, force_slow);
         } else if (next && sample)
             launch(NextT(), std::true_type());
         else if (next)
