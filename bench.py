@@ -291,6 +291,19 @@ def _rocprof_counters(args, counters, kernel_like, timeout_s):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def tabular_kernel(env_id, env_kwargs=None):
+    """Which rollout kernel mi_rollout launches for a ToyText id with the on-device policy in NEXT_STEP mode (engine.hip): the branch-free kernels for
+    Blackjack and for one plain table of <= 3 outcomes per (state, action) that fits into LDS in its packed form; MI355ENV_TAB_LEAN=0 is the A/B switch."""
+    kw = env_kwargs or {}
+    if os.environ.get("MI355ENV_TAB_LEAN", "1")[:1] == "0":
+        return "tab_rollout_kernel"
+    if env_id.startswith("Blackjack"):
+        return "bj_rollout_lean_kernel"
+    if kw.get("fickle_passenger") or kw.get("is_rainy") or ("map_name" in kw and kw["map_name"] is None) or isinstance(kw.get("desc"), (list, tuple)) and kw["desc"] and not isinstance(kw["desc"][0], str):
+        return "tab_rollout_kernel"  # Taxi's fickle rule, 3 x 3 000 outcomes (192 KB packed), one table per sub-environment
+    return "tab_rollout_lean_kernel"
+
+
 def child_args(env_id, N, inner, env_kwargs=None, warm=1):
     return ["--env", env_id, "--num-envs", str(N), "--inner", str(inner), "--steps", "3", "--warmup", str(warm), "--env-kwargs", json.dumps(env_kwargs or {})]
 
@@ -485,7 +498,7 @@ class Config:
                 return "rollout_duo_kernel"
             return "rollout_kernel"
         if self.eng.obs_dtype is np.int64:
-            return "tab_rollout_kernel"
+            return tabular_kernel(self.env_id, self.env_kwargs)
         return "mj_physics_kernel" if self.env_id in MJ_COOP else "mj_rollout_kernel"
 
     def traffic_request(self, key, warm=1):

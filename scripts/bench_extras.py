@@ -71,7 +71,7 @@ def dominant_kernel_of(env_id, inner):
         return "rollout_duo_kernel" if (chunk and inner % chunk == 0 and os.environ.get("MI355ENV_ROLLOUT_DUO", "1")[:1] != "0") else "rollout_kernel"
     if env_id in MJ_COOP:
         return "mj_physics_kernel"
-    return "tab_rollout_kernel" if env_id.split("-")[0] in ("FrozenLake", "FrozenLake8x8", "Taxi", "Blackjack", "CliffWalking") else "mj_rollout_kernel"
+    return bench.tabular_kernel(env_id) if env_id.split("-")[0] in ("FrozenLake", "FrozenLake8x8", "Taxi", "Blackjack", "CliffWalking") else "mj_rollout_kernel"
 
 
 # ---- counters -------------------------------------------------------------------------------------------------------------------------
