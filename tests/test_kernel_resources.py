@@ -66,7 +66,7 @@ def test_inline_asm_fma_only_in_kernels_without_agpr_traffic(kernels):
 
 def test_classic_and_toytext_kernels_do_not_use_scratch(kernels):
     for name, ins in kernels.items():
-        if ("mi::" in name and "T<mi::" in name) or "tab_" in name:
+        if ("mi::" in name and "T<mi::" in name) or "tab_" in name or "bj_rollout" in name:
             n = sum(op.startswith("scratch_") for op in ins)
             assert n == 0, f"{name[:140]}: {n} scratch instructions"
 
@@ -98,3 +98,17 @@ def test_two_role_rollout_kernels_fit_two_wavefronts_per_simd():
         assert r["vgpr_count"] + r.get("agpr_count", 0) <= 256, f"{r['name']}: {r['vgpr_count']} registers: two wavefronts no longer fit a SIMD"
         assert r.get("vgpr_spill_count", 0) == 0 and r.get("private_segment_fixed_size", 0) == 0, r["name"]
         assert r["group_segment_fixed_size"] <= 160 * 1024, r["name"]
+
+
+def test_branch_free_tabular_rollouts_are_instantiated_and_stay_in_registers(kernels):
+    """tab_rollout_lean_kernel<KL, FULL, ONE_START, APOW2> (16 instantiations) and bj_rollout_lean_kernel<FULL> (2): what mi_rollout launches for the collector's
+    ToyText configurations (engine.hip).  None may spill, and all stay within 128 VGPRs (four wavefronts per SIMD at the batch sizes beyond the benchmark's)."""
+    from kernel_resources import resources
+
+    lean = [n for n in kernels if "tab_rollout_lean_kernel<" in n]
+    bj = [n for n in kernels if "bj_rollout_lean_kernel<" in n]
+    assert len(lean) == 16 and len(bj) == 2, (len(lean), len(bj))
+    for r in resources(LIB):
+        if "rollout_lean_kernel" in r["name"]:
+            assert r.get("vgpr_spill_count", 0) == 0 and r.get("private_segment_fixed_size", 0) == 0, r["name"]
+            assert r["vgpr_count"] <= 128, f"{r['name']}: {r['vgpr_count']} VGPRs"
