@@ -1054,13 +1054,15 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                             float o[E::OBS];
                             double rew;
                             uint32_t bits;
+                            uint32_t pre_pending = 0u;  // E::AUX_PRE_SQUARES: which of pre[]'s leading entries are still arguments, not squares (bit j)
                             if constexpr (AUXREW) {  // (of a sub-environment in its autoreset step too: the aux role discards that reward)
                                 double pre[E::AUX_PRE];
-                                E::aux_pre(L.s, pre);
+                                pre_pending = E::aux_pre(L.s, pre);
 #pragma unroll
                                 for (int j = 0; j < E::AUX_PRE; j++) sh_pre[buf][k][slot][j] = pre[j];
                             }
                             duo_env_step<E>(d, L, a_k, q, o, rew, bits);
+                            if constexpr (AUXREW && E::AUX_PRE_SQUARES > 0) bits |= pre_pending << 3;
 #pragma unroll
                             for (int j = 0; j < E::OBS; j++) sh_obs[buf][k][slot][j] = o[j];
                             if constexpr (PASS_REWARD) sh_rew[buf][k][slot] = rew;
@@ -1072,6 +1074,24 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                 const int c = p - 2;
                 if (is_book && c >= 0) {  // what became of chunk c: episode statistics (RecordEpisodeStatistics order: the raw reward), totals, the trajectory rows
                     const int buf = c & 1;
+                    if constexpr (AUXREW && E::AUX_PRE_SQUARES > 0) {
+                        // The squares the env role could not take as plain products (flag bits 3 ..; 1 argument in 32): the exact pow routine, one pass per
+                        // pending argument of this lane's chunk, all lanes of the wavefront side by side -- the wavefront runs as many passes as its
+                        // unluckiest lane has pending arguments (2.7 on average for 2 x 8), not one per argument.  In place: a lane reads and writes
+                        // only its own ring entries.
+                        static_assert(E::AUX_PRE_SQUARES * C <= 32 && E::AUX_PRE_SQUARES <= 4 && sizeof(MI_DUO_FLAG_T) == 1, "pending bits: one word per chunk, bits 3 .. 6 of the flag byte");
+                        uint32_t pend = 0u;
+#pragma unroll
+                        for (int k = 0; k < C; k++)
+                            pend |= (((uint32_t)sh_bits[buf][k][slot] >> 3) & ((1u << E::AUX_PRE_SQUARES) - 1u)) << (E::AUX_PRE_SQUARES * k);
+#pragma nounroll
+                        while (pend) {
+                            const int idx = __builtin_ctz(pend);
+                            double *x = &sh_pre[buf][idx / E::AUX_PRE_SQUARES][slot][idx % E::AUX_PRE_SQUARES];
+                            *x = E::aux_square(*x);
+                            pend &= pend - 1u;
+                        }
+                    }
 #pragma unroll
                     for (int k = 0; k < C; k++) {
                         const size_t t = (size_t)c * C + k;

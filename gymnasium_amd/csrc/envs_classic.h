@@ -42,6 +42,28 @@ static __shared__ uint64_t g_powf_exp2[32];
 struct TwoPi {
     static constexpr double value = 2 * kPi;
 };
+// Several IEEE quotients by ONE divisor.  The compiler's float64 division is v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 FMAs),
+// q0 = a r, e = fma(-b, q0, a), v_div_fmas (= fma(e, r, q0) when nothing was scaled) and v_div_fixup: 11 instructions, one of them a 17-tick
+// transcendental.  v_div_scale leaves both operands alone unless an exponent is extreme (divisor or quotient near the ends of the range, or a
+// numerator below 2^-969), so for operands of ordinary magnitude the refined reciprocal depends on the divisor only and can be shared: the same
+// operations on the same values, hence the same quotient bit for bit, in 5 + 4 per quotient.  The caller guarantees the ranges (ordinary()).
+struct SharedDivisor {
+    double b, r;
+    MI_DEV explicit SharedDivisor(double divisor) : b(divisor) {
+        const double r0 = __builtin_amdgcn_rcp(divisor);
+        const double e0 = __builtin_fma(-divisor, r0, 1.0);
+        const double r1 = __builtin_fma(r0, e0, r0);
+        const double e1 = __builtin_fma(-divisor, r1, 1.0);
+        r = __builtin_fma(r1, e1, r1);
+    }
+    MI_DEV double under(double a) const {  // a / b
+        const double q0 = a * r;
+        const double e = __builtin_fma(-b, q0, a);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q0), b, a);
+    }
+    // 2^-511 <= |a| < 2^513: far inside what v_div_scale passes through for a divisor of ordinary size (a zero goes the long way round as well)
+    static MI_DEV bool ordinary(double a) { return (((uint32_t)(mi_sincos::bits(a) >> 32) & 0x7fffffffu) - 0x20000000u) < 0x40000000u; }
+};
 // KASM: constant Horner steps as inline-asm v_fma_f64 (sincos_exact.h fma_k); false for kernels whose registers overflow into AGPRs
 template <bool KASM>
 struct ExactMathT {
@@ -74,6 +96,11 @@ struct ExactMathT {
     static MI_DEV double fmod_2pi(double x) { return mi_sincos::fmod_const(x, TwoPi()); }  // fmod(x, 2 pi): exact, like the library's, in half the instructions
     static MI_DEV double sq(double x) { return mi_pow::square<KASM>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
     static MI_DEV float sqf(float x) { return mi_pow::squaref<KASM>(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2
+    // three / two np.float64 ** 2 at once: the table routine runs once per group for the lanes whose square is not provably the plain product (pow_exact.h)
+    static MI_DEV void sq3(double a, double b, double c, double &ra, double &rb, double &rc) { mi_pow::square3<KASM>(g_pow_log, g_pow_exp, a, b, c, ra, rb, rc); }
+    static MI_DEV void sq2(double a, double b, double &ra, double &rb) { mi_pow::square2<KASM>(g_pow_log, g_pow_exp, a, b, ra, rb); }
+    // the test alone, for a caller that collects the arguments which need the table routine (the two-role Pendulum rollout, engine.hip): true = `hi` IS x ** 2
+    static MI_DEV bool sq_is_plain(double x, double &hi) { return mi_pow::square_is_plain(x, hi); }
 };
 typedef ExactMathT<true> ExactMath;
 typedef ExactMathT<false> ExactMathBuiltinFma;  // Acrobot: its kernels use AGPRs (see sincos_exact.h fma_k)
@@ -113,6 +140,9 @@ struct FastMath {
     static MI_DEV double fmod_2pi(double x) { return ::fmod(x, 2 * kPi); }
     static MI_DEV double sq(double x) { return x * x; }
     static MI_DEV float sqf(float x) { return x * x; }
+    static MI_DEV void sq3(double a, double b, double c, double &ra, double &rb, double &rc) { ra = a * a, rb = b * b, rc = c * c; }
+    static MI_DEV void sq2(double a, double b, double &ra, double &rb) { ra = a * a, rb = b * b; }
+    static MI_DEV bool sq_is_plain(double x, double &hi) { return hi = x * x, true; }
 };
 template <class E>
 MI_DEV void tables_init() {
@@ -219,7 +249,9 @@ struct CartPoleT {
     template <class A>
     static MI_DEV double reward_of_action(bool, A) { return 0.0; }
     static constexpr int AUX_PRE = 1;
-    static MI_DEV void aux_pre(const double *, double *) {}
+    static constexpr int AUX_PRE_SQUARES = 0;
+    static MI_DEV uint32_t aux_pre(const double *, double *) { return 0u; }
+    static MI_DEV double aux_square(double x) { return x; }
     static MI_DEV double aux_reward(const double *, int64_t) { return 0.0; }
     static constexpr int AUX_F64 = 2, AUX_F32 = 2;
     static MI_DEV void aux_pack(const double s[S], double w64[AUX_F64], float w32[AUX_F32]) {
@@ -358,7 +390,18 @@ struct PendulumT {
         }
         return md - kPi;
     }
-    static MI_DEV void aux_pre(const double s[S], double pre[AUX_PRE]) { pre[0] = angle_normalize(s[0]), pre[1] = 0.1 * M::sq(s[1]); }
+    // (round 6, third cut: the two float64 squares.  31 of 32 arguments' `** 2` is provably the plain product -- pow_exact.h square_is_plain -- so the env
+    //  role hands over the squares it could take that way and the raw arguments otherwise, with one bit each saying which; the aux role runs the table
+    //  routine once per PENDING argument of a chunk's 16, all lanes side by side: 2.7 passes per chunk on average instead of 16.)
+    static constexpr int AUX_PRE_SQUARES = 2;  // pre[0 .. 1] become squares on the aux role
+    static MI_DEV uint32_t aux_pre(const double s[S], double pre[AUX_PRE]) {
+        const double an = angle_normalize(s[0]);
+        double h0, h1;
+        const bool p0 = M::sq_is_plain(an, h0), p1 = M::sq_is_plain(s[1], h1);
+        pre[0] = p0 ? h0 : an, pre[1] = p1 ? h1 : s[1];
+        return (p0 ? 0u : 1u) | (p1 ? 0u : 2u);
+    }
+    static MI_DEV double aux_square(double x) { return M::sq(x); }
 
     static MI_DEV void default_bounds(double &b0, double &b1) { b0 = kPi, b1 = 1.0; }  // DEFAULT_X, DEFAULT_Y
 
@@ -398,19 +441,20 @@ struct PendulumT {
             cu = (double)(0.001f * M::sqf(u));  // float32: 0.001 * (u ** 2); NumPy scalar ** is libm powf / pow (pendulum.py:131)
         else
             cu = 0.001 * M::sq(u);  // all float64
-        const double costs = M::sq(an) + 0.1 * M::sq(thdot) + cu;
+        double sq_an, sq_thdot;
+        M::sq2(an, thdot, sq_an, sq_thdot);
+        const double costs = sq_an + 0.1 * sq_thdot + cu;
         return -costs;
     }
-    // ... and the reward from it on the aux role: reward_of with the normalised angle and 0.1 * thdot ** 2 already evaluated (the sums in the reference's order)
+    // ... and the reward from it on the aux role: reward_of with angle_normalize(th) ** 2 and thdot ** 2 already evaluated (the sums in the reference's order)
     static MI_DEV double aux_reward(const double pre[AUX_PRE], Act action) {
         const Act u = clip_torque(action);
-        const double an = pre[0];
         double cu;
         if constexpr (ACT_KIND == MI_F32)
             cu = (double)(0.001f * M::sqf(u));
         else
             cu = 0.001 * M::sq(u);
-        const double costs = M::sq(an) + pre[1] + cu;
+        const double costs = pre[0] + 0.1 * pre[1] + cu;
         return -costs;
     }
     // pendulum.py:133-141 the dynamics alone
@@ -495,11 +539,23 @@ struct AcrobotT {
         const double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
         const double d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
         const double phi2 = m2 * lc2 * g * M::cos_bounded(theta1 + theta2 - kPi / 2.0);
-        const double phi1 = -m2 * l1 * lc2 * M::sq(dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+        double sq_dtheta2, sq_dtheta1, sq_d2;  // dtheta2 ** 2, dtheta1 ** 2, d2 ** 2 (acrobot.py:263-275): one pass of the pow routine for the three
+        M::sq3(dtheta2, dtheta1, d2, sq_dtheta2, sq_dtheta1, sq_d2);
+        const double phi1 = -m2 * l1 * lc2 * sq_dtheta2 * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
                             (m1 * lc1 + m2 * l1) * g * M::cos_bounded(theta1 - kPi / 2) + phi2;
-        const double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * M::sq(dtheta1) * s2 - phi2) /
-                                (m2 * (lc2 * lc2) + I2 - M::sq(d2) / d1);
-        const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+        double ddtheta2, ddtheta1;
+        if constexpr (M::EXACT) {
+            // three of the four divisions are by d1, which lies in [2.5, 4.5] (|c2| <= 1); d2 in [0.75, 1.75] and its square are ordinary by
+            // construction, the third numerator is tested
+            const SharedDivisor by_d1(d1);
+            ddtheta2 = (a + by_d1.under(d2) * phi1 - m2 * l1 * lc2 * sq_dtheta1 * s2 - phi2) / (m2 * (lc2 * lc2) + I2 - by_d1.under(sq_d2));
+            const double n1 = -(d2 * ddtheta2 + phi1);
+            ddtheta1 = by_d1.under(n1);
+            if (__builtin_expect(!SharedDivisor::ordinary(n1), 0)) ddtheta1 = n1 / d1;
+        } else {
+            ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * sq_dtheta1 * s2 - phi2) / (m2 * (lc2 * lc2) + I2 - sq_d2 / d1);
+            ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+        }
         d[0] = dtheta1, d[1] = dtheta2, d[2] = ddtheta1, d[3] = ddtheta2;
     }
     static MI_DEV double wrap(double x, double lo, double hi) {
@@ -575,7 +631,9 @@ struct MountainCarT {
     template <class A>
     static MI_DEV double reward_of_action(bool, A) { return 0.0; }
     static constexpr int AUX_PRE = 1;
-    static MI_DEV void aux_pre(const double *, double *) {}
+    static constexpr int AUX_PRE_SQUARES = 0;
+    static MI_DEV uint32_t aux_pre(const double *, double *) { return 0u; }
+    static MI_DEV double aux_square(double x) { return x; }
     static MI_DEV double aux_reward(const double *, int64_t) { return 0.0; }
     static constexpr int AUX_F64 = 2, AUX_F32 = 0;
     static MI_DEV void aux_pack(const double s[S], double w64[AUX_F64], float *) { w64[0] = s[0], w64[1] = s[1]; }
@@ -657,7 +715,9 @@ struct MountainCarContinuousT {
         }
     }
     static constexpr int AUX_PRE = 1;
-    static MI_DEV void aux_pre(const double *, double *) {}
+    static constexpr int AUX_PRE_SQUARES = 0;
+    static MI_DEV uint32_t aux_pre(const double *, double *) { return 0u; }
+    static MI_DEV double aux_square(double x) { return x; }
     typedef typename AK::T Act;
     static MI_DEV double aux_reward(const double *, Act) { return 0.0; }
 

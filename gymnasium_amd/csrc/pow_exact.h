@@ -135,6 +135,52 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     return (special || huge) ? x * x : res;
 }
 
+// ---- three squares for the price of (little more than) one ------------------------------------------------------------------------------
+// x * x is exact as hi + lo (lo = fma(x, x, -hi)), and glibc's pow is within 0.509 ulp + 4e-5 ulp * |y log x| of the true value (the error
+// budget in e_pow.c's header: 0.5 from the final rounding, 0.009 from exp_inline's polynomial and table tail, the rest is log_inline's
+// relative error 1.3 * 2^-68 scaled by |y log x|).  So whenever the true square is at least 1/64 ulp away from the rounding boundary --
+// |lo| <= 31/64 ulp(hi) -- and |2 log x| < 128, pow(x, 2.0) can only be hi, the correctly rounded product; measured on this libm: every
+// one of the 0.084 % of arguments with pow(x, 2.0) != x * x has |lo| > (1/2 - 0.0087) ulp (tests/test_pow_exact.py samples that band).
+// 31/32 of the arguments pass.  square3() evaluates the test for three arguments and the table routine above ONCE, on the first argument
+// of each lane that did not pass (lanes without one recompute their last argument and keep hi), and again only while some lane of the
+// wavefront still has one pending (a lane needs a second pass with probability 0.3 %, a wavefront in one group of six).
+MI_PW_DEV bool square_is_plain(double x, double &hi) {
+    hi = x * x;
+    const double lo = fma_(x, x, -hi);
+    // the exponent field of hi, taken one binade lower when the top 20 mantissa bits are zero: an exact power of two has the smaller ulp on its
+    // lower side.  hi >= 0 or nan; zero, subnormal, inf and nan fail the range test (the table routine selects x * x for them)
+    const uint32_t e = ((uint32_t)(bits(hi) >> 32) - 1u) & 0x7ff00000u;
+    const double thr = from_bits((uint64_t)(e - 0x03510000u) << 32);  // 2^(E - 54) * 31/16 = 31/64 ulp(hi)
+    const bool in_range = e - (843u << 20) < (361u << 20);           // 2^-180 <= hi < 2^181: |2 log x| < 128
+    return in_range & (__builtin_fabs(lo) <= thr);
+}
+// (the loop condition is the lane's own: the compiler turns it into "while any lane is pending" with the others masked off.  A wavefront-uniform
+//  condition through a ballot -- a convergent operation -- stops LLVM from unrolling the rollout loop that contains the call.)
+#define MI_PW_ANY(p) (p)
+template <bool KASM = true>
+MI_PW_DEV void square3(const double *log_tab, const uint64_t *exp_tab, double a, double b, double c, double &ra, double &rb, double &rc) {
+    bool fa = !square_is_plain(a, ra), fb = !square_is_plain(b, rb), fc = !square_is_plain(c, rc);
+#pragma nounroll  // (the trip count is provably <= 3: left alone, the compiler lays out three copies of the table routine)
+    do {
+        const double r = square<KASM>(log_tab, exp_tab, fa ? a : (fb ? b : c));
+        const bool wb = !fa && fb, wc = !fa && !fb && fc;
+        ra = fa ? r : ra, rb = wb ? r : rb, rc = wc ? r : rc;
+        fb = fb && !wb, fc = fc && !wc, fa = false;
+    } while (MI_PW_ANY(fa || fb || fc));
+}
+// two squares, same scheme
+template <bool KASM = true>
+MI_PW_DEV void square2(const double *log_tab, const uint64_t *exp_tab, double a, double b, double &ra, double &rb) {
+    bool fa = !square_is_plain(a, ra), fb = !square_is_plain(b, rb);
+#pragma nounroll
+    do {
+        const double r = square<KASM>(log_tab, exp_tab, fa ? a : b);
+        const bool wb = !fa && fb;
+        ra = fa ? r : ra, rb = wb ? r : rb;
+        fb = fb && !wb, fa = false;
+    } while (MI_PW_ANY(fa || fb));
+}
+
 // powf(x, 2.0f).  log2_tab: kLog2fTab (or a copy), exp2_tab: kExp2fTab (or a copy)
 template <bool KASM = true>
 MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float x) {
