@@ -33,7 +33,7 @@ enum : uint32_t { kNeedsReset = 1u, kStateF32 = 2u };
 // The tables of sincos_exact.h / pow_exact.h live in LDS for the lifetime of a kernel (5.2 KB + 5 KB + 0.5 KB; a kernel allocates only the
 // ones its environment reads): every kernel that steps / resets / observes a classic env calls tables_init<E>() first.  A per-lane table
 // index into global memory inside the rollout loop would tie the loop's loads to its stores (one in-order vmcnt on gfx950).
-static __shared__ double g_trig6[660];
+static __shared__ double g_trig6[660 + 18];  // the 6-wide sin / cos table and the reduction constants behind it (sincos_exact.h fill_hot)
 static __shared__ double g_pow_log[384];
 static __shared__ uint64_t g_pow_exp[256];
 static __shared__ double g_powf_log2[32];
@@ -71,6 +71,7 @@ struct ExactMathT {
     template <bool POW, bool POWF>
     static MI_DEV void init() {
         for (int e = threadIdx.x; e < 110; e += blockDim.x) mi_sincos::expand6(mi_sincos::kTable, g_trig6, e);
+        if (threadIdx.x == 0) mi_sincos::fill_hot(g_trig6);
         if (POW) {
             for (int k = threadIdx.x; k < 384; k += blockDim.x) g_pow_log[k] = mi_pow::kLogTab[k];
             for (int k = threadIdx.x; k < 256; k += blockDim.x) g_pow_exp[k] = mi_pow::kExpTab[k];
@@ -90,9 +91,11 @@ struct ExactMathT {
     static MI_DEV void sincos_spread(double x, double &s, double &c) { mi_sincos::sincos_bf<false, false, KASM>(g_trig6, x, s, c); }  // any range, no small-angle short cut
     // for angles the environment wraps or clips (|x| far below 1e8): no hand-over to the platform's huge-argument routine, and lanes
     // spread over all ranges (no wavefront-uniform short cut)
-    static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true, KASM>(g_trig6, x); }
-    static MI_DEV double cos_bounded(double x) { return mi_sincos::cos_bf<true, KASM>(g_trig6, x); }
-    static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false, KASM>(g_trig6, x, s, c); }
+    // (HOT: the reduction's constants from LDS for the kernel that evaluates 14 reductions per step at the SGPR limit -- Acrobot, the one with KASM = false)
+    static constexpr bool HOT = !KASM;
+    static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true, KASM, HOT>(g_trig6, x); }
+    static MI_DEV double cos_bounded(double x) { return mi_sincos::cos_bf<true, KASM, HOT>(g_trig6, x); }
+    static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false, KASM, HOT>(g_trig6, x, s, c); }
     static MI_DEV double fmod_2pi(double x) { return mi_sincos::fmod_const(x, TwoPi()); }  // fmod(x, 2 pi): exact, like the library's, in half the instructions
     static MI_DEV double sq(double x) { return mi_pow::square<KASM>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
     static MI_DEV float sqf(float x) { return mi_pow::squaref<KASM>(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2

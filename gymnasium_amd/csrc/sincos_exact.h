@@ -22,9 +22,11 @@
 
 #if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
 #define MI_SC_DEV __device__ __forceinline__
+#define MI_SC_MEMBER __device__ __forceinline__
 #define MI_SC_TABLE __device__
 #else
 #define MI_SC_DEV static inline
+#define MI_SC_MEMBER inline
 #define MI_SC_TABLE static
 #endif
 
@@ -41,6 +43,47 @@ constexpr double kS1 = -0x1.5555555555555p-3, kS2 = 0x1.1111111110ecep-7, kS3 = 
 constexpr double kHp0 = 0x1.921fb54442d18p+0, kHp1 = 0x1.1a62633145c07p-54;  // pi/2 as a double-double
 constexpr double kHpInv = 0x1.45f306dc9c883p-1, kToInt = 0x1.8000000000000p+52;
 constexpr double kMp1 = 0x1.921fb58000000p+0, kMp2 = -0x1.dde973c000000p-27, kPp3 = -0x1.cb3b398000000p-55, kPp4 = -0x1.d747f23e32ed7p-83;
+// HOT: the range reduction's constants read from eight doubles behind the 6-wide table (T6[kHotAt ..], fill_hot()) instead of written as literals.
+// A float64 literal costs the instruction that uses it two scalar moves unless an SGPR pair holds it, and a kernel at the 106-SGPR limit (Acrobot:
+// 14 reductions per step) re-materialises these on every use; a value that comes from memory the compiler keeps in vector registers across the loop.
+constexpr int kHotAt = 660, kHotCount = 18;
+MI_SC_DEV void fill_hot(double *T6) {
+    double *h = T6 + kHotAt;
+    h[0] = kHpInv, h[1] = kToInt, h[2] = kMp1, h[3] = kMp2, h[4] = kPp3, h[5] = kPp4, h[6] = kHp0, h[7] = kHp1;
+    h[8] = kBig, h[9] = kSn3, h[10] = kSn5, h[11] = kCs4, h[12] = kCs6, h[13] = kS1, h[14] = kS2, h[15] = kS3, h[16] = kS4, h[17] = kS5;
+}
+template <bool HOT>
+struct RedK {
+    const double *h;
+    MI_SC_MEMBER explicit RedK(const double *T6) : h(T6 + kHotAt) {}
+    MI_SC_MEMBER double hp_inv() const { return HOT ? h[0] : kHpInv; }
+    MI_SC_MEMBER double to_int() const { return HOT ? h[1] : kToInt; }
+    MI_SC_MEMBER double mp1() const { return HOT ? h[2] : kMp1; }
+    MI_SC_MEMBER double mp2() const { return HOT ? h[3] : kMp2; }
+    MI_SC_MEMBER double pp3() const { return HOT ? h[4] : kPp3; }
+    MI_SC_MEMBER double pp4() const { return HOT ? h[5] : kPp4; }
+    MI_SC_MEMBER double hp0() const { return HOT ? h[6] : kHp0; }
+    MI_SC_MEMBER double hp1() const { return HOT ? h[7] : kHp1; }
+};
+// ... and the constants of do_sin / do_cos / TAYLOR_SIN (POLY: a kernel chooses how many of its registers go to constants)
+template <bool POLY>
+struct PolyK {
+    const double *h;
+    MI_SC_MEMBER explicit PolyK(const double *T6) : h(T6 + kHotAt) {}
+    MI_SC_MEMBER double big() const { return POLY ? h[8] : kBig; }
+    MI_SC_MEMBER double sn3() const { return POLY ? h[9] : kSn3; }
+    MI_SC_MEMBER double sn5() const { return POLY ? h[10] : kSn5; }
+    MI_SC_MEMBER double cs4() const { return POLY ? h[11] : kCs4; }
+    MI_SC_MEMBER double cs6() const { return POLY ? h[12] : kCs6; }
+    MI_SC_MEMBER double s1() const { return POLY ? h[13] : kS1; }
+    MI_SC_MEMBER double s2() const { return POLY ? h[14] : kS2; }
+    MI_SC_MEMBER double s3() const { return POLY ? h[15] : kS3; }
+    MI_SC_MEMBER double s4() const { return POLY ? h[16] : kS4; }
+    MI_SC_MEMBER double s5() const { return POLY ? h[17] : kS5; }
+};
+#ifndef MI_SC_HOT_POLY
+#define MI_SC_HOT_POLY 1
+#endif
 
 MI_SC_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // the same fused multiply-add for a Horner step whose multiplier AND addend are constants: on the device one v_fma_f64 with all three
@@ -195,21 +238,22 @@ MI_SC_DEV void expand6(const double *T4, double *T6, int entry) {
 }
 MI_SC_DEV double sel(bool c, double a, double b) { return c ? a : b; }
 
-template <bool KASM = true>
+template <bool KASM = true, bool HOT = false>
 MI_SC_DEV double core(const double *T6, double a, double da, bool cm) {
     const double ax = fabs(a);
-    const double u = kBig + ax;
-    const double x0 = ax - (u - kBig);
+    const PolyK<HOT && MI_SC_HOT_POLY> P(T6);
+    const double u = P.big() + ax;
+    const double x0 = ax - (u - P.big());
     const int idx = (int)(uint32_t)bits(u) * 6 + (cm ? 2 : 0);
     const double p = T6[idx], pp = T6[idx + 1], q = T6[idx + 2], qq = T6[idx + 3];
     const bool flip = cm ? (a < 0) : (a <= 0);  // do_cos: if (x < 0) dx = -dx;  do_sin: if (x <= 0) dx = -dx
     const double dxs = flip ? -da : da;
     const double xr = cm ? x0 + dxs : x0;
     const double xx = xr * xr;
-    const double poly_s = fma_k<KASM>(xx, kSn5, kSn3);
+    const double poly_s = fma_k<KASM>(xx, P.sn5(), P.sn3());
     const double tt = fma_(xr * xx, poly_s, sel(cm, xr, dxs));
     const double s = cm ? -tt : xr + tt;  // cos: -s with s = fma(xr^3, q, xr);  sin: s = xr + fma(xr^3, q, dx)
-    double c0 = fma_k<KASM>(xx, kCs6, kCs4);
+    double c0 = fma_k<KASM>(xx, P.cs6(), P.cs4());
     c0 = fma_k<KASM>(xx, c0, kCs2);
     const double xc = xx * c0;
     const double c = cm ? xc : fma_(xr, dxs, xc);
@@ -219,8 +263,8 @@ MI_SC_DEV double core(const double *T6, double a, double da, bool cm) {
     double res = p + cor;
     // TAYLOR_SIN for the sin of |a| < 0.126 (signed a, dx as given)
     const double axx = a * a;
-    double tp = fma_k<KASM>(axx, kS5, kS4);
-    tp = fma_k<KASM>(axx, tp, kS3), tp = fma_k<KASM>(axx, tp, kS2), tp = fma_k<KASM>(axx, tp, kS1);
+    double tp = fma_k<KASM>(axx, P.s5(), P.s4());
+    tp = fma_k<KASM>(axx, tp, P.s3()), tp = fma_k<KASM>(axx, tp, P.s2()), tp = fma_k<KASM>(axx, tp, P.s1());
     const double t1 = fma_(a, tp, -(0.5 * da));
     const double rt = a + fma_(t1, axx, da);
     res = (!cm && ax < 0.126) ? rt : res;
@@ -228,51 +272,52 @@ MI_SC_DEV double core(const double *T6, double a, double da, bool cm) {
 }
 
 // reduced argument of sin(x) (want_cos = false) or cos(x) (true) for |x| < 105414350
-template <bool KASM = true>
-MI_SC_DEV void prep(double x, bool want_cos, double &a, double &da, bool &cm, bool &neg) {
+template <bool KASM = true, bool HOT = false>
+MI_SC_DEV void prep(const double *T6, double x, bool want_cos, double &a, double &da, bool &cm, bool &neg) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     const double ax = fabs(x);
+    const RedK<HOT> K(T6);
     // |x| >= 2.426265: n pi/2 + (b + db)
-    const double t = fma_k<KASM>(x, kHpInv, kToInt);
-    const double xn = t - kToInt;
+    const double t = fma_k<KASM>(x, K.hp_inv(), K.to_int());
+    const double xn = t - K.to_int();
     const uint32_t n = ((uint32_t)bits(t) + (want_cos ? 1u : 0u)) & 3u;
-    double y = fma_(-xn, kMp1, x);
-    y = fma_(-xn, kMp2, y);
-    const double t2 = fma_(-xn, kPp3, y);
-    const double db = fma_(-kPp3, xn, y - t2);
-    const double b = fma_(-xn, kPp4, t2);
-    const double db2 = fma_(-xn, kPp4, t2 - b);
+    double y = fma_(-xn, K.mp1(), x);
+    y = fma_(-xn, K.mp2(), y);
+    const double t2 = fma_(-xn, K.pp3(), y);
+    const double db = fma_(-K.pp3(), xn, y - t2);
+    const double b = fma_(-xn, K.pp4(), t2);
+    const double db2 = fma_(-xn, K.pp4(), t2 - b);
     // 0.855469 <= |x| < 2.426265: sin = copysign(do_cos(pi/2 - |x|, lo), x);  cos = do_sin(two-sum of the same)
-    const double ym = kHp0 - ax;
-    const double am = ym + kHp1;
-    const double dam = (ym - am) + kHp1;
+    const double ym = K.hp0() - ax;
+    const double am = ym + K.hp1();
+    const double dam = (ym - am) + K.hp1();
     const bool main = k < 0x3feb6000u, mid = k < 0x400368fdu;
     a = main ? x : (mid ? (want_cos ? am : ym) : b);
-    da = main ? 0.0 : (mid ? (want_cos ? dam : kHp1) : db + db2);
+    da = main ? 0.0 : (mid ? (want_cos ? dam : K.hp1()) : db + db2);
     cm = main ? want_cos : (mid ? !want_cos : (n & 1u) != 0);
     neg = main ? false : (mid ? (!want_cos && x < 0) : (n & 2u) != 0);
 }
 
 // BOUNDED: the caller guarantees |x| < 105414336 (an angle that the environment wraps or clips), so the hand-over to the platform's sin / cos
 // for huge arguments -- a test, a branch and a page of never-executed code per call site -- is left out.
-template <bool BOUNDED = false, bool KASM = true>
+template <bool BOUNDED = false, bool KASM = true, bool HOT = false>
 MI_SC_DEV double sin_bf(const double *T6, double x) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (!BOUNDED && __builtin_expect(k >= 0x419921fbu, 0)) return sin(x);
     double a, da;
     bool cm, neg;
-    prep<KASM>(x, false, a, da, cm, neg);
-    const double r = core<KASM>(T6, a, da, cm);
+    prep<KASM, HOT>(T6, x, false, a, da, cm, neg);
+    const double r = core<KASM, HOT>(T6, a, da, cm);
     return neg ? -r : r;
 }
-template <bool BOUNDED = false, bool KASM = true>
+template <bool BOUNDED = false, bool KASM = true, bool HOT = false>
 MI_SC_DEV double cos_bf(const double *T6, double x) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (!BOUNDED && __builtin_expect(k >= 0x419921fbu, 0)) return cos(x);
     double a, da;
     bool cm, neg;
-    prep<KASM>(x, true, a, da, cm, neg);
-    const double r = core<KASM>(T6, a, da, cm);
+    prep<KASM, HOT>(T6, x, true, a, da, cm, neg);
+    const double r = core<KASM, HOT>(T6, a, da, cm);
     return neg ? -r : r;
 }
 
@@ -315,19 +360,20 @@ MI_SC_DEV void sincos_main(const double *T6, double x, double &sn_out, double &c
 //   beyond:          x = n pi/2 + (b + db):  n even: sin = +-do_sin(b, db), cos = +-do_cos(b, db);  n odd: the two swap roles
 // so the pair costs one shared reduction, one dedicated do_sin stream (TAYLOR_SIN selected in) and one dedicated do_cos stream -- none of the
 // role selects the one-function core() above needs -- and two output selects.  Same operations on the same operands as sin_bf / cos_bf.
-template <bool KASM = true>
+template <bool KASM = true, bool HOT = false>
 MI_SC_DEV double do_sin_bf(const double *T6, double a, double da) {
     const double ax = fabs(a);
-    const double u = kBig + ax;
-    const double x0 = ax - (u - kBig);
+    const PolyK<HOT && MI_SC_HOT_POLY> P(T6);
+    const double u = P.big() + ax;
+    const double x0 = ax - (u - P.big());
     const int idx = (int)(uint32_t)bits(u) * 6;
     const double sn = T6[idx], ssn = T6[idx + 1], cs = T6[idx + 2], ccs = T6[idx + 3];
     const double dxs = (a <= 0) ? -da : da;
     const double xx = x0 * x0;
-    const double q = fma_k<KASM>(xx, kSn5, kSn3);
+    const double q = fma_k<KASM>(xx, P.sn5(), P.sn3());
     const double si = fma_(x0 * xx, q, dxs);
     const double sv = x0 + si;
-    double c0 = fma_k<KASM>(xx, kCs6, kCs4);
+    double c0 = fma_k<KASM>(xx, P.cs6(), P.cs4());
     c0 = fma_k<KASM>(xx, c0, kCs2);
     const double c = fma_(x0, dxs, xx * c0);
     double cor = fma_(sv, ccs, ssn);
@@ -335,25 +381,26 @@ MI_SC_DEV double do_sin_bf(const double *T6, double a, double da) {
     cor = fma_(sv, cs, cor);
     double res = sn + cor;
     const double axx = a * a;
-    double tp = fma_k<KASM>(axx, kS5, kS4);
-    tp = fma_k<KASM>(axx, tp, kS3), tp = fma_k<KASM>(axx, tp, kS2), tp = fma_k<KASM>(axx, tp, kS1);
+    double tp = fma_k<KASM>(axx, P.s5(), P.s4());
+    tp = fma_k<KASM>(axx, tp, P.s3()), tp = fma_k<KASM>(axx, tp, P.s2()), tp = fma_k<KASM>(axx, tp, P.s1());
     const double t1 = fma_(a, tp, -(0.5 * da));
     const double rt = a + fma_(t1, axx, da);
     res = ax < 0.126 ? rt : res;
     return copysign_(res, a);
 }
-template <bool KASM = true>
+template <bool KASM = true, bool HOT = false>
 MI_SC_DEV double do_cos_bf(const double *T6, double a, double da) {
     const double ax = fabs(a);
-    const double u = kBig + ax;
+    const PolyK<HOT && MI_SC_HOT_POLY> P(T6);
+    const double u = P.big() + ax;
     const double dxs = (a < 0) ? -da : da;
-    const double xr = (ax - (u - kBig)) + dxs;
+    const double xr = (ax - (u - P.big())) + dxs;
     const int idx = (int)(uint32_t)bits(u) * 6;
     const double sn = T6[idx], ssn = T6[idx + 1], cs = T6[idx + 2], ccs = T6[idx + 3];
     const double xx = xr * xr;
-    const double q = fma_k<KASM>(xx, kSn5, kSn3);
+    const double q = fma_k<KASM>(xx, P.sn5(), P.sn3());
     const double sv = fma_(xr * xx, q, xr);
-    double c0 = fma_k<KASM>(xx, kCs6, kCs4);
+    double c0 = fma_k<KASM>(xx, P.cs6(), P.cs4());
     c0 = fma_k<KASM>(xx, c0, kCs2);
     const double c = xx * c0;
     double cor = fma_(-sv, ssn, ccs);
@@ -361,7 +408,7 @@ MI_SC_DEV double do_cos_bf(const double *T6, double a, double da) {
     cor = fma_(-sv, sn, cor);
     return cs + cor;
 }
-template <bool BOUNDED = false, bool KASM = true>
+template <bool BOUNDED = false, bool KASM = true, bool HOT = false>
 MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &cs_out) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (!BOUNDED && __builtin_expect(k >= 0x419921fbu, 0)) {
@@ -369,24 +416,25 @@ MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &c
         return;
     }
     const double ax = fabs(x);
+    const RedK<HOT> K(T6);
     // |x| >= 2.426265: n pi/2 + (b + db)
-    const double t = fma_k<KASM>(x, kHpInv, kToInt);
-    const double xn = t - kToInt;
+    const double t = fma_k<KASM>(x, K.hp_inv(), K.to_int());
+    const double xn = t - K.to_int();
     const uint32_t n = (uint32_t)bits(t);
-    double y = fma_(-xn, kMp1, x);
-    y = fma_(-xn, kMp2, y);
-    const double t2 = fma_(-xn, kPp3, y);
-    const double db = fma_(-kPp3, xn, y - t2);
-    const double b = fma_(-xn, kPp4, t2);
-    const double db2 = fma_(-xn, kPp4, t2 - b);
+    double y = fma_(-xn, K.mp1(), x);
+    y = fma_(-xn, K.mp2(), y);
+    const double t2 = fma_(-xn, K.pp3(), y);
+    const double db = fma_(-K.pp3(), xn, y - t2);
+    const double b = fma_(-xn, K.pp4(), t2);
+    const double db2 = fma_(-xn, K.pp4(), t2 - b);
     // 0.855469 <= |x| < 2.426265
-    const double ym = kHp0 - ax;
-    const double am = ym + kHp1;
-    const double dam = (ym - am) + kHp1;
+    const double ym = K.hp0() - ax;
+    const double am = ym + K.hp1();
+    const double dam = (ym - am) + K.hp1();
     const bool main = k < 0x3feb6000u, mid = k < 0x400368fdu;
     const double as = main ? x : (mid ? am : b), das = main ? 0.0 : (mid ? dam : db + db2);
-    const double ac = main ? x : (mid ? ym : b), dac = main ? 0.0 : (mid ? kHp1 : db + db2);
-    const double S = do_sin_bf<KASM>(T6, as, das), C = do_cos_bf<KASM>(T6, ac, dac);
+    const double ac = main ? x : (mid ? ym : b), dac = main ? 0.0 : (mid ? K.hp1() : db + db2);
+    const double S = do_sin_bf<KASM, HOT>(T6, as, das), C = do_cos_bf<KASM, HOT>(T6, ac, dac);
     const bool swap = main ? false : (mid ? true : (n & 1u) != 0);
     const bool neg_s = main ? false : (mid ? (x < 0) : (n & 2u) != 0);
     const bool neg_c = (main || mid) ? false : ((n + 1u) & 2u) != 0;
@@ -412,13 +460,13 @@ MI_SC_DEV double fmod_const(double x, Y) {
 }
 
 // MAIN_FIRST: the arguments of all lanes are expected inside |x| < 0.855469 (CartPole), worth a wavefront-uniform test for the short routine
-template <bool BOUNDED = false, bool MAIN_FIRST = true, bool KASM = true>
+template <bool BOUNDED = false, bool MAIN_FIRST = true, bool KASM = true, bool HOT = false>
 MI_SC_DEV void sincos_bf(const double *T6, double x, double &sn_out, double &cs_out) {
     const uint32_t k = (uint32_t)(bits(x) >> 32) & 0x7fffffffu;
     if (MAIN_FIRST && k < 0x3feb6000u) {
         sincos_main<KASM>(T6, x, sn_out, cs_out);
     } else {
-        sincos_pair<BOUNDED, KASM>(T6, x, sn_out, cs_out);
+        sincos_pair<BOUNDED, KASM, HOT>(T6, x, sn_out, cs_out);
     }
 }
 

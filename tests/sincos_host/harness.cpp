@@ -36,6 +36,29 @@ __attribute__((visibility("default"))) void sincos_pair_batch(const double *x, d
     const double *t6 = table6();
     for (long i = 0; i < n; i++) mi_sincos::sincos_pair<true>(t6, x[i], s[i], c[i]);
 }
+// ... with the reduction's and the polynomials' constants read from behind the table (HOT: what the Acrobot kernels instantiate)
+static const double *table6_hot() {
+    static double t6[mi_sincos::kHotAt + mi_sincos::kHotCount];
+    static bool done = false;
+    if (!done) {
+        for (int e = 0; e < 110; e++) mi_sincos::expand6(mi_sincos::kTable, t6, e);
+        mi_sincos::fill_hot(t6);
+        done = true;
+    }
+    return t6;
+}
+__attribute__((visibility("default"))) void sin_bf_hot_batch(const double *x, double *out, long n) {
+    const double *t6 = table6_hot();
+    for (long i = 0; i < n; i++) out[i] = mi_sincos::sin_bf<true, false, true>(t6, x[i]);
+}
+__attribute__((visibility("default"))) void cos_bf_hot_batch(const double *x, double *out, long n) {
+    const double *t6 = table6_hot();
+    for (long i = 0; i < n; i++) out[i] = mi_sincos::cos_bf<true, false, true>(t6, x[i]);
+}
+__attribute__((visibility("default"))) void sincos_pair_hot_batch(const double *x, double *s, double *c, long n) {
+    const double *t6 = table6_hot();
+    for (long i = 0; i < n; i++) mi_sincos::sincos_pair<true, false, true>(t6, x[i], s[i], c[i]);
+}
 struct TwoPi {
     static constexpr double value = 6.283185307179586;
 };

@@ -61,6 +61,10 @@ def check_all_forms(x):
     assert same_bits(s, rs[inside]) and same_bits(c, rc[inside]), "merged sincos"
     s, c = run_sincos(x[inside], "sincos_pair_batch")
     assert same_bits(s, rs[inside]) and same_bits(c, rc[inside]), "one-reduction sincos pair (every range)"
+    # the BOUNDED instantiations with their constants read from behind the table (Acrobot's): same bits
+    assert same_bits(run("sin_bf_hot_batch", x[inside]), rs[inside]) and same_bits(run("cos_bf_hot_batch", x[inside]), rc[inside]), "branch-free sin / cos, constants from the table"
+    s, c = run_sincos(x[inside], "sincos_pair_hot_batch")
+    assert same_bits(s, rs[inside]) and same_bits(c, rc[inside]), "sincos pair, constants from the table"
 
 
 def same_bits(a, b):
