@@ -34,7 +34,7 @@ enum : uint32_t { kNeedsReset = 1u, kStateF32 = 2u };
 // ones its environment reads): every kernel that steps / resets / observes a classic env calls tables_init<E>() first.  A per-lane table
 // index into global memory inside the rollout loop would tie the loop's loads to its stores (one in-order vmcnt on gfx950).
 static __shared__ double g_trig6[660 + 18];  // the 6-wide sin / cos table and the reduction constants behind it (sincos_exact.h fill_hot)
-static __shared__ double g_pow_log[384];
+static __shared__ double g_pow_log[384 + 18];  // the log table and the routine's constants behind it (pow_exact.h fill_hot)
 static __shared__ uint64_t g_pow_exp[256];
 static __shared__ double g_powf_log2[32];
 static __shared__ uint64_t g_powf_exp2[32];
@@ -42,6 +42,12 @@ static __shared__ uint64_t g_powf_exp2[32];
 struct TwoPi {
     static constexpr double value = 2 * kPi;
 };
+#ifndef MI_HOT_TRIG
+#define MI_HOT_TRIG true
+#endif
+#ifndef MI_HOT_POW
+#define MI_HOT_POW true
+#endif
 // Several IEEE quotients by ONE divisor.  The compiler's float64 division is v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 FMAs),
 // q0 = a r, e = fma(-b, q0, a), v_div_fmas (= fma(e, r, q0) when nothing was scaled) and v_div_fixup: 11 instructions, one of them a 17-tick
 // transcendental.  v_div_scale leaves both operands alone unless an exponent is extreme (divisor or quotient near the ends of the range, or a
@@ -74,6 +80,7 @@ struct ExactMathT {
         if (threadIdx.x == 0) mi_sincos::fill_hot(g_trig6);
         if (POW) {
             for (int k = threadIdx.x; k < 384; k += blockDim.x) g_pow_log[k] = mi_pow::kLogTab[k];
+            if (threadIdx.x == 0) mi_pow::fill_hot(g_pow_log);
             for (int k = threadIdx.x; k < 256; k += blockDim.x) g_pow_exp[k] = mi_pow::kExpTab[k];
         }
         if (POWF) {
@@ -81,27 +88,31 @@ struct ExactMathT {
         }
         __syncthreads();
     }
-    static MI_DEV double sin(double x) { return mi_sincos::sin_bf<false, KASM>(g_trig6, x); }
-    static MI_DEV double cos(double x) { return mi_sincos::cos_bf<false, KASM>(g_trig6, x); }
-    static MI_DEV void sincos(double x, double &s, double &c) { mi_sincos::sincos_bf<false, true, KASM>(g_trig6, x, s, c); }
+    // HOT: the range reduction's and the polynomials' constants are read from behind the table (sincos_exact.h fill_hot) instead of written as float64
+    // literals: a literal costs two scalar moves at every use unless an SGPR pair holds it, and these kernels sit at the 106-SGPR limit; what comes
+    // from LDS the compiler keeps in vector registers across the step loop.  (CartPole's short routine, sincos_main, keeps its literals.)
+    static constexpr bool HOT = MI_HOT_TRIG;
+    static MI_DEV double sin(double x) { return mi_sincos::sin_bf<false, KASM, HOT>(g_trig6, x); }
+    static MI_DEV double cos(double x) { return mi_sincos::cos_bf<false, KASM, HOT>(g_trig6, x); }
+    static MI_DEV void sincos(double x, double &s, double &c) { mi_sincos::sincos_bf<false, true, KASM>(g_trig6, x, s, c); }  // (CartPole: literals, its general path is rare)
     // the two halves of sincos() for a caller that defers the rare case: the short routine of |x| < 0.855469 evaluated unconditionally (its result
     // is only meaningful when in_main_range(x); an index outside the table reads zeros from LDS, no fault), and the test
     static MI_DEV void sincos_main_unchecked(double x, double &s, double &c) { mi_sincos::sincos_main<KASM>(g_trig6, x, s, c); }
     static MI_DEV bool in_main_range(double x) { return ((uint32_t)(mi_sincos::bits(x) >> 32) & 0x7fffffffu) < 0x3feb6000u; }
-    static MI_DEV void sincos_spread(double x, double &s, double &c) { mi_sincos::sincos_bf<false, false, KASM>(g_trig6, x, s, c); }  // any range, no small-angle short cut
+    static MI_DEV void sincos_spread(double x, double &s, double &c) { mi_sincos::sincos_bf<false, false, KASM, HOT>(g_trig6, x, s, c); }  // any range, no small-angle short cut
     // for angles the environment wraps or clips (|x| far below 1e8): no hand-over to the platform's huge-argument routine, and lanes
     // spread over all ranges (no wavefront-uniform short cut)
-    // (HOT: the reduction's constants from LDS for the kernel that evaluates 14 reductions per step at the SGPR limit -- Acrobot, the one with KASM = false)
-    static constexpr bool HOT = !KASM;
     static MI_DEV double sin_bounded(double x) { return mi_sincos::sin_bf<true, KASM, HOT>(g_trig6, x); }
     static MI_DEV double cos_bounded(double x) { return mi_sincos::cos_bf<true, KASM, HOT>(g_trig6, x); }
     static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false, KASM, HOT>(g_trig6, x, s, c); }
+    static MI_DEV double cos_bounded_literals(double x) { return mi_sincos::cos_bf<true, KASM>(g_trig6, x); }  // (MountainCar: -0.8 % with HOT, profiles/r06_hot_constants_all_ab.txt)
     static MI_DEV double fmod_2pi(double x) { return mi_sincos::fmod_const(x, TwoPi()); }  // fmod(x, 2 pi): exact, like the library's, in half the instructions
-    static MI_DEV double sq(double x) { return mi_pow::square<KASM>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
+    static constexpr bool HOTP = MI_HOT_POW;  // the pow routine's constants from LDS at every call (pow_exact.h PowK)
+    static MI_DEV double sq(double x) { return mi_pow::square<KASM, HOTP>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
     static MI_DEV float sqf(float x) { return mi_pow::squaref<KASM>(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2
     // three / two np.float64 ** 2 at once: the table routine runs once per group for the lanes whose square is not provably the plain product (pow_exact.h)
-    static MI_DEV void sq3(double a, double b, double c, double &ra, double &rb, double &rc) { mi_pow::square3<KASM>(g_pow_log, g_pow_exp, a, b, c, ra, rb, rc); }
-    static MI_DEV void sq2(double a, double b, double &ra, double &rb) { mi_pow::square2<KASM>(g_pow_log, g_pow_exp, a, b, ra, rb); }
+    static MI_DEV void sq3(double a, double b, double c, double &ra, double &rb, double &rc) { mi_pow::square3<KASM, HOTP>(g_pow_log, g_pow_exp, a, b, c, ra, rb, rc); }
+    static MI_DEV void sq2(double a, double b, double &ra, double &rb) { mi_pow::square2<KASM, HOTP>(g_pow_log, g_pow_exp, a, b, ra, rb); }
     // the test alone, for a caller that collects the arguments which need the table routine (the two-role Pendulum rollout, engine.hip): true = `hi` IS x ** 2
     static MI_DEV bool sq_is_plain(double x, double &hi) { return mi_pow::square_is_plain(x, hi); }
 };
@@ -139,6 +150,7 @@ struct FastMath {
     static MI_DEV void sincos_spread(double x, double &s, double &c) { ::sincos(x, &s, &c); }
     static MI_DEV double sin_bounded(double x) { return ::sin(x); }
     static MI_DEV double cos_bounded(double x) { return ::cos(x); }
+    static MI_DEV double cos_bounded_literals(double x) { return ::cos(x); }
     static MI_DEV void sincos_bounded(double x, double &s, double &c) { ::sincos(x, &s, &c); }
     static MI_DEV double fmod_2pi(double x) { return ::fmod(x, 2 * kPi); }
     static MI_DEV double sq(double x) { return x * x; }
@@ -666,7 +678,7 @@ struct MountainCarT {
         const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5;
         const double force = 0.001, gravity = 0.0025;
         double position = s[0], velocity = s[1];
-        velocity += (double)(action - 1) * force + M::cos_bounded(3 * position) * (-gravity);
+        velocity += (double)(action - 1) * force + M::cos_bounded_literals(3 * position) * (-gravity);
         velocity = velocity < -max_speed ? -max_speed : velocity;
         velocity = velocity > max_speed ? max_speed : velocity;
         position += velocity;
