@@ -34,7 +34,7 @@ enum : uint32_t { kNeedsReset = 1u, kStateF32 = 2u };
 // ones its environment reads): every kernel that steps / resets / observes a classic env calls tables_init<E>() first.  A per-lane table
 // index into global memory inside the rollout loop would tie the loop's loads to its stores (one in-order vmcnt on gfx950).
 static __shared__ double g_trig6[660 + 18];  // the 6-wide sin / cos table and the reduction constants behind it (sincos_exact.h fill_hot)
-static __shared__ double g_pow_log[384 + 18];  // the log table and the routine's constants behind it (pow_exact.h fill_hot)
+static __shared__ double g_pow_log[384];
 static __shared__ uint64_t g_pow_exp[256];
 static __shared__ double g_powf_log2[32];
 static __shared__ uint64_t g_powf_exp2[32];
@@ -45,9 +45,7 @@ struct TwoPi {
 #ifndef MI_HOT_TRIG
 #define MI_HOT_TRIG true
 #endif
-#ifndef MI_HOT_POW
-#define MI_HOT_POW true
-#endif
+
 // Several IEEE quotients by ONE divisor.  The compiler's float64 division is v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 FMAs),
 // q0 = a r, e = fma(-b, q0, a), v_div_fmas (= fma(e, r, q0) when nothing was scaled) and v_div_fixup: 11 instructions, one of them a 17-tick
 // transcendental.  v_div_scale leaves both operands alone unless an exponent is extreme (divisor or quotient near the ends of the range, or a
@@ -80,7 +78,6 @@ struct ExactMathT {
         if (threadIdx.x == 0) mi_sincos::fill_hot(g_trig6);
         if (POW) {
             for (int k = threadIdx.x; k < 384; k += blockDim.x) g_pow_log[k] = mi_pow::kLogTab[k];
-            if (threadIdx.x == 0) mi_pow::fill_hot(g_pow_log);
             for (int k = threadIdx.x; k < 256; k += blockDim.x) g_pow_exp[k] = mi_pow::kExpTab[k];
         }
         if (POWF) {
@@ -107,12 +104,11 @@ struct ExactMathT {
     static MI_DEV void sincos_bounded(double x, double &s, double &c) { mi_sincos::sincos_bf<true, false, KASM, HOT>(g_trig6, x, s, c); }
     static MI_DEV double cos_bounded_literals(double x) { return mi_sincos::cos_bf<true, KASM>(g_trig6, x); }  // (MountainCar: -0.8 % with HOT, profiles/r06_hot_constants_all_ab.txt)
     static MI_DEV double fmod_2pi(double x) { return mi_sincos::fmod_const(x, TwoPi()); }  // fmod(x, 2 pi): exact, like the library's, in half the instructions
-    static constexpr bool HOTP = MI_HOT_POW;  // the pow routine's constants from LDS at every call (pow_exact.h PowK)
-    static MI_DEV double sq(double x) { return mi_pow::square<KASM, HOTP>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
+    static MI_DEV double sq(double x) { return mi_pow::square<KASM>(g_pow_log, g_pow_exp, x); }    // np.float64 ** 2
     static MI_DEV float sqf(float x) { return mi_pow::squaref<KASM>(g_powf_log2, g_powf_exp2, x); }  // np.float32 ** 2
     // three / two np.float64 ** 2 at once: the table routine runs once per group for the lanes whose square is not provably the plain product (pow_exact.h)
-    static MI_DEV void sq3(double a, double b, double c, double &ra, double &rb, double &rc) { mi_pow::square3<KASM, HOTP>(g_pow_log, g_pow_exp, a, b, c, ra, rb, rc); }
-    static MI_DEV void sq2(double a, double b, double &ra, double &rb) { mi_pow::square2<KASM, HOTP>(g_pow_log, g_pow_exp, a, b, ra, rb); }
+    static MI_DEV void sq3(double a, double b, double c, double &ra, double &rb, double &rc) { mi_pow::square3<KASM>(g_pow_log, g_pow_exp, a, b, c, ra, rb, rc); }
+    static MI_DEV void sq2(double a, double b, double &ra, double &rb) { mi_pow::square2<KASM>(g_pow_log, g_pow_exp, a, b, ra, rb); }
     // the test alone, for a caller that collects the arguments which need the table routine (the two-role Pendulum rollout, engine.hip): true = `hi` IS x ** 2
     static MI_DEV bool sq_is_plain(double x, double &hi) { return mi_pow::square_is_plain(x, hi); }
 };

@@ -21,11 +21,9 @@
 
 #if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
 #define MI_PW_DEV __device__ __forceinline__
-#define MI_PW_MEMBER __device__ __forceinline__
 #define MI_PW_TABLE __device__
 #else
 #define MI_PW_DEV static inline
-#define MI_PW_MEMBER inline
 #define MI_PW_TABLE static
 #endif
 
@@ -78,39 +76,9 @@ MI_PW_DEV float from_bitsf(uint32_t u) {
     return v.f;
 }
 
-// HOTP: the routine's 17 float64 constants read from behind the log table (log_tab[kPowHotAt ..], fill_hot()) at every call instead of written as
-// literals -- a literal costs the instruction that uses it two scalar moves (or two vector moves for the KASM form) unless a register pair holds it, and
-// the kernels that call this sit at their register limits; nine LDS reads ride on the waits the routine's table reads need anyway.  The address is
-// made opaque per call so that the compiler does NOT keep the 34 registers live across the caller's loop.
-constexpr int kPowHotAt = 384, kPowHotCount = 18;
-MI_PW_DEV void fill_hot(double *log_tab) {
-    double *h = log_tab + kPowHotAt;
-    for (int j = 0; j < 7; j++) h[j] = kLogPoly[j];
-    for (int j = 0; j < 4; j++) h[7 + j] = kExpPoly[j];
-    h[11] = MI_POW_LN2HI, h[12] = MI_POW_LN2LO, h[13] = MI_EXP_INVLN2N, h[14] = MI_EXP_SHIFT, h[15] = MI_EXP_NEGLN2HIN, h[16] = MI_EXP_NEGLN2LON, h[17] = 0.0;
-}
-template <bool HOTP>
-struct PowK {
-    const double *h;
-    MI_PW_MEMBER explicit PowK(const double *log_tab) : h(log_tab + kPowHotAt) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (HOTP) asm volatile("" : "+v"(h));
-#endif
-    }
-    MI_PW_MEMBER double log_poly(int j) const { return HOTP ? h[j] : kLogPoly[j]; }
-    MI_PW_MEMBER double exp_poly(int j) const { return HOTP ? h[7 + j] : kExpPoly[j]; }
-    MI_PW_MEMBER double ln2hi() const { return HOTP ? h[11] : MI_POW_LN2HI; }
-    MI_PW_MEMBER double ln2lo() const { return HOTP ? h[12] : MI_POW_LN2LO; }
-    MI_PW_MEMBER double inv_ln2n() const { return HOTP ? h[13] : MI_EXP_INVLN2N; }
-    MI_PW_MEMBER double shift() const { return HOTP ? h[14] : MI_EXP_SHIFT; }
-    MI_PW_MEMBER double neg_ln2hin() const { return HOTP ? h[15] : MI_EXP_NEGLN2HIN; }
-    MI_PW_MEMBER double neg_ln2lon() const { return HOTP ? h[16] : MI_EXP_NEGLN2LON; }
-};
-
 // pow(x, 2.0).  log_tab: kLogTab (or a copy), exp_tab: kExpTab (or a copy)
-template <bool KASM = true, bool HOTP = false>
+template <bool KASM = true>
 MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x) {
-    const PowK<HOTP> K(log_tab);
     // Written without data-dependent branches (a wavefront runs alone on its SIMD: every s_cbranch / exec-mask pair is issue slots, and
     // the special cases below practically never occur): the main path is evaluated on whatever bits arrive -- the table indices are masked,
     // nothing traps -- and the rare results are selected in at the end.
@@ -124,16 +92,16 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     const double z = from_bits(ix - (tmp & 0xfff0000000000000ull)), kd = (double)k;
     const double invc = log_tab[3 * i], logc = log_tab[3 * i + 1], logctail = log_tab[3 * i + 2];
     const double r = fma_(z, invc, -1.0);
-    const double t1 = fma_(kd, K.ln2hi(), logc);
+    const double t1 = fma_(kd, MI_POW_LN2HI, logc);
     const double t2 = t1 + r;
-    const double lo1 = fma_(kd, K.ln2lo(), logctail);
+    const double lo1 = fma_(kd, MI_POW_LN2LO, logctail);
     const double lo2 = (t1 - t2) + r;
     const double ar = kLogPoly[0] * r;  // A[0] = -0.5
     const double ar2 = r * ar, ar3 = r * ar2;
     const double hi = t2 + ar2;
     const double lo3 = fma_(ar, r, -ar2);
     const double lo4 = (t2 - hi) + ar2;
-    const double pa = fma_k<KASM>(r, K.log_poly(2), K.log_poly(1)), pb = fma_k<KASM>(r, K.log_poly(4), K.log_poly(3)), pc = fma_k<KASM>(r, K.log_poly(6), K.log_poly(5));
+    const double pa = fma_k<KASM>(r, kLogPoly[2], kLogPoly[1]), pb = fma_k<KASM>(r, kLogPoly[4], kLogPoly[3]), pc = fma_k<KASM>(r, kLogPoly[6], kLogPoly[5]);
     const double p = fma_(ar2, fma_(pc, ar2, pb), pa);
     const double lo = fma_(ar3, p, ((lo1 + lo2) + lo3) + lo4);
     const double lhi = hi + lo;
@@ -147,18 +115,18 @@ MI_PW_DEV double square(const double *log_tab, const uint64_t *exp_tab, double x
     const uint32_t abstop = (uint32_t)(bits(ehi) >> 52) & 0x7ffu;
     const bool tiny = abstop < 0x3c9u;                                 // |2 log x| < 2^-54: x is 1 to working precision: 1.0 + ehi
     const bool huge = abstop - 0x3c9u >= 0x3fu && !tiny;               // |2 log x| >= 512: over / underflow range (never reached by the environments): x * x
-    const double zz = fma_k<KASM>(ehi, K.inv_ln2n(), K.shift());
+    const double zz = fma_k<KASM>(ehi, MI_EXP_INVLN2N, MI_EXP_SHIFT);
     const uint64_t ki = bits(zz);
-    const double kdd = zz - K.shift();
-    double rr = fma_(kdd, K.neg_ln2hin(), ehi);
-    rr = fma_(kdd, K.neg_ln2lon(), rr);
+    const double kdd = zz - MI_EXP_SHIFT;
+    double rr = fma_(kdd, MI_EXP_NEGLN2HIN, ehi);
+    rr = fma_(kdd, MI_EXP_NEGLN2LON, rr);
     rr = elo + rr;
     const int idx = 2 * (int)(ki & 127);
     const uint64_t sbits = exp_tab[idx + 1] + (ki << 45);
     const double tail = from_bits(exp_tab[idx]);
-    const double q23 = fma_k<KASM>(rr, K.exp_poly(1), K.exp_poly(0));
+    const double q23 = fma_k<KASM>(rr, kExpPoly[1], kExpPoly[0]);
     const double r2 = rr * rr;
-    const double q45 = fma_k<KASM>(rr, K.exp_poly(3), K.exp_poly(2));
+    const double q45 = fma_k<KASM>(rr, kExpPoly[3], kExpPoly[2]);
     const double s1 = fma_(q23, r2, rr + tail);
     const double tmp2 = fma_(q45, r2 * r2, s1);
     const double scale = from_bits(sbits);
@@ -189,24 +157,24 @@ MI_PW_DEV bool square_is_plain(double x, double &hi) {
 // (the loop condition is the lane's own: the compiler turns it into "while any lane is pending" with the others masked off.  A wavefront-uniform
 //  condition through a ballot -- a convergent operation -- stops LLVM from unrolling the rollout loop that contains the call.)
 #define MI_PW_ANY(p) (p)
-template <bool KASM = true, bool HOTP = false>
+template <bool KASM = true>
 MI_PW_DEV void square3(const double *log_tab, const uint64_t *exp_tab, double a, double b, double c, double &ra, double &rb, double &rc) {
     bool fa = !square_is_plain(a, ra), fb = !square_is_plain(b, rb), fc = !square_is_plain(c, rc);
 #pragma nounroll  // (the trip count is provably <= 3: left alone, the compiler lays out three copies of the table routine)
     do {
-        const double r = square<KASM, HOTP>(log_tab, exp_tab, fa ? a : (fb ? b : c));
+        const double r = square<KASM>(log_tab, exp_tab, fa ? a : (fb ? b : c));
         const bool wb = !fa && fb, wc = !fa && !fb && fc;
         ra = fa ? r : ra, rb = wb ? r : rb, rc = wc ? r : rc;
         fb = fb && !wb, fc = fc && !wc, fa = false;
     } while (MI_PW_ANY(fa || fb || fc));
 }
 // two squares, same scheme
-template <bool KASM = true, bool HOTP = false>
+template <bool KASM = true>
 MI_PW_DEV void square2(const double *log_tab, const uint64_t *exp_tab, double a, double b, double &ra, double &rb) {
     bool fa = !square_is_plain(a, ra), fb = !square_is_plain(b, rb);
 #pragma nounroll
     do {
-        const double r = square<KASM, HOTP>(log_tab, exp_tab, fa ? a : b);
+        const double r = square<KASM>(log_tab, exp_tab, fa ? a : b);
         const bool wb = !fa && fb;
         ra = fa ? r : ra, rb = wb ? r : rb;
         fb = fb && !wb, fa = false;

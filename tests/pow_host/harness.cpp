@@ -89,26 +89,6 @@ __attribute__((visibility("default"))) void square_brute(uint64_t seed, long n, 
     }
     *closest = far;
 }
-// the instantiation with the routine's constants read from behind the log table (HOTP: what the kernels use)
-static const double *log_tab_hot() {
-    static double t[mi_pow::kPowHotAt + mi_pow::kPowHotCount];
-    static bool done = false;
-    if (!done) {
-        for (int i = 0; i < mi_pow::kPowHotAt; i++) t[i] = mi_pow::kLogTab[i];
-        mi_pow::fill_hot(t);
-        done = true;
-    }
-    return t;
-}
-__attribute__((visibility("default"))) void square_hot_batch(const double *x, double *out, long n) {
-    const double *t = log_tab_hot();
-    for (long i = 0; i < n; i++) out[i] = mi_pow::square<false, true>(t, mi_pow::kExpTab, x[i]);
-}
-__attribute__((visibility("default"))) void square3_hot_batch(const double *x, double *out, long n3) {
-    const double *t = log_tab_hot();
-    for (long i = 0; i < n3; i++)
-        mi_pow::square3<false, true>(t, mi_pow::kExpTab, x[3 * i], x[3 * i + 1], x[3 * i + 2], out[3 * i], out[3 * i + 1], out[3 * i + 2]);
-}
 __attribute__((visibility("default"))) void square_batch(const double *x, double *out, long n) {
     for (long i = 0; i < n; i++) out[i] = mi_pow::square(mi_pow::kLogTab, mi_pow::kExpTab, x[i]);
 }

@@ -151,14 +151,3 @@ def test_the_plain_product_test_never_passes_an_argument_libm_rounds_the_other_w
     assert wrong == 0 and grouped_wrong == 0
     if mode < 4:
         assert passed > 0.96 * examined  # 31/32 of all arguments take the plain product
-
-
-def test_the_instantiation_with_constants_from_the_table_is_the_same_function():
-    """square<.., HOTP = true> reads its 17 constants from behind the log table (what the kernels instantiate): same bits as the literal form and as libm."""
-    x = np.random.default_rng(11).uniform(-12, 12, 900_000)
-    ref = np.array([libm.pow(v, 2.0) for v in x])
-    out = np.empty_like(x)
-    lib().square_hot_batch(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_long(x.size))
-    assert np.array_equal(out, ref) and np.array_equal(out, square(x))
-    lib().square3_hot_batch(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_long(x.size // 3))
-    assert np.array_equal(out, ref)
