@@ -443,7 +443,7 @@ MI_SC_DEV void sincos_pair(const double *T6, double x, double &sn_out, double &c
 }
 
 // fmod(x, Y) for a positive compile-time modulus Y and |x| < 2^52 Y, exact like the C function (the remainder of a division is always
-// representable) and branch-free: q = trunc(x / Y) is right or off by one (the division rounds), the residual x - q Y is ONE fused
+// representable) and branch-free: q = trunc(x (1 / Y)) is right or off by one (two roundings), the residual x - q Y is ONE fused
 // multiply-add -- exact whenever the right q is used, because then |x - q Y| < Y -- and a wrong q shows as a residual outside [0, Y)
 // (for x >= 0; mirrored for x < 0), which is redone with the neighbouring q.  ~25 instructions against ~56 of the general library routine
 // (Pendulum's angle_normalize, pendulum.py:281-282).  Checked against the C library on millions of arguments by tests/test_sincos_exact.py.
@@ -451,7 +451,8 @@ template <class Y>
 MI_SC_DEV double fmod_const(double x, Y) {
     constexpr double y = Y::value;
     const double ax = fabs(x);
-    double q = trunc(ax / y);
+    constexpr double inv_y = 1.0 / y;
+    double q = trunc(ax * inv_y);  // (the product with the rounded reciprocal is within 0.75 of x / Y for |x| < 2^52 Y: right or off by one, like the quotient -- and 1 instruction instead of 11)
     double r = fma_(-q, y, ax);
     const double qlo = q - 1.0, qhi = q + 1.0;
     const double rlo = fma_(-qlo, y, ax), rhi = fma_(-qhi, y, ax);

@@ -112,3 +112,21 @@ def test_branch_free_tabular_rollouts_are_instantiated_and_stay_in_registers(ker
         if "rollout_lean_kernel" in r["name"]:
             assert r.get("vgpr_spill_count", 0) == 0 and r.get("private_segment_fixed_size", 0) == 0, r["name"]
             assert r["vgpr_count"] <= 128, f"{r['name']}: {r['vgpr_count']} VGPRs"
+
+
+def test_acrobot_rollout_kernels_fit_two_wavefronts_per_simd_and_keep_their_constants_in_registers(kernels):
+    """Round 6: the exact-math Acrobot rollouts hold at most 256 registers (beyond 65 536 sub-environments two wavefronts then share a SIMD: x1.4 at 262 144,
+    profiles/r06_acrobot_shared_divisor_ab.txt), and the trig routines' float64 constants come from LDS once instead of being re-materialised as literals at every
+    use (profiles/r06_acrobot_hot_constants_ab.txt): scalar moves were 12 - 15 % of the kernels' instructions before, 6 % after."""
+    from kernel_resources import resources
+
+    rows = [r for r in resources(LIB) if "rollout_kernel<mi::AcrobotT<mi::ExactMathT<false>" in r["name"].replace("> >", ">>").replace(" >", ">")]
+    assert len(rows) >= 5, [r["name"] for r in rows]
+    for r in rows:
+        assert r["vgpr_count"] + r.get("agpr_count", 0) <= 256, f"{r['name']}: {r['vgpr_count']} + {r.get('agpr_count', 0)} registers"
+        assert r.get("vgpr_spill_count", 0) == 0 and r.get("private_segment_fixed_size", 0) == 0, r["name"]
+    body = [ins for name, ins in kernels.items() if "rollout_kernel<mi::AcrobotT<mi::ExactMathT<false>" in name.replace("> >", ">>").replace(" >", ">")]
+    assert len(body) >= 5
+    for ins in body:
+        moves = sum(1 for op in ins if op in ("s_mov_b32", "s_brev_b32", "s_mov_b64", "s_movk_i32"))
+        assert moves <= 0.09 * len(ins), f"{moves} scalar moves in {len(ins)} instructions (12 - 15 % before the constants came from LDS: sincos_exact.h RedK / PolyK, envs_classic.h HOT)"
