@@ -451,8 +451,12 @@ template <class Y>
 MI_SC_DEV double fmod_const(double x, Y) {
     constexpr double y = Y::value;
     const double ax = fabs(x);
+#ifdef MI_FMOD_BY_DIVISION  // (A/B builds: scripts/build_variant.py ... -DMI_FMOD_BY_DIVISION)
+    double q = trunc(ax / y);
+#else
     constexpr double inv_y = 1.0 / y;
-    double q = trunc(ax * inv_y);  // (the product with the rounded reciprocal is within 0.75 of x / Y for |x| < 2^52 Y: right or off by one, like the quotient -- and 1 instruction instead of 11)
+    double q = trunc(ax * inv_y);  // (two roundings of 2^-53 each: the product is within 1 of x / Y for |x| < 2^52 Y, so its integer part is right or off by one, like the quotient's -- and 1 instruction instead of 11)
+#endif
     double r = fma_(-q, y, ax);
     const double qlo = q - 1.0, qhi = q + 1.0;
     const double rlo = fma_(-qlo, y, ax), rhi = fma_(-qhi, y, ax);
