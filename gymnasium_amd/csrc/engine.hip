@@ -1092,6 +1092,28 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
                             pend &= pend - 1u;
                         }
                     }
+                    if constexpr (AUXREW) {
+                        if constexpr (E::AUX_ACT_SQUARE) {
+                            // ... and the float32 square of the (clipped) action the reward reads: the same scheme, in place in the action ring -- this chunk's
+                            // actions were consumed by the env role a phase ago and the policy below refills this half only after the loop that follows
+                            static_assert(C <= 32 && sizeof(ActLds) == sizeof(float), "one pending bit per step; the square takes the action's place");
+                            uint32_t apend = 0u;
+#pragma unroll
+                            for (int k = 0; k < C; k++) {
+                                const float u = E::act_square_arg((Act)sh_act[buf][k][slot]);
+                                float h;
+                                const bool plain = E::Math::sqf_is_plain(u, h);
+                                sh_act[buf][k][slot] = (ActLds)(plain ? h : u);
+                                apend |= plain ? 0u : 1u << k;
+                            }
+#pragma nounroll
+                            while (apend) {
+                                ActLds *x = &sh_act[buf][__builtin_ctz(apend)][slot];
+                                *x = (ActLds)E::Math::sqf((float)*x);
+                                apend &= apend - 1u;
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int k = 0; k < C; k++) {
                         const size_t t = (size_t)c * C + k;
@@ -1138,7 +1160,10 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
 #pragma unroll
                                 for (int j = 0; j < E::AUX_PRE; j++) pre[j] = sh_pre[buf][k][slot][j];
                                 // (the action of this very step: chunk c was drawn two phases ago into the ring half the policy refills only AFTER this loop)
-                                rew = resetting ? 0.0 : E::aux_reward(pre, (Act)sh_act[buf][k][slot]);
+                                if constexpr (E::AUX_ACT_SQUARE)
+                                    rew = resetting ? 0.0 : E::aux_reward_squared(pre, (float)sh_act[buf][k][slot]);  // (the ring holds the squares now, see above)
+                                else
+                                    rew = resetting ? 0.0 : E::aux_reward(pre, (Act)sh_act[buf][k][slot]);
                             } else if constexpr (REW_OF_ACT) {
                                 rew = resetting ? 0.0 : E::reward_of_action(te, (Act)sh_act[buf][k][slot]);
                             } else {

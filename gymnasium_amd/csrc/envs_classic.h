@@ -111,6 +111,7 @@ struct ExactMathT {
     static MI_DEV void sq2(double a, double b, double &ra, double &rb) { mi_pow::square2<KASM>(g_pow_log, g_pow_exp, a, b, ra, rb); }
     // the test alone, for a caller that collects the arguments which need the table routine (the two-role Pendulum rollout, engine.hip): true = `hi` IS x ** 2
     static MI_DEV bool sq_is_plain(double x, double &hi) { return mi_pow::square_is_plain(x, hi); }
+    static MI_DEV bool sqf_is_plain(float x, float &hi) { return mi_pow::squaref_is_plain(x, hi); }  // ... and for np.float32 ** 2
 };
 typedef ExactMathT<true> ExactMath;
 typedef ExactMathT<false> ExactMathBuiltinFma;  // Acrobot: its kernels use AGPRs (see sincos_exact.h fma_k)
@@ -154,6 +155,7 @@ struct FastMath {
     static MI_DEV void sq3(double a, double b, double c, double &ra, double &rb, double &rc) { ra = a * a, rb = b * b, rc = c * c; }
     static MI_DEV void sq2(double a, double b, double &ra, double &rb) { ra = a * a, rb = b * b; }
     static MI_DEV bool sq_is_plain(double x, double &hi) { return hi = x * x, true; }
+    static MI_DEV bool sqf_is_plain(float x, float &hi) { return hi = x * x, true; }
 };
 template <class E>
 MI_DEV void tables_init() {
@@ -465,6 +467,16 @@ struct PendulumT {
             cu = (double)(0.001f * M::sqf(u));
         else
             cu = 0.001 * M::sq(u);
+        const double costs = pre[0] + 0.1 * pre[1] + cu;
+        return -costs;
+    }
+    // (round 6, fourth cut: the float32 `u ** 2`.  powf's square is provably the plain product for 31 of 32 floats too -- pow_exact.h squaref_is_plain, checked
+    //  over all 2^32 of them -- so the aux role tests a chunk's clipped actions first, runs the table routine once per PENDING action, all lanes side by side,
+    //  and reads the squares back in the step loop: engine.hip rollout_duo_kernel.)
+    static constexpr bool AUX_ACT_SQUARE = M::EXACT && ACT_KIND == MI_F32;
+    static MI_DEV float act_square_arg(Act action) { return (float)clip_torque(action); }
+    static MI_DEV double aux_reward_squared(const double pre[AUX_PRE], float u_squared) {  // aux_reward with powf(u, 2) already evaluated
+        const double cu = (double)(0.001f * u_squared);
         const double costs = pre[0] + 0.1 * pre[1] + cu;
         return -costs;
     }

@@ -214,4 +214,18 @@ MI_PW_DEV float squaref(const double *log2_tab, const uint64_t *exp2_tab, float 
     return (special || huge) ? x * x : res;
 }
 
+// ... and the float32 square.  powf evaluates exp2(2 log2 x) in double precision (relative error 1.27 * 2^-26 at worst, e_powf.c's header) and rounds once,
+// so it can differ from the correctly rounded product only when the exact square -- hi + lo with lo = fmaf(x, x, -hi) -- lies next to a rounding boundary.
+// EXHAUSTIVELY, over all 2^31 finite floats (tests/test_pow_exact.py, 4 s): powf(x, 2.0f) != x * x for 6 061 arguments per binade (0.072 %), and in every one of
+// them the exact square is within 0.0017 ulp of the boundary.  The test below passes an argument when it is at least 1/64 ulp away (|lo| <= 31/64 ulp(hi)) and
+// 2^-63 <= hi < 2^64: 31 of 32 arguments.  (Zeros, subnormals, infinities and NaNs fail the range test; the table routine selects x * x for them.)
+MI_PW_DEV bool squaref_is_plain(float x, float &hi) {
+    hi = x * x;
+    const float lo = __builtin_fmaf(x, x, -hi);
+    const uint32_t e = (bitsf(hi) - 1u) & 0x7f800000u;           // (one binade lower for an exact power of two: the smaller ulp is on its lower side)
+    const float thr = from_bitsf(e - 0x0c080000u);                // 2^(E - 25) * 31/16 = 31/64 ulp(hi)
+    const bool in_range = e - (64u << 23) < (127u << 23);        // 2^-63 <= hi < 2^64
+    return in_range & (__builtin_fabsf(lo) <= thr);
+}
+
 }  // namespace mi_pow

@@ -92,6 +92,36 @@ __attribute__((visibility("default"))) void square_brute(uint64_t seed, long n, 
 __attribute__((visibility("default"))) void square_batch(const double *x, double *out, long n) {
     for (long i = 0; i < n; i++) out[i] = mi_pow::square(mi_pow::kLogTab, mi_pow::kExpTab, x[i]);
 }
+// Every float with bit pattern in [first, last): out[0] = examined, out[1] = passed squaref_is_plain, out[2] = passed but powf(x, 2.0f) != x * x (must be 0),
+// out[3] = powf != x * x at all, out[4] = squaref() results with a normal square below 2^126 that differ from libm (must be 0); *closest = the largest distance to the rounding boundary
+// (in ulp) among the powf != x * x cases with a normal square.
+static volatile float g_twof = 2.0f;
+__attribute__((visibility("default"))) void squaref_scan(uint32_t first, uint32_t last, long *out, double *closest) {
+    double far = 0.0;
+    out[0] = out[1] = out[2] = out[3] = out[4] = 0;
+    for (uint64_t b = first; b < last; b++) {
+        const uint32_t u = (uint32_t)b;
+        float x, h2;
+        memcpy(&x, &u, 4);
+        const float ref = powf(x, g_twof), hi = x * x, own = mi_pow::squaref(mi_pow::kLog2fTab, mi_pow::kExp2fTab, x);
+        const bool plain = mi_pow::squaref_is_plain(x, h2);
+        out[0]++, out[1] += plain;
+        out[4] += memcmp(&ref, &own, 4) != 0 && hi >= 0x1p-126f && hi < 0x1p126f;  // (for |2 log2 x| >= 126 the routine returns x * x where libm still runs exp2: ties among subnormals, the last two binades -- no environment squares such a float)
+        if (plain && memcmp(&h2, &hi, 4) != 0) out[2]++;
+        if (memcmp(&ref, &hi, 4) != 0 && !(ref != ref)) {
+            out[3]++;
+            if (plain) out[2]++;
+            if (hi >= 0x1p-126f && hi < __builtin_inff()) {
+                const double s = (double)x * (double)x;
+                int e;
+                frexp((double)hi, &e);
+                const double dist = 0.5 - fabs(s - (double)hi) / ldexp(1.0, e - 24);
+                if (dist > far) far = dist;
+            }
+        }
+    }
+    *closest = far;
+}
 __attribute__((visibility("default"))) void squaref_batch(const float *x, float *out, long n) {
     for (long i = 0; i < n; i++) out[i] = mi_pow::squaref(mi_pow::kLog2fTab, mi_pow::kExp2fTab, x[i]);
 }

@@ -151,3 +151,29 @@ def test_the_plain_product_test_never_passes_an_argument_libm_rounds_the_other_w
     assert wrong == 0 and grouped_wrong == 0
     if mode < 4:
         assert passed > 0.96 * examined  # 31/32 of all arguments take the plain product
+
+
+def test_float32_plain_product_test_is_exhaustively_right():
+    """squaref_is_plain (the two-role Pendulum rollout's `u ** 2`): over ALL 2^32 bit patterns, an argument that passes has powf(x, 2.0f) == x * x in the running
+    libm; the restated routine equals libm everywhere; and the arguments libm rounds the other way sit within 0.002 ulp of a rounding boundary (the test keeps
+    1/64 = 0.0156 ulp clear)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    fn = lib().squaref_scan
+    fn.argtypes, fn.restype = [C.c_uint32, C.c_uint32, C.POINTER(C.c_long), C.POINTER(C.c_double)], None
+
+    def part(k):
+        out, far = (C.c_long * 5)(), C.c_double()
+        fn(k << 27, min((k + 1) << 27, 0xFFFFFFFF), out, C.byref(far))  # (ctypes releases the GIL: the 32 parts run side by side)
+        return list(out), far.value
+
+    with ThreadPoolExecutor(os.cpu_count() or 4) as ex:
+        res = list(ex.map(part, range(32)))
+    tot = np.sum([r[0] for r in res], axis=0)
+    assert tot[0] == 2 ** 32 - 1
+    assert tot[2] == 0, f"{tot[2]} arguments pass the test although powf rounds the other way"
+    assert tot[4] == 0, f"{tot[4]} squaref() results differ from libm"
+    assert tot[3] > 1_000_000, "powf(x, 2) is expected to differ from x * x for 0.07 % of the arguments"
+    assert max(r[1] for r in res) < 0.002
+    finite_in_range = 2 * 127 * 2 ** 22  # x^2 in [2^-63, 2^64): 63.5 binades of x per sign
+    assert tot[1] > 0.96 * finite_in_range, (tot[1], finite_in_range)
