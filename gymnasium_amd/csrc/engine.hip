@@ -1022,10 +1022,13 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
 #ifdef MI_DUO_TIMING
     unsigned long long t_work = 0, t_wait = 0, t_mark = __builtin_readcyclecounter();
 #endif
-#pragma unroll 1
-    for (int p = 0; p < chunks + 2; p++) {
+    // One phase of one role.  (Round 6, last cut: a loop per ROLE instead of one loop with both roles' code in it.  The values
+    // a role keeps in scalar registers across the phases -- the env role's float64 constants, the aux role's pointers and multipliers -- were live through the
+    // other role's code as well: Pendulum's bookkeeping loop reloaded 11 spilled scalars per step.  Both loops meet at the same number of barriers.)
+    auto phase = [&](auto env_tag, const int p) __attribute__((always_inline)) {
+        constexpr bool ENV = decltype(env_tag)::value;
         if (active) {
-            if (is_env) {
+            if constexpr (ENV) {
                 const int c = p - 1;
                 if (c >= 0 && c < chunks) {
                     const int buf = c & 1;
@@ -1211,6 +1214,13 @@ __global__ __launch_bounds__(kDuoBlock) void rollout_duo_kernel(DevEnv d, Rollou
             t_wait += now - t_mark, t_mark = now;
         }
 #endif
+    };
+    if (__builtin_amdgcn_readfirstlane((int)is_env)) {  // (a role is a whole number of wavefronts: the branch is uniform)
+#pragma unroll 1
+        for (int p = 0; p < chunks + 2; p++) phase(std::true_type(), p);
+    } else {
+#pragma unroll 1
+        for (int p = 0; p < chunks + 2; p++) phase(std::false_type(), p);
     }
 #ifdef MI_DUO_TIMING  // scripts/r04/duo_timing.py: where each role's time goes
     if (blockIdx.x == 7 && (threadIdx.x & 63) == 0)
