@@ -306,6 +306,23 @@ struct CartPoleT {
         return (Act)(((hi ^ lo) >> ((rot + 63u) & 63u)) & 1ull);
     }
 
+    struct Accel {
+        double thetaacc, xacc;
+    };
+    // the rare lanes' accelerations through the general routines, OUT OF LINE: the hot path then carries neither this body's scalar registers nor the
+    // spill of the saved exec mask around it
+    static __device__ __attribute__((noinline)) Accel general_accel(double theta, double theta_dot, double force) {
+        const double gravity = 9.8, masspole = 0.1, length = 0.5;
+        const double polemass_length = masspole * length;
+        double sintheta, costheta;
+        M::sincos(theta, sintheta, costheta);
+        const double temp = div_by_constant(force + polemass_length * (theta_dot * theta_dot) * sintheta, TotalMass());
+        Accel r;
+        r.thetaacc = (gravity * sintheta - costheta * temp) /
+                     (length * (4.0 / 3.0 - div_by_constant(masspole * (costheta * costheta), TotalMass())));
+        r.xacc = temp - div_by_constant(polemass_length * r.thetaacc * costheta, TotalMass());
+        return r;
+    }
     // cartpole.py:164-226: explicit Euler with the OLD velocities, all float64.
     static MI_DEV void step(double s[S], uint32_t &, Act action, const EnvParams &P, double &reward, bool &terminated, Trig &) {
         const double gravity = 9.8, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
@@ -334,11 +351,8 @@ struct CartPoleT {
             // (`&`, not `&&`: three flags combined by scalar instructions, no control flow of their own)
             const bool common = main_range & div_by_constant_in_range(t1) & div_by_constant_in_range(t3);
             if (__builtin_expect(!common, 0)) {
-                M::sincos(theta, sintheta, costheta);
-                temp = div_by_constant(force + polemass_length * (theta_dot * theta_dot) * sintheta, TotalMass());
-                thetaacc = (gravity * sintheta - costheta * temp) /
-                           (length * (4.0 / 3.0 - div_by_constant(masspole * (costheta * costheta), TotalMass())));
-                xacc = temp - div_by_constant(polemass_length * thetaacc * costheta, TotalMass());
+                const Accel r = general_accel(theta, theta_dot, force);
+                thetaacc = r.thetaacc, xacc = r.xacc;
             }
         } else {
             M::sincos(theta, sintheta, costheta);
