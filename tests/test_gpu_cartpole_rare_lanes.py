@@ -1,0 +1,88 @@
+"""-m gpu: CartPole's RARE lanes against the oracle, bit for bit.
+
+CartPoleT::step (gymnasium_amd/csrc/envs_classic.h; cartpole.py:164-226) takes a short path when the pole angle is inside the short sincos routine's
+range (|theta| < ~0.855) and the two divisions' operands are inside the three-FMA range; every other lane redoes its accelerations through the general
+routines in an out-of-line function (`general_accel`).  Episodes end at |theta| > 0.2095, so no trajectory that starts from reset() ever reaches that
+code: the states here are put there with set_state() -- angles up to 1e5 rad, angular velocities up to 1e8, the range's own boundary from both sides
+-- and stepped by BOTH kernels that contain the code: step() (step_kernel) and rollout() (rollout_duo_kernel, whose first step then runs on them)."""
+import numpy as np
+import pytest
+
+import gymnasium_amd
+
+pytestmark = pytest.mark.gpu
+
+EDGE = np.frombuffer(np.array([0x3FEB6000 << 32], dtype=np.uint64).tobytes(), dtype=np.float64)[0]  # in_main_range()'s bound: 0.85546875
+
+
+def wide_states(n, seed):
+    rng = np.random.default_rng(seed)
+    s = np.empty((n, 4), dtype=np.float64)
+    s[:, 0] = rng.uniform(-2.3, 2.3, n)
+    s[:, 1] = rng.uniform(-30.0, 30.0, n)
+    kind = rng.integers(0, 6, n)
+    theta = np.where(kind == 0, rng.uniform(-0.2, 0.2, n), 0.0)  # the common lanes, interleaved with the rare ones inside every wavefront
+    theta = np.where(kind == 1, rng.uniform(-0.9, 0.9, n), theta)
+    theta = np.where(kind == 2, rng.uniform(-10.0, 10.0, n), theta)
+    theta = np.where(kind == 3, rng.uniform(-1.0, 1.0, n) * 1e5, theta)
+    around = np.nextafter(EDGE, np.where(rng.integers(0, 2, n) == 0, 0.0, 1.0)) * np.where(rng.integers(0, 2, n) == 0, -1.0, 1.0)
+    theta = np.where(kind == 4, np.where(rng.integers(0, 3, n) == 0, EDGE, around), theta)
+    theta = np.where(kind == 5, rng.uniform(-np.pi, np.pi, n), theta)
+    s[:, 2] = theta
+    mag = rng.integers(0, 4, n)
+    s[:, 3] = rng.uniform(-1.0, 1.0, n) * np.choose(mag, [5.0, 1e3, 1e8, 1e-300])  # (theta_dot ** 2 carries the divisions' operands out of their range)
+    return s
+
+
+def pair(n, output="numpy", **kw):
+    from oracle import oracle
+
+    gpu = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, device=0, output=output, **kw)
+    cpu = gymnasium_amd.make_vec("CartPole-v1", num_envs=n, _engine_factory=oracle.engine_factory, **kw)
+    first = gpu.reset(seed=5)[0]
+    assert np.array_equal(first.cpu().numpy() if output == "torch" else first, cpu.reset(seed=5)[0])
+    return gpu, cpu
+
+
+@pytest.mark.parametrize("n", [1000, 65536])
+def test_step_kernel_on_rare_lanes(n):
+    gpu, cpu = pair(n, autoreset_mode="Disabled", max_episode_steps=10**6)
+    zeros = np.zeros(n, dtype=np.int32)
+    for seed in range(3):
+        s = wide_states(n, seed)
+        a = np.random.default_rng(100 + seed).integers(0, 2, n)
+        for env in (gpu, cpu):
+            env.reset(seed=seed)
+            env.set_state(s, zeros, np.zeros(n, dtype=np.uint8))
+        g, c = gpu.step(a), cpu.step(a)
+        for j, name in enumerate(("obs", "rewards", "terminations", "truncations")):
+            assert np.array_equal(g[j], c[j], equal_nan=True), (seed, name, s[np.flatnonzero((g[j] != c[j]).reshape(n, -1).any(axis=1))[:4]])
+        sg, sc = gpu.get_state(), cpu.get_state()
+        assert np.array_equal(sg[0].view(np.uint64), sc[0].view(np.uint64)), (seed, "state words")
+        assert c[2].mean() > 0.5  # (most of these states are beyond the termination thresholds, as intended)
+    gpu.close(), cpu.close()
+
+
+@pytest.mark.parametrize("n", [1000, 65536])
+def test_rollout_kernel_on_rare_lanes(n):
+    """rollout(T) right after set_state(): the two-role kernel's first step runs on the wide states (then NEXT_STEP resets the finished sub-environments)."""
+    T = 8
+    gpu, cpu = pair(n, output="torch")
+    zeros = np.zeros(n, dtype=np.int32)
+    for seed in range(2):
+        s = wide_states(n, 50 + seed)
+        for env in (gpu, cpu):
+            env.reset(seed=seed)
+            env.action_space.seed(9 + seed)
+            env.set_state(s, zeros, np.zeros(n, dtype=np.uint8))
+        out = gpu.rollout(T)
+        host = lambda x: x.cpu().numpy()
+        for k in range(T):
+            a = cpu.action_space.sample()
+            c = cpu.step(a)
+            assert np.array_equal(host(out["actions"][k]).reshape(a.shape), a), (seed, k, "policy")
+            for name, j in (("obs", 0), ("rewards", 1), ("terminations", 2), ("truncations", 3)):
+                assert np.array_equal(host(out[name][k]), c[j], equal_nan=True), (seed, k, name)
+        sg, sc = gpu.get_state(), cpu.get_state()
+        assert all(np.array_equal(x, y) for x, y in zip(sg, sc)), (seed, "state after the rollout")
+    gpu.close(), cpu.close()
