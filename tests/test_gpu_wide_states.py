@@ -1,10 +1,15 @@
-"""-m gpu: CartPole's RARE lanes against the oracle, bit for bit.
+"""-m gpu: states no trajectory from reset() reaches, put there with set_state() -- CartPole's RARE lanes and Pendulum's far angles against the oracle, bit for bit.
 
 CartPoleT::step (gymnasium_amd/csrc/envs_classic.h; cartpole.py:164-226) takes a short path when the pole angle is inside the short sincos routine's
 range (|theta| < ~0.855) and the two divisions' operands are inside the three-FMA range; every other lane redoes its accelerations through the general
 routines in an out-of-line function (`general_accel`).  Episodes end at |theta| > 0.2095, so no trajectory that starts from reset() ever reaches that
 code: the states here are put there with set_state() -- angles up to 1e5 rad, angular velocities up to 1e8, the range's own boundary from both sides
--- and stepped by BOTH kernels that contain the code: step() (step_kernel) and rollout() (rollout_duo_kernel, whose first step then runs on them)."""
+-- and stepped by BOTH kernels that contain the code: step() (step_kernel) and rollout() (rollout_duo_kernel, whose first step then runs on them).
+
+Pendulum's angle is never wrapped (pendulum.py:139-150 keeps th; only the cost normalises it), so the exact fmod by the rounded reciprocal and the
+general sin / cos are checked far beyond the 80 rad an episode can reach -- up to 1e8, the edge of the range the restated libm routines cover
+(|x| < 1.05e8, docs/classic_kernels.md: beyond it glibc switches to Payne-Hanek and the kernels defer to ocml; with angles of 1e12 this test
+fails in the float64 reward of the second step, as that note says it would)."""
 import numpy as np
 import pytest
 
@@ -83,6 +88,63 @@ def test_rollout_kernel_on_rare_lanes(n):
             assert np.array_equal(host(out["actions"][k]).reshape(a.shape), a), (seed, k, "policy")
             for name, j in (("obs", 0), ("rewards", 1), ("terminations", 2), ("truncations", 3)):
                 assert np.array_equal(host(out[name][k]), c[j], equal_nan=True), (seed, k, name)
+        sg, sc = gpu.get_state(), cpu.get_state()
+        assert all(np.array_equal(x, y) for x, y in zip(sg, sc)), (seed, "state after the rollout")
+    gpu.close(), cpu.close()
+
+
+def wide_pendulum_states(n, seed):
+    """Angles far outside what 200 steps can reach (|theta| grows by at most 0.4 per step): fmod(theta + pi, 2 pi) of pendulum.py:262 by the rounded
+    reciprocal (sincos_exact.h fmod_const) has its quotient off by one exactly around the multiples of 2 pi -- those, from both sides, are a third of the lanes."""
+    rng = np.random.default_rng(seed)
+    s = np.empty((n, 2), dtype=np.float64)
+    kind = rng.integers(0, 6, n)
+    k = rng.integers(-10**6, 10**6, n).astype(np.float64)
+    near = k * (2 * np.pi) - np.pi  # theta + pi lands on a multiple of 2 pi, give or take the roundings
+    for _ in range(3):
+        near = np.where(rng.integers(0, 2, n) == 0, near, np.nextafter(near, np.where(rng.integers(0, 2, n) == 0, -np.inf, np.inf)))
+    th = np.where(kind == 0, rng.uniform(-np.pi, np.pi, n), 0.0)
+    th = np.where(kind == 1, rng.uniform(-100.0, 100.0, n), th)
+    th = np.where(kind == 2, rng.uniform(-1.0, 1.0, n) * 1e6, th)
+    th = np.where(kind == 3, rng.uniform(-1.0, 1.0, n) * 1e8, th)  # (the restated sin / cos are glibc's below 1.05e8: docs/classic_kernels.md; beyond it the kernels defer to ocml)
+    th = np.where(kind >= 4, near, th)
+    s[:, 0] = th
+    s[:, 1] = rng.uniform(-8.0, 8.0, n)
+    return s
+
+
+@pytest.mark.parametrize("n", [1000, 65536])
+def test_pendulum_wide_angles(n):
+    from oracle import oracle
+
+    gpu = gymnasium_amd.make_vec("Pendulum-v1", num_envs=n, device=0, output="torch")
+    cpu = gymnasium_amd.make_vec("Pendulum-v1", num_envs=n, _engine_factory=oracle.engine_factory)
+    zeros = np.zeros(n, dtype=np.int32)
+    host = lambda x: x.cpu().numpy()
+    for seed in range(2):
+        s = wide_pendulum_states(n, seed)
+        for env in (gpu, cpu):
+            env.reset(seed=seed)
+            env.action_space.seed(3 + seed)
+            env.set_state(s, zeros, np.zeros(n, dtype=np.uint8))
+        import torch
+
+        a = cpu.action_space.sample()  # step(): step_kernel
+        g, c = gpu.step(torch.from_numpy(a).cuda()), cpu.step(a)
+        for j, name in enumerate(("obs", "rewards", "terminations", "truncations")):
+            assert np.array_equal(host(g[j]), c[j]), (seed, "step", name, s[np.flatnonzero((host(g[j]) != c[j]).reshape(n, -1).any(axis=1))[:4]])
+        assert np.array_equal(gpu.get_state()[0].view(np.uint64), cpu.get_state()[0].view(np.uint64)), (seed, "state words after step()")
+        for env in (gpu, cpu):
+            env.set_state(s, zeros, np.zeros(n, dtype=np.uint8))
+        gpu.action_space.np_random.bit_generator.state = cpu.action_space.np_random.bit_generator.state
+        T = 16  # rollout(): the two-role kernel
+        out = gpu.rollout(T)
+        for k in range(T):
+            a = cpu.action_space.sample()
+            c = cpu.step(a)
+            assert np.array_equal(host(out["actions"][k]).reshape(a.shape), a), (seed, k, "policy")
+            for name, j in (("obs", 0), ("rewards", 1), ("terminations", 2), ("truncations", 3)):
+                assert np.array_equal(host(out[name][k]), c[j]), (seed, k, name)
         sg, sc = gpu.get_state(), cpu.get_state()
         assert all(np.array_equal(x, y) for x, y in zip(sg, sc)), (seed, "state after the rollout")
     gpu.close(), cpu.close()
