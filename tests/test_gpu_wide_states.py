@@ -148,3 +148,67 @@ def test_pendulum_wide_angles(n):
         sg, sc = gpu.get_state(), cpu.get_state()
         assert all(np.array_equal(x, y) for x, y in zip(sg, sc)), (seed, "state after the rollout")
     gpu.close(), cpu.close()
+
+
+def wide_acrobot_states(n, seed):
+    """acrobot.py:244-279: angles the wrap() loop has to bring back over up to 16 turns, velocities far outside bound()'s limits (4 pi, 9 pi), into RK4."""
+    rng = np.random.default_rng(seed)
+    s = np.empty((n, 4), dtype=np.float64)
+    big = rng.integers(0, 3, (n, 2))
+    s[:, :2] = rng.uniform(-1.0, 1.0, (n, 2)) * np.choose(big, [np.pi, 10.0, 100.0])
+    s[:, 2:] = rng.uniform(-1.0, 1.0, (n, 2)) * np.choose(rng.integers(0, 3, (n, 2)), [4 * np.pi, 30.0, 1e-200])
+    return s
+
+
+def wide_mountaincar_states(n, seed):
+    """mountain_car.py:137-160 / continuous_mountain_car.py:150-178: positions and velocities far outside the clips, the goal line and the wall from both sides."""
+    rng = np.random.default_rng(seed)
+    s = np.empty((n, 2), dtype=np.float64)
+    kind = rng.integers(0, 5, n)
+    p = np.where(kind == 0, rng.uniform(-1.2, 0.6, n), 0.0)
+    p = np.where(kind == 1, rng.uniform(-1e3, 1e3, n), p)
+    p = np.where(kind == 2, rng.uniform(-1.0, 1.0, n) * 1e7, p)
+    p = np.where(kind == 3, np.nextafter(-1.2, rng.choice([-2.0, 0.0], n)), p)
+    p = np.where(kind == 4, np.nextafter(rng.choice([0.5, 0.45, 0.6], n), rng.choice([-1.0, 1.0], n)), p)
+    s[:, 0] = p
+    s[:, 1] = rng.uniform(-1.0, 1.0, n) * np.choose(rng.integers(0, 4, n), [0.07, 1.0, 1e-3, 1e-300])
+    return s
+
+
+@pytest.mark.parametrize("env_id,states,T", [("Acrobot-v1", wide_acrobot_states, 8), ("MountainCar-v0", wide_mountaincar_states, 16),
+                                             ("MountainCarContinuous-v0", wide_mountaincar_states, 16)])
+def test_other_classic_envs_on_wide_states(env_id, states, T):
+    import torch
+    from oracle import oracle
+
+    n = 20000  # (not a multiple of the workgroup's 256 sub-environments)
+    gpu = gymnasium_amd.make_vec(env_id, num_envs=n, device=0, output="torch")
+    cpu = gymnasium_amd.make_vec(env_id, num_envs=n, _engine_factory=oracle.engine_factory)
+    zeros, flags = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.uint8)
+    host = lambda x: x.cpu().numpy()
+    for seed in range(2):
+        s = states(n, 20 + seed)
+        for env in (gpu, cpu):
+            env.reset(seed=seed)
+            env.action_space.seed(3 + seed)
+            env.set_state(s, zeros, flags)
+        a = cpu.action_space.sample()
+        g, c = gpu.step(torch.from_numpy(a).cuda()), cpu.step(a)
+        for j, name in enumerate(("obs", "rewards", "terminations", "truncations")):
+            assert np.array_equal(host(g[j]), c[j]), (seed, "step", name, s[np.flatnonzero((host(g[j]) != c[j]).reshape(n, -1).any(axis=1))[:4]])
+        sg, sc = gpu.get_state(), cpu.get_state()
+        assert np.array_equal(sg[0].view(np.uint64), sc[0].view(np.uint64)), (seed, "state words after step()", s[np.flatnonzero((sg[0] != sc[0]).any(axis=1))[:4]])
+        for env in (gpu, cpu):
+            env.reset(seed=seed)
+            env.set_state(s, zeros, flags)
+        gpu.action_space.np_random.bit_generator.state = cpu.action_space.np_random.bit_generator.state
+        out = gpu.rollout(T)
+        for k in range(T):
+            a = cpu.action_space.sample()
+            c = cpu.step(a)
+            assert np.array_equal(host(out["actions"][k]).reshape(a.shape), a), (seed, k, "policy")
+            for name, j in (("obs", 0), ("rewards", 1), ("terminations", 2), ("truncations", 3)):
+                assert np.array_equal(host(out[name][k]), c[j]), (seed, k, name)
+        sg, sc = gpu.get_state(), cpu.get_state()
+        assert all(np.array_equal(x, y) for x, y in zip(sg, sc)), (seed, "state after the rollout")
+    gpu.close(), cpu.close()
