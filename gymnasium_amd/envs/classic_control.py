@@ -42,6 +42,24 @@ class _ClassicControlVectorEnv(HipVectorEnv):
 
         return _native.CFG_FAST_MATH if self.fast_math else 0
 
+    # set_state() is this package's own entry (checkpoint / resume; the reference has none), so its domain is stated here: the restated libm
+    # sin / cos are glibc's below EXACT_TRIG_RANGE (beyond it glibc switches to Payne-Hanek, docs/classic_kernels.md), and the routines of the
+    # environments that wrap or clip their angle leave the test for it out.  _STATE_LIMITS: (columns, largest magnitude accepted).  The limits are
+    # far outside anything a trajectory reaches (tests/test_gpu_wide_states.py steps states up to them bit for bit against the oracle).
+    EXACT_TRIG_RANGE = 105414336.0
+    _STATE_LIMITS: tuple = ()
+
+    def set_state(self, state=None, elapsed_steps=None, flags=None):
+        if state is not None:
+            arr = np.asarray(state, dtype=np.float64)
+            for cols, limit in self._STATE_LIMITS:
+                bad = np.abs(arr[:, list(cols)]) > limit  # (NaN compares false: it propagates, as it does in the reference)
+                if bad.any():
+                    i, j = np.argwhere(bad)[0]
+                    raise ValueError(f"{type(self).__name__}.set_state: state[{i}, {cols[j]}] = {arr[i, cols[j]]!r} is outside the accepted range "
+                                     f"|x| <= {limit:g} (the exact sin / cos cover |angle| < {self.EXACT_TRIG_RANGE:g})")
+        super().set_state(state, elapsed_steps, flags)
+
 
 class CartPoleVectorEnv(_ClassicControlVectorEnv):
     """``rng="per_env"`` (default): the semantics of ``SyncVectorEnv`` over scalar ``CartPoleEnv`` objects -- sub-environment ``i`` owns the stream
@@ -55,6 +73,7 @@ class CartPoleVectorEnv(_ClassicControlVectorEnv):
     ``register_envs(override_stock_ids=True)`` attaches this mode to the stock id, so that switching changes no seeded trajectory."""
 
     KIND = "cartpole"
+    _STATE_LIMITS = (((2,), 1e8),)  # theta
     DEFAULT_MAX_EPISODE_STEPS = 500
     DEFAULT_RNG = "per_env"
 
@@ -183,6 +202,7 @@ _SHORT_STEP_OWNERS.add(CartPoleVectorEnv.step)  # (it only adds to the result wi
 
 class PendulumVectorEnv(_ClassicControlVectorEnv):
     KIND = "pendulum"
+    _STATE_LIMITS = (((0,), 1e8),)  # th (never wrapped: pendulum.py:139-150)
     DEFAULT_MAX_EPISODE_STEPS = 200
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, g: float = 10.0, **kwargs):
@@ -207,6 +227,7 @@ class PendulumVectorEnv(_ClassicControlVectorEnv):
 
 class AcrobotVectorEnv(_ClassicControlVectorEnv):
     KIND = "acrobot"
+    _STATE_LIMITS = (((0, 1), 1e6), ((2, 3), 100.0))  # (the velocities too: RK4's intermediate angles grow with their fourth power)
     DEFAULT_MAX_EPISODE_STEPS = 500
 
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, **kwargs):
@@ -221,6 +242,8 @@ class AcrobotVectorEnv(_ClassicControlVectorEnv):
 
 
 class _MountainCarBase(_ClassicControlVectorEnv):
+    _STATE_LIMITS = (((0,), 3e7),)  # position: cos(3 * position)
+
     def __init__(self, num_envs: int = 1, max_episode_steps: int | None = None, goal_velocity: float = 0, **kwargs):
         self.goal_velocity = goal_velocity
         super().__init__(num_envs=num_envs, max_episode_steps=max_episode_steps, **kwargs)
