@@ -68,9 +68,16 @@ def test_step_kernel_on_rare_lanes(n):
     gpu.close(), cpu.close()
 
 
+@pytest.fixture(params=[1, 0], ids=["two_roles", "one_role"])
+def rollout_kernel(request, monkeypatch):
+    """Both kernels behind rollout(): rollout_duo_kernel (the default for this configuration) and the one-role rollout_kernel it replaced (engine.hip)."""
+    monkeypatch.setenv("MI355ENV_ROLLOUT_DUO", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("n", [1000, 65536])
-def test_rollout_kernel_on_rare_lanes(n):
-    """rollout(T) right after set_state(): the two-role kernel's first step runs on the wide states (then NEXT_STEP resets the finished sub-environments)."""
+def test_rollout_kernel_on_rare_lanes(n, rollout_kernel):
+    """rollout(T) right after set_state(): the rollout kernel's first step runs on the wide states (then NEXT_STEP resets the finished sub-environments)."""
     T = 8
     gpu, cpu = pair(n, output="torch")
     zeros = np.zeros(n, dtype=np.int32)
@@ -114,7 +121,7 @@ def wide_pendulum_states(n, seed):
 
 
 @pytest.mark.parametrize("n", [1000, 65536])
-def test_pendulum_wide_angles(n):
+def test_pendulum_wide_angles(n, rollout_kernel):
     from oracle import oracle
 
     gpu = gymnasium_amd.make_vec("Pendulum-v1", num_envs=n, device=0, output="torch")
