@@ -335,7 +335,10 @@ int mi_reset_stats(mi_vecenv *env);
 /* MuJoCo kinds: a state row is [qpos(nq), qvel(nv), qacc_warmstart(nv), tracked_x, tracked_y] -- the Cartesian position
  * the next step's velocity reward is differenced against comes from the last forward pass and lags qpos. */
 /* Physics state rows [N][state_dim] float64 (host pointers); checkpoint/resume + teacher-forced tests.
- * Replaces poking env.unwrapped.state (tests/envs/test_env_implementation.py:255-321 compares it). */
+ * Replaces poking env.unwrapped.state (tests/envs/test_env_implementation.py:255-321 compares it).
+ * Domain of mi_set_state for the classic-control kinds: angles that go into sin / cos within |x| < 105414336 (the range in which the engine's
+ * routines ARE glibc's; CartPole and Pendulum defer to the device library beyond it, Acrobot and MountainCar -- which wrap / clip their angle --
+ * assume it).  The host classes refuse rows outside it (gymnasium_amd/envs/classic_control.py _STATE_LIMITS); a binding of its own should too. */
 int mi_get_state(mi_vecenv *env, double *state, int32_t *elapsed_steps, uint8_t *flags);
 int mi_set_state(mi_vecenv *env, const double *state, const int32_t *elapsed_steps, const uint8_t *flags);
 /* Per-env PCG64 words, same layout as mi_seed (host pointer). */
