@@ -236,28 +236,30 @@ def make_episode_stats():
     save("episode_stats.npz", **out)
 
 
+def _teacher_run(env_id, states, actions, f32_state=None, tuple_state=False):
+    env = gym.make(env_id).unwrapped
+    env.reset(seed=0)
+    ns, ob, rw, te = [], [], [], []
+    for k in range(len(states)):
+        s = states[k]
+        if f32_state is not None and f32_state[k]:
+            env.state = np.array(s, dtype=np.float32)
+        elif tuple_state:
+            env.state = (np.float64(s[0]), np.float64(s[1]))
+        else:
+            env.state = np.array(s, dtype=np.float64)
+        if hasattr(env, "steps_beyond_terminated"):
+            env.steps_beyond_terminated = None
+        o, r, t, _, _ = env.step(actions[k])
+        ns.append(np.asarray(env.state, dtype=np.float64).ravel()), ob.append(o), rw.append(r), te.append(t)
+    return np.stack(ns), np.stack(ob), np.array(rw, dtype=np.float64), np.array(te, dtype=bool)
+
+
 def make_teacher():
     """Teacher-forced single steps: poke env.unwrapped.state, step once, record everything."""
     rng = np.random.default_rng(2024)
     M = 3000
-
-    def run(env_id, states, actions, f32_state=None, tuple_state=False):
-        env = gym.make(env_id).unwrapped
-        env.reset(seed=0)
-        ns, ob, rw, te = [], [], [], []
-        for k in range(len(states)):
-            s = states[k]
-            if f32_state is not None and f32_state[k]:
-                env.state = np.array(s, dtype=np.float32)
-            elif tuple_state:
-                env.state = (np.float64(s[0]), np.float64(s[1]))
-            else:
-                env.state = np.array(s, dtype=np.float64)
-            if hasattr(env, "steps_beyond_terminated"):
-                env.steps_beyond_terminated = None
-            o, r, t, _, _ = env.step(actions[k])
-            ns.append(np.asarray(env.state, dtype=np.float64).ravel()), ob.append(o), rw.append(r), te.append(t)
-        return np.stack(ns), np.stack(ob), np.array(rw, dtype=np.float64), np.array(te, dtype=bool)
+    run = _teacher_run
 
     # CartPole: around and beyond the thresholds
     s = np.stack([rng.uniform(-2.6, 2.6, M), rng.uniform(-3, 3, M), rng.uniform(-0.25, 0.25, M), rng.uniform(-3.5, 3.5, M)], 1)
@@ -290,6 +292,26 @@ def make_teacher():
     a = rng.uniform(-1.3, 1.3, (M, 1)).astype(np.float32)
     ns, ob, rw, te = run("MountainCarContinuous-v0", s, a, f32_state=f32)
     save("teacher_mountaincar_continuous.npz", state=s, f32=f32, action=a, next_state=ns, obs=ob, reward=rw, term=te)
+
+
+def make_teacher_wide():
+    """The same, from states no trajectory reaches (tests/wide_states.py): CartPole's pole far beyond the threshold (|theta| to 1e5, the 0.855 boundary of
+    the engine's short sin / cos routine from both sides, angular velocities to 1e8), Pendulum's unwrapped angle to 1e8 and within 3 ulps of the multiples
+    of 2 pi, Acrobot through 16 turns of wrap() and velocities beyond bound(), MountainCar far outside the clips and at the wall / goal line."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import wide_states as w
+
+    rng = np.random.default_rng(4048)
+    M = 3000
+    for key, env_id, states, kw in (("cartpole", "CartPole-v1", w.wide_states, {}), ("pendulum", "Pendulum-v1", w.wide_pendulum_states, {}),
+                                    ("acrobot", "Acrobot-v1", w.wide_acrobot_states, {}), ("mountaincar", "MountainCar-v0", w.wide_mountaincar_states, {"tuple_state": True}),
+                                    ("mountaincar_continuous", "MountainCarContinuous-v0", w.wide_mountaincar_states, {"f32_state": np.zeros(M, dtype=bool)})):
+        s = states(M, 77)
+        space = gym.make(env_id).action_space
+        a = rng.uniform(-3, 3, (M, 1)).astype(np.float32) if key in ("pendulum", "mountaincar_continuous") else rng.integers(0, space.n, M)
+        ns, ob, rw, te = _teacher_run(env_id, s, a, **kw)
+        extra = {"f32": np.zeros(M, dtype=bool)} if key == "mountaincar_continuous" else {}
+        save(f"teacher_wide_{key}.npz", state=s, action=a, next_state=ns, obs=ob, reward=rw, term=te, **extra)
 
 
 def make_action_samples():
@@ -561,6 +583,9 @@ if __name__ == "__main__":
     if "--wrappers-only" in sys.argv:
         make_wrappers()
         sys.exit(0)
+    if "--teacher-wide-only" in sys.argv:
+        make_teacher_wide()
+        sys.exit(0)
     if "--infos-only" in sys.argv:
         make_same_step_infos()
         sys.exit(0)
@@ -572,6 +597,7 @@ if __name__ == "__main__":
     make_options()
     make_episode_stats()
     make_teacher()
+    make_teacher_wide()
     make_action_samples()
     make_toytext()
     make_wrappers()

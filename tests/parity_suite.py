@@ -250,9 +250,10 @@ def check_episode_stats(factory, tol):
             env.close()
 
 
-def check_teacher(key, factory, tol):
-    """Teacher-forced single steps from random (state, action) pairs covering the whole state box."""
-    g = golden(f"teacher_{key}.npz")
+def check_teacher(key, factory, tol, fixture="teacher"):
+    """Teacher-forced single steps from random (state, action) pairs covering the whole state box (fixture="teacher_wide": from states no trajectory
+    reaches, tests/wide_states.py -- the reference's own numbers for what tests/test_gpu_wide_states.py compares with the oracle)."""
+    g = golden(f"{fixture}_{key}.npz")
     M = g["state"].shape[0]
     env = make(key, M, factory, max_episode_steps=10**6, autoreset_mode="Disabled")
     env.reset(seed=0)

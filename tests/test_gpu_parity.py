@@ -39,6 +39,12 @@ def test_teacher_forced_vs_reference_golden(key):
     ps.check_teacher(key, None, ps.EXACT)
 
 
+@pytest.mark.parametrize("key", list(ENV_IDS))
+def test_teacher_forced_from_wide_states_vs_reference_golden(key):
+    """The same from 3000 states no trajectory reaches (CartPole's rare lanes, Pendulum's angle to 1e8, ...: tests/wide_states.py), recorded from the reference."""
+    ps.check_teacher(key, None, ps.EXACT, fixture="teacher_wide")
+
+
 def test_config1_cartpole_known_answer():
     ps.check_config1(None, ps.EXACT)
 
