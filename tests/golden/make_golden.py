@@ -15,6 +15,7 @@ weak-scalar promotion) and records
   options.npz               reset(options=...) bounds, seed lists
   episode_stats.npz         wrappers.vector.RecordEpisodeStatistics r / l
   teacher_<env>.npz         teacher-forced single steps from random (state, action) pairs
+  teacher_wide_<env>.npz    the same from states no trajectory reaches (tests/wide_states.py); --teacher-wide-only regenerates just these
   config1_cartpole.npz      BASELINE.json configs[0]: CartPole-v1, Sync, 4 envs, 1000 steps, seed 0
   wrappers_*.npz            NormalizeObservation / NormalizeReward / ClipReward (wrappers/vector) inputs and outputs
   toytext_<env>.npz         FrozenLake / CliffWalking / Taxi: the reference's transition table P and initial distribution,
